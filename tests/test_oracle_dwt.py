@@ -1,0 +1,85 @@
+"""Pins oracle/dwt_ref.py against PyWavelets 1.1.1 outputs (tests/golden/dwt_pywt.npz)."""
+import numpy as np
+import pytest
+
+from oracle import dwt_ref as R
+from tests.helpers import load_npz
+
+G = load_npz('dwt_pywt.npz')
+TOL = 1e-12
+
+
+def _err(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.abs(a - b).max()
+
+
+@pytest.mark.parametrize('tag', ['ref', 'small', 'db4', 'sym4', 'haar', 'b13'])
+def test_dwt2_periodization(tag):
+    w = str(G[f'dwt2per_{tag}_wave'])
+    yl, yh = R.dwt2(G[f'dwt2per_{tag}_x'], w, 'periodization')
+    assert _err(yl, G[f'dwt2per_{tag}_yl']) < TOL
+    assert _err(yh, G[f'dwt2per_{tag}_yh']) < TOL
+    rec = R.idwt2(G[f'idwt2per_{tag}_yl'], G[f'idwt2per_{tag}_yh'], w, 'periodization')
+    assert _err(rec, G[f'idwt2per_{tag}_x']) < TOL
+
+
+def test_dwt2_reference_sizes():
+    yl, yh = R.dwt2(G['dwt2per_ref_x'], 'bior2.4', 'periodization')
+    assert yl.shape == (1, 2, 41, 60) and yh.shape == (1, 2, 3, 41, 60)       # 81x120 -> 41x60
+    assert R.idwt2(yl, yh, 'bior2.4', 'periodization').shape == (1, 2, 82, 120)  # callers crop to 81
+    t = R.burgers_coef_to_tensor(yl, yh, pad=True)
+    assert t.shape == (1, 2, 4, 64, 64) and np.all(t[..., 41:, :] == 0) and np.all(t[..., 60:] == 0)
+
+
+@pytest.mark.parametrize('tag', ['per', 'perodd', 'zero', 'zeroodd', 'zdb4'])
+def test_dwt1(tag):
+    w, m = str(G[f'dwt1_{tag}_wave']), str(G[f'dwt1_{tag}_mode'])
+    lo, hi = R.dwt1d(G[f'dwt1_{tag}_x'], w, m)
+    assert _err(lo, G[f'dwt1_{tag}_lo']) < TOL and _err(hi, G[f'dwt1_{tag}_hi']) < TOL
+    assert _err(R.idwt1d(G[f'idwt1_{tag}_lo'], G[f'idwt1_{tag}_hi'], w, m), G[f'idwt1_{tag}_x']) < TOL
+
+
+@pytest.mark.parametrize('tag', ['ref', 'odd'])
+def test_dwt2_zero(tag):
+    yl, yh = R.dwt2(G[f'dwt2zero_{tag}_x'], str(G[f'dwt2zero_{tag}_wave']), 'zero')
+    assert _err(yl, G[f'dwt2zero_{tag}_yl']) < TOL and _err(yh, G[f'dwt2zero_{tag}_yh']) < TOL
+
+
+@pytest.mark.parametrize('tag', ['mid', 'odd', 'db2'])
+def test_dwt3_zero(tag):
+    w = str(G[f'dwt3_{tag}_wave'])
+    lll, det = R.dwt3(G[f'dwt3_{tag}_x'], w)
+    assert _err(R.smoke_coef_to_tensor(lll, det), G[f'dwt3_{tag}_coef']) < TOL
+    c = G[f'idwt3_{tag}_coef']
+    rec = R.idwt3(c[:, 0], {k: c[:, i + 1] for i, k in enumerate(R.BANDS3[1:])}, w)
+    assert _err(rec, G[f'idwt3_{tag}_x']) < TOL
+
+
+def test_perfect_reconstruction_and_packing_roundtrip():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 32, 64, 64))
+    lll, det = R.dwt3(x, 'bior1.3')
+    assert lll.shape == (3, 18, 34, 34)
+    assert np.abs(R.idwt3(lll, det, 'bior1.3') - x).max() < 1e-12
+    t = R.smoke_coef_to_tensor(lll, det)                      # [3, 8, 18, 34, 34]
+    packed = np.zeros((1, 24, 24, 40, 40))
+    packed[0, :, :18, :34, :34] = t.reshape(24, 18, 34, 34)
+    yl, yh = R.smoke_tensor_to_coef(packed, (18, 34, 34), nfields=3)
+    assert np.array_equal(yl, lll) and all(np.array_equal(yh[k], det[k]) for k in det)
+    x2 = rng.standard_normal((2, 2, 80, 120))
+    yl, yh = R.dwt2(x2, 'bior2.4', 'periodization')
+    assert np.abs(R.idwt2(yl, yh, 'bior2.4', 'periodization') - x2).max() < 1e-12
+    t = R.burgers_coef_to_tensor(yl, yh, pad=True).reshape(2, 8, 64, 64)
+    yl2, yh2 = R.burgers_tensor_to_coef(t, (40, 60))
+    assert np.array_equal(yl2, yl) and np.array_equal(yh2, yh)
+
+
+def test_upsample_coef():
+    a = np.arange(2 * 3 * 2 * 2, dtype=np.float64).reshape(2, 3, 2, 2)
+    u = R.upsample_coef_2d(a)
+    assert u.shape == (2, 3, 4, 4) and u[0, 0, 1, 1] == a[0, 0, 0, 0] and u[1, 2, 3, 2] == a[1, 2, 1, 1]
+    b = np.arange(1 * 2 * 3 * 2 * 2, dtype=np.float64).reshape(1, 2, 3, 2, 2)
+    assert R.upsample_coef_3d(b, 'time').shape == (1, 4, 3, 2, 2)
+    assert R.upsample_coef_3d(b, 'space').shape == (1, 2, 3, 4, 4)
+    assert np.array_equal(R.upsample_coef_3d(b, 'time')[0, 1], b[0, 0])
