@@ -1,0 +1,212 @@
+/* wdno_hip.h -- C ABI of libwdno_hip.so: hand-written gfx950 (MI355X) kernels for the WDNO hot path.
+ *
+ * The reference (AI4Science-WestlakeU/wdno) has no FFI of its own: its hot path is stock torch.nn + three
+ * third-party wavelet packages. Each entry point below therefore cites the reference *operator* it replaces
+ * (file:line relative to the reference root). INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a device pointer to contiguous fp32 unless stated; int64 for timestep indices;
+ *   - "CL" = channels-last activations [N, (D,) H, W, C]; API layout = the reference's own tensor layout;
+ *   - every call enqueues on `stream` and returns immediately: 0 on success, <0 = WDNO_E* (wdno_strerror);
+ *   - no call allocates, synchronises or throws. Workspaces are caller-provided (size queried by *_ws_bytes).
+ */
+#ifndef WDNO_HIP_H
+#define WDNO_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wdno_stream_t; /* hipStream_t */
+
+enum { WDNO_OK = 0, WDNO_EINVAL = -1, WDNO_ELAUNCH = -2, WDNO_EUNSUPPORTED = -3, WDNO_EWORKSPACE = -4 };
+const char* wdno_strerror(int code);
+int wdno_version(void);
+/* last hip error string seen by the library on this thread (diagnostics only) */
+const char* wdno_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------------------ wavelets
+ * Separable single-level filter banks. mode: 0 = periodization, 1 = zero padding. Filters: 4 x L floats
+ * (dec_lo, dec_hi, rec_lo, rec_hi) on the HOST (copied into kernel arguments; L <= 16).
+ *
+ * wdno_dwt_fwd : x [n_img, dims...] -> coef [n_img, 2^nd, out dims...] with sub-bands stacked on axis 1 in
+ *   pywt order (letters over axes slowest..fastest, a before d): 1-D (lo,hi); 2-D (LL,'da','ad','dd') =
+ *   coef_to_tensor order burgers/wave_trans.py:43-62 ; 3-D 'aaa'..'ddd' = smoke/wave_trans_2d.py:55-58.
+ *   Replaces pytorch_wavelets.DWTForward/DWT1DForward (burgers/wave_trans.py:94-107, data_burgers_1d.py:72)
+ *   and ptwt.wavedec3 (smoke/wave_trans_2d.py:129). The packed output may be strided/padded:
+ *   coef element (img, band, i0,i1,i2) lives at img*cs_img + band*cs_band + i0*cs0 + i1*cs1 + i2.
+ * wdno_dwt_inv : the inverse (DWTInverse / DWT1DInverse / ptwt.waverec3), reading coef with the same strides.
+ * wdno_dwt_inv_adjoint : d(loss)/d(coef) given d(loss)/d(x) for x = wdno_dwt_inv(coef)  (guidance back-prop,
+ *   burgers/ddpm_burgers/model_utils.py:35-50, smoke/inference_2d.py:30-66).
+ * wdno_dwt_fwd_adjoint : d(loss)/d(x) given d(loss)/d(coef) for coef = wdno_dwt_fwd(x).
+ */
+typedef struct {
+  int nd;             /* 1, 2 or 3 transformed axes (the trailing ones) */
+  int mode;           /* 0 periodization, 1 zero */
+  int L;              /* filter length */
+  int n_img;          /* product of all leading dims */
+  int in_dims[3];     /* signal extent along each transformed axis (unused leading entries = 1) */
+  int out_dims[3];    /* coefficient extent along each axis */
+  int64_t cs_img, cs_band, cs0, cs1;   /* coefficient tensor strides (elements); innermost stride is 1.
+                                          the signal tensor x is contiguous [n_img, in_dims...] */
+} wdno_dwt_desc;
+size_t wdno_dwt_ws_bytes(const wdno_dwt_desc* d);
+int wdno_dwt_fwd(const float* x, float* coef, const wdno_dwt_desc* d, const float* filters_host, void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_dwt_inv(const float* coef, float* x, const wdno_dwt_desc* d, const float* filters_host, void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_dwt_fwd_adjoint(const float* dcoef, float* dx, const wdno_dwt_desc* d, const float* filters_host, void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_dwt_inv_adjoint(const float* dx, float* dcoef, const wdno_dwt_desc* d, const float* filters_host, void* ws, size_t ws_bytes, wdno_stream_t s);
+/* nearest x2 up-sampling of coefficient tensors (burgers/ddpm_burgers/wavelet_utils.py:5-16,
+ * smoke/ddpm/wave_utils.py:1-14): in [outer, a, mid, b, c] -> out [outer, a*fa, mid, b*fb, c*fc]. */
+int wdno_upsample_coef(const float* in, float* out, int64_t outer, int a, int mid, int b, int c, int fa, int fb, int fc, wdno_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ layout
+ * API layout [N, C, S] (S = product of spatial dims) <-> channels-last [N, S, Cp] (Cp >= C, zero padded). */
+int wdno_nc_to_cl(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s);
+int wdno_cl_to_nc(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s);
+int wdno_concat2_cl(const float* a, int Ca, const float* b, int Cb, float* out, int64_t P, wdno_stream_t s);
+int wdno_split2_cl(const float* in, float* a, int Ca, float* b, int Cb, int64_t P, wdno_stream_t s);
+/* nearest x2 in H and W of CL [N, H, W, C] (nn.Upsample, burgers/ddpm_burgers/unet.py:35-39) and its adjoint */
+int wdno_upsample2x_cl_fwd(const float* in, float* out, int64_t N, int H, int W, int C, wdno_stream_t s);
+int wdno_upsample2x_cl_bwd(const float* dout, float* din, int64_t N, int H, int W, int C, wdno_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ convolution
+ * Implicit-GEMM convolution on MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+ * Replaces nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d / nn.Linear forward, data-gradient and weight-gradient
+ * (burgers/ddpm_burgers/unet.py:133,162,190-192,233-234,317,336,361,369 ;
+ *  smoke/.../video_diffusion_pytorch_conv3d.py:159-163,192,216,238-239,291-292,393,471).
+ *
+ * Input x is CL [N, D, H, W, C] (C % 4 == 0). Weights are pre-packed as wp[kd][kh][K][kw*C] (innermost run
+ * kw*C is contiguous in both x and wp). Output pixel (n, od, oh, ow) reads input rows
+ *   d = od*sd - pd + dz, h = oh*sh - ph + dy, w = ow*sw - pw + dx
+ * and is stored at physical position (n, od*osd+ood, oh*osh+ooh, ow*osw+oow) of y [N, YD, YH, YW, K]
+ * (the placement terms express the 4 parity classes of a stride-2 transposed convolution).
+ */
+typedef struct {
+  int N, D, H, W, C;
+  int OD, OH, OW, K;
+  int kd, kh, kw;
+  int sd, sh, sw;
+  int pd, ph, pw;
+  int YD, YH, YW;
+  int osd, osh, osw, ood, ooh, oow;
+} wdno_conv_geom;
+/* y = conv(x, wp) (+ bias[K]) (+ residual, same layout as y). bias/residual may be NULL. */
+int wdno_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, float* y,
+                  const wdno_conv_geom* g, wdno_stream_t s);
+/* dwp[kd][kh][K][kw*C] = sum over output pixels of dy (x) shifted x. ws: caller workspace. */
+size_t wdno_conv_wgrad_ws_bytes(const wdno_conv_geom* g);
+int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_t ws_bytes,
+                    const wdno_conv_geom* g, wdno_stream_t s);
+/* out[C] = sum_p in[p][C]  (bias gradients and other per-channel reductions). ws >= wdno_colsum_ws_bytes. */
+size_t wdno_colsum_ws_bytes(int64_t P, int C);
+int wdno_colsum(const float* in, float* out, int64_t P, int C, void* ws, size_t ws_bytes, wdno_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ normalisation
+ * GroupNorm (+ optional (scale+1, shift) modulation) + optional SiLU on CL [N, S, C]:
+ *   y = act( (GN(x)*gamma + beta) * (ss[n, c] + 1) + ss[n, C + c] ),  ss = [N, 2C] or NULL.
+ * burgers/ddpm_burgers/unet.py:139-148 ; smoke/.../video_diffusion_pytorch_conv3d.py:196-204.
+ * stats [N, G, 2] (mean, rstd) is written by fwd and read by bwd.
+ */
+size_t wdno_groupnorm_ws_bytes(int64_t N, int64_t S, int C, int G);
+int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+                           float* stats, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                           void* ws, size_t ws_bytes, wdno_stream_t s);
+/* dx, dgamma_beta_partial [N, 2, C] (per-sample; caller sums over N), dss [N, 2C] or NULL */
+int wdno_groupnorm_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                           const float* stats, float* dx, float* dgb_partial, float* dss,
+                           int64_t N, int64_t S, int C, int G, int silu, void* ws, size_t ws_bytes, wdno_stream_t s);
+/* Channel LayerNorm over C of CL rows [P, C], gain only (unet.py:55-65, conv3d.py:165-174) */
+int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s);
+size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C);
+int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
+                       float eps, void* ws, size_t ws_bytes, wdno_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ attention
+ * qkv rows are [row][3*heads*32] = (q | k | v), each [heads][32]; outputs are [row][heads*32].
+ * Row index of (unit (uo, ui), token j) = uo*so + ui*si + j*st.
+ *
+ * Softmax attention over <= 1024 tokens (burgers unet.py:240-259 ; smoke conv3d.py:294-353): optional rotary
+ * tables rot_cos/rot_sin [n][32] (q and k), optional additive bias [heads][n][n]; q is scaled by `scale`.
+ */
+typedef struct {
+  int n_uo, n_ui, n_tok, heads;
+  int64_t so, si, st;
+} wdno_attn_desc;
+int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
+                  const wdno_attn_desc* d, float scale, wdno_stream_t s);
+/* dqkv (same layout as qkv), dbias [heads][n][n] accumulated with atomics (must be zeroed by caller) or NULL */
+int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* dout,
+                  float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s);
+/* Linear attention (unet.py:203-223 ; conv3d.py:241-258): q softmax over the 32 head channels, k softmax over
+ * tokens, ctx = k^T v, out = ctx^T q * scale. units x n_tok rows, contiguous. ws holds k statistics and ctx. */
+size_t wdno_linattn_ws_bytes(int64_t units, int heads);
+int wdno_linattn_fwd(const float* qkv, float* out, float* kstats /*[units,heads,32,2]*/, float* ctx /*[units,heads,32,32]*/,
+                     int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
+int wdno_linattn_bwd(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv,
+                     void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ pointwise
+ * act: 0 = SiLU, 1 = GELU(erf). */
+int wdno_act_fwd(const float* x, float* y, int64_t n, int act, wdno_stream_t s);
+int wdno_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, wdno_stream_t s);
+int wdno_add(const float* a, const float* b, float* out, int64_t n, wdno_stream_t s);
+/* out[b, :] = cat(sin(t_b f_k), cos(t_b f_k)), f_k = exp(-k ln(theta)/(dim/2-1))  (unet.py:88-96, conv3d.py:144-151) */
+int wdno_sinusoidal_emb(const int64_t* t, float* out, int B, int dim, float theta, wdno_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ diffusion operator
+ * All tensors in the reference's API layout: smoke [B, F, C, H, W]; Burgers [B, C, H, W] (F = 1).
+ * Conditioning predicate descriptor (diffusion_2d.py:1008-1033 ; diffusion_1d.py:276-288, order pad,u0,uT,f,low):
+ */
+typedef struct {
+  int tree;              /* 0 = smoke (wavelet), 1 = Burgers (wavelet) */
+  int B, F, C, H, W;
+  int cT, cH, cW;        /* padded_shape / coef_shape: valid coefficient extent (smoke: T',H',W'; Burgers: H',W') */
+  int cond_pad, cond_a, cond_b, cond_c, cond_low;
+  /* smoke  : cond_a = is_condition_control (channels 24:40), init-density channel C-2 is always conditioned;
+   * Burgers: cond_a = u0, cond_b = uT, cond_c = f ; u0 rows [0, u_rows), uT rows [H-uT_rows, H) */
+  int u_rows, uT_rows;
+} wdno_cond_desc;
+/* training: x = sqrt_ac[t_b]*x0 + sqrt_1mac[t_b]*noise, then conditions imposed on x (clean values from x0) and the
+ * same regions of the target zeroed. x_out and target_out may not alias the inputs. */
+int wdno_q_sample_cond(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                       float* x_out, float* target_out, const wdno_cond_desc* c, wdno_stream_t s);
+/* sampling: impose the conditions in place; `src` holds the clean values at conditioned positions (same shape as x) */
+int wdno_apply_cond(float* x, const float* src, const wdno_cond_desc* c, wdno_stream_t s);
+/* loss = sum_e (out-target)^2 * wc[c(e)] * wb[b(e)] * inv_count ; grad = dloss/dout (written if grad != NULL).
+ * (diffusion_1d.py:640-645 ; diffusion_2d.py:1045-1050). loss is a device scalar. per_sample = F*C*H*W, inner = H*W; channel of element e = (e / inner) % C. */
+int wdno_weighted_mse(const float* out, const float* target, const float* wc, const float* wb, float inv_count,
+                      float* loss, float* grad, int64_t B, int64_t per_sample, int C, int64_t inner,
+                      void* ws, size_t ws_bytes, wdno_stream_t s);
+size_t wdno_weighted_mse_ws_bytes(int64_t n);
+/* grad = d(loss)/d(out) * gscale[0] (gscale: device scalar = upstream gradient, NULL -> 1) */
+int wdno_weighted_mse_bwd(const float* out, const float* target, const float* wc, const float* wb, float inv_count,
+                          const float* gscale, float* grad, int64_t B, int64_t per_sample, int C, int64_t inner, wdno_stream_t s);
+/* coefficient tables are the registered buffers [T]; t is per-sample [B].
+ * p_sample (diffusion_1d.py:242-258 ; diffusion_2d.py:757-785): x_start = clamp(c1 x - c2 eps), mean = m1 x_start + m2 x,
+ * x_next = mean + exp(0.5 logvar) * noise  (noise == NULL -> t == 0 step). */
+int wdno_p_sample_update(const float* x, const float* eps, const float* noise, const int64_t* t,
+                         const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* pm1, const float* pm2,
+                         const float* plogvar, float* x_next, float* x_start, int64_t B, int64_t per_sample, int clamp, wdno_stream_t s);
+/* DDIM (diffusion_1d.py:419-435 ; diffusion_2d.py:894-911): x_start = clamp(c1 x - c2 eps); eps' = (c1 x - x_start)/c2;
+ * x_next = x_start*sqrt_an + c*eps' + sigma*noise. last step (noise == NULL): x_next = x_start. */
+int wdno_ddim_update(const float* x, const float* eps, const float* noise, const int64_t* t,
+                     const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, float sqrt_an, float c, float sigma,
+                     float* x_next, float* x_start, int64_t B, int64_t per_sample, wdno_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------ trainer step
+ * Flat-buffer optimiser (train_diffusion.py:117,211-216 ; diffusion_2d.py:1159,1283-1291).
+ * wdno_sumsq: out[0] (+)= sum g^2 (double accumulate, device scalar float).
+ * wdno_adam_clip_step: g *= min(1, max_norm/(sqrt(sumsq)+1e-6)) then torch.optim.Adam update. */
+size_t wdno_sumsq_ws_bytes(int64_t n);
+int wdno_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
+                        float grad_scale, float lr, float beta1, float beta2, float eps, int step, wdno_stream_t s);
+/* ema = ema*beta + p*(1-beta)  (ema_pytorch lerp) */
+int wdno_ema_update(float* ema, const float* p, int64_t n, float beta, wdno_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WDNO_HIP_H */

@@ -1,0 +1,227 @@
+"""End-to-end parity of the HIP module trees against the reference golden vectors and the CPU oracle (GPU box only).
+
+The modules are imported through the reference's own import paths (ddpm_burgers.unet, ddpm.diffusion_2d, ...) from the
+drop-in trees wdno_amd/burgers and wdno_amd/smoke. Tolerance: rel-L2 < 1e-5 (north-star bar for fp32 fields)."""
+import sys
+
+import pytest
+import torch
+
+from tests.helpers import load_npz, manifest, noise_seq, rel_l2, weights
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+M = manifest()
+TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def trees():
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion as GD1
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion as GD2
+    return dict(Unet2D=Unet2D, GD1=GD1, Unet3D=Unet3D_with_Conv3D, GD2=GD2)
+
+
+def load_into(module, npz, prefix):
+    module.load_state_dict(weights(npz, prefix), strict=True)
+    return module.to(DEV)
+
+
+def check_unet(net, gz, tol=TOL):
+    x = torch.from_numpy(gz['x']).to(DEV).requires_grad_(True)
+    out = net(x, torch.from_numpy(gz['t']).to(DEV))
+    assert rel_l2(out.detach(), gz['out']) < tol, 'forward'
+    (out * torch.from_numpy(gz['gout']).to(DEV)).sum().backward()
+    assert rel_l2(x.grad, gz['gx']) < 3 * tol, 'input grad'
+    params = dict(net.named_parameters())
+    worst = 0.0
+    for k in gz.files:
+        if k.startswith('gn::'):
+            ref = float(gz[k]); got = params[k[4:]].grad.double().norm().item()
+            assert abs(got - ref) <= 1e-4 * max(ref, 1e-6), (k, got, ref)
+        if k.startswith('g::'):
+            e = rel_l2(params[k[3:]].grad, gz[k])
+            worst = max(worst, e)
+            assert e < 1e-4, (k, e)
+    return worst
+
+
+def test_unet3d_tiny_vs_reference(trees):
+    c = M['unet3d_tiny']
+    net = trees['Unet3D'](dim=c['dim'], dim_mults=tuple(c['dim_mults']), channels=c['channels'], resnet_groups=c['resnet_groups'])
+    gz = load_npz('ref_unet3d_tiny.npz')
+    check_unet(load_into(net, gz, 'w::'), gz)
+
+
+def test_unet2d_tiny_vs_reference(trees):
+    c = M['unet2d_tiny']
+    net = trees['Unet2D'](dim=c['dim'], dim_mults=tuple(c['dim_mults']), channels=c['channels'], resnet_block_groups=c['resnet_block_groups'])
+    gz = load_npz('ref_unet2d_tiny.npz')
+    check_unet(load_into(net, gz, 'w::'), gz)
+
+
+def test_unet2d_grouped_vs_reference(trees):
+    c = M['unet2d_g4']
+    net = trees['Unet2D'](dim=c['dim'], dim_mults=tuple(c['dim_mults']), channels=c['channels'], resnet_block_groups=c['resnet_block_groups'])
+    gz = load_npz('ref_unet2d_g4.npz')
+    check_unet(load_into(net, gz, 'w::'), gz)
+
+
+def _smoke(trees):
+    gz = load_npz('ref_smoke_diffusion.npz')
+    c = M['smoke_diffusion']
+    u, d = c['unet'], dict(c['diffusion'])
+    net = trees['Unet3D'](dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_groups=u['resnet_groups'])
+    d['padded_shape'] = tuple(d['padded_shape']); d['ori_shape'] = tuple(d['ori_shape'])
+    return gz, d, net
+
+
+def test_smoke_diffusion_loss_and_grads(trees):
+    gz, d, net = _smoke(trees)
+    dif = trees['GD2'](net, loss_layer_weight=torch.from_numpy(gz['lw']), **d)
+    load_into(dif, gz, 'w::')
+    x0, t, noise = (torch.from_numpy(gz[k]).to(DEV) for k in ('x0', 't', 'noise'))
+    assert (dif.q_sample(x0, t, noise).cpu() - torch.from_numpy(gz['q_sample'])).abs().max() < 1e-6
+    loss = dif.p_losses(x0, t, noise=noise)
+    assert abs(loss.item() - float(gz['loss'])) < TOL * abs(float(gz['loss']))
+    loss.backward()
+    params = dict(dif.named_parameters())
+    for k in gz.files:
+        if k.startswith('gn::'):
+            ref = float(gz[k]); got = params[k[4:]].grad.double().norm().item()
+            assert abs(got - ref) <= 2e-4 * max(ref, 1e-7), (k, got, ref)
+
+
+def test_smoke_sampling(trees):
+    gz, d, net = _smoke(trees)
+    dif = load_into(trees['GD2'](net, loss_layer_weight=torch.from_numpy(gz['lw']), **d), gz, 'w::')
+    xt = torch.from_numpy(gz['psample_xt']).to(DEV)
+    for tt in (0, 500, 999):
+        nz = torch.from_numpy(gz[f'psample_{tt}_noise']).to(DEV)
+        dif.sample_noise = lambda shape, device, _n=nz: _n
+        pred, xs = dif.p_sample(tuple(xt.shape), xt.clone(), tt)
+        assert rel_l2(pred, gz[f'psample_{tt}_pred']) < TOL and rel_l2(xs, gz[f'psample_{tt}_xstart']) < TOL
+    init, control = torch.from_numpy(gz['ddim_init']).to(DEV), torch.from_numpy(gz['ddim_control']).to(DEV)
+    seq = iter([n.to(DEV) for n in noise_seq(gz, 'ddim')])
+    dif.sample_noise = lambda shape, device: next(seq)
+    out = dif.sample(batch_size=2, init=init, control=control)
+    assert rel_l2(out, gz['ddim_out']) < 2 * TOL
+    dif5 = trees['GD2'](dif.model, loss_layer_weight=torch.from_numpy(gz['lw']), **{**d, 'timesteps': 5, 'sampling_timesteps': None}).to(DEV)
+    seq5 = iter([n.to(DEV) for n in noise_seq(gz, 'ddpm5')])
+    dif5.sample_noise = lambda shape, device: next(seq5)
+    out = dif5.sample(batch_size=2, init=init, control=control)
+    assert rel_l2(out, gz['ddpm5_out']) < 2 * TOL
+
+
+def _burgers(trees, **over):
+    gz = load_npz('ref_burgers_diffusion.npz')
+    c = M['burgers_diffusion']
+    u, d = c['unet'], dict(c['diffusion'])
+    d.update(over)
+    net = trees['Unet2D'](dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_block_groups=u['resnet_block_groups'])
+    d['seq_length'] = tuple(d['seq_length'])
+    dif = trees['GD1'](net, loss_layer_weight=torch.from_numpy(gz['lw']), **d)
+    sd = {k: v for k, v in weights(gz, 'w::').items()}
+    if over.get('timesteps'):
+        sd = {k: v for k, v in sd.items() if k.startswith('model.')}
+        dif.load_state_dict(sd, strict=False)
+    else:
+        dif.load_state_dict(sd, strict=True)
+    return gz, dif.to(DEV)
+
+
+def test_burgers_diffusion_loss_and_grads(trees):
+    gz, dif = _burgers(trees)
+    assert torch.allclose(dif.alphas, torch.from_numpy(gz['alphas'])) and torch.allclose(dif.alphas_prev, torch.from_numpy(gz['alphas_prev']))
+    x0, t, noise = (torch.from_numpy(gz[k]).to(DEV) for k in ('x0', 't', 'noise'))
+    loss = dif.p_losses(x0, t, noise=noise)
+    assert abs(loss.item() - float(gz['loss'])) < TOL * abs(float(gz['loss']))
+    loss.backward()
+    params = dict(dif.named_parameters())
+    for k in gz.files:
+        if k.startswith('gn::'):
+            ref = float(gz[k]); got = params[k[4:]].grad.double().norm().item()
+            assert abs(got - ref) <= 2e-4 * max(ref, 1e-7), (k, got, ref)
+    gz2, dif2 = _burgers(trees, is_condition_uT=True)
+    l2 = dif2.p_losses(x0, t, noise=noise)
+    assert abs(l2.item() - float(gz['loss_all_cond'])) < TOL * abs(float(gz['loss_all_cond']))
+
+
+def test_burgers_sampling(trees):
+    gz, dif = _burgers(trees)
+    u_init, f = torch.from_numpy(gz['ddim_u_init']).to(DEV), torch.from_numpy(gz['ddim_f']).to(DEV)
+    seq = iter([n.to(DEV) for n in noise_seq(gz, 'ddim')])
+    dif.sample_noise = lambda shape, device: next(seq)
+    out = dif.sample(batch_size=2, u_init=u_init, f=f)
+    assert rel_l2(out, gz['ddim_out']) < 2 * TOL
+    gz5, dif5 = _burgers(trees, timesteps=5, sampling_timesteps=None)
+    seq5 = iter([n.to(DEV) for n in noise_seq(gz, 'ddpm5')])
+    dif5.sample_noise = lambda shape, device: next(seq5)
+    out = dif5.sample(batch_size=2, u_init=u_init, f=f)
+    assert rel_l2(out, gz['ddpm5_out']) < 2 * TOL
+
+
+def test_three_optimizer_steps_vs_reference(trees):
+    """T1 row: loss -> backward -> clip(1.0) -> Adam(1e-4, (0.9, 0.99)) -> CosineAnnealingLR(10000), three steps."""
+    from wdno_amd.trainer import TrainStep, cosine_annealing_lr
+    gz = load_npz('ref_train_burgers.npz')
+    c = M['train_burgers']
+    u = c['unet']
+    net = trees['Unet2D'](dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_block_groups=u['resnet_block_groups'])
+    dif = trees['GD1'](net, seq_length=tuple(c['seq_length']), padded_shape=c['padded_shape'], ori_shape=[10, 14],
+                       loss_layer_weight=torch.ones(1, 9, 1, 1), is_condition_pad=True, is_condition_u0=True, is_condition_f=True)
+    dif.load_state_dict(weights(gz, 'w0::'), strict=True)
+    dif = dif.to(DEV)
+    ts = TrainStep(dif, lr=1e-4, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=lambda b, s: cosine_annealing_lr(b, s, 10000), use_ema=False)
+    for step in range(3):
+        x0, t, noise = (torch.from_numpy(gz[f's{step}_{k}']).to(DEV) for k in ('x0', 't', 'noise'))
+        loss, gn = ts.step_with(x0, t, noise)
+        assert abs(loss.item() - float(gz[f's{step}_loss'])) < 5e-5 * abs(float(gz[f's{step}_loss'])), step
+        assert abs(gn.item() - float(gz[f's{step}_gnorm'])) < 2e-4 * float(gz[f's{step}_gnorm']), step
+    ref = weights(gz, 'w3::')
+    sd = dif.state_dict()
+    for k, v in ref.items():
+        if v.is_floating_point():
+            d0 = torch.from_numpy(gz['w0::' + k])
+            if (v - d0).abs().max() > 0:      # parameter moved: compare the update, not just the value
+                assert rel_l2(sd[k].cpu() - d0, v - d0) < 2e-3, k
+
+
+def test_unet3d_real_width_vs_oracle(trees):
+    """dim = 64 (the real smoke width) at a reduced grid: HIP vs the CPU oracle, forward and parameter gradients."""
+    from oracle import unet_ref as U
+    torch.manual_seed(0)
+    net = trees['Unet3D'](dim=64, dim_mults=(1, 2, 4), channels=42)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(1, 6, 42, 16, 16)
+    t = torch.tensor([321])
+    go = torch.randn(1, 6, 42, 16, 16)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith('freqs') else v) for k, v in sd.items()}
+    out_ref = U.unet3d_forward(sdr, x, t, dim=64, dim_mults=(1, 2, 4), groups=8)
+    (out_ref * go).sum().backward()
+    net = net.to(DEV)
+    out = net(x.to(DEV), t.to(DEV))
+    assert rel_l2(out.detach(), out_ref.detach()) < TOL
+    (out * go.to(DEV)).sum().backward()
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            assert rel_l2(p.grad, sdr[k].grad) < 2e-4, k
+
+
+def test_unet2d_real_width_vs_oracle(trees):
+    from oracle import unet_ref as U
+    torch.manual_seed(1)
+    net = trees['Unet2D'](dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x, t = torch.randn(1, 9, 32, 32), torch.tensor([77])
+    with torch.no_grad():
+        out_ref = U.unet2d_forward(sd, x, t, dim=128, dim_mults=(1, 2, 4, 8), groups=1)
+        out = net.to(DEV)(x.to(DEV), t.to(DEV))
+    assert rel_l2(out, out_ref) < TOL

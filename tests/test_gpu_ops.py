@@ -1,0 +1,451 @@
+"""Parity of every C-ABI operator (through wdno_amd.ops) against a plain PyTorch / oracle CPU reference.
+
+GPU box only (`-m gpu`). fp32 kernels are compared with float64 CPU references; tolerances are rel-L2 <= 2e-6 for
+single operators (the north-star bar is 1e-5 end to end), bit-exact for pure layout / index work.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import load_npz, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 2e-6
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from wdno_amd import ops as o
+    o._lib_()          # fails loudly if libwdno_hip.so is missing
+    return o
+
+
+def g(shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64) * scale)
+
+
+def dev(t, grad=False):
+    x = t.to(torch.float32).to(DEV).contiguous()
+    return x.requires_grad_(True) if grad else x
+
+
+def to_cl(x):      # [N, C, *sp] -> [N, *sp, C]
+    return x.permute(0, *range(2, x.dim()), 1).contiguous()
+
+
+def from_cl(x):
+    return x.permute(0, x.dim() - 1, *range(1, x.dim() - 1)).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------- layout (bit exact)
+@pytest.mark.parametrize('shape,cp', [((3, 42, 5, 7), 44), ((2, 9, 16, 16), 12), ((1, 64, 33), 64), ((4, 3, 8, 12), 4)])
+def test_layout_roundtrip(ops, shape, cp):
+    x = g(shape, 1).float()
+    y = ops.nc_to_cl(x.to(DEV), cp)
+    ref = torch.zeros(shape[0], *shape[2:], cp)
+    ref[..., :shape[1]] = to_cl(x)
+    assert torch.equal(y.cpu(), ref)
+    z = ops.cl_to_nc(y, shape[1])
+    assert torch.equal(z.cpu(), x)
+
+
+def test_concat_upsample_exact(ops):
+    a, b = g((2, 5, 6, 8), 2).float(), g((2, 5, 6, 12), 3).float()
+    c = ops.concat_cl(a.to(DEV), b.to(DEV))
+    assert torch.equal(c.cpu(), torch.cat([a, b], dim=-1))
+    x = dev(g((2, 3, 5, 8), 4), grad=True)
+    y = ops.upsample2x_cl(x)
+    ref = F.interpolate(from_cl(x.detach().cpu()), scale_factor=2, mode='nearest')
+    assert torch.equal(from_cl(y.detach().cpu()), ref)
+    go = g(tuple(y.shape), 5).float()
+    y.backward(go.to(DEV))
+    xr = from_cl(x.detach().cpu()).requires_grad_(True)
+    F.interpolate(xr, scale_factor=2, mode='nearest').backward(from_cl(go))
+    assert rel_l2(from_cl(x.grad.cpu()), xr.grad) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------- pointwise
+def test_activations_and_add(ops):
+    x = g((1000,), 6, 3.0)
+    for fn, ref in ((ops.silu, F.silu), (ops.gelu, F.gelu)):
+        xd = dev(x, grad=True)
+        y = fn(xd)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        assert rel_l2(y.detach(), yr.detach()) < TOL
+        go = g((1000,), 7)
+        y.backward(dev(go)); yr.backward(go)
+        assert rel_l2(xd.grad, xr.grad) < TOL
+    a, b = g((77,), 8), g((77,), 9)
+    assert torch.equal(ops.add(dev(a), dev(b)).cpu(), a.float() + b.float())
+
+
+def test_sinusoidal(ops):
+    from oracle.unet_ref import sinusoidal_embedding
+    t = torch.tensor([0, 1, 17, 500, 999])
+    for dim in (8, 64, 128):
+        out = ops.sinusoidal_embedding(t.to(DEV), dim)
+        ref = sinusoidal_embedding(t, dim)
+        assert (out.cpu() - ref).abs().max() < 2e-6
+
+
+# ----------------------------------------------------------------------------------------------------- convolution
+def conv_case(ops, xs, ws, stride, padding, seed, transposed=False, bias=True, residual=False, tol=TOL):
+    nd = len(ws) - 2
+    x = g(xs, seed)
+    w = g(ws, seed + 1, 1.0 / math.sqrt(np.prod(ws[1:])))
+    b = g((ws[1] if transposed else ws[0],), seed + 2) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    if transposed:
+        yr = F.conv_transpose3d(xr, wr, br, stride=stride, padding=padding)
+    elif nd == 3:
+        yr = F.conv3d(xr, wr, br, stride=stride, padding=padding)
+    elif nd == 2:
+        yr = F.conv2d(xr, wr, br, stride=stride, padding=padding)
+    else:
+        yr = F.linear(xr, wr, br)
+    res = g(tuple(yr.shape), seed + 3) if residual else None
+    if residual:
+        rr = res.clone().requires_grad_(True)
+        yr = yr + rr
+    go = g(tuple(yr.shape), seed + 4)
+    yr.backward(go)
+
+    cpad = ops.pad4(xs[1]) if nd else ops.pad4(xs[-1])
+    if nd:
+        xd = torch.zeros(xs[0], *xs[2:], cpad, dtype=torch.float64)
+        xd[..., :xs[1]] = to_cl(x)
+    else:
+        xd = torch.zeros(*xs[:-1], cpad, dtype=torch.float64)
+        xd[..., :xs[-1]] = x
+    xd = dev(xd, grad=True)
+    wd, bd = dev(w, grad=True), (dev(b, grad=True) if bias else None)
+    k = yr.shape[1] if nd else yr.shape[-1]
+    kp = ops.pad4(k)
+    rd = None
+    if residual:
+        rd = torch.zeros(*((yr.shape[0], *yr.shape[2:], kp) if nd else (*yr.shape[:-1], kp)), dtype=torch.float64)
+        rd[..., :k] = to_cl(res) if nd else res
+        rd = dev(rd, grad=True)
+    if transposed:
+        y = ops.conv_transpose_cl(xd, wd, bd)
+    else:
+        y = ops.conv_cl(xd, wd, bd, stride=stride, padding=padding, residual=rd)
+    yc = from_cl(y.detach().cpu())[:, :k] if nd else y.detach().cpu()[..., :k]
+    assert rel_l2(yc, yr.detach()) < tol, 'forward'
+    god = torch.zeros(tuple(y.shape), dtype=torch.float64)
+    god[..., :k] = to_cl(go) if nd else go
+    y.backward(dev(god))
+    gx = from_cl(xd.grad.cpu())[:, :xs[1]] if nd else xd.grad.cpu()[..., :xs[-1]]
+    assert rel_l2(gx, xr.grad) < tol, 'dgrad'
+    assert rel_l2(wd.grad, wr.grad) < tol, 'wgrad'
+    if bias:
+        assert rel_l2(bd.grad, br.grad) < tol, 'bias grad'
+    if residual:
+        assert rel_l2((from_cl(rd.grad.cpu())[:, :k] if nd else rd.grad.cpu()[..., :k]), rr.grad) < tol, 'residual grad'
+
+
+CONV_CASES = [
+    # (x shape NC..., weight shape, stride, padding)
+    ('3x3x3_64', (1, 64, 4, 10, 12), (64, 64, 3, 3, 3), 1, 1),
+    ('3x3x3_wide', (2, 128, 3, 6, 6), (256, 128, 3, 3, 3), 1, 1),
+    ('3x3x3_tiny', (2, 8, 4, 8, 8), (16, 8, 3, 3, 3), 1, 1),
+    ('3x3x3_oddC', (1, 36, 3, 5, 7), (20, 36, 3, 3, 3), 1, 1),
+    ('7x7x7_init', (1, 42, 6, 9, 9), (64, 42, 7, 7, 7), 1, 3),
+    ('1x1x1', (2, 64, 3, 7, 5), (42, 64, 1, 1, 1), 1, 0),
+    ('down_144', (2, 16, 3, 8, 12), (16, 16, 1, 4, 4), (1, 2, 2), (0, 1, 1)),
+    ('down_144_64', (1, 64, 2, 20, 20), (64, 64, 1, 4, 4), (1, 2, 2), (0, 1, 1)),
+    ('2d_3x3', (2, 128, 16, 12), (128, 128, 3, 3), 1, 1),
+    ('2d_3x3_cat', (1, 384, 8, 8), (256, 384, 3, 3), 1, 1),
+    ('2d_7x7', (2, 9, 16, 16), (128, 9, 7, 7), 1, 3),
+    ('2d_1x1', (2, 128, 8, 8), (384, 128, 1, 1), 1, 0),
+    ('2d_patch2', (2, 8, 8, 12), (16, 8, 2, 2), 2, 0),
+]
+
+
+@pytest.mark.parametrize('name,xs,ws,stride,padding', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(ops, name, xs, ws, stride, padding):
+    conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000)
+
+
+def test_conv_residual_nobias(ops):
+    conv_case(ops, (1, 16, 2, 6, 6), (24, 16, 1, 1, 1), 1, 0, seed=11, bias=False, residual=True)
+
+
+def test_linear(ops):
+    conv_case(ops, (37, 64), (256, 64), 1, 0, seed=12)
+    conv_case(ops, (2, 5, 3, 128), (64, 128), 1, 0, seed=13, bias=False, residual=True)
+
+
+@pytest.mark.parametrize('c', [16, 64])
+def test_conv_transpose(ops, c):
+    conv_case(ops, (2, c, 3, 5, 6), (c, c, 1, 4, 4), (1, 2, 2), (0, 1, 1), seed=14 + c, transposed=True)
+
+
+# ----------------------------------------------------------------------------------------------------- normalisation
+@pytest.mark.parametrize('shape,groups,use_ss,act', [((2, 64, 3, 10, 10), 8, True, True), ((2, 16, 5, 5), 1, True, True),
+                                                      ((1, 8, 2, 4, 4), 4, False, True), ((3, 128, 8, 8), 1, False, False),
+                                                      ((2, 1024, 4, 4), 1, True, True)])
+def test_groupnorm_act(ops, shape, groups, use_ss, act):
+    n, c = shape[0], shape[1]
+    x, gam, bet = g(shape, 20, 2.0) + 0.7, g((c,), 21) * 0.3 + 1, g((c,), 22) * 0.3
+    ss = g((n, 2 * c), 23, 0.5) if use_ss else None
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gam, bet))
+    sr = ss.clone().requires_grad_(True) if use_ss else None
+    yr = F.group_norm(xr, groups, gr, br, eps=1e-5)
+    if use_ss:
+        e = sr.reshape(n, 2 * c, *([1] * (len(shape) - 2)))
+        yr = yr * (e[:, :c] + 1) + e[:, c:]
+    if act:
+        yr = F.silu(yr)
+    go = g(shape, 24)
+    yr.backward(go)
+    xd, gd, bd = dev(to_cl(x), True), dev(gam, True), dev(bet, True)
+    sd = dev(ss, True) if use_ss else None
+    y = ops.groupnorm_act(xd, gd, bd, groups, sd, act=act)
+    assert rel_l2(from_cl(y.detach().cpu()), yr.detach()) < TOL
+    y.backward(dev(to_cl(go)))
+    assert rel_l2(from_cl(xd.grad.cpu()), xr.grad) < 5e-6
+    assert rel_l2(gd.grad, gr.grad) < 5e-6 and rel_l2(bd.grad, br.grad) < 5e-6
+    if use_ss:
+        assert rel_l2(sd.grad, sr.grad) < 5e-6
+
+
+@pytest.mark.parametrize('rows,c', [(50, 8), (300, 64), (77, 128), (40, 256), (9, 1024), (33, 96)])
+def test_layernorm(ops, rows, c):
+    from oracle.unet_ref import channel_layernorm
+    x, gam = g((rows, c), 30, 1.5) + 0.3, g((c,), 31) * 0.2 + 1
+    xr, gr = x.clone().requires_grad_(True), gam.clone().requires_grad_(True)
+    yr = channel_layernorm(xr.t()[None], gr.reshape(1, c, 1))[0].t()
+    go = g((rows, c), 32)
+    yr.backward(go)
+    xd, gd = dev(x, True), dev(gam.reshape(1, c, 1, 1), True)
+    y = ops.layernorm_cl(xd, gd)
+    assert rel_l2(y.detach(), yr.detach()) < TOL
+    y.backward(dev(go))
+    assert rel_l2(xd.grad, xr.grad) < 5e-6 and rel_l2(gd.grad.reshape(-1), gr.grad) < 5e-6
+
+
+# ----------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize('kind,b,f,h,w', [('temporal', 2, 24, 3, 5), ('temporal', 1, 7, 2, 2), ('spatial', 2, 3, 10, 10), ('spatial', 1, 1, 8, 8)])
+def test_softmax_attention(ops, kind, b, f, h, w):
+    from oracle import unet_ref as U
+    heads, dh = 4, 32
+    qkv = g((b, f, h, w, 3 * heads * dh), 40)
+    freqs = 1.0 / (10000 ** (torch.arange(0, 32, 2).double() / 32))
+    qr = qkv.clone().requires_grad_(True)
+    if kind == 'temporal':
+        bias = g((heads, f, f), 41)
+        br = bias.clone().requires_grad_(True)
+        tok = qr.permute(0, 2, 3, 1, 4).reshape(b, h * w, f, -1)
+        ntok = f
+    else:
+        bias, br = None, None
+        tok = qr.reshape(b, f, h * w, -1)
+        ntok = h * w
+    q, k, v = tok.chunk(3, dim=-1)
+    split = lambda z: z.reshape(*z.shape[:-1], heads, dh).transpose(-2, -3)
+    q, k, v = split(q) * dh ** -0.5, split(k), split(v)
+    if kind == 'temporal':
+        q, k = U.rotary(q, freqs), U.rotary(k, freqs)
+    sim = q @ k.transpose(-1, -2)
+    if br is not None:
+        sim = sim + br
+    o = (sim.softmax(dim=-1) @ v).transpose(-2, -3).reshape(*tok.shape[:-1], heads * dh)
+    outr = o.reshape(b, h, w, f, -1).permute(0, 3, 1, 2, 4) if kind == 'temporal' else o.reshape(b, f, h, w, -1)
+    go = g(tuple(outr.shape), 42)
+    outr.backward(go)
+
+    qd = dev(qkv.reshape(-1, qkv.shape[-1]), True)
+    if kind == 'temporal':
+        bd = dev(bias, True)
+        ang = (torch.arange(f).double()[:, None] * freqs[None]).repeat_interleave(2, dim=-1)
+        rot = (dev(ang.cos()), dev(ang.sin()))
+        out = ops.softmax_attention(qd, heads, b, h * w, f, f * h * w, 1, h * w, dh ** -0.5, bias=bd, rot=rot)
+    else:
+        out = ops.softmax_attention(qd, heads, b * f, 1, h * w, h * w, 0, 1, dh ** -0.5)
+    assert rel_l2(out.detach().reshape(outr.shape), outr.detach()) < TOL
+    out.backward(dev(go.reshape(-1, heads * dh)))
+    assert rel_l2(qd.grad.reshape(qkv.shape), qr.grad) < 5e-6
+    if kind == 'temporal':
+        assert rel_l2(bd.grad, br.grad) < 5e-6
+
+
+@pytest.mark.parametrize('units,n', [(3, 100), (2, 1600), (1, 37), (4, 16)])
+def test_linear_attention(ops, units, n):
+    heads, dh = 4, 32
+    qkv = g((units, n, 3 * heads * dh), 50)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = (z.reshape(units, n, heads, dh).permute(0, 2, 3, 1) for z in qr.chunk(3, dim=-1))   # b h d n
+    q = q.softmax(dim=-2) * dh ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum('bhdn,bhen->bhde', k, v)
+    outr = torch.einsum('bhde,bhdn->bhen', ctx, q).permute(0, 3, 1, 2).reshape(units, n, heads * dh)
+    go = g(tuple(outr.shape), 51)
+    outr.backward(go)
+    qd = dev(qkv.reshape(-1, qkv.shape[-1]), True)
+    out = ops.linear_attention(qd, units, n, heads, dh ** -0.5)
+    assert rel_l2(out.detach().reshape(outr.shape), outr.detach()) < TOL
+    out.backward(dev(go.reshape(-1, heads * dh)))
+    assert rel_l2(qd.grad.reshape(qkv.shape), qr.grad) < 5e-6
+
+
+# ----------------------------------------------------------------------------------------------------- wavelets
+G = load_npz('dwt_pywt.npz')
+
+
+def _dw():
+    from wdno_amd import wavelets as W
+    return W
+
+
+@pytest.mark.parametrize('tag', ['ref', 'small', 'db4', 'sym4', 'haar', 'b13'])
+def test_dwt2_periodization_vs_pywt(ops, tag):
+    W = _dw()
+    wave = str(G[f'dwt2per_{tag}_wave'])
+    x = torch.from_numpy(G[f'dwt2per_{tag}_x'])
+    packed = W.dwt_packed(dev(x), wave, 'periodization', 2).cpu().double()
+    assert (packed[:, :, 0] - torch.from_numpy(G[f'dwt2per_{tag}_yl'])).abs().max() < 3e-6
+    assert (packed[:, :, 1:] - torch.from_numpy(G[f'dwt2per_{tag}_yh'])).abs().max() < 3e-6
+    yl, yh = W.DWTForward(J=1, wave=wave, mode='periodization')(dev(x))
+    assert torch.equal(yl.cpu().double(), packed[:, :, 0]) and torch.equal(yh[0].cpu().double(), packed[:, :, 1:])   # layout is bit-exact
+    rec = W.DWTInverse(wave=wave, mode='periodization')((dev(torch.from_numpy(G[f'idwt2per_{tag}_yl'])), [dev(torch.from_numpy(G[f'idwt2per_{tag}_yh']))]))
+    assert (rec.cpu().double() - torch.from_numpy(G[f'idwt2per_{tag}_x'])).abs().max() < 3e-6
+
+
+@pytest.mark.parametrize('tag', ['per', 'perodd', 'zero', 'zeroodd', 'zdb4'])
+def test_dwt1_vs_pywt(ops, tag):
+    W = _dw()
+    wave, mode = str(G[f'dwt1_{tag}_wave']), str(G[f'dwt1_{tag}_mode'])
+    lo, hi = W.DWT1DForward(J=1, wave=wave, mode=mode)(dev(torch.from_numpy(G[f'dwt1_{tag}_x'])))
+    assert (lo.cpu().double() - torch.from_numpy(G[f'dwt1_{tag}_lo'])).abs().max() < 3e-6
+    assert (hi[0].cpu().double() - torch.from_numpy(G[f'dwt1_{tag}_hi'])).abs().max() < 3e-6
+    rec = W.DWT1DInverse(wave=wave, mode=mode)((dev(torch.from_numpy(G[f'idwt1_{tag}_lo'])), [dev(torch.from_numpy(G[f'idwt1_{tag}_hi']))]))
+    assert (rec.cpu().double() - torch.from_numpy(G[f'idwt1_{tag}_x'])).abs().max() < 3e-6
+
+
+@pytest.mark.parametrize('tag', ['ref', 'odd'])
+def test_dwt2_zero_vs_pywt(ops, tag):
+    W = _dw()
+    yl, yh = W.DWTForward(J=1, wave=str(G[f'dwt2zero_{tag}_wave']), mode='zero')(dev(torch.from_numpy(G[f'dwt2zero_{tag}_x'])))
+    assert (yl.cpu().double() - torch.from_numpy(G[f'dwt2zero_{tag}_yl'])).abs().max() < 3e-6
+    assert (yh[0].cpu().double() - torch.from_numpy(G[f'dwt2zero_{tag}_yh'])).abs().max() < 3e-6
+
+
+@pytest.mark.parametrize('tag', ['mid', 'odd', 'db2'])
+def test_dwt3_vs_pywt(ops, tag):
+    W = _dw()
+    wave = str(G[f'dwt3_{tag}_wave'])
+    packed = W.wavedec3_packed(dev(torch.from_numpy(G[f'dwt3_{tag}_x'])), wave)
+    assert (packed.cpu().double() - torch.from_numpy(G[f'dwt3_{tag}_coef'])).abs().max() < 3e-6
+    c = torch.from_numpy(G[f'idwt3_{tag}_coef'])
+    rec = W.waverec3([dev(c[:, 0]), {k: dev(c[:, i + 1]) for i, k in enumerate(W.BANDS3[1:])}], wave)
+    assert (rec.cpu().double() - torch.from_numpy(G[f'idwt3_{tag}_x'])).abs().max() < 3e-6
+
+
+@pytest.mark.parametrize('nd,mode,wave,shape', [(2, 'periodization', 'bior2.4', (3, 2, 81, 120)), (2, 'periodization', 'bior2.4', (2, 2, 160, 128)),
+                                                (3, 'zero', 'bior1.3', (4, 32, 64, 64)), (3, 'zero', 'bior1.3', (2, 9, 11, 13)),
+                                                (1, 'zero', 'bior1.3', (5, 33)), (1, 'periodization', 'db4', (4, 31)), (2, 'zero', 'bior1.3', (2, 17, 20))])
+def test_dwt_vs_oracle_and_adjoints(ops, nd, mode, wave, shape):
+    """fp32 HIP vs the fp32 numpy oracle, perfect reconstruction, and <A x, y> == <x, A^T y> for both autograd adjoints."""
+    from oracle import dwt_ref as R
+    W = _dw()
+    x = g(shape, 60).float()
+    xd = dev(x, True)
+    packed = W.dwt_packed(xd, wave, mode, nd)
+    xn = x.numpy()
+    if nd == 1:
+        lo, hi = R.dwt1d(xn[:, None], wave, mode)
+        ref = np.stack([lo[:, 0], hi[:, 0]], axis=1)
+    elif nd == 2:
+        yl, yh = R.dwt2(xn[:, None], wave, mode)
+        ref = np.concatenate([yl[:, :, None], yh], axis=2)[:, 0]
+    else:
+        lll, det = R.dwt3(xn, wave, mode)
+        ref = R.smoke_coef_to_tensor(lll, det)
+    assert packed.shape == ref.shape
+    assert rel_l2(packed.detach(), torch.from_numpy(ref)) < 2e-6
+    y = g(tuple(packed.shape), 61).float()
+    (packed * dev(y)).sum().backward()
+    lhs = (packed.detach().cpu().double() * y.double()).sum()
+    rhs = (x.double() * xd.grad.cpu().double()).sum()
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), 1.0), 'analysis adjoint'
+    cd = dev(y, True)
+    rec = W.idwt_packed(cd, wave, mode, nd)
+    z = g(tuple(rec.shape), 62).float()
+    (rec * dev(z)).sum().backward()
+    lhs = (rec.detach().cpu().double() * z.double()).sum()
+    rhs = (y.double() * cd.grad.cpu().double()).sum()
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), 1.0), 'synthesis adjoint'
+    back = W.idwt_packed(packed.detach(), wave, mode, nd).cpu()
+    crop = tuple(slice(0, s) for s in shape[-nd:])
+    assert (back[(Ellipsis, *crop)] - x).abs().max() < 1e-4, 'perfect reconstruction'
+
+
+def test_upsample_coef(ops):
+    import sys
+    from wdno_amd import tree_path
+    from oracle import dwt_ref as R
+    a = g((2, 3, 5, 7), 70).float()
+    out = ops.upsample_coef_raw(a.to(DEV), 6, 5, 1, 1, 7, 2, 1, 2).reshape(2, 3, 10, 14)
+    assert torch.equal(out.cpu(), torch.from_numpy(R.upsample_coef_2d(a.numpy())))
+    b = g((2, 4, 3, 5, 5), 71).float()
+    t = ops.upsample_coef_raw(b.to(DEV), 2, 4, 75, 1, 1, 2, 1, 1).reshape(2, 8, 3, 5, 5)
+    s = ops.upsample_coef_raw(b.to(DEV), 24, 5, 1, 1, 5, 2, 1, 2).reshape(2, 4, 3, 10, 10)
+    assert torch.equal(t.cpu(), torch.from_numpy(R.upsample_coef_3d(b.numpy(), 'time')))
+    assert torch.equal(s.cpu(), torch.from_numpy(R.upsample_coef_3d(b.numpy(), 'space')))
+
+
+# ----------------------------------------------------------------------------------------------------- diffusion elementwise
+def test_q_sample_cond_smoke_and_burgers(ops):
+    from oracle import diffusion_ref as D
+    from wdno_amd import diffusion_core as K
+    buf = D.make_buffers('sigmoid', 1000)
+    x0, nz = g((2, 6, 42, 8, 8), 80).float(), g((2, 6, 42, 8, 8), 81).float()
+    t = torch.tensor([3, 900])
+    for ctrl, pad in ((True, True), (False, True), (True, False)):
+        xr = D.q_sample(buf, x0, t, nz)
+        tr = nz.clone()
+        kw = dict(is_condition_control=ctrl, is_condition_pad=pad)
+        D.smoke_apply_conditions(xr, (4, 6, 5), init=x0[:, :, -2], control=x0[:, :, 24:40], **kw)
+        D.smoke_apply_conditions(tr, (4, 6, 5), init=tr[:, :, -2], control=tr[:, :, 24:40], zero=True, **kw)
+        desc = K.cond_desc(0, tuple(x0.shape), (4, 6, 5), pad, ctrl, 0, 0, False)
+        xd, td = K.q_sample_cond(x0.to(DEV), nz.to(DEV), t.to(DEV), buf['sqrt_alphas_cumprod'].to(DEV), buf['sqrt_one_minus_alphas_cumprod'].to(DEV), desc)
+        assert (xd.cpu() - xr).abs().max() < 1e-6 and torch.equal(td.cpu(), tr)
+    bufb = D.make_buffers('cosine', 1000)
+    x0, nz = g((2, 9, 16, 12), 82).float(), g((2, 9, 16, 12), 83).float()
+    for flags in (dict(pad=True, u0=True, uT=False, f=True), dict(pad=True, u0=True, uT=True, f=True), dict(pad=False, u0=False, uT=True, f=False)):
+        xr = D.q_sample(bufb, x0, t, nz)
+        tr = nz.clone()
+        D.burgers_apply_conditions(xr, (11, 10), flags, u0=x0[:, -1, :8], uT=x0[:, -1, 8:], f=x0[:, 4:8])
+        z = torch.zeros_like
+        D.burgers_apply_conditions(tr, (11, 10), flags, u0=z(x0[:, -1, :8]), uT=z(x0[:, -1, 8:]), f=z(x0[:, 4:8]))
+        desc = K.cond_desc(1, tuple(x0.shape), (11, 10), flags['pad'], flags['u0'], flags['uT'], flags['f'], False, 8, 8)
+        xd, td = K.q_sample_cond(x0.to(DEV), nz.to(DEV), t.to(DEV), bufb['sqrt_alphas_cumprod'].to(DEV), bufb['sqrt_one_minus_alphas_cumprod'].to(DEV), desc)
+        assert (xd.cpu() - xr).abs().max() < 1e-6 and torch.equal(td.cpu(), tr)
+
+
+def test_flat_adam_matches_torch(ops):
+    from wdno_amd.trainer import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.randn(37, 5), torch.randn(101), torch.randn(3, 3, 3)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    opt_ref = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.99))
+    opt = FlatAdam(mine, lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0)
+    for step in range(4):
+        grads = [torch.randn_like(p) * (3.0 if step % 2 else 0.01) for p in ps]
+        for r, m, gr in zip(ref, mine, grads):
+            r.grad = gr.clone()
+            m.grad.copy_(gr.to(DEV))
+        gn_ref = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt_ref.step()
+        gn = opt.step()
+        assert abs(float(gn) - float(gn_ref)) < 1e-5 * max(1.0, float(gn_ref))
+    for r, m in zip(ref, mine):
+        assert rel_l2(m.detach(), r.detach()) < 1e-6

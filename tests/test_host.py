@@ -1,0 +1,161 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/wdno_hip.h, the drop-in module trees
+have the reference's state_dict layout and schedule buffers, host-side helpers match the oracle, and the product path
+refuses to run without a GPU (no silent CPU fallback)."""
+import json
+import math
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, load_npz, manifest
+
+ROOT = os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0]
+M = manifest()
+
+
+@pytest.fixture(scope='module')
+def trees():
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion as GD1
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D, RelativePositionBias
+    from ddpm.diffusion_2d import GaussianDiffusion as GD2
+    return dict(Unet2D=Unet2D, GD1=GD1, Unet3D=Unet3D_with_Conv3D, GD2=GD2, RPB=RelativePositionBias)
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from wdno_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from wdno_amd.build import build_library
+        build_library()
+    header = open(os.path.join(ROOT, 'include', 'wdno_hip.h')).read()
+    declared = set(re.findall(r'\b(wdno_[a-z0-9_]+)\s*\(', header))
+    declared -= {'wdno_stream_t'}
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in wdno_hip.h but not exported'
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+    l = _lib.load()
+    assert l.wdno_version() >= 100 and l.wdno_strerror(-1) == b'invalid argument'
+
+
+def test_state_dict_layout_matches_reference(trees):
+    with torch.device('meta'):
+        a = trees['Unet2D'](dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+        b = trees['Unet3D'](dim=64, dim_mults=(1, 2, 4), channels=42)
+    assert {k: list(v.shape) for k, v in a.state_dict().items()} == M['state_dict_unet2d_full']
+    assert {k: list(v.shape) for k, v in b.state_dict().items()} == M['state_dict_unet3d_full']
+    assert list(a.state_dict().keys()) == list(M['state_dict_unet2d_full'].keys())      # same order too
+    assert list(b.state_dict().keys()) == list(M['state_dict_unet3d_full'].keys())
+    assert sum(p.numel() for p in a.parameters()) == M['n_params_unet2d_full'] == 140748553
+    assert sum(p.numel() for p in b.parameters() if p.requires_grad) == M['n_params_unet3d_full'] == 23837482
+    assert a.channels == 9 and a.out_dim == 9 and a.self_condition is False and b.channels == 42
+
+
+def test_schedule_buffers_match_reference(trees):
+    g = load_npz('ref_schedules.npz')
+    net2 = trees['Unet2D'](dim=8, dim_mults=(1,), channels=2)
+    for sched in ('cosine', 'linear'):
+        m = trees['GD1'](net2, seq_length=(8, 8), beta_schedule=sched, ori_shape=[8, 8])
+        sd = {k: v for k, v in m.state_dict().items() if not k.startswith('model.')}
+        assert list(sd.keys()) == M['diffusion_buffers']
+        for k, v in sd.items():
+            assert torch.allclose(v, torch.from_numpy(g[f'burgers_{sched}::{k}']), rtol=1e-6, atol=1e-7), (sched, k)
+    net3 = trees['Unet3D'](dim=8, dim_mults=(1,), channels=2)
+    for sched in ('sigmoid', 'cosine', 'linear'):
+        m = trees['GD2'](net3, None, False, False, True, False, 'bior1.3', 'zero', None, None, image_size=8, frames=2, beta_schedule=sched)
+        for k, v in m.state_dict().items():
+            if not k.startswith('model.'):
+                assert torch.allclose(v, torch.from_numpy(g[f'smoke_{sched}::{k}']), rtol=1e-6, atol=1e-7), (sched, k)
+    with pytest.raises(ValueError):
+        trees['GD2'](net3, None, False, False, True, False, 'bior1.3', 'zero', None, None, image_size=8, frames=2, beta_schedule='nope')
+    with pytest.raises(NotImplementedError):
+        trees['GD2'](net3, None, False, False, False, False, 'bior1.3', 'zero', None, None, image_size=8, frames=2)
+
+
+def test_reference_checkpoint_keys_load(trees):
+    g = load_npz('ref_smoke_diffusion.npz')
+    c = M['smoke_diffusion']
+    net = trees['Unet3D'](dim=c['unet']['dim'], dim_mults=tuple(c['unet']['dim_mults']), channels=42, resnet_groups=c['unet']['resnet_groups'])
+    d = dict(c['diffusion'])
+    dif = trees['GD2'](net, loss_layer_weight=torch.from_numpy(g['lw']), **d)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('w::')}
+    res = dif.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_relative_position_buckets_match_oracle(trees):
+    from oracle.unet_ref import relative_position_bucket
+    rpb = trees['RPB'](heads=4, max_distance=32)
+    for n in (4, 24, 48):
+        pos = torch.arange(n)
+        assert torch.equal(rpb.bucket_table(n, 'cpu'), relative_position_bucket(pos[None, :] - pos[:, None]))
+
+
+def test_no_cpu_fallback(trees):
+    from wdno_amd import ops
+    net = trees['Unet2D'](dim=8, dim_mults=(1, 2), channels=3)
+    with pytest.raises(RuntimeError, match='GPU'):
+        net(torch.randn(1, 3, 8, 8), torch.tensor([1]))
+    with pytest.raises(RuntimeError, match='GPU'):
+        ops.silu(torch.randn(4))
+
+
+def test_packing_helpers_match_oracle(trees):
+    import wave_trans
+    import wave_trans_2d
+    from oracle import dwt_ref as R
+    rng = np.random.default_rng(0)
+    yl, yh = rng.standard_normal((2, 2, 41, 60)).astype(np.float32), rng.standard_normal((2, 2, 3, 41, 60)).astype(np.float32)
+    t = wave_trans.coef_to_tensor(torch.from_numpy(yl), [torch.from_numpy(yh)], pad=True)
+    assert np.array_equal(t.numpy(), R.burgers_coef_to_tensor(yl, yh, pad=True))
+    a, b = wave_trans.tensor_to_coef(t.reshape(2, 8, 64, 64), (41, 60))
+    ra, rb = R.burgers_tensor_to_coef(t.reshape(2, 8, 64, 64).numpy(), (41, 60))
+    assert np.array_equal(a.numpy(), ra) and np.array_equal(b[0].numpy(), rb)
+    packed = rng.standard_normal((2, 42, 24, 40, 40)).astype(np.float32)
+    for up in (None, 'time', 'space'):
+        yl3, det = wave_trans_2d.tensor_to_coef(torch.from_numpy(packed), (18, 34, 34), up)
+        ryl, rdet = R.smoke_tensor_to_coef(packed, (18, 34, 34), up)
+        assert np.array_equal(yl3.numpy(), ryl) and all(np.array_equal(det[k].numpy(), rdet[k]) for k in rdet)
+    c = wave_trans_2d.coef_to_tensor([torch.from_numpy(ryl), {k: torch.from_numpy(v) for k, v in rdet.items()}])
+    assert np.array_equal(c.numpy(), R.smoke_coef_to_tensor(ryl, rdet))
+
+
+def test_pywt_shim_and_filters():
+    from wdno_amd import tree_path
+    sys.path.insert(0, tree_path('third_party'))
+    import pywt
+    w = pywt.Wavelet('bior2.4')
+    assert w.dec_len == 10 and abs(sum(w.dec_lo) - math.sqrt(2)) < 1e-12
+    assert pywt.dwt_max_level(80, 'bior2.4') == 3 and pywt.dwt_max_level(32, 'bior1.3') == 2
+    assert pywt.dwt_coeff_len(81, 10, 'periodization') == 41 and pywt.dwt_coeff_len(64, 6, 'zero') == 34
+    g = load_npz('dwt_pywt.npz')
+    assert str(g['dwt2per_ref_wave']) == 'bior2.4'
+
+
+def test_lr_schedules_match_torch():
+    from wdno_amd.trainer import cosine_annealing_lr, multistep_lr
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.SGD(p, lr=1e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10000)
+    for step in range(5):
+        assert abs(opt.param_groups[0]['lr'] - cosine_annealing_lr(1e-4, step, 10000)) < 1e-15
+        opt.step(); sch.step()
+    assert multistep_lr(1e-3, 49999) == 1e-3 and abs(multistep_lr(1e-3, 50000) - 1e-4) < 1e-18 and abs(multistep_lr(1e-3, 200000) - 1e-5) < 1e-18
+
+
+def test_ddim_time_pairs():
+    from wdno_amd.diffusion_core import ddim_time_pairs
+    from oracle.diffusion_ref import ddim_times
+    for T, S in ((1000, 4), (1000, 50), (1000, 100), (1000, 250)):
+        assert ddim_time_pairs(T, S) == ddim_times(T, S)
+    assert ddim_time_pairs(1000, 4)[0] == (999, 749) and ddim_time_pairs(1000, 4)[-1][1] == -1

@@ -1,0 +1,34 @@
+"""Coefficient <-> tensor packing helpers of burgers/wave_trans.py:18-62 (single-level J = 1 path).
+
+With the HIP transform the packed tensor is produced directly (wdno_amd.wavelets.DWTForward.packed); these helpers
+keep the reference's names and argument order for callers that hold (Yl, Yh) pairs. They are views / concatenations
+only -- no arithmetic."""
+import torch
+from torch import nn
+
+from ddpm_burgers.wavelet_utils import upsample_coef  # noqa: F401  (re-export, as in the reference module)
+
+
+def tensor_to_coef(coef_tensor, shape):
+    """[N, >= 8, Hp, Wp] -> (Yl [N, 2, h, w], [Yh [N, 2, 3, h, w]]) cropping the zero padding."""
+    h, w = int(shape[-2]), int(shape[-1])
+    u = coef_tensor[:, 0:4, :h, :w]
+    f = coef_tensor[:, 4:8, :h, :w]
+    yl = torch.stack((u[:, 0], f[:, 0]), dim=1)
+    yh = [torch.stack((u[:, 1:4], f[:, 1:4]), dim=1)]
+    return yl, yh
+
+
+tensor_to_coef_super = tensor_to_coef
+
+
+def coef_to_tensor(Yl, Yh, pad=False):
+    """(Yl [N,C,h,w], [Yh [N,C,3,h,w]]) -> [N, C, 4, h, w]; pad=True zero-pads to multiples of 64 x 64 like the reference."""
+    if len(Yh) != 1:
+        raise NotImplementedError('single-level (J = 1) packing only; WDNO never uses J > 1 (wave_trans.py:107)')
+    t = torch.cat((Yl.unsqueeze(2), Yh[0]), dim=2)
+    if pad:
+        up_t = int(t.shape[-2] / 40)
+        up_x = int(t.shape[-1] / 60)
+        t = nn.functional.pad(t, (0, 64 * up_x - t.shape[-1], 0, 64 * up_t - t.shape[-2]), 'constant', 0)
+    return t

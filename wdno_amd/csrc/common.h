@@ -1,0 +1,70 @@
+// common.h -- shared host/device helpers for libwdno_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/wdno_hip.h"
+
+extern thread_local hipError_t wdno_tls_last_hip_error;
+
+static inline int wdno_check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    wdno_tls_last_hip_error = e;
+    return WDNO_ELAUNCH;
+  }
+  return WDNO_OK;
+}
+
+#define WDNO_REQUIRE(cond)            \
+  do {                                \
+    if (!(cond)) return WDNO_EINVAL;  \
+  } while (0)
+
+static inline hipStream_t as_stream(wdno_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// memory-bound kernels: cap the grid and grid-stride the rest (256 CUs x 8 blocks)
+static inline int stream_grid(int64_t work_items, int block) {
+  int64_t g = cdiv64(work_items, block);
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reductions inside aligned lane groups of width W (power of two <= 64)
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+__device__ __forceinline__ float silu_grad_f(float z) {
+  float sg = 1.0f / (1.0f + expf(-z));
+  return sg * (1.0f + z * (1.0f - sg));
+}
+#endif

@@ -1,0 +1,206 @@
+// diffusion.hip -- fused elementwise kernels of the two GaussianDiffusion operators (HBM-bound, 3-5 streams).
+// Tensors are in the reference's API layout: smoke [B,F,C,H,W], Burgers [B,C,H,W] (F = 1).
+#include "common.h"
+
+// 0 = free (diffused), 1 = forced zero, 2 = clean value.
+// smoke  : smoke/ddpm/diffusion_2d.py:1008-1033 -- order init, control, pad, low (later statements win)
+// Burgers: burgers/ddpm_burgers/diffusion_1d.py:276-288, call order pad, u0, uT, f, low
+__device__ __forceinline__ int cond_code(const wdno_cond_desc& d, int f, int c, int h, int w) {
+  if (d.tree == 0) {
+    if (d.cond_low && c >= 40 && c < 80) return 2;
+    if (d.cond_pad) {
+      if ((f >= d.cT && c != d.C - 2) || (c != d.C - 1 && (h >= d.cH || w >= d.cW))) return 1;
+    }
+    if (c == d.C - 2) return 2;
+    if (d.cond_a && c >= 24 && c < 40) return 2;
+    return 0;
+  } else {
+    bool inside = (h < d.cH) && (w < d.cW);
+    if (d.cond_low && c >= 8 && c < 16 && inside) return 2;
+    if (d.cond_c && c >= 4 && c < 8 && inside) return 2;
+    if (d.cond_b && c == d.C - 1 && h >= d.H - d.uT_rows && w < d.cW) return 2;
+    if (d.cond_a && c == d.C - 1 && h < d.u_rows && w < d.cW) return 2;
+    if (d.cond_pad && ((c != d.C - 1 && h >= d.cH) || w >= d.cW)) return 1;
+    return 0;
+  }
+}
+
+__device__ __forceinline__ void decode(const wdno_cond_desc& d, int64_t i, int& b, int& f, int& c, int& h, int& w) {
+  w = (int)(i % d.W); i /= d.W;
+  h = (int)(i % d.H); i /= d.H;
+  c = (int)(i % d.C); i /= d.C;
+  f = (int)(i % d.F);
+  b = (int)(i / d.F);
+}
+
+__global__ __launch_bounds__(256) void q_sample_cond_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                             const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                                             const float* __restrict__ sb, float* __restrict__ xo,
+                                                             float* __restrict__ to, wdno_cond_desc d, int64_t total) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int b, f, c, h, w;
+    decode(d, i, b, f, c, h, w);
+    int code = cond_code(d, f, c, h, w);
+    float v0 = x0[i], nz = noise[i];
+    int64_t tb = t[b];
+    float xv = sa[tb] * v0 + sb[tb] * nz;
+    xo[i] = code == 0 ? xv : (code == 1 ? 0.0f : v0);
+    to[i] = code == 0 ? nz : 0.0f;
+  }
+}
+static int check_cond(const wdno_cond_desc* c) {
+  if (!c || (c->tree != 0 && c->tree != 1)) return WDNO_EINVAL;
+  if (c->B <= 0 || c->F <= 0 || c->C <= 0 || c->H <= 0 || c->W <= 0) return WDNO_EINVAL;
+  if (c->tree == 1 && c->F != 1) return WDNO_EINVAL;
+  return WDNO_OK;
+}
+extern "C" int wdno_q_sample_cond(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                                  float* x_out, float* target_out, const wdno_cond_desc* c, wdno_stream_t s) {
+  int rc = check_cond(c);
+  if (rc) return rc;
+  int64_t total = (int64_t)c->B * c->F * c->C * c->H * c->W;
+  q_sample_cond_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x0, noise, t, sqrt_ac, sqrt_1mac, x_out, target_out, *c, total);
+  return wdno_check_launch();
+}
+
+__global__ __launch_bounds__(256) void apply_cond_kernel(float* __restrict__ x, const float* __restrict__ src, wdno_cond_desc d, int64_t total) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int b, f, c, h, w;
+    decode(d, i, b, f, c, h, w);
+    int code = cond_code(d, f, c, h, w);
+    if (code == 1) x[i] = 0.0f;
+    else if (code == 2) x[i] = src[i];
+  }
+}
+extern "C" int wdno_apply_cond(float* x, const float* src, const wdno_cond_desc* c, wdno_stream_t s) {
+  int rc = check_cond(c);
+  if (rc) return rc;
+  int64_t total = (int64_t)c->B * c->F * c->C * c->H * c->W;
+  apply_cond_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, src, *c, total);
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- weighted MSE
+__global__ __launch_bounds__(256) void wmse_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                    const float* __restrict__ wc, const float* __restrict__ wb, float inv_count,
+                                                    float* __restrict__ grad, double* __restrict__ ws, int64_t total,
+                                                    int64_t per_sample, int C, int64_t inner) {
+  __shared__ double red[4];
+  int64_t stride = (int64_t)gridDim.x * 256;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int64_t b = i / per_sample;
+    int c = (int)((i / inner) % C);
+    float wgt = wc[c] * wb[b];
+    float df = out[i] - tgt[i];
+    acc += (double)(df * df) * (double)wgt;
+    if (grad) grad[i] = 2.0f * df * wgt * inv_count;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void wmse_final_kernel(const double* __restrict__ ws, int nb, float* __restrict__ out, float scale) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += ws[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) * (double)scale);
+}
+extern "C" size_t wdno_weighted_mse_ws_bytes(int64_t n) { return (size_t)stream_grid(n, 256) * sizeof(double); }
+extern "C" int wdno_weighted_mse(const float* out, const float* target, const float* wc, const float* wb, float inv_count,
+                                 float* loss, float* grad, int64_t B, int64_t per_sample, int C, int64_t inner,
+                                 void* ws, size_t ws_bytes, wdno_stream_t s) {
+  WDNO_REQUIRE(B > 0 && per_sample > 0 && C > 0 && inner > 0);
+  int64_t total = B * per_sample;
+  if (ws_bytes < wdno_weighted_mse_ws_bytes(total)) return WDNO_EWORKSPACE;
+  int nb = stream_grid(total, 256);
+  wmse_kernel<<<nb, 256, 0, as_stream(s)>>>(out, target, wc, wb, inv_count, grad, (double*)ws, total, per_sample, C, inner);
+  wmse_final_kernel<<<1, 256, 0, as_stream(s)>>>((const double*)ws, nb, loss, inv_count);
+  return wdno_check_launch();
+}
+
+// backward of the weighted MSE: grad = 2 (out - target) * wc[c] * wb[b] * inv_count * gscale[0]
+__global__ __launch_bounds__(256) void wmse_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                        const float* __restrict__ wc, const float* __restrict__ wb, float inv_count,
+                                                        const float* __restrict__ gscale, float* __restrict__ grad, int64_t total,
+                                                        int64_t per_sample, int C, int64_t inner) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  const float gs = 2.0f * inv_count * (gscale ? gscale[0] : 1.0f);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int64_t b = i / per_sample;
+    int c = (int)((i / inner) % C);
+    grad[i] = (out[i] - tgt[i]) * (wc[c] * wb[b]) * gs;
+  }
+}
+extern "C" int wdno_weighted_mse_bwd(const float* out, const float* target, const float* wc, const float* wb, float inv_count,
+                                     const float* gscale, float* grad, int64_t B, int64_t per_sample, int C, int64_t inner,
+                                     wdno_stream_t s) {
+  WDNO_REQUIRE(B > 0 && per_sample > 0 && C > 0 && inner > 0 && grad != nullptr);
+  int64_t total = B * per_sample;
+  wmse_bwd_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(out, target, wc, wb, inv_count, gscale, grad, total, per_sample, C, inner);
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- sampler updates
+__global__ __launch_bounds__(256) void p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                        const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                                        const float* __restrict__ c1, const float* __restrict__ c2,
+                                                        const float* __restrict__ m1, const float* __restrict__ m2,
+                                                        const float* __restrict__ lv, float* __restrict__ xn, float* __restrict__ xs,
+                                                        int64_t total, int64_t per_sample, int clamp) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int64_t tb = t[i / per_sample];
+    float xv = x[i];
+    float st = c1[tb] * xv - c2[tb] * eps[i];
+    if (clamp) st = fminf(fmaxf(st, -1.0f), 1.0f);
+    float mean = m1[tb] * st + m2[tb] * xv;
+    float o = mean;
+    if (noise) o = mean + expf(0.5f * lv[tb]) * noise[i];
+    xn[i] = o;
+    if (xs) xs[i] = st;
+  }
+}
+extern "C" int wdno_p_sample_update(const float* x, const float* eps, const float* noise, const int64_t* t,
+                                    const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* pm1, const float* pm2,
+                                    const float* plogvar, float* x_next, float* x_start, int64_t B, int64_t per_sample, int clamp,
+                                    wdno_stream_t s) {
+  WDNO_REQUIRE(B > 0 && per_sample > 0);
+  int64_t total = B * per_sample;
+  p_sample_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, eps, noise, t, sqrt_recip_ac, sqrt_recipm1_ac, pm1, pm2, plogvar,
+                                                                   x_next, x_start, total, per_sample, clamp);
+  return wdno_check_launch();
+}
+
+__global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                    const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                                    const float* __restrict__ c1, const float* __restrict__ c2, float sqrt_an, float cc,
+                                                    float sigma, float* __restrict__ xn, float* __restrict__ xs, int64_t total,
+                                                    int64_t per_sample) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int64_t tb = t[i / per_sample];
+    float a = c1[tb] * x[i];
+    float st = fminf(fmaxf(a - c2[tb] * eps[i], -1.0f), 1.0f);
+    float e2 = (a - st) / c2[tb];
+    float o = st;
+    if (noise) o = st * sqrt_an + cc * e2 + sigma * noise[i];
+    xn[i] = o;
+    if (xs) xs[i] = st;
+  }
+}
+extern "C" int wdno_ddim_update(const float* x, const float* eps, const float* noise, const int64_t* t,
+                                const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, float sqrt_an, float c, float sigma,
+                                float* x_next, float* x_start, int64_t B, int64_t per_sample, wdno_stream_t s) {
+  WDNO_REQUIRE(B > 0 && per_sample > 0);
+  int64_t total = B * per_sample;
+  ddim_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, eps, noise, t, sqrt_recip_ac, sqrt_recipm1_ac, sqrt_an, c, sigma,
+                                                               x_next, x_start, total, per_sample);
+  return wdno_check_launch();
+}

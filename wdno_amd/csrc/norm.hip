@@ -1,0 +1,441 @@
+// norm.hip -- GroupNorm(+scale/shift)+SiLU and channel LayerNorm on channels-last tensors (HBM-bound).
+//
+// GroupNorm [N, S, C] with G groups (G = 1 is a whole-sample reduction of up to 1024*64*64 elements for Burgers):
+//   pass 1  gn_partial  : per (sample, row-chunk) per-channel sum / sum-of-squares, accumulated in fp64
+//   pass 2  gn_finalize : per sample: group mean / rstd (fp64), folded per-channel affine  y = act(a[c]*x + b[c])
+//   pass 3  gn_apply    : one read of x, one write of y
+// Backward mirrors it: per-channel sums of dz and dz*xhat, a per-sample finalize producing the parameter
+// gradients and the two group means, then one elementwise pass for dx.
+#include "common.h"
+
+#define GN_MAXC 1024
+
+static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline int gn_chunks(int64_t S) {
+  int64_t c = cdiv64(S, 64);
+  if (c > 64) c = 64;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+// ---------------------------------------------------------------------------------------------- per-channel partial sums
+// MODE 0: (sum x, sum x^2)         MODE 1: (sum dz, sum dz*xhat) with dz = dy * act'(a x + b)
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ cb /*[N][C][4]*/, const float* __restrict__ gb /*[N][G][4]*/,
+                                                          double* __restrict__ part, int64_t S, int C, int cg, int G, int txp,
+                                                          int64_t rows_per_chunk, int silu) {
+  __shared__ double red[256 * 8];
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int C4 = C >> 2;
+  const int tx = threadIdx.x & (txp - 1), ty = threadIdx.x / txp, nty = 256 / txp;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > S) r1 = S;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (tx < C4) {
+    float ca[4], cbb[4], mean[4], rstd[4];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int c = tx * 4 + j;
+        ca[j] = cb[((int64_t)n * C + c) * 4 + 0];
+        cbb[j] = cb[((int64_t)n * C + c) * 4 + 1];
+        int g = c / cg;
+        mean[j] = gb[((int64_t)n * G + g) * 4 + 0];
+        rstd[j] = gb[((int64_t)n * G + g) * 4 + 1];
+      }
+    }
+    const float* xp = x + ((int64_t)n * S) * C + tx * 4;
+    const float* dp = MODE == 1 ? dy + ((int64_t)n * S) * C + tx * 4 : nullptr;
+    for (int64_t r = r0 + ty; r < r1; r += nty) {
+      float4 v = *reinterpret_cast<const float4*>(xp + r * C);
+      float xv[4] = {v.x, v.y, v.z, v.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s0[j] += (double)xv[j]; s1[j] += (double)xv[j] * (double)xv[j]; }
+      } else {
+        float4 d = *reinterpret_cast<const float4*>(dp + r * C);
+        float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float dz = dv[j];
+          if (silu) dz *= silu_grad_f(ca[j] * xv[j] + cbb[j]);
+          float xh = (xv[j] - mean[j]) * rstd[j];
+          s0[j] += (double)dz;
+          s1[j] += (double)dz * (double)xh;
+        }
+      }
+    }
+  }
+  // reduce over the row groups: red[ty][tx][8]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[(ty * txp + tx) * 8 + j] = s0[j]; red[(ty * txp + tx) * 8 + 4 + j] = s1[j]; }
+  __syncthreads();
+  if (ty == 0 && tx < C4) {
+    for (int t = 1; t < nty; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] += red[(t * txp + tx) * 8 + j]; s1[j] += red[(t * txp + tx) * 8 + 4 + j]; }
+    double* o = part + (((int64_t)n * nchunk + chunk) * C + tx * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j * 2] = s0[j]; o[j * 2 + 1] = s1[j]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- forward finalize
+// one block per sample. writes stats[n][g] = (mean, rstd), cb[n][c] = (a, b, k1, 0), gb[n][g] = (mean, rstd, 0, 0)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ stats_in,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ ss, float* __restrict__ stats_out,
+                                                           float* __restrict__ cb, float* __restrict__ gb, int64_t S, int C, int G,
+                                                           int nchunk, float eps) {
+  __shared__ double chs[GN_MAXC], chq[GN_MAXC];
+  __shared__ float gmean[GN_MAXC], grstd[GN_MAXC];
+  const int n = blockIdx.x, cg = C / G;
+  if (part) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      double a = 0, b = 0;
+      for (int k = 0; k < nchunk; ++k) {
+        const double* q = part + (((int64_t)n * nchunk + k) * C + c) * 2;
+        a += q[0]; b += q[1];
+      }
+      chs[c] = a; chq[c] = b;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+      double a = 0, b = 0;
+      for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chs[c]; b += chq[c]; }
+      double m = (double)cg * (double)S;
+      double mean = a / m;
+      double var = b / m - mean * mean;
+      if (var < 0) var = 0;
+      float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      gmean[g] = (float)mean; grstd[g] = rstd;
+      stats_out[((int64_t)n * G + g) * 2 + 0] = (float)mean;
+      stats_out[((int64_t)n * G + g) * 2 + 1] = rstd;
+    }
+  } else {
+    for (int g = threadIdx.x; g < G; g += 256) {
+      gmean[g] = stats_in[((int64_t)n * G + g) * 2 + 0];
+      grstd[g] = stats_in[((int64_t)n * G + g) * 2 + 1];
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float* o = gb + ((int64_t)n * G + g) * 4;
+    o[0] = gmean[g]; o[1] = grstd[g]; o[2] = 0.f; o[3] = 0.f;
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    int g = c / cg;
+    float sc1 = ss ? ss[(int64_t)n * 2 * C + c] + 1.0f : 1.0f;
+    float sh = ss ? ss[(int64_t)n * 2 * C + C + c] : 0.0f;
+    float k1 = grstd[g] * gamma[c];
+    float a = k1 * sc1;
+    float b = (beta[c] - gmean[g] * k1) * sc1 + sh;
+    float* o = cb + ((int64_t)n * C + c) * 4;
+    o[0] = a; o[1] = b; o[2] = a; o[3] = 0.f;   // k1*(s+1) == a
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ cb, float* __restrict__ y,
+                                                        int64_t S, int C, int silu) {
+  const int n = blockIdx.y;
+  const int C4 = C >> 2;
+  const int64_t total4 = S * C4;
+  const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)n * S * C);
+  float4* yp = reinterpret_cast<float4*>(y + (int64_t)n * S * C);
+  const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    int c4 = (int)(i % C4);
+    float4 v = xp[i];
+    float4 k0 = cbp[c4 * 4 + 0], k1 = cbp[c4 * 4 + 1], k2 = cbp[c4 * 4 + 2], k3 = cbp[c4 * 4 + 3];
+    float4 o;
+    o.x = k0.x * v.x + k0.y; o.y = k1.x * v.y + k1.y; o.z = k2.x * v.z + k2.y; o.w = k3.x * v.w + k3.y;
+    if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
+    yp[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- backward finalize / apply
+// one block per sample: parameter-gradient pieces and the two group means
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ ss,
+                                                               float* __restrict__ gb, float* __restrict__ dgb, float* __restrict__ dss,
+                                                               int64_t S, int C, int G, int nchunk) {
+  __shared__ double chA[GN_MAXC], chB[GN_MAXC];
+  const int n = blockIdx.x, cg = C / G;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double a = 0, b = 0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* q = part + (((int64_t)n * nchunk + k) * C + c) * 2;
+      a += q[0]; b += q[1];
+    }
+    float sc1 = ss ? ss[(int64_t)n * 2 * C + c] + 1.0f : 1.0f;
+    if (dss) {
+      dss[(int64_t)n * 2 * C + c] = (float)((double)gamma[c] * b + (double)beta[c] * a);   // d scale
+      dss[(int64_t)n * 2 * C + C + c] = (float)a;                                          // d shift
+    }
+    dgb[((int64_t)n * 2 + 0) * C + c] = (float)((double)sc1 * b);   // d gamma (this sample)
+    dgb[((int64_t)n * 2 + 1) * C + c] = (float)((double)sc1 * a);   // d beta
+    double w = (double)gamma[c] * (double)sc1;
+    chA[c] = w * a; chB[c] = w * b;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) {
+    double a = 0, b = 0;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chA[c]; b += chB[c]; }
+    double m = (double)cg * (double)S;
+    float* o = gb + ((int64_t)n * G + g) * 4;
+    float rstd = o[1];
+    o[2] = (float)(a / m) * rstd;
+    o[3] = (float)(b / m) * rstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ cb, const float* __restrict__ gb,
+                                                            float* __restrict__ dx, int64_t S, int C, int cg, int G, int silu) {
+  const int n = blockIdx.y;
+  const int C4 = C >> 2;
+  const int64_t total4 = S * C4;
+  const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)n * S * C);
+  const float4* dp = reinterpret_cast<const float4*>(dy + (int64_t)n * S * C);
+  float4* op = reinterpret_cast<float4*>(dx + (int64_t)n * S * C);
+  const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
+  const float4* gbp = reinterpret_cast<const float4*>(gb + (int64_t)n * G * 4);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    int c4 = (int)(i % C4);
+    float4 v = xp[i], d = dp[i];
+    float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w}, o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int c = c4 * 4 + j;
+      float4 k = cbp[c];
+      float4 gq = gbp[c / cg];
+      float dz = dv[j];
+      if (silu) dz *= silu_grad_f(k.x * xv[j] + k.y);
+      float xh = (xv[j] - gq.x) * gq.y;
+      o[j] = k.z * dz - gq.z - xh * gq.w;
+    }
+    op[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- host
+// ws layout: [ double part[N][nchunk][C][2] | float cb[N][C][4] | float gb[N][G][4] ]
+extern "C" size_t wdno_groupnorm_ws_bytes(int64_t N, int64_t S, int C, int G) {
+  size_t part = (size_t)N * gn_chunks(S) * C * 2 * sizeof(double);
+  return part + (size_t)N * C * 4 * sizeof(float) + (size_t)N * G * 4 * sizeof(float) + 64;
+}
+static int gn_check(int64_t N, int64_t S, int C, int G) {
+  if (N <= 0 || S <= 0 || C <= 0 || G <= 0 || N > 65535) return WDNO_EINVAL;
+  if ((C & 3) || C > GN_MAXC || (C % G) != 0) return WDNO_EUNSUPPORTED;
+  return WDNO_OK;
+}
+extern "C" int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+                                      float* stats, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                      void* ws, size_t ws_bytes, wdno_stream_t s) {
+  int rc = gn_check(N, S, C, G);
+  if (rc) return rc;
+  if (ws_bytes < wdno_groupnorm_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
+  const int nchunk = gn_chunks(S);
+  double* part = (double*)ws;
+  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
+  float* gb = cb + (size_t)N * C * 4;
+  const int txp = pow2ceil(C / 4);
+  const int64_t rpc = cdiv64(S, nchunk);
+  hipStream_t st = as_stream(s);
+  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0);
+  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps);
+  int gx = stream_grid(S * (C / 4), 256);
+  if (gx > 512) gx = 512;
+  gn_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, y, S, C, silu);
+  return wdno_check_launch();
+}
+extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                                      const float* stats, float* dx, float* dgb_partial, float* dss,
+                                      int64_t N, int64_t S, int C, int G, int silu, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  int rc = gn_check(N, S, C, G);
+  if (rc) return rc;
+  if (ws_bytes < wdno_groupnorm_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
+  const int nchunk = gn_chunks(S);
+  double* part = (double*)ws;
+  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
+  float* gb = cb + (size_t)N * C * 4;
+  const int txp = pow2ceil(C / 4);
+  const int64_t rpc = cdiv64(S, nchunk);
+  hipStream_t st = as_stream(s);
+  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(nullptr, stats, gamma, beta, ss, nullptr, cb, gb, S, C, G, nchunk, 0.f);
+  gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu);
+  gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk);
+  int gx = stream_grid(S * (C / 4), 256);
+  if (gx > 512) gx = 512;
+  gn_bwd_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, dx, S, C, C / G, G, silu);
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- channel LayerNorm
+// rows [P][C]; a row is handled by TPR lanes holding VPL float4 each. y = (x - mean) / sqrt(var + eps) * g
+template <int TPR, int VPL, bool BWD>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ dy, float* __restrict__ out,
+                                                         float* __restrict__ dg_part, int64_t P, int C, float eps) {
+  constexpr int RPB = 256 / TPR;
+  __shared__ float red[BWD ? 256 * VPL * 4 : 1];
+  const int C4 = C >> 2;
+  const int lane = threadIdx.x % TPR, rloc = threadIdx.x / TPR;
+  float4 gv[VPL];
+  bool cok[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    int c4 = lane + v * TPR;
+    cok[v] = c4 < C4;
+    gv[v] = cok[v] ? reinterpret_cast<const float4*>(g)[c4] : make_float4(0, 0, 0, 0);
+  }
+  float dgacc[VPL][4];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dgacc[v][j] = 0.f;
+  const float invC = 1.0f / (float)C;
+  const int64_t rstride = (int64_t)gridDim.x * RPB;
+  // all lanes of a row group iterate together (uniform trip count per group)
+  for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < P; r0 += rstride) {
+    int64_t r = r0 + rloc;
+    bool rok = r < P;
+    float4 xv[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      xv[v] = (rok && cok[v]) ? reinterpret_cast<const float4*>(x + r * C)[lane + v * TPR] : make_float4(0, 0, 0, 0);
+      s += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
+    }
+    float mean = group_sum<TPR>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      if (cok[v]) {
+        xv[v].x -= mean; xv[v].y -= mean; xv[v].z -= mean; xv[v].w -= mean;
+        q += (xv[v].x * xv[v].x + xv[v].y * xv[v].y) + (xv[v].z * xv[v].z + xv[v].w * xv[v].w);
+      }
+    }
+    float var = group_sum<TPR>(q) * invC;
+    float rstd = 1.0f / sqrtf(var + eps);
+    if (!BWD) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+        if (rok && cok[v]) {
+          float4 o;
+          o.x = xv[v].x * rstd * gv[v].x; o.y = xv[v].y * rstd * gv[v].y;
+          o.z = xv[v].z * rstd * gv[v].z; o.w = xv[v].w * rstd * gv[v].w;
+          reinterpret_cast<float4*>(out + r * C)[lane + v * TPR] = o;
+        }
+    } else {
+      float4 dv[VPL];
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        dv[v] = (rok && cok[v]) ? reinterpret_cast<const float4*>(dy + r * C)[lane + v * TPR] : make_float4(0, 0, 0, 0);
+        // xhat in xv, dxhat = dy * g
+        xv[v].x *= rstd; xv[v].y *= rstd; xv[v].z *= rstd; xv[v].w *= rstd;
+        dgacc[v][0] += dv[v].x * xv[v].x; dgacc[v][1] += dv[v].y * xv[v].y;
+        dgacc[v][2] += dv[v].z * xv[v].z; dgacc[v][3] += dv[v].w * xv[v].w;
+        dv[v].x *= gv[v].x; dv[v].y *= gv[v].y; dv[v].z *= gv[v].z; dv[v].w *= gv[v].w;
+        m1 += (dv[v].x + dv[v].y) + (dv[v].z + dv[v].w);
+        m2 += (dv[v].x * xv[v].x + dv[v].y * xv[v].y) + (dv[v].z * xv[v].z + dv[v].w * xv[v].w);
+      }
+      m1 = group_sum<TPR>(m1) * invC;
+      m2 = group_sum<TPR>(m2) * invC;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+        if (rok && cok[v]) {
+          float4 o;
+          o.x = rstd * (dv[v].x - m1 - xv[v].x * m2); o.y = rstd * (dv[v].y - m1 - xv[v].y * m2);
+          o.z = rstd * (dv[v].z - m1 - xv[v].z * m2); o.w = rstd * (dv[v].w - m1 - xv[v].w * m2);
+          reinterpret_cast<float4*>(out + r * C)[lane + v * TPR] = o;
+        }
+    }
+  }
+  if (BWD) {
+    // reduce dg over the RPB row groups of the block, write one partial row per block
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[((rloc * TPR + lane) * VPL + v) * 4 + j] = dgacc[v][j];
+    __syncthreads();
+    if (rloc == 0) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        if (!cok[v]) continue;
+        float a[4] = {0, 0, 0, 0};
+        for (int t = 0; t < RPB; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] += red[((t * TPR + lane) * VPL + v) * 4 + j];
+        reinterpret_cast<float4*>(dg_part + (int64_t)blockIdx.x * C)[lane + v * TPR] = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    }
+  }
+}
+
+__global__ void ln_dg_final_kernel(const float* __restrict__ part, float* __restrict__ dg, int nb, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0;
+  for (int b = 0; b < nb; ++b) a += (double)part[(int64_t)b * C + c];
+  dg[c] = (float)a;
+}
+
+static inline int ln_blocks(int64_t P, int rpb) {
+  int64_t nb = cdiv64(P, rpb);
+  if (nb > 1024) nb = 1024;
+  return (int)nb;
+}
+static inline void ln_shape(int C, int& tpr, int& vpl) {
+  int c4 = C / 4;
+  if (c4 <= 64) { tpr = pow2ceil(c4); if (tpr < 2) tpr = 2; vpl = 1; }
+  else { tpr = 64; vpl = pow2ceil(cdiv(c4, 64)); }
+}
+template <bool BWD>
+static int ln_launch(const float* x, const float* g, const float* dy, float* out, float* dgp, int64_t P, int C, float eps, hipStream_t st) {
+  int tpr, vpl;
+  ln_shape(C, tpr, vpl);
+  int nb = ln_blocks(P, 256 / tpr);
+#define LN_CASE(T, V) layernorm_kernel<T, V, BWD><<<nb, 256, 0, st>>>(x, g, dy, out, dgp, P, C, eps)
+  if (vpl == 1) {
+    switch (tpr) {
+      case 2: LN_CASE(2, 1); break;
+      case 4: LN_CASE(4, 1); break;
+      case 8: LN_CASE(8, 1); break;
+      case 16: LN_CASE(16, 1); break;
+      case 32: LN_CASE(32, 1); break;
+      default: LN_CASE(64, 1); break;
+    }
+  } else if (vpl == 2) LN_CASE(64, 2);
+  else if (vpl == 4) LN_CASE(64, 4);
+  else return WDNO_EUNSUPPORTED;
+#undef LN_CASE
+  return WDNO_OK;
+}
+extern "C" int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s) {
+  WDNO_REQUIRE(P > 0 && C >= 4);
+  if ((C & 3) || C > 1024) return WDNO_EUNSUPPORTED;
+  int rc = ln_launch<false>(x, g, nullptr, y, nullptr, P, C, eps, as_stream(s));
+  if (rc) return rc;
+  return wdno_check_launch();
+}
+extern "C" size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C) { return (size_t)1024 * C * sizeof(float); }
+extern "C" int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
+                                  float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  WDNO_REQUIRE(P > 0 && C >= 4);
+  if ((C & 3) || C > 1024) return WDNO_EUNSUPPORTED;
+  if (ws_bytes < wdno_layernorm_bwd_ws_bytes(P, C)) return WDNO_EWORKSPACE;
+  int tpr, vpl;
+  ln_shape(C, tpr, vpl);
+  int nb = ln_blocks(P, 256 / tpr);
+  int rc = ln_launch<true>(x, g, dy, dx, (float*)ws, P, C, eps, as_stream(s));
+  if (rc) return rc;
+  ln_dg_final_kernel<<<cdiv(C, 128), 128, 0, as_stream(s)>>>((const float*)ws, dg, nb, C);
+  return wdno_check_launch();
+}

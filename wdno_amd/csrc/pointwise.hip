@@ -1,0 +1,389 @@
+// pointwise.hip -- HBM-bound elementwise, layout and reduction kernels (gfx950).
+// All kernels are grid-stride with 16-byte accesses where the layout allows it.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- activations
+template <int ACT>
+__device__ __forceinline__ float act_apply(float x) {
+  if (ACT == 0) return silu_f(x);
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float x) {
+  if (ACT == 0) return silu_grad_f(x);
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t n4 = n >> 2;
+  for (int64_t k = i; k < n4; k += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[k];
+    v.x = act_apply<ACT>(v.x); v.y = act_apply<ACT>(v.y); v.z = act_apply<ACT>(v.z); v.w = act_apply<ACT>(v.w);
+    reinterpret_cast<float4*>(y)[k] = v;
+  }
+  for (int64_t k = (n4 << 2) + i; k < n; k += stride) y[k] = act_apply<ACT>(x[k]);
+}
+template <int ACT>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t n4 = n >> 2;
+  for (int64_t k = i; k < n4; k += stride) {
+    float4 v = reinterpret_cast<const float4*>(x)[k];
+    float4 g = reinterpret_cast<const float4*>(dy)[k];
+    g.x *= act_grad<ACT>(v.x); g.y *= act_grad<ACT>(v.y); g.z *= act_grad<ACT>(v.z); g.w *= act_grad<ACT>(v.w);
+    reinterpret_cast<float4*>(dx)[k] = g;
+  }
+  for (int64_t k = (n4 << 2) + i; k < n; k += stride) dx[k] = dy[k] * act_grad<ACT>(x[k]);
+}
+
+extern "C" int wdno_act_fwd(const float* x, float* y, int64_t n, int act, wdno_stream_t s) {
+  WDNO_REQUIRE(n >= 0 && (act == 0 || act == 1));
+  if (n == 0) return WDNO_OK;
+  int grid = stream_grid(n / 4 + 1, 256);
+  if (act == 0) act_fwd_kernel<0><<<grid, 256, 0, as_stream(s)>>>(x, y, n);
+  else act_fwd_kernel<1><<<grid, 256, 0, as_stream(s)>>>(x, y, n);
+  return wdno_check_launch();
+}
+extern "C" int wdno_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, wdno_stream_t s) {
+  WDNO_REQUIRE(n >= 0 && (act == 0 || act == 1));
+  if (n == 0) return WDNO_OK;
+  int grid = stream_grid(n / 4 + 1, 256);
+  if (act == 0) act_bwd_kernel<0><<<grid, 256, 0, as_stream(s)>>>(x, dy, dx, n);
+  else act_bwd_kernel<1><<<grid, 256, 0, as_stream(s)>>>(x, dy, dx, n);
+  return wdno_check_launch();
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   float* __restrict__ o, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t n4 = n >> 2;
+  for (int64_t k = i; k < n4; k += stride) {
+    float4 u = reinterpret_cast<const float4*>(a)[k];
+    float4 v = reinterpret_cast<const float4*>(b)[k];
+    u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+    reinterpret_cast<float4*>(o)[k] = u;
+  }
+  for (int64_t k = (n4 << 2) + i; k < n; k += stride) o[k] = a[k] + b[k];
+}
+extern "C" int wdno_add(const float* a, const float* b, float* out, int64_t n, wdno_stream_t s) {
+  WDNO_REQUIRE(n >= 0);
+  if (n == 0) return WDNO_OK;
+  add_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, as_stream(s)>>>(a, b, out, n);
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- time embedding
+__global__ void sinusoidal_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim, float neg_step) {
+  int half = dim >> 1;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  int b = i / half, k = i - b * half;
+  float f = expf((float)k * neg_step);
+  float a = (float)t[b] * f;
+  out[(int64_t)b * dim + k] = sinf(a);
+  out[(int64_t)b * dim + half + k] = cosf(a);
+}
+extern "C" int wdno_sinusoidal_emb(const int64_t* t, float* out, int B, int dim, float theta, wdno_stream_t s) {
+  WDNO_REQUIRE(B > 0 && dim >= 4 && (dim % 2) == 0 && theta > 1.0f);
+  int half = dim / 2;
+  float neg_step = (float)(-(log((double)theta) / (double)(half - 1)));
+  int n = B * half;
+  sinusoidal_kernel<<<cdiv(n, 128), 128, 0, as_stream(s)>>>(t, out, B, dim, neg_step);
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- layout transforms
+// src [N][C][S] -> dst [N][S][Cp]: 32x32 tile transpose through LDS; reads coalesced along S, writes along C.
+__global__ __launch_bounds__(256) void nc_to_cl_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        int C, int64_t S, int Cp) {
+  __shared__ float tile[32][33];
+  int64_t n = blockIdx.z;
+  int64_t s0 = (int64_t)blockIdx.x * 32;
+  int c0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* sp = src + n * (int64_t)C * S;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int c = c0 + ty + r * 8;
+    int64_t sidx = s0 + tx;
+    tile[ty + r * 8][tx] = (c < C && sidx < S) ? sp[(int64_t)c * S + sidx] : 0.0f;
+  }
+  __syncthreads();
+  float* dp = dst + n * S * (int64_t)Cp;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int64_t sidx = s0 + ty + r * 8;
+    int c = c0 + tx;
+    if (sidx < S && c < Cp) dp[sidx * Cp + c] = tile[tx][ty + r * 8];
+  }
+}
+__global__ __launch_bounds__(256) void cl_to_nc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        int C, int64_t S, int Cp) {
+  __shared__ float tile[32][33];
+  int64_t n = blockIdx.z;
+  int64_t s0 = (int64_t)blockIdx.x * 32;
+  int c0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* sp = src + n * S * (int64_t)Cp;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int64_t sidx = s0 + ty + r * 8;
+    int c = c0 + tx;
+    tile[ty + r * 8][tx] = (sidx < S && c < C) ? sp[sidx * Cp + c] : 0.0f;
+  }
+  __syncthreads();
+  float* dp = dst + n * (int64_t)C * S;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int c = c0 + ty + r * 8;
+    int64_t sidx = s0 + tx;
+    if (c < C && sidx < S) dp[(int64_t)c * S + sidx] = tile[tx][ty + r * 8];
+  }
+}
+extern "C" int wdno_nc_to_cl(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s) {
+  WDNO_REQUIRE(N > 0 && C > 0 && S > 0 && Cp >= C && N < 65536);
+  dim3 grid((unsigned)cdiv64(S, 32), (unsigned)cdiv(Cp, 32), (unsigned)N);
+  nc_to_cl_kernel<<<grid, 256, 0, as_stream(s)>>>(src, dst, C, S, Cp);
+  return wdno_check_launch();
+}
+extern "C" int wdno_cl_to_nc(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s) {
+  WDNO_REQUIRE(N > 0 && C > 0 && S > 0 && Cp >= C && N < 65536);
+  dim3 grid((unsigned)cdiv64(S, 32), (unsigned)cdiv(C, 32), (unsigned)N);
+  cl_to_nc_kernel<<<grid, 256, 0, as_stream(s)>>>(src, dst, C, S, Cp);
+  return wdno_check_launch();
+}
+
+// out[p] = (a[p] | b[p]) ; Ca, Cb multiples of 4
+__global__ __launch_bounds__(256) void concat2_kernel(const float4* __restrict__ a, int Ca4, const float4* __restrict__ b, int Cb4,
+                                                       float4* __restrict__ out, int64_t total4) {
+  int Ct4 = Ca4 + Cb4;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    int64_t p = i / Ct4;
+    int c = (int)(i - p * Ct4);
+    out[i] = (c < Ca4) ? a[p * Ca4 + c] : b[p * Cb4 + (c - Ca4)];
+  }
+}
+__global__ __launch_bounds__(256) void split2_kernel(const float4* __restrict__ in, float4* __restrict__ a, int Ca4,
+                                                      float4* __restrict__ b, int Cb4, int64_t total4) {
+  int Ct4 = Ca4 + Cb4;
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    int64_t p = i / Ct4;
+    int c = (int)(i - p * Ct4);
+    float4 v = in[i];
+    if (c < Ca4) a[p * Ca4 + c] = v; else b[p * Cb4 + (c - Ca4)] = v;
+  }
+}
+extern "C" int wdno_concat2_cl(const float* a, int Ca, const float* b, int Cb, float* out, int64_t P, wdno_stream_t s) {
+  WDNO_REQUIRE(P > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0);
+  int64_t total4 = P * ((Ca + Cb) / 4);
+  concat2_kernel<<<stream_grid(total4, 256), 256, 0, as_stream(s)>>>((const float4*)a, Ca / 4, (const float4*)b, Cb / 4, (float4*)out, total4);
+  return wdno_check_launch();
+}
+extern "C" int wdno_split2_cl(const float* in, float* a, int Ca, float* b, int Cb, int64_t P, wdno_stream_t s) {
+  WDNO_REQUIRE(P > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0);
+  int64_t total4 = P * ((Ca + Cb) / 4);
+  split2_kernel<<<stream_grid(total4, 256), 256, 0, as_stream(s)>>>((const float4*)in, (float4*)a, Ca / 4, (float4*)b, Cb / 4, total4);
+  return wdno_check_launch();
+}
+
+// nearest x2 on CL [N,H,W,C] -> [N,2H,2W,C]
+__global__ __launch_bounds__(256) void up2x_fwd_kernel(const float4* __restrict__ in, float4* __restrict__ out,
+                                                        int H, int W, int C4, int64_t total4) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  int W2 = 2 * W, H2 = 2 * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    int c = (int)(i % C4);
+    int64_t p = i / C4;
+    int w = (int)(p % W2);
+    int64_t q = p / W2;
+    int h = (int)(q % H2);
+    int64_t n = q / H2;
+    out[i] = in[((n * H + (h >> 1)) * W + (w >> 1)) * C4 + c];
+  }
+}
+__global__ __launch_bounds__(256) void up2x_bwd_kernel(const float4* __restrict__ dout, float4* __restrict__ din,
+                                                        int H, int W, int C4, int64_t total4) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  int W2 = 2 * W, H2 = 2 * H;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
+    int c = (int)(i % C4);
+    int64_t p = i / C4;
+    int w = (int)(p % W);
+    int64_t q = p / W;
+    int h = (int)(q % H);
+    int64_t n = q / H;
+    int64_t base = ((n * H2 + 2 * h) * W2 + 2 * w) * C4 + c;
+    float4 a = dout[base], b = dout[base + C4], d = dout[base + (int64_t)W2 * C4], e = dout[base + (int64_t)W2 * C4 + C4];
+    float4 r;
+    r.x = (a.x + b.x) + (d.x + e.x); r.y = (a.y + b.y) + (d.y + e.y);
+    r.z = (a.z + b.z) + (d.z + e.z); r.w = (a.w + b.w) + (d.w + e.w);
+    din[i] = r;
+  }
+}
+extern "C" int wdno_upsample2x_cl_fwd(const float* in, float* out, int64_t N, int H, int W, int C, wdno_stream_t s) {
+  WDNO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+  int64_t total4 = N * 4 * H * W * (C / 4);
+  up2x_fwd_kernel<<<stream_grid(total4, 256), 256, 0, as_stream(s)>>>((const float4*)in, (float4*)out, H, W, C / 4, total4);
+  return wdno_check_launch();
+}
+extern "C" int wdno_upsample2x_cl_bwd(const float* dout, float* din, int64_t N, int H, int W, int C, wdno_stream_t s) {
+  WDNO_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0);
+  int64_t total4 = N * H * W * (C / 4);
+  up2x_bwd_kernel<<<stream_grid(total4, 256), 256, 0, as_stream(s)>>>((const float4*)dout, (float4*)din, H, W, C / 4, total4);
+  return wdno_check_launch();
+}
+
+// coefficient nearest up-sampling: in [outer,a,mid,b,c] -> out [outer,a*fa,mid,b*fb,c*fc]
+__global__ __launch_bounds__(256) void upsample_coef_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int a, int mid, int b, int c, int fa, int fb, int fc, int64_t total) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  int oc = c * fc, ob = b * fb, oa = a * fa;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int ic = (int)(i % oc);
+    int64_t r = i / oc;
+    int ib = (int)(r % ob); r /= ob;
+    int im = (int)(r % mid); r /= mid;
+    int ia = (int)(r % oa);
+    int64_t o = r / oa;
+    out[i] = in[(((o * a + ia / fa) * mid + im) * b + ib / fb) * c + ic / fc];
+  }
+}
+extern "C" int wdno_upsample_coef(const float* in, float* out, int64_t outer, int a, int mid, int b, int c,
+                                  int fa, int fb, int fc, wdno_stream_t s) {
+  WDNO_REQUIRE(outer > 0 && a > 0 && mid > 0 && b > 0 && c > 0 && fa > 0 && fb > 0 && fc > 0);
+  int64_t total = outer * a * fa * mid * b * fb * c * fc;
+  upsample_coef_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(in, out, a, mid, b, c, fa, fb, fc, total);
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- column sums
+// out[c] = sum_p in[p][c]. Stage 1: block b sums rows [b*rpb, (b+1)*rpb) in double -> ws[b][C]; stage 2: sum over blocks.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ in, double* __restrict__ ws,
+                                                              int64_t P, int C, int64_t rows_per_block) {
+  __shared__ double red[4][64];
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    int c = c0 + tx;
+    double acc = 0.0;
+    if (c < C)
+      for (int64_t r = r0 + ty; r < r1; r += 4) acc += (double)in[r * C + c];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) ws[(int64_t)blockIdx.x * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    __syncthreads();
+  }
+}
+__global__ void colsum_final_kernel(const double* __restrict__ ws, float* __restrict__ out, int nb, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double acc = 0.0;
+  for (int b = 0; b < nb; ++b) acc += ws[(int64_t)b * C + c];
+  out[c] = (float)acc;
+}
+static inline int colsum_blocks(int64_t P) {
+  int64_t nb = cdiv64(P, 64);
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+extern "C" size_t wdno_colsum_ws_bytes(int64_t P, int C) { return (size_t)colsum_blocks(P) * (size_t)C * sizeof(double); }
+extern "C" int wdno_colsum(const float* in, float* out, int64_t P, int C, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  WDNO_REQUIRE(P > 0 && C > 0);
+  if (ws_bytes < wdno_colsum_ws_bytes(P, C)) return WDNO_EWORKSPACE;
+  int nb = colsum_blocks(P);
+  int64_t rpb = cdiv64(P, nb);
+  colsum_partial_kernel<<<nb, 256, 0, as_stream(s)>>>(in, (double*)ws, P, C, rpb);
+  colsum_final_kernel<<<cdiv(C, 128), 128, 0, as_stream(s)>>>((const double*)ws, out, nb, C);
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- trainer step
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ ws) {
+  __shared__ double red[4];
+  int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t n4 = n >> 2;
+  double acc = 0.0;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += stride) {
+    float4 v = reinterpret_cast<const float4*>(g)[k];
+    acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  for (int64_t k = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) acc += (double)g[k] * g[k];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sum_final_kernel(const double* __restrict__ ws, int nb, float* __restrict__ out, float scale) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += ws[i];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) * (double)scale);
+}
+extern "C" size_t wdno_sumsq_ws_bytes(int64_t n) { return (size_t)stream_grid(n / 4 + 1, 256) * sizeof(double); }
+extern "C" int wdno_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  WDNO_REQUIRE(n > 0);
+  if (ws_bytes < wdno_sumsq_ws_bytes(n)) return WDNO_EWORKSPACE;
+  int nb = stream_grid(n / 4 + 1, 256);
+  sumsq_partial_kernel<<<nb, 256, 0, as_stream(s)>>>(g, n, (double*)ws);
+  sum_final_kernel<<<1, 256, 0, as_stream(s)>>>((const double*)ws, nb, out, 1.0f);
+  return wdno_check_launch();
+}
+
+// torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (single-tensor formulation) on a flat buffer
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, const float* __restrict__ sumsq,
+                                                    float max_norm, float grad_scale, float step_size, float beta1, float beta2,
+                                                    float eps, float bc2_sqrt) {
+  float coef = grad_scale;
+  if (sumsq != nullptr && max_norm > 0.0f) {
+    float total = sqrtf(sumsq[0]) * grad_scale;
+    float c = max_norm / (total + 1e-6f);
+    coef *= fminf(c, 1.0f);
+  }
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+    float gr = g[k] * coef;
+    float mk = m[k] + (gr - m[k]) * (1.0f - beta1);   // exp_avg.lerp_(grad, 1 - beta1)
+    float vk = v[k] * beta2 + (1.0f - beta2) * gr * gr;
+    m[k] = mk;
+    v[k] = vk;
+    float denom = sqrtf(vk) / bc2_sqrt + eps;
+    p[k] = p[k] - step_size * (mk / denom);
+  }
+}
+extern "C" int wdno_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
+                                   float grad_scale, float lr, float beta1, float beta2, float eps, int step, wdno_stream_t s) {
+  WDNO_REQUIRE(n > 0 && step >= 1);
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  float step_size = (float)((double)lr / bc1);
+  float bc2_sqrt = (float)sqrt(bc2);
+  adam_kernel<<<stream_grid(n, 256), 256, 0, as_stream(s)>>>(p, g, m, v, n, sumsq, max_norm, grad_scale, step_size, beta1, beta2, eps, bc2_sqrt);
+  return wdno_check_launch();
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, int64_t n, float w) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) e[k] = e[k] + (p[k] - e[k]) * w;  // lerp_(p, 1-beta)
+}
+extern "C" int wdno_ema_update(float* ema, const float* p, int64_t n, float beta, wdno_stream_t s) {
+  WDNO_REQUIRE(n > 0);
+  ema_kernel<<<stream_grid(n, 256), 256, 0, as_stream(s)>>>(ema, p, n, 1.0f - beta);
+  return wdno_check_launch();
+}

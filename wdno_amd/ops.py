@@ -1,0 +1,661 @@
+"""Autograd-aware wrappers around the C ABI (include/wdno_hip.h).
+
+PyTorch is used for device memory, streams and the autograd tape only; every forward / backward body below is one
+or more launches of libwdno_hip.so. Activations are channels-last ("CL"): [N, (D,) H, W, C] with C padded to a
+multiple of 4. There is no CPU path: non-CUDA tensors raise.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, CondDesc, ConvGeom, DwtDesc
+
+WEIGHT_EPOCH = 0          # bumped by wdno_amd.trainer after every in-place optimiser step (invalidates packed weights)
+_pack_cache = {}
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError(f'wdno_amd: {name} must live on the GPU (no CPU fallback on the hot path)')
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'wdno_amd: {name} must be float32, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+# ----------------------------------------------------------------------------------------------------- layout
+class _NcToCl(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cp):
+        x = _chk(x, 'x')
+        n, c = x.shape[0], x.shape[1]
+        sp = tuple(x.shape[2:])
+        s = int(math.prod(sp))
+        out = torch.empty((n, *sp, cp), device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_nc_to_cl(_p(x), _p(out), n, c, s, cp, _stream()), 'nc_to_cl')
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return cl_to_nc_raw(_chk(g, 'grad'), ctx.c), None
+
+
+def cl_to_nc_raw(x, c):
+    n, cp = x.shape[0], x.shape[-1]
+    sp = tuple(x.shape[1:-1])
+    s = int(math.prod(sp))
+    out = torch.empty((n, c, *sp), device=x.device, dtype=torch.float32)
+    _lib.check(_lib_().wdno_cl_to_nc(_p(x), _p(out), n, c, s, cp, _stream()), 'cl_to_nc')
+    return out
+
+
+class _ClToNc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        x = _chk(x, 'x')
+        ctx.cp = x.shape[-1]
+        return cl_to_nc_raw(x, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g, 'grad')
+        n, c = g.shape[0], g.shape[1]
+        sp = tuple(g.shape[2:])
+        out = torch.empty((n, *sp, ctx.cp), device=g.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_nc_to_cl(_p(g), _p(out), n, c, int(math.prod(sp)), ctx.cp, _stream()), 'nc_to_cl')
+        return out, None
+
+
+def nc_to_cl(x, cp=None):
+    """[N, C, *spatial] -> [N, *spatial, Cp] (zero-padded channels)."""
+    return _NcToCl.apply(x, pad4(x.shape[1]) if cp is None else cp)
+
+
+def cl_to_nc(x, c):
+    """[N, *spatial, Cp] -> [N, C, *spatial]."""
+    return _ClToNc.apply(x, c)
+
+
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, 'a'), _chk(b, 'b')
+        ca, cb = a.shape[-1], b.shape[-1]
+        p = a.numel() // ca
+        out = torch.empty((*a.shape[:-1], ca + cb), device=a.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_concat2_cl(_p(a), ca, _p(b), cb, _p(out), p, _stream()), 'concat2_cl')
+        ctx.ca, ctx.cb = ca, cb
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g, 'grad')
+        ca, cb = ctx.ca, ctx.cb
+        p = g.numel() // (ca + cb)
+        ga = torch.empty((*g.shape[:-1], ca), device=g.device, dtype=torch.float32)
+        gb = torch.empty((*g.shape[:-1], cb), device=g.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_split2_cl(_p(g), _p(ga), ca, _p(gb), cb, p, _stream()), 'split2_cl')
+        return ga, gb
+
+
+def concat_cl(a, b):
+    return _Concat.apply(a, b)
+
+
+class _Up2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, 'x')
+        n, h, w, c = x.shape
+        out = torch.empty((n, 2 * h, 2 * w, c), device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_upsample2x_cl_fwd(_p(x), _p(out), n, h, w, c, _stream()), 'upsample2x_fwd')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _chk(g, 'grad')
+        n, h2, w2, c = g.shape
+        out = torch.empty((n, h2 // 2, w2 // 2, c), device=g.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_upsample2x_cl_bwd(_p(g), _p(out), n, h2 // 2, w2 // 2, c, _stream()), 'upsample2x_bwd')
+        return out
+
+
+def upsample2x_cl(x):
+    return _Up2x.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------------- pointwise
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _chk(x, 'x')
+        y = torch.empty_like(x)
+        _lib.check(_lib_().wdno_act_fwd(_p(x), _p(y), x.numel(), kind, _stream()), 'act_fwd')
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _chk(g, 'grad')
+        dx = torch.empty_like(x)
+        _lib.check(_lib_().wdno_act_bwd(_p(x), _p(g), _p(dx), x.numel(), ctx.kind, _stream()), 'act_bwd')
+        return dx, None
+
+
+def silu(x):
+    return _Act.apply(x, 0)
+
+
+def gelu(x):
+    return _Act.apply(x, 1)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, 'a'), _chk(b, 'b')
+        assert a.shape == b.shape
+        out = torch.empty_like(a)
+        _lib.check(_lib_().wdno_add(_p(a), _p(b), _p(out), a.numel(), _stream()), 'add')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+def sinusoidal_embedding(t, dim, theta=10000.0):
+    """[B] int64 -> [B, dim] (no gradient: timesteps are integers)."""
+    t = t.to(torch.int64).contiguous()
+    if not t.is_cuda:
+        raise RuntimeError('wdno_amd: timesteps must live on the GPU')
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    _lib.check(_lib_().wdno_sinusoidal_emb(_p(t), _p(out), t.shape[0], dim, float(theta), _stream()), 'sinusoidal_emb')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------- convolution
+def _geom(x_shape, c, k, ks, st, pd, out_sp, y_sp=None, ostride=(1, 1, 1), ooff=(0, 0, 0)):
+    n, d, h, w = x_shape
+    y_sp = out_sp if y_sp is None else y_sp
+    return ConvGeom(n, d, h, w, c, out_sp[0], out_sp[1], out_sp[2], k, ks[0], ks[1], ks[2], st[0], st[1], st[2],
+                    pd[0], pd[1], pd[2], y_sp[0], y_sp[1], y_sp[2], ostride[0], ostride[1], ostride[2],
+                    ooff[0], ooff[1], ooff[2])
+
+
+def _as5(w):
+    """Reference weight layouts -> [K, C, kd, kh, kw]."""
+    if w.dim() == 2:
+        return w[:, :, None, None, None]
+    if w.dim() == 4:
+        return w[:, :, None]
+    return w
+
+
+def _cached(w, kind, cp, kp, build):
+    key = (w.data_ptr(), kind, cp, kp)
+    ver = (w._version, WEIGHT_EPOCH, tuple(w.shape))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        packed = build().contiguous()
+    _pack_cache[key] = (ver, packed)
+    return packed
+
+
+def _padded(w5, kp, cp):
+    k, c = w5.shape[0], w5.shape[1]
+    if k == kp and c == cp:
+        return w5
+    out = w5.new_zeros((kp, cp, *w5.shape[2:]))
+    out[:k, :c] = w5
+    return out
+
+
+def pack_fwd(w, cp, kp):
+    """[K, C, kd, kh, kw] -> [kd, kh, Kp, kw, Cp]"""
+    return _cached(w, 'f', cp, kp, lambda: _padded(_as5(w.detach()), kp, cp).permute(2, 3, 0, 4, 1))
+
+
+def pack_dgrad(w, cp, kp):
+    """stride-1 data gradient: dx = conv(dy, flipped/transposed w): [kd, kh, Cp, kw, Kp]"""
+    return _cached(w, 'd', cp, kp, lambda: _padded(_as5(w.detach()), kp, cp).flip(2, 3, 4).permute(2, 3, 1, 4, 0))
+
+
+def pack_transposed(w_io, cin_p, cout_p):
+    """k=(1,4,4), s=(1,2,2), p=(0,1,1) transposed convolution, weight [in, out, 1, 4, 4]:
+    four parity classes (py, px), each a (1,2,2) stride-1 convolution: -> [2, 2][1, 2, Cout_p, 2, Cin_p]
+    with wt[py][px][0][dy][o][dx][i] = w[i][o][0][3 - py - 2 dy][3 - px - 2 dx]."""
+    def build():
+        w = w_io.detach()
+        cin, cout = w.shape[0], w.shape[1]
+        out = w.new_zeros((2, 2, 1, 2, cout_p, 2, cin_p))
+        for py in range(2):
+            for px in range(2):
+                for dy in range(2):
+                    for dx in range(2):
+                        out[py, px, 0, dy, :cout, dx, :cin] = w[:, :, 0, 3 - py - 2 * dy, 3 - px - 2 * dx].t()
+        return out
+    return _cached(w_io, 't', cin_p, cout_p, build)
+
+
+def _out_size(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def conv_fwd_raw(x, wp, bias_p, residual, ks, st, pd, kp):
+    """x CL [N,D,H,W,Cp], wp [kd,kh,Kp,kw*Cp] packed -> y CL [N,OD,OH,OW,Kp]"""
+    n, d, h, w, cp = x.shape
+    osp = tuple(_out_size(a, k, s, p) for a, k, s, p in zip((d, h, w), ks, st, pd))
+    y = torch.empty((n, *osp, kp), device=x.device, dtype=torch.float32)
+    g = _geom((n, d, h, w), cp, kp, ks, st, pd, osp)
+    _lib.check(_lib_().wdno_conv_fwd(_p(x), _p(wp), _p(bias_p), _p(residual), _p(y), C.byref(g), _stream()), 'conv_fwd')
+    return y
+
+
+def conv_wgrad_raw(x, dy, ks, st, pd):
+    """-> dwp [kd, kh, Kp, kw, Cp] for y = conv(x, w) with dy CL [N,OD,OH,OW,Kp]"""
+    n, d, h, w, cp = x.shape
+    kp = dy.shape[-1]
+    osp = tuple(dy.shape[1:4])
+    g = _geom((n, d, h, w), cp, kp, ks, st, pd, osp)
+    lib = _lib_()
+    nb = lib.wdno_conv_wgrad_ws_bytes(C.byref(g))
+    ws = _ws(nb, x.device)
+    dwp = torch.empty((ks[0], ks[1], kp, ks[2], cp), device=x.device, dtype=torch.float32)
+    _lib.check(lib.wdno_conv_wgrad(_p(x), _p(dy), _p(dwp), _p(ws), nb, C.byref(g), _stream()), 'conv_wgrad')
+    return dwp
+
+
+def conv_transpose_raw(x, wt, bias_p, cout_p):
+    """(1,4,4)/(1,2,2)/(0,1,1) transposed convolution as 4 parity-class stride-1 convolutions.
+    x CL [N,D,H,W,Cin_p] -> y CL [N,D,2H,2W,Cout_p]"""
+    n, d, h, w, cp = x.shape
+    y = torch.empty((n, d, 2 * h, 2 * w, cout_p), device=x.device, dtype=torch.float32)
+    lib = _lib_()
+    for py in range(2):
+        for px in range(2):
+            g = _geom((n, d, h, w), cp, cout_p, (1, 2, 2), (1, 1, 1), (0, 1 - py, 1 - px), (d, h, w),
+                      y_sp=(d, 2 * h, 2 * w), ostride=(1, 2, 2), ooff=(0, py, px))
+            _lib.check(lib.wdno_conv_fwd(_p(x), _p(wt[py, px]), _p(bias_p), None, _p(y), C.byref(g), _stream()), 'conv_transpose')
+    return y
+
+
+def colsum(x2d):
+    p, c = x2d.shape
+    lib = _lib_()
+    nb = lib.wdno_colsum_ws_bytes(p, c)
+    ws = _ws(nb, x2d.device)
+    out = torch.empty((c,), device=x2d.device, dtype=torch.float32)
+    _lib.check(lib.wdno_colsum(_p(x2d), _p(out), p, c, _p(ws), nb, _stream()), 'colsum')
+    return out
+
+
+def _pad_vec(v, n):
+    if v is None or v.shape[0] == n:
+        return v
+    out = v.new_zeros((n,))
+    out[:v.shape[0]] = v
+    return out
+
+
+class _Conv(torch.autograd.Function):
+    """y = conv(x, weight) + bias (+ residual). weight in the reference layout [K, C, (kd,) (kh, kw)] or [K, C]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, padding):
+        x = _chk(x, 'x')
+        lead = None
+        if x.dim() != 5:       # [P, C] rows (nn.Linear) or [N, H, W, C]
+            lead = x.shape[:-1]
+            x5 = x.reshape(1, 1, 1, -1, x.shape[-1]) if x.dim() != 4 else x.unsqueeze(1)
+        else:
+            x5 = x
+        w5 = _as5(weight)
+        k, c = w5.shape[0], w5.shape[1]
+        cp, kp = x5.shape[-1], pad4(k)
+        assert cp == pad4(c), f'channel mismatch: tensor has {cp}, weight expects {c}'
+        ks = tuple(w5.shape[2:])
+        wp = pack_fwd(weight, cp, kp)
+        with torch.no_grad():
+            bias_p = _pad_vec(bias.detach() if bias is not None else None, kp)
+        res5 = None
+        if residual is not None:
+            residual = _chk(residual, 'residual')
+            res5 = residual
+        y = conv_fwd_raw(x5, wp, bias_p, res5, ks, stride, padding, kp)
+        ctx.save_for_backward(x5, weight)
+        ctx.meta = (ks, stride, padding, k, c, cp, kp, bias is not None, residual is not None, lead, x.dim())
+        if lead is not None:
+            y = y.reshape(*lead, kp) if x.dim() != 4 else y.squeeze(1)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x5, weight = ctx.saved_tensors
+        ks, stride, padding, k, c, cp, kp, has_bias, has_res, lead, xdim = ctx.meta
+        gy = _chk(gy, 'grad')
+        n, d, h, w, _ = x5.shape
+        osp = tuple(_out_size(a, kk, s, p) for a, kk, s, p in zip((d, h, w), ks, stride, padding))
+        gy5 = gy.reshape(n, *osp, kp)
+        gx = gw = gb = gr = None
+        if ctx.needs_input_grad[0]:
+            if stride == (1, 1, 1):
+                wd = pack_dgrad(weight, cp, kp)
+                pd = tuple(kk - 1 - p for kk, p in zip(ks, padding))
+                gx5 = conv_fwd_raw(gy5, wd, None, None, ks, (1, 1, 1), pd, cp)
+            elif ks == (1, 4, 4) and stride == (1, 2, 2) and padding == (0, 1, 1):
+                wt = pack_transposed(_as5(weight), kp, cp)      # "in" = K (dy channels), "out" = C
+                gx5 = conv_transpose_raw(gy5, wt, None, cp)
+            elif ks == (1, 2, 2) and stride == (1, 2, 2) and padding == (0, 0, 0):
+                # non-overlapping patches (Burgers Downsample2d folded into a 2x2/s2 conv): each input pixel has one tap
+                gx5 = _patch2_dgrad(gy5, weight, cp, kp)
+            else:
+                raise RuntimeError(f'wdno_amd: unsupported convolution geometry for dgrad {ks} {stride} {padding}')
+            gx = gx5
+            if lead is not None:
+                gx = gx5.reshape(*lead, cp) if xdim != 4 else gx5.squeeze(1)
+        if ctx.needs_input_grad[1]:
+            dwp = conv_wgrad_raw(x5, gy5, ks, stride, padding)
+            gw = dwp[:, :, :k, :, :c].permute(2, 4, 0, 1, 3).reshape(weight.shape).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(gy5.reshape(-1, kp))[:k].contiguous()
+        if has_res and ctx.needs_input_grad[3]:
+            gr = gy
+        return gx, gw, gb, gr, None, None
+
+
+def _patch2_dgrad(gy5, weight, cp, kp):
+    """dgrad of a (1,2,2)/s(1,2,2)/p0 conv: four 1x1 convolutions scattered to the four pixel parities."""
+    n, d, oh, ow, _ = gy5.shape
+    w5 = _as5(weight)
+    gx = torch.empty((n, d, 2 * oh, 2 * ow, cp), device=gy5.device, dtype=torch.float32)
+    lib = _lib_()
+
+    def build():
+        wz = _padded(w5.detach(), kp, cp)           # [Kp, Cp, 1, 2, 2]
+        return wz.permute(3, 4, 1, 0, 2).reshape(2, 2, cp, kp)   # [py][px][C][K]
+    wq = _cached(weight, 'p2', cp, kp, build)
+    for py in range(2):
+        for px in range(2):
+            g = _geom((n, d, oh, ow), kp, cp, (1, 1, 1), (1, 1, 1), (0, 0, 0), (d, oh, ow),
+                      y_sp=(d, 2 * oh, 2 * ow), ostride=(1, 2, 2), ooff=(0, py, px))
+            _lib.check(lib.wdno_conv_fwd(_p(gy5), _p(wq[py, px]), None, None, _p(gx), C.byref(g), _stream()), 'patch2_dgrad')
+    return gx
+
+
+def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None):
+    """Channels-last convolution / linear layer with the reference's weight layout.
+
+    x: [N, D, H, W, Cp] or [N, H, W, Cp] with a conv weight [K, C, (kd,) kh, kw]; any [..., Cp] with a 2-D
+    (nn.Linear) or 1x1 weight. stride / padding follow torch.nn conventions for the weight's rank."""
+    nd = weight.dim() - 2
+
+    def trip(v, fill):
+        if nd == 0:
+            return (fill,) * 3
+        v = (v,) * nd if isinstance(v, int) else tuple(v)
+        return (fill,) * (3 - nd) + v
+    return _Conv.apply(x, weight, bias, residual, trip(stride, 1), trip(padding, 0) if nd else (0, 0, 0))
+
+
+class _ConvT(torch.autograd.Function):
+    """nn.ConvTranspose3d(dim, dim, (1,4,4), (1,2,2), (0,1,1)) on CL tensors; weight [in, out, 1, 4, 4]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _chk(x, 'x')
+        cin, cout = weight.shape[0], weight.shape[1]
+        cin_p, cout_p = x.shape[-1], pad4(cout)
+        assert cin_p == pad4(cin) and tuple(weight.shape[2:]) == (1, 4, 4)
+        wt = pack_transposed(weight, cin_p, cout_p)
+        with torch.no_grad():
+            bias_p = _pad_vec(bias.detach() if bias is not None else None, cout_p)
+        y = conv_transpose_raw(x, wt, bias_p, cout_p)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (cin, cout, cin_p, cout_p, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        cin, cout, cin_p, cout_p, has_bias = ctx.meta
+        gy = _chk(gy, 'grad')
+        ks, st, pd = (1, 4, 4), (1, 2, 2), (0, 1, 1)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # dx = conv_s2(dy, W) with W read as a conv weight [K' = in, C' = out, 1, 4, 4]
+            wp = pack_fwd(weight, cout_p, cin_p)
+            gx = conv_fwd_raw(gy, wp, None, None, ks, st, pd, cin_p)
+        if ctx.needs_input_grad[1]:
+            dwp = conv_wgrad_raw(gy, x, ks, st, pd)              # [1, 4, Cin_p, 4, Cout_p]
+            gw = dwp[:, :, :cin, :, :cout].permute(2, 4, 0, 1, 3).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(gy.reshape(-1, cout_p))[:cout].contiguous()
+        return gx, gw, gb
+
+
+def conv_transpose_cl(x, weight, bias=None):
+    return _ConvT.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------------------------------- normalisation
+class _GroupNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, groups, act_silu, eps):
+        x = _chk(x, 'x')
+        n, c = x.shape[0], x.shape[-1]
+        s = x.numel() // (n * c)
+        lib = _lib_()
+        nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
+        ws = _ws(nb, x.device)
+        y = torch.empty_like(x)
+        stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
+        ssc = None if ss is None else _chk(ss, 'scale_shift')
+        _lib.check(lib.wdno_groupnorm_act_fwd(_p(x), _p(gamma), _p(beta), _p(ssc), _p(y), _p(stats), n, s, c, groups,
+                                              float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
+        ctx.save_for_backward(x, gamma, beta, ssc, stats)
+        ctx.meta = (n, s, c, groups, int(act_silu))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, ss, stats = ctx.saved_tensors
+        n, s, c, groups, act_silu = ctx.meta
+        gy = _chk(gy, 'grad')
+        lib = _lib_()
+        nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
+        ws = _ws(nb, x.device)
+        dx = torch.empty_like(x)
+        dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
+        dss = None if ss is None else torch.empty_like(ss)
+        _lib.check(lib.wdno_groupnorm_act_bwd(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(dx), _p(dgb), _p(dss),
+                                              n, s, c, groups, act_silu, _p(ws), nb, _stream()), 'groupnorm_bwd')
+        red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
+        return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None
+
+
+def groupnorm_act(x, gamma, beta, groups, scale_shift=None, act=True, eps=1e-5):
+    """CL GroupNorm -> optional x*(scale+1)+shift with scale_shift [N, 2C] -> optional SiLU."""
+    return _GroupNormAct.apply(x, gamma, beta, scale_shift, groups, act, eps)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, eps):
+        x = _chk(x, 'x')
+        c = x.shape[-1]
+        p = x.numel() // c
+        y = torch.empty_like(x)
+        gf = g.reshape(-1)
+        _lib.check(_lib_().wdno_layernorm_fwd(_p(x), _p(gf), _p(y), p, c, float(eps), _stream()), 'layernorm_fwd')
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g = ctx.saved_tensors
+        gy = _chk(gy, 'grad')
+        c = x.shape[-1]
+        p = x.numel() // c
+        lib = _lib_()
+        nb = lib.wdno_layernorm_bwd_ws_bytes(p, c)
+        ws = _ws(nb, x.device)
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), device=x.device, dtype=torch.float32)
+        _lib.check(lib.wdno_layernorm_bwd(_p(x), _p(g.reshape(-1)), _p(gy), _p(dx), _p(dg), p, c, float(ctx.eps), _p(ws), nb, _stream()),
+                   'layernorm_bwd')
+        return dx, dg.reshape(g.shape), None
+
+
+def layernorm_cl(x, g, eps=1e-5):
+    """Channel LayerNorm over the last (channel) axis of a CL tensor; g is the reference's [1, C, 1, 1(, 1)] gain."""
+    return _LayerNorm.apply(x, g, eps)
+
+
+# ----------------------------------------------------------------------------------------------------- attention
+class _Attn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bias, rot_cos, rot_sin, desc_args, scale):
+        qkv = _chk(qkv, 'qkv')
+        heads = desc_args[3]
+        out = torch.empty((*qkv.shape[:-1], heads * 32), device=qkv.device, dtype=torch.float32)
+        d = AttnDesc(*desc_args)
+        bc = None if bias is None else _chk(bias, 'bias')
+        _lib.check(_lib_().wdno_attn_fwd(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bc), _p(out), C.byref(d), float(scale), _stream()), 'attn_fwd')
+        ctx.save_for_backward(qkv, bc, rot_cos, rot_sin)
+        ctx.meta = (desc_args, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, bias, rot_cos, rot_sin = ctx.saved_tensors
+        desc_args, scale = ctx.meta
+        go = _chk(go, 'grad')
+        dqkv = torch.empty_like(qkv)
+        dbias = None
+        if bias is not None and ctx.needs_input_grad[1]:
+            dbias = torch.zeros_like(bias)
+        d = AttnDesc(*desc_args)
+        _lib.check(_lib_().wdno_attn_bwd(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(go), _p(dqkv), _p(dbias), C.byref(d),
+                                         float(scale), _stream()), 'attn_bwd')
+        return dqkv, dbias, None, None, None, None
+
+
+def softmax_attention(qkv, heads, n_uo, n_ui, n_tok, so, si, st, scale, bias=None, rot=None):
+    """qkv rows [R, 3*heads*32]; unit (uo, ui), token j -> row uo*so + ui*si + j*st. Returns [R, heads*32]."""
+    rc, rs = (None, None) if rot is None else rot
+    return _Attn.apply(qkv, bias, rc, rs, (n_uo, n_ui, n_tok, heads, so, si, st), scale)
+
+
+class _LinAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, units, n_tok, heads, scale):
+        qkv = _chk(qkv, 'qkv')
+        hd = heads * 32
+        out = torch.empty((*qkv.shape[:-1], hd), device=qkv.device, dtype=torch.float32)
+        kstats = torch.empty((units, hd, 2), device=qkv.device, dtype=torch.float32)
+        cx = torch.empty((units, heads, 32, 32), device=qkv.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_linattn_fwd(_p(qkv), _p(out), _p(kstats), _p(cx), units, n_tok, heads, float(scale), _stream()), 'linattn_fwd')
+        ctx.save_for_backward(qkv, kstats, cx)
+        ctx.meta = (units, n_tok, heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, kstats, cx = ctx.saved_tensors
+        units, n_tok, heads, scale = ctx.meta
+        go = _chk(go, 'grad')
+        lib = _lib_()
+        nb = lib.wdno_linattn_ws_bytes(units, heads)
+        ws = _ws(nb, qkv.device)
+        dqkv = torch.empty_like(qkv)
+        _lib.check(lib.wdno_linattn_bwd(_p(qkv), _p(go), _p(kstats), _p(cx), _p(dqkv), _p(ws), nb, units, n_tok, heads, float(scale), _stream()),
+                   'linattn_bwd')
+        return dqkv, None, None, None, None
+
+
+def linear_attention(qkv, units, n_tok, heads, scale):
+    """qkv [units*n_tok, 3*heads*32] (contiguous units) -> [units*n_tok, heads*32]."""
+    return _LinAttn.apply(qkv, units, n_tok, heads, scale)
+
+
+_rot_cache = {}
+
+
+def rotary_tables(freqs, n):
+    """cos/sin tables [n, 32] for interleaved-pair rotary embedding (rotary_embedding_torch semantics)."""
+    key = (freqs.data_ptr(), freqs._version, n, str(freqs.device))
+    hit = _rot_cache.get(key)
+    if hit is None:
+        with torch.no_grad():
+            ang = (torch.arange(n, device=freqs.device, dtype=freqs.dtype)[:, None] * freqs[None, :]).repeat_interleave(2, dim=-1)
+            hit = (ang.cos().contiguous(), ang.sin().contiguous())
+        _rot_cache.clear()
+        _rot_cache[key] = hit
+    return hit
+
+
+# ----------------------------------------------------------------------------------------------------- wavelets
+def _dwt_desc(nd, mode, L, n_img, in_dims, out_dims, cs):
+    d = DwtDesc()
+    d.nd, d.mode, d.L, d.n_img = nd, mode, L, n_img
+    for i in range(3):
+        d.in_dims[i] = in_dims[i]
+        d.out_dims[i] = out_dims[i]
+    d.cs_img, d.cs_band, d.cs0, d.cs1 = cs
+    return d
+
+
+def dwt_call(kind, src, dst, nd, mode, filters, n_img, in_dims, out_dims, cs):
+    """kind in {'fwd','inv','fwd_adjoint','inv_adjoint'}; filters = 4*L python floats (dec_lo, dec_hi, rec_lo, rec_hi)."""
+    lib = _lib_()
+    L = len(filters) // 4
+    d = _dwt_desc(nd, mode, L, n_img, in_dims, out_dims, cs)
+    nb = lib.wdno_dwt_ws_bytes(C.byref(d))
+    ws = _ws(nb, src.device)
+    fl = (C.c_float * len(filters))(*filters)
+    fn = getattr(lib, 'wdno_dwt_' + kind)
+    _lib.check(fn(_p(src), _p(dst), C.byref(d), fl, _p(ws), nb, _stream()), 'dwt_' + kind)
+
+
+def upsample_coef_raw(x, outer, a, mid, b, c, fa, fb, fc):
+    x = _chk(x, 'coef')
+    out = torch.empty((outer * a * fa * mid * b * fb * c * fc,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib_().wdno_upsample_coef(_p(x), _p(out), outer, a, mid, b, c, fa, fb, fc, _stream()), 'upsample_coef')
+    return out

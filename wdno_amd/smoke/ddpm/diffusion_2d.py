@@ -1,0 +1,296 @@
+"""GaussianDiffusion (smoke, 3-D wavelet-coefficient videos) on MI355X -- drop-in for smoke/ddpm/diffusion_2d.py:568-1058.
+
+Same constructor signature, attributes, buffer names and method surface (forward / p_losses / q_sample / p_sample /
+p_sample_loop / ddim_sample / sample / model_predictions) as the reference. What changed is *how* a step runs:
+
+  training : one fused launch builds the noisy state, imposes every conditioning overwrite (init density, control
+             channels, zero padding, low-resolution channels) and produces the masked noise target
+             (diffusion_2d.py:1003-1033); the U-Net runs on HIP kernels; one fused launch reduces the loss.
+  sampling : per step, one launch for the posterior / DDIM update and one for re-imposing the conditions, instead of
+             ~20 indexed assignments and ~10 broadcast arithmetic ops.
+
+Only the wavelet parametrisation (is_wavelet=True) is implemented: that is the WDNO path (train_2d.py:104-121).
+All draws go through `self.sample_noise`, so tests can inject the exact noise the reference consumed.
+"""
+import math
+from collections import namedtuple
+
+import torch
+from torch import nn
+
+from wdno_amd import diffusion_core as K
+
+ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def identity(t, *args, **kwargs):
+    return t
+
+
+def extract(a, t, x_shape):
+    b, *_ = t.shape
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+linear_beta_schedule = K.linear_beta_schedule
+cosine_beta_schedule = K.cosine_beta_schedule
+sigmoid_beta_schedule = K.sigmoid_beta_schedule
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(
+        self,
+        model,
+        loss_layer_weight,
+        is_condition_control,
+        is_condition_pad,
+        is_wavelet,
+        is_super_model,
+        wave_type,
+        pad_mode,
+        padded_shape,
+        ori_shape,
+        *,
+        image_size,
+        frames,
+        timesteps=1000,
+        sampling_timesteps=None,
+        loss_type='l2',
+        beta_schedule='sigmoid',
+        schedule_fn_kwargs=dict(),
+        ddim_sampling_eta=0.,
+        min_snr_loss_weight=False,
+        min_snr_gamma=5,
+        standard_fixed_ratio=0.01,
+        coeff_ratio=0.1,
+    ):
+        super().__init__()
+        if not is_wavelet:
+            raise NotImplementedError('wdno_amd implements the wavelet parametrisation only (is_wavelet=True)')
+        if loss_type != 'l2':
+            raise NotImplementedError("only loss_type='l2' is used on the WDNO path (train_2d.py:119)")
+        self.model = model
+        self.loss_layer_weight = loss_layer_weight
+        self.is_condition_control = is_condition_control
+        self.is_condition_pad = is_condition_pad
+        self.channels = self.model.channels
+        self.self_condition = self.model.self_condition
+        self.image_size = image_size
+        self.frames = frames
+        self.is_wavelet = is_wavelet
+        self.is_super_model = is_super_model
+        self.wave_type = wave_type
+        self.pad_mode = pad_mode
+        self.padded_shape = padded_shape
+        self.ori_shape = ori_shape
+        self.standard_fixed_ratio = standard_fixed_ratio
+        self.coeff_ratio = coeff_ratio
+        self.loss_type = loss_type
+
+        if beta_schedule == 'linear':
+            fn = linear_beta_schedule
+        elif beta_schedule == 'cosine':
+            fn = cosine_beta_schedule
+        elif beta_schedule == 'sigmoid':
+            fn = sigmoid_beta_schedule
+        else:
+            raise ValueError(f'unknown beta schedule {beta_schedule}')
+        betas = fn(timesteps, **schedule_fn_kwargs)
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.sampling_timesteps = default(sampling_timesteps, timesteps)
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+
+        def loss_weight(snr):
+            clipped = snr.clone()
+            if min_snr_loss_weight:
+                clipped.clamp_(max=min_snr_gamma)
+            return clipped / snr
+        K.register_schedule(self, betas, loss_weight)
+        self._ac_host = self.alphas_cumprod.clone()      # host copy for the scalar DDIM coefficients
+        self._lw_cache = None
+
+    # ------------------------------------------------------------------ helpers
+    def _coef_shape(self, shape, N_upsample=None):
+        b, f, c, h, w = shape
+        if not self.is_super_model:
+            return self.padded_shape
+        if N_upsample is None:      # training: infer the level from the tensor size (diffusion_2d.py:990-996)
+            N_upsample = int(math.log2(40 / w)) if self.is_condition_control else int(math.log2(24 / f))
+        ps = self.padded_shape[N_upsample]
+        if self.is_condition_control:
+            return [ps[0], ps[1] + 2, ps[2] + 2]
+        return [ps[0] + 2, ps[1], ps[2]]
+
+    def _desc(self, shape, coef_shape):
+        return K.cond_desc(0, shape, coef_shape, self.is_condition_pad, self.is_condition_control, 0, 0, self.is_super_model)
+
+    def _loss_weights(self, b, c, device):
+        lw = self.loss_layer_weight
+        key = (id(lw), c, b, str(device))
+        if self._lw_cache is None or self._lw_cache[0] != key:
+            mean = float(torch.as_tensor(lw, dtype=torch.float32).mean()) if lw is not None else 1.0
+            wc = torch.full((c,), mean, device=device, dtype=torch.float32)
+            wb = torch.ones((b,), device=device, dtype=torch.float32)
+            self._lw_cache = (key, wc, wb)
+        return self._lw_cache[1], self._lw_cache[2]
+
+    # ------------------------------------------------------------------ closed-form pieces (API parity; thin torch glue)
+    def predict_start_from_noise(self, x_t, t, noise):
+        return extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
+        return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    def sample_noise(self, shape, device):
+        return torch.randn(shape, device=device)
+
+    # ------------------------------------------------------------------ sampling
+    def model_predictions(self, shape, x, t, x_self_cond=None, clip_x_start=False, rederive_pred_noise=False, design_fn=None,
+                          design_guidance='standard', low=None, init=None, init_u=None):
+        pred_noise = self.model(x, t, x_self_cond)
+        maybe_clip = (lambda v: v.clamp(-1., 1.)) if clip_x_start else identity
+        x_start = maybe_clip(self.predict_start_from_noise(x, t, pred_noise))
+        if design_fn is not None:       # guidance hook (inference_2d.py:30-66): user callback under autograd
+            with torch.enable_grad():
+                x_clone = x_start.clone().detach().requires_grad_()
+                g = design_fn(x_clone, low=low, init=init, init_u=init_u)
+            if design_guidance == 'standard':
+                grad_final = self.standard_fixed_ratio * g
+            elif design_guidance == 'standard-alpha':
+                grad_final = extract(self.coeff_ratio * self.betas.clone().flip(0), t, x.shape) * g
+            else:
+                raise ValueError(design_guidance)
+            pred_noise = pred_noise + grad_final
+            x_start = maybe_clip(self.predict_start_from_noise(x, t, pred_noise))
+        if clip_x_start and rederive_pred_noise:
+            pred_noise = self.predict_noise_from_start(x, t, x_start)
+        return ModelPrediction(pred_noise, x_start)
+
+    def p_mean_variance(self, shape, x, t, x_self_cond=None, clip_denoised=True, **kw):
+        preds = self.model_predictions(shape, x, t, x_self_cond, **kw)
+        x_start = preds.pred_x_start
+        if clip_denoised:
+            x_start = x_start.clamp(-1., 1.)
+        mean, var, logvar = self.q_posterior(x_start=x_start, x_t=x, t=t)
+        return mean, var, logvar, x_start
+
+    @torch.no_grad()
+    def p_sample(self, shape, x, t: int, x_self_cond=None, clip_denoised=True, design_fn=None, design_guidance='standard',
+                 low=None, init=None, init_u=None):
+        b, device = x.shape[0], x.device
+        bt = torch.full((b,), t, device=device, dtype=torch.long)
+        noise = self.sample_noise(tuple(x.shape), device) if t > 0 else None
+        if design_fn is None:
+            eps = self.model(x, bt, x_self_cond)
+            return K.p_sample_update(self, x, eps, noise, bt, clamp=clip_denoised)
+        mean, _, logvar, x_start = self.p_mean_variance(shape, x=x, t=bt, x_self_cond=x_self_cond, clip_denoised=clip_denoised,
+                                                        design_fn=design_fn, design_guidance=design_guidance, low=low, init=init, init_u=init_u)
+        pred = mean if noise is None else mean + (0.5 * logvar).exp() * noise
+        return pred, x_start
+
+    def _condition_source(self, shape, device, init, control, low):
+        """Clean values for every conditioned position, assembled once per sampling call."""
+        src = torch.zeros(shape, device=device, dtype=torch.float32)
+        assert init is not None
+        src[:, :, -2] = init.to(device)
+        if self.is_condition_control:
+            src[:, :, 24:40] = control.to(device)
+        if self.is_super_model:
+            src[:, :, 40:80] = low.to(device)
+        return src
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, N_upsample=0, design_fn=None, design_guidance='standard', return_all_timesteps=None, init=None,
+                      init_u=None, control=None, low=None, device=None):
+        device = self.betas.device
+        shape = tuple(shape)
+        desc = self._desc(shape, self._coef_shape(shape, N_upsample))
+        src = self._condition_source(shape, device, init, control, low)
+        x = K.apply_cond(self.sample_noise(list(shape), device).contiguous(), src, desc)
+        x_start = None
+        for t in reversed(range(0, self.num_timesteps)):
+            self_cond = x_start if self.self_condition else None
+            x, x_start = self.p_sample(shape, x, t, self_cond, design_fn=design_fn, design_guidance=design_guidance, low=low, init=init, init_u=init_u)
+            x = K.apply_cond(x.contiguous(), src, desc)
+        return x
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, N_upsample=0, design_fn=None, design_guidance='standard', init=None, init_u=None, control=None,
+                    low=None, device=None):
+        device, eta = self.betas.device, self.ddim_sampling_eta
+        shape = tuple(shape)
+        batch = shape[0]
+        desc = self._desc(shape, self._coef_shape(shape, N_upsample))
+        src = self._condition_source(shape, device, init, control, low)
+        img = K.apply_cond(self.sample_noise(shape, device).contiguous(), src, desc)
+        x_start = None
+        for time, time_next in K.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps):
+            tc = torch.full((batch,), time, device=device, dtype=torch.long)
+            self_cond = x_start if self.self_condition else None
+            last = time_next < 0
+            if design_fn is None:
+                eps = self.model(img, tc, self_cond)
+                if last:
+                    img, x_start = K.ddim_update(self, img, eps, None, tc, 0., 0., 0.)
+                    continue
+                sigma, c, sqrt_an = K.ddim_coefficients(self._ac_host, time, time_next, eta)
+                img, x_start = K.ddim_update(self, img, eps, self.sample_noise(shape, device), tc, sqrt_an, c, sigma)
+            else:
+                pred_noise, x_start = self.model_predictions(shape, img, tc, self_cond, clip_x_start=True, rederive_pred_noise=True,
+                                                             design_fn=design_fn, design_guidance=design_guidance, init=init, init_u=init_u, low=low)
+                if last:
+                    img = x_start
+                    continue
+                sigma, c, sqrt_an = K.ddim_coefficients(self._ac_host, time, time_next, eta)
+                img = x_start * sqrt_an + c * pred_noise + sigma * self.sample_noise(shape, device)
+            img = K.apply_cond(img.contiguous(), src, desc)
+        return img
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, N_upsample=0, design_fn=None, design_guidance='standard', init=None, init_u=None, control=None,
+               low=None, device=None):
+        assert batch_size == init.shape[0]
+        if not self.is_super_model:
+            size = (batch_size, self.frames, self.channels, self.image_size, self.image_size)
+        else:
+            size = (batch_size, low.shape[1], self.channels, low.shape[-2], low.shape[-1])
+        fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        return fn(size, N_upsample, design_fn, design_guidance, init=init, init_u=init_u, control=control, low=low, device=device)
+
+    # ------------------------------------------------------------------ training
+    def q_sample(self, x_start, t, noise=None):
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        x, _ = K.q_sample_cond(x_start, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, K.plain_desc(x_start))
+        return x
+
+    def p_losses(self, state_start, t, noise=None):
+        b, f, c, h, w = state_start.shape
+        noise = default(noise, lambda: self.sample_noise(tuple(state_start.shape), state_start.device))
+        desc = self._desc(tuple(state_start.shape), self._coef_shape(state_start.shape))
+        state, target = K.q_sample_cond(state_start, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, desc)
+        model_out = self.model(state, t, None)
+        wc, wb = self._loss_weights(b, c, state.device)
+        # reference: mse(mean) * loss_layer_weight[1,1,C,1,1] -> .mean()  ==  mse * mean(loss_layer_weight)
+        return K.weighted_mse(model_out, target, wc, wb, c, h * w)
+
+    def forward(self, state, *args, **kwargs):
+        b, device = state.shape[0], state.device
+        t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
+        return self.p_losses(state, t, *args, **kwargs)
