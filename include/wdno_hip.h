@@ -152,8 +152,9 @@ int wdno_linattn_bwd(const float* qkv, const float* dout, const float* kstats, c
 int wdno_act_fwd(const float* x, float* y, int64_t n, int act, wdno_stream_t s);
 int wdno_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, wdno_stream_t s);
 int wdno_add(const float* a, const float* b, float* out, int64_t n, wdno_stream_t s);
-/* out[b, :] = cat(sin(t_b f_k), cos(t_b f_k)), f_k = exp(-k ln(theta)/(dim/2-1))  (unet.py:88-96, conv3d.py:144-151) */
-int wdno_sinusoidal_emb(const int64_t* t, float* out, int B, int dim, float theta, wdno_stream_t s);
+/* out[b, :] = cat(sin(t_b f_k), cos(t_b f_k)); freqs[dim/2] = exp(-k ln(theta)/(dim/2-1)) is a device table built by
+ * the caller with the reference's own host arithmetic (unet.py:88-96, conv3d.py:144-151) */
+int wdno_sinusoidal_emb(const int64_t* t, const float* freqs, float* out, int B, int dim, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ diffusion operator
  * All tensors in the reference's API layout: smoke [B, F, C, H, W]; Burgers [B, C, H, W] (F = 1).

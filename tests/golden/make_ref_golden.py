@@ -96,7 +96,7 @@ def randomise(model, gen, scale=0.05):
 
 
 def sd_np(model, prefix='w::'):
-    return {prefix + k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    return {prefix + k: v.detach().cpu().clone().numpy() for k, v in model.state_dict().items()}
 
 
 def grads_np(model, prefix='g::', full_below=6000):

@@ -107,7 +107,9 @@ def test_smoke_sampling(trees):
         nz = torch.from_numpy(gz[f'psample_{tt}_noise']).to(DEV)
         dif.sample_noise = lambda shape, device, _n=nz: _n
         pred, xs = dif.p_sample(tuple(xt.shape), xt.clone(), tt)
-        assert rel_l2(pred, gz[f'psample_{tt}_pred']) < TOL and rel_l2(xs, gz[f'psample_{tt}_xstart']) < TOL
+        # x_start = c1 x - c2 eps_hat multiplies the U-Net's fp32 round-off by c2 = sqrt(1/ac_t - 1) (~1e2 near t = T)
+        amp = max(1.0, float(dif.sqrt_recipm1_alphas_cumprod[tt]))
+        assert rel_l2(pred, gz[f'psample_{tt}_pred']) < TOL and rel_l2(xs, gz[f'psample_{tt}_xstart']) < TOL * amp, (tt, amp)
     init, control = torch.from_numpy(gz['ddim_init']).to(DEV), torch.from_numpy(gz['ddim_control']).to(DEV)
     seq = iter([n.to(DEV) for n in noise_seq(gz, 'ddim')])
     dif.sample_noise = lambda shape, device: next(seq)

@@ -363,8 +363,10 @@ def test_dwt_vs_oracle_and_adjoints(ops, nd, mode, wave, shape):
         lo, hi = R.dwt1d(xn[:, None], wave, mode)
         ref = np.stack([lo[:, 0], hi[:, 0]], axis=1)
     elif nd == 2:
-        yl, yh = R.dwt2(xn[:, None], wave, mode)
-        ref = np.concatenate([yl[:, :, None], yh], axis=2)[:, 0]
+        x4 = xn if xn.ndim == 4 else xn[:, None]
+        yl, yh = R.dwt2(x4, wave, mode)
+        ref = np.concatenate([yl[:, :, None], yh], axis=2)
+        ref = ref if xn.ndim == 4 else ref[:, 0]
     else:
         lll, det = R.dwt3(xn, wave, mode)
         ref = R.smoke_coef_to_tensor(lll, det)

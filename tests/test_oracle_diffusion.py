@@ -100,3 +100,27 @@ def test_burgers_sampling():
         assert rel_l2(out, g['ddim_out']) < 1e-5
         out = D.burgers_p_sample_loop(model, D.make_buffers('cosine', 5), noise_seq(g, 'ddpm5'), 5, **kw)
         assert rel_l2(out, g['ddpm5_out']) < 1e-5
+
+
+def test_three_optimizer_steps_oracle_vs_reference():
+    """T1 row: the oracle p_losses + torch Adam/clip/cosine schedule reproduces the reference's 3-step trajectory."""
+    g = load_npz('ref_train_burgers.npz')
+    c = M['train_burgers']
+    sd = weights(g, 'w0::model.', requires_grad=True)
+    params = [v for v in sd.values() if v.requires_grad]
+    u = c['unet']
+    model = lambda x, t: U.unet2d_forward(sd, x, t, dim=u['dim'], dim_mults=tuple(u['dim_mults']), groups=u['resnet_block_groups'])
+    buf = D.make_buffers('cosine', 1000)
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99))
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10000)
+    for step in range(3):
+        x0, t, noise = (torch.from_numpy(g[f's{step}_{k}']) for k in ('x0', 't', 'noise'))
+        loss = D.burgers_p_losses(model, buf, x0, t, noise, padded_shape=c['padded_shape'], loss_layer_weight=torch.ones(1, 9, 1, 1),
+                                  flags=dict(pad=True, u0=True, f=True))
+        opt.zero_grad()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step(); sch.step()
+        assert abs(loss.item() - float(g[f's{step}_loss'])) < 1e-5 * abs(float(g[f's{step}_loss']))
+        assert abs(gn.item() - float(g[f's{step}_gnorm'])) < 1e-4 * float(g[f's{step}_gnorm'])
+    assert not np.array_equal(g['w0::model.init_conv.weight'], g['w3::model.init_conv.weight'])

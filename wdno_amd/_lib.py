@@ -6,6 +6,8 @@ raised. Nothing in this package computes on the CPU.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be imported first: libwdno_hip.so has to bind to the HIP runtime instance torch already loaded
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libwdno_hip.so')
 
@@ -74,7 +76,7 @@ PROTOTYPES = {
     'wdno_act_fwd': (I, [P, P, L, I, P]),
     'wdno_act_bwd': (I, [P, P, P, L, I, P]),
     'wdno_add': (I, [P, P, P, L, P]),
-    'wdno_sinusoidal_emb': (I, [P, P, I, I, F, P]),
+    'wdno_sinusoidal_emb': (I, [P, P, P, I, I, P]),
     'wdno_q_sample_cond': (I, [P, P, P, P, P, P, P, PC, P]),
     'wdno_apply_cond': (I, [P, P, PC, P]),
     'wdno_weighted_mse_ws_bytes': (Z, [L]),

@@ -81,22 +81,19 @@ extern "C" int wdno_add(const float* a, const float* b, float* out, int64_t n, w
 }
 
 // ---------------------------------------------------------------------------------------------- time embedding
-__global__ void sinusoidal_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim, float neg_step) {
+__global__ void sinusoidal_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int B, int dim) {
   int half = dim >> 1;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * half) return;
   int b = i / half, k = i - b * half;
-  float f = expf((float)k * neg_step);
-  float a = (float)t[b] * f;
+  float a = (float)t[b] * freqs[k];
   out[(int64_t)b * dim + k] = sinf(a);
   out[(int64_t)b * dim + half + k] = cosf(a);
 }
-extern "C" int wdno_sinusoidal_emb(const int64_t* t, float* out, int B, int dim, float theta, wdno_stream_t s) {
-  WDNO_REQUIRE(B > 0 && dim >= 4 && (dim % 2) == 0 && theta > 1.0f);
-  int half = dim / 2;
-  float neg_step = (float)(-(log((double)theta) / (double)(half - 1)));
-  int n = B * half;
-  sinusoidal_kernel<<<cdiv(n, 128), 128, 0, as_stream(s)>>>(t, out, B, dim, neg_step);
+extern "C" int wdno_sinusoidal_emb(const int64_t* t, const float* freqs, float* out, int B, int dim, wdno_stream_t s) {
+  WDNO_REQUIRE(B > 0 && dim >= 4 && (dim % 2) == 0 && freqs != nullptr);
+  int n = B * (dim / 2);
+  sinusoidal_kernel<<<cdiv(n, 128), 128, 0, as_stream(s)>>>(t, freqs, out, B, dim);
   return wdno_check_launch();
 }
 

@@ -16,6 +16,29 @@ WEIGHT_EPOCH = 0          # bumped by wdno_amd.trainer after every in-place opti
 _pack_cache = {}
 
 
+PROFILE = None            # bench.py sets this to a dict: kernel symbol -> list of (start_event, end_event, flops)
+
+
+class _timed:
+    """Brackets one launch with HIP events on the current stream when bench.py has switched profiling on."""
+
+    def __init__(self, key, flops):
+        self.key, self.flops = key, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.setdefault(self.key, []).append((self.e0, self.e1, self.flops))
+        return False
+
+
 def bump_weight_epoch():
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
@@ -197,13 +220,21 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+_freq_cache = {}
+
+
 def sinusoidal_embedding(t, dim, theta=10000.0):
-    """[B] int64 -> [B, dim] (no gradient: timesteps are integers)."""
+    """[B] int64 -> [B, dim] (no gradient: timesteps are integers). The frequency table is built once on the host
+    with the same torch CPU arithmetic the reference uses, so the fp32 arguments t*f are bit-identical to it."""
     t = t.to(torch.int64).contiguous()
     if not t.is_cuda:
         raise RuntimeError('wdno_amd: timesteps must live on the GPU')
+    key = (dim, float(theta), str(t.device))
+    if key not in _freq_cache:
+        half = dim // 2
+        _freq_cache[key] = torch.exp(torch.arange(half) * -(math.log(theta) / (half - 1))).to(torch.float32).to(t.device)
     out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
-    _lib.check(_lib_().wdno_sinusoidal_emb(_p(t), _p(out), t.shape[0], dim, float(theta), _stream()), 'sinusoidal_emb')
+    _lib.check(_lib_().wdno_sinusoidal_emb(_p(t), _p(_freq_cache[key]), _p(out), t.shape[0], dim, _stream()), 'sinusoidal_emb')
     return out
 
 
@@ -226,14 +257,18 @@ def _as5(w):
 
 
 def _cached(w, kind, cp, kp, build):
-    key = (w.data_ptr(), kind, cp, kp)
-    ver = (w._version, WEIGHT_EPOCH, tuple(w.shape))
+    """Packed-weight cache. The entry keeps a reference to the weight's storage, so its address cannot be recycled by
+    another tensor while the entry is alive (a recycled address with equal shape/version would be a stale hit)."""
+    key = (w.data_ptr(), kind, cp, kp, tuple(w.shape), tuple(w.stride()))
+    ver = (w._version, WEIGHT_EPOCH)
     hit = _pack_cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     with torch.no_grad():
         packed = build().contiguous()
-    _pack_cache[key] = (ver, packed)
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (ver, packed, w.detach())
     return packed
 
 
@@ -283,7 +318,9 @@ def conv_fwd_raw(x, wp, bias_p, residual, ks, st, pd, kp):
     osp = tuple(_out_size(a, k, s, p) for a, k, s, p in zip((d, h, w), ks, st, pd))
     y = torch.empty((n, *osp, kp), device=x.device, dtype=torch.float32)
     g = _geom((n, d, h, w), cp, kp, ks, st, pd, osp)
-    _lib.check(_lib_().wdno_conv_fwd(_p(x), _p(wp), _p(bias_p), _p(residual), _p(y), C.byref(g), _stream()), 'conv_fwd')
+    flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp
+    with _timed('conv_fwd_kernel<128,2,2>' if kp > 64 else 'conv_fwd_kernel<64,4,1>', flops):
+        _lib.check(_lib_().wdno_conv_fwd(_p(x), _p(wp), _p(bias_p), _p(residual), _p(y), C.byref(g), _stream()), 'conv_fwd')
     return y
 
 
@@ -297,7 +334,9 @@ def conv_wgrad_raw(x, dy, ks, st, pd):
     nb = lib.wdno_conv_wgrad_ws_bytes(C.byref(g))
     ws = _ws(nb, x.device)
     dwp = torch.empty((ks[0], ks[1], kp, ks[2], cp), device=x.device, dtype=torch.float32)
-    _lib.check(lib.wdno_conv_wgrad(_p(x), _p(dy), _p(dwp), _p(ws), nb, C.byref(g), _stream()), 'conv_wgrad')
+    flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp
+    with _timed('conv_wgrad_kernel<128,2,2>' if kp > 64 else 'conv_wgrad_kernel<64,1,4>', flops):
+        _lib.check(lib.wdno_conv_wgrad(_p(x), _p(dy), _p(dwp), _p(ws), nb, C.byref(g), _stream()), 'conv_wgrad')
     return dwp
 
 
@@ -627,8 +666,8 @@ def rotary_tables(freqs, n):
             ang = (torch.arange(n, device=freqs.device, dtype=freqs.dtype)[:, None] * freqs[None, :]).repeat_interleave(2, dim=-1)
             hit = (ang.cos().contiguous(), ang.sin().contiguous())
         _rot_cache.clear()
-        _rot_cache[key] = hit
-    return hit
+        _rot_cache[key] = hit + (freqs.detach(),)
+    return hit[0], hit[1]
 
 
 # ----------------------------------------------------------------------------------------------------- wavelets
