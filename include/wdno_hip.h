@@ -136,9 +136,10 @@ typedef struct {
 } wdno_attn_desc;
 int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
                   const wdno_attn_desc* d, float scale, wdno_stream_t s);
-/* dqkv (same layout as qkv), dbias [heads][n][n] accumulated with atomics (must be zeroed by caller) or NULL */
-int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* dout,
-                  float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s);
+/* out = the forward result (saved); dqkv (same layout as qkv); dbias [heads][n][n] accumulated with atomics (zeroed by
+ * the caller) or NULL. n_tok <= 128. */
+int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                  const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s);
 /* Linear attention (unet.py:203-223 ; conv3d.py:241-258): q softmax over the 32 head channels, k softmax over
  * tokens, ctx = k^T v, out = ctx^T q * scale. units x n_tok rows, contiguous. ws holds k statistics and ctx. */
 size_t wdno_linattn_ws_bytes(int64_t units, int heads);

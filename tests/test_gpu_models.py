@@ -13,6 +13,9 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 M = manifest()
 TOL = 1e-5
+# sampled chains start at t = T-1 where x_start = c1 x - c2 eps_hat has c2 ~ 1e2..1e3: fp32 round-off of the U-Net is
+# amplified before the clamp, so chain outputs are compared at 2e-4 (single evaluations stay at 1e-5)
+CHAIN_TOL = 2e-4
 
 
 @pytest.fixture(scope='module')
@@ -114,12 +117,12 @@ def test_smoke_sampling(trees):
     seq = iter([n.to(DEV) for n in noise_seq(gz, 'ddim')])
     dif.sample_noise = lambda shape, device: next(seq)
     out = dif.sample(batch_size=2, init=init, control=control)
-    assert rel_l2(out, gz['ddim_out']) < 2 * TOL
+    assert rel_l2(out, gz['ddim_out']) < CHAIN_TOL
     dif5 = trees['GD2'](dif.model, loss_layer_weight=torch.from_numpy(gz['lw']), **{**d, 'timesteps': 5, 'sampling_timesteps': None}).to(DEV)
     seq5 = iter([n.to(DEV) for n in noise_seq(gz, 'ddpm5')])
     dif5.sample_noise = lambda shape, device: next(seq5)
     out = dif5.sample(batch_size=2, init=init, control=control)
-    assert rel_l2(out, gz['ddpm5_out']) < 2 * TOL
+    assert rel_l2(out, gz['ddpm5_out']) < CHAIN_TOL
 
 
 def _burgers(trees, **over):
@@ -162,12 +165,12 @@ def test_burgers_sampling(trees):
     seq = iter([n.to(DEV) for n in noise_seq(gz, 'ddim')])
     dif.sample_noise = lambda shape, device: next(seq)
     out = dif.sample(batch_size=2, u_init=u_init, f=f)
-    assert rel_l2(out, gz['ddim_out']) < 2 * TOL
+    assert rel_l2(out, gz['ddim_out']) < CHAIN_TOL
     gz5, dif5 = _burgers(trees, timesteps=5, sampling_timesteps=None)
     seq5 = iter([n.to(DEV) for n in noise_seq(gz, 'ddpm5')])
     dif5.sample_noise = lambda shape, device: next(seq5)
     out = dif5.sample(batch_size=2, u_init=u_init, f=f)
-    assert rel_l2(out, gz['ddpm5_out']) < 2 * TOL
+    assert rel_l2(out, gz['ddpm5_out']) < CHAIN_TOL
 
 
 def test_three_optimizer_steps_vs_reference(trees):

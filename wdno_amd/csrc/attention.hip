@@ -14,242 +14,282 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define KST 33
 
 // ================================================================================================ softmax attention
+// One THREAD per (unit, head, query row). The rotated K rows of an item live in LDS (every thread of the item reads the
+// same row -> broadcast ds_read_b128, no conflicts); V rows and dO rows are read straight from global memory as
+// wave-broadcast float4 loads (one cache line per item per load). Scores are recomputed in a second pass instead of
+// being stored (n is 24..400), so the forward needs no per-thread arrays beyond q[32] / out[32].
 struct AttnP {
   wdno_attn_desc d;
   float scale;
   int RW;   // 3*heads*32
   int HD;   // heads*32
+  int ipb;  // items (unit, head) per block
+  int kst;  // LDS floats per item for one [n][32] matrix (padded)
+  int64_t n_items;
 };
 
-__device__ __forceinline__ float rot_fwd(float v, float cs, float sn, int dd) {
-  float partner = __shfl_xor(v, 1, 64);
-  return v * cs + ((dd & 1) ? partner : -partner) * sn;
+#define ATT_THREADS 256
+#define ATT_BWD_THREADS 128
+
+__device__ __forceinline__ void load_row32(const float* __restrict__ p, float* v) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { float4 t = q[e]; v[4 * e] = t.x; v[4 * e + 1] = t.y; v[4 * e + 2] = t.z; v[4 * e + 3] = t.w; }
 }
-__device__ __forceinline__ float rot_bwd(float g, float cs, float sn, int dd) {
-  float partner = __shfl_xor(g, 1, 64);
-  return g * cs + ((dd & 1) ? -partner : partner) * sn;
+__device__ __forceinline__ void store_row32(float* __restrict__ p, const float* v) {
+  float4* q = reinterpret_cast<float4*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) q[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
+}
+// interleaved-pair rotary: (x0, x1) -> (x0 c - x1 s, x1 c + x0 s); inverse = transpose
+__device__ __forceinline__ void rotate32(float* v, const float* __restrict__ cs, const float* __restrict__ sn, bool inverse) {
+  float c[DH], s[DH];
+  load_row32(cs, c);
+  load_row32(sn, s);
+#pragma unroll
+  for (int e = 0; e < DH; e += 2) {
+    float x0 = v[e], x1 = v[e + 1];
+    float s0 = inverse ? -s[e] : s[e], s1 = inverse ? -s[e + 1] : s[e + 1];
+    v[e] = x0 * c[e] - x1 * s0;
+    v[e + 1] = x1 * c[e + 1] + x0 * s1;
+  }
+}
+__device__ __forceinline__ float dot32_lds(const float* q, const float* __restrict__ krow) {
+  const float4* k4 = reinterpret_cast<const float4*>(krow);
+  float a = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float4 t = k4[e];
+    a = fmaf(q[4 * e], t.x, a); a = fmaf(q[4 * e + 1], t.y, a); a = fmaf(q[4 * e + 2], t.z, a); a = fmaf(q[4 * e + 3], t.w, a);
+  }
+  return a;
 }
 
-#define ATT_MAXJ 8   // 64 * 8 = 512 tokens max
-
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
-                                                       const float* __restrict__ rsin, const float* __restrict__ bias,
-                                                       float* __restrict__ out, AttnP p) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+                                                                const float* __restrict__ rsin, const float* __restrict__ bias,
+                                                                float* __restrict__ out, AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = p.d.n_tok;
-  float* Ks = smem;                 // [n][33]
-  float* Vs = Ks + n * KST;         // [n][33]
-  float* Ps = Vs + n * KST;         // [n]
-  float* Qs = Ps + ((n + 3) & ~3);  // [32]
-  const int lane = threadIdx.x, dd = lane & 31, half = lane >> 5;
-  const int h = blockIdx.x % p.d.heads;
-  const int unit = blockIdx.x / p.d.heads;
-  const int uo = unit / p.d.n_ui, ui = unit - uo * p.d.n_ui;
+  const int il = threadIdx.x / n;                 // item slot inside the block (valid when < ipb)
+  const int i0 = threadIdx.x - il * n;            // first row of this thread
+  const int64_t item = (int64_t)blockIdx.x * p.ipb + il;
+  const bool active = il < p.ipb && item < p.n_items;
+  const int h = active ? (int)(item % p.d.heads) : 0;
+  const int64_t unit = active ? item / p.d.heads : 0;
+  const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
   const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
-  for (int j = half; j < n; j += 2) {
-    const float* rp = qkv + (row0 + (int64_t)j * p.d.st) * p.RW + h * DH + dd;
-    float kv = rp[p.HD];
-    if (rcos) kv = rot_fwd(kv, rcos[j * DH + dd], rsin[j * DH + dd], dd);
-    Ks[j * KST + dd] = kv;
-    Vs[j * KST + dd] = rp[2 * p.HD];
+  float* Ks = smem + (active ? il : 0) * p.kst;
+  const int rstep = p.ipb > 1 ? n : ATT_THREADS;  // ipb == 1: threads stride over rows
+  if (active) {
+    for (int j = i0; j < n; j += rstep) {
+      float k[DH];
+      load_row32(qkv + (row0 + (int64_t)j * p.d.st) * p.RW + p.HD + h * DH, k);
+      if (rcos) rotate32(k, rcos + j * DH, rsin + j * DH, false);
+      store_row32(Ks + j * DH, k);
+    }
   }
   __syncthreads();
-  for (int i = 0; i < n; ++i) {
-    float qv = qkv[(row0 + (int64_t)i * p.d.st) * p.RW + h * DH + dd] * p.scale;
-    if (rcos) qv = rot_fwd(qv, rcos[i * DH + dd], rsin[i * DH + dd], dd);
-    if (half == 0) Qs[dd] = qv;
-    __syncthreads();
-    float sreg[ATT_MAXJ];
-    float m = -INFINITY;
+  if (!active) return;
+  for (int i = i0; i < n; i += rstep) {
+    float q[DH];
+    load_row32(qkv + (row0 + (int64_t)i * p.d.st) * p.RW + h * DH, q);
 #pragma unroll
-    for (int jj = 0; jj < ATT_MAXJ; ++jj) {
-      int j = lane + 64 * jj;
-      float sv = -INFINITY;
-      if (j < n) {
-        sv = 0.f;
+    for (int e = 0; e < DH; ++e) q[e] *= p.scale;
+    if (rcos) rotate32(q, rcos + i * DH, rsin + i * DH, false);
+    const float* brow = bias ? bias + ((int64_t)h * n + i) * n : nullptr;
+    float m = -INFINITY, l = 0.f;
+    for (int j = 0; j < n; ++j) {
+      float sv = dot32_lds(q, Ks + j * DH);
+      if (brow) sv += brow[j];
+      float mn = fmaxf(m, sv);
+      l = l * expf(m - mn) + expf(sv - mn);
+      m = mn;
+    }
+    const float inv = 1.0f / l;
+    float o[DH];
 #pragma unroll
-        for (int e = 0; e < DH; ++e) sv = fmaf(Qs[e], Ks[j * KST + e], sv);
-        if (bias) sv += bias[((int64_t)h * n + i) * n + j];
+    for (int e = 0; e < DH; ++e) o[e] = 0.f;
+    for (int j = 0; j < n; ++j) {
+      float sv = dot32_lds(q, Ks + j * DH);
+      if (brow) sv += brow[j];
+      float pj = expf(sv - m) * inv;
+      const float4* v4 = reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)j * p.d.st) * p.RW + 2 * p.HD + h * DH);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float4 t = v4[e];
+        o[4 * e] = fmaf(pj, t.x, o[4 * e]); o[4 * e + 1] = fmaf(pj, t.y, o[4 * e + 1]);
+        o[4 * e + 2] = fmaf(pj, t.z, o[4 * e + 2]); o[4 * e + 3] = fmaf(pj, t.w, o[4 * e + 3]);
       }
-      sreg[jj] = sv;
-      m = fmaxf(m, sv);
     }
-    m = wave_max(m);
-    float l = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < ATT_MAXJ; ++jj) {
-      int j = lane + 64 * jj;
-      float pv = (j < n) ? expf(sreg[jj] - m) : 0.f;
-      sreg[jj] = pv;
-      l += pv;
-    }
-    l = wave_sum(l);
-    float inv = 1.0f / l;
-#pragma unroll
-    for (int jj = 0; jj < ATT_MAXJ; ++jj) {
-      int j = lane + 64 * jj;
-      if (j < n) Ps[j] = sreg[jj] * inv;
-    }
-    __syncthreads();
-    float acc = 0.f;
-    for (int j = half; j < n; j += 2) acc = fmaf(Ps[j], Vs[j * KST + dd], acc);
-    acc += __shfl_xor(acc, 32, 64);
-    if (half == 0) out[(row0 + (int64_t)i * p.d.st) * p.HD + h * DH + dd] = acc;
-    __syncthreads();
+    store_row32(out + (row0 + (int64_t)i * p.d.st) * p.HD + h * DH, o);
   }
 }
 
-// backward: one wavefront per (unit, head) item, grid-strided so that the bias gradient is accumulated in LDS and
-// flushed with one atomic per entry per block.
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
-                                                       const float* __restrict__ rsin, const float* __restrict__ bias,
-                                                       const float* __restrict__ dout, float* __restrict__ dqkv,
-                                                       float* __restrict__ dbias, AttnP p, int units_total) {
+// backward. Phase A (thread = query row i): p_ij, dS_ij, dQ_i ; phase B (thread = key row j): dK_j, dV_j from the P / dS
+// matrices and the rotated Q rows left in LDS. delta_i = <dO_i, O_i> uses the saved forward output.
+__global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+                                                                    const float* __restrict__ rsin, const float* __restrict__ bias,
+                                                                    const float* __restrict__ fout, const float* __restrict__ dout,
+                                                                    float* __restrict__ dqkv, float* __restrict__ dbias, AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = p.d.n_tok;
-  const int nn = n * KST;
-  float* Qs = smem;
-  float* Ks = Qs + nn;
-  float* Vs = Ks + nn;
-  float* Os = Vs + nn;     // dO
-  float* dKs = Os + nn;
-  float* dVs = dKs + nn;
-  float* Ps = dVs + nn;               // [n]
-  float* Ss = Ps + ((n + 3) & ~3);    // dS [n]
-  float* dBs = Ss + ((n + 3) & ~3);   // [n*n] when dbias
-  const int lane = threadIdx.x, dd = lane & 31, half = lane >> 5;
-  const int h = blockIdx.x % p.d.heads;
-  const int ustride = gridDim.x / p.d.heads;
+  const int n = p.d.n_tok, n1 = n + 1;
+  const int item_lds = 2 * p.kst + 2 * n * n1;       // K, Q, P, dS per item
+  float* dBs = smem + p.ipb * item_lds;              // [heads][n][n] when dbias
+  const int il = threadIdx.x / n;
+  const int i = threadIdx.x - il * n;
+  const bool slot_ok = il < p.ipb;
+  float* Ks = smem + (slot_ok ? il : 0) * item_lds;
+  float* Qs = Ks + p.kst;
+  float* Ps = Qs + p.kst;
+  float* Ss = Ps + n * n1;
   if (dbias)
-    for (int e = lane; e < n * n; e += 64) dBs[e] = 0.f;
-  for (int unit = blockIdx.x / p.d.heads; unit < units_total; unit += ustride) {
-    const int uo = unit / p.d.n_ui, ui = unit - uo * p.d.n_ui;
+    for (int e = threadIdx.x; e < p.d.heads * n * n; e += ATT_BWD_THREADS) dBs[e] = 0.f;
+  const int64_t ngroups = (p.n_items + p.ipb - 1) / p.ipb;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t item = grp * p.ipb + il;
+    const bool active = slot_ok && item < p.n_items;
+    const int h = active ? (int)(item % p.d.heads) : 0;
+    const int64_t unit = active ? item / p.d.heads : 0;
+    const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
+    const int64_t row = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si + (int64_t)i * p.d.st;
     const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
-    __syncthreads();
-    for (int j = half; j < n; j += 2) {
-      const int64_t row = row0 + (int64_t)j * p.d.st;
-      const float* rp = qkv + row * p.RW + h * DH + dd;
-      float qv = rp[0] * p.scale, kv = rp[p.HD];
+    float q[DH];
+    __syncthreads();                                  // previous group's phase B is done with the LDS matrices
+    if (active) {
+      float k[DH];
+      load_row32(qkv + row * p.RW + p.HD + h * DH, k);
+      load_row32(qkv + row * p.RW + h * DH, q);
+#pragma unroll
+      for (int e = 0; e < DH; ++e) q[e] *= p.scale;
       if (rcos) {
-        float cs = rcos[j * DH + dd], sn = rsin[j * DH + dd];
-        qv = rot_fwd(qv, cs, sn, dd);
-        kv = rot_fwd(kv, cs, sn, dd);
+        rotate32(k, rcos + i * DH, rsin + i * DH, false);
+        rotate32(q, rcos + i * DH, rsin + i * DH, false);
       }
-      Qs[j * KST + dd] = qv;
-      Ks[j * KST + dd] = kv;
-      Vs[j * KST + dd] = rp[2 * p.HD];
-      Os[j * KST + dd] = dout[row * p.HD + h * DH + dd];
-      dKs[j * KST + dd] = 0.f;
-      dVs[j * KST + dd] = 0.f;
+      store_row32(Ks + i * DH, k);
+      store_row32(Qs + i * DH, q);
     }
     __syncthreads();
-    for (int i = 0; i < n; ++i) {
-      float sreg[ATT_MAXJ], dpreg[ATT_MAXJ];
-      float m = -INFINITY;
+    if (active) {
+      float go[DH], dq[DH];
+      load_row32(dout + row * p.HD + h * DH, go);
+      float delta = 0.f;
+      {
+        const float4* o4 = reinterpret_cast<const float4*>(fout + row * p.HD + h * DH);
 #pragma unroll
-      for (int jj = 0; jj < ATT_MAXJ; ++jj) {
-        int j = lane + 64 * jj;
-        float sv = -INFINITY, dp = 0.f;
-        if (j < n) {
-          sv = 0.f;
-#pragma unroll
-          for (int e = 0; e < DH; ++e) {
-            sv = fmaf(Qs[i * KST + e], Ks[j * KST + e], sv);
-            dp = fmaf(Os[i * KST + e], Vs[j * KST + e], dp);
-          }
-          if (bias) sv += bias[((int64_t)h * n + i) * n + j];
-        }
-        sreg[jj] = sv; dpreg[jj] = dp;
-        m = fmaxf(m, sv);
-      }
-      m = wave_max(m);
-      float l = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < ATT_MAXJ; ++jj) {
-        int j = lane + 64 * jj;
-        float pv = (j < n) ? expf(sreg[jj] - m) : 0.f;
-        sreg[jj] = pv;
-        l += pv;
-      }
-      l = wave_sum(l);
-      float inv = 1.0f / l, delta = 0.f;
-#pragma unroll
-      for (int jj = 0; jj < ATT_MAXJ; ++jj) { sreg[jj] *= inv; delta = fmaf(sreg[jj], dpreg[jj], delta); }
-      delta = wave_sum(delta);
-#pragma unroll
-      for (int jj = 0; jj < ATT_MAXJ; ++jj) {
-        int j = lane + 64 * jj;
-        if (j < n) {
-          float ds = sreg[jj] * (dpreg[jj] - delta);
-          Ps[j] = sreg[jj];
-          Ss[j] = ds;
-          if (dbias) dBs[i * n + j] += ds;
+        for (int e = 0; e < 8; ++e) {
+          float4 t = o4[e];
+          delta = fmaf(go[4 * e], t.x, delta); delta = fmaf(go[4 * e + 1], t.y, delta);
+          delta = fmaf(go[4 * e + 2], t.z, delta); delta = fmaf(go[4 * e + 3], t.w, delta);
         }
       }
-      __syncthreads();
-      float dq = 0.f;
-      const float qi = Qs[i * KST + dd], oi = Os[i * KST + dd];
-      for (int j = half; j < n; j += 2) {
-        float ds = Ss[j], pj = Ps[j];
-        dq = fmaf(ds, Ks[j * KST + dd], dq);
-        dKs[j * KST + dd] = fmaf(ds, qi, dKs[j * KST + dd]);
-        dVs[j * KST + dd] = fmaf(pj, oi, dVs[j * KST + dd]);
+      const float* brow = bias ? bias + ((int64_t)h * n + i) * n : nullptr;
+      float m = -INFINITY, l = 0.f;
+      for (int j = 0; j < n; ++j) {
+        float sv = dot32_lds(q, Ks + j * DH);
+        if (brow) sv += brow[j];
+        float mn = fmaxf(m, sv);
+        l = l * expf(m - mn) + expf(sv - mn);
+        m = mn;
       }
-      dq += __shfl_xor(dq, 32, 64);
-      if (rcos) dq = rot_bwd(dq, rcos[i * DH + dd], rsin[i * DH + dd], dd);
-      if (half == 0) dqkv[(row0 + (int64_t)i * p.d.st) * p.RW + h * DH + dd] = dq * p.scale;
-      __syncthreads();
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int e = 0; e < DH; ++e) dq[e] = 0.f;
+      for (int j = 0; j < n; ++j) {
+        const float4* k4 = reinterpret_cast<const float4*>(Ks + j * DH);
+        const float4* v4 = reinterpret_cast<const float4*>(qkv + (row0 + (int64_t)j * p.d.st) * p.RW + 2 * p.HD + h * DH);
+        float sv = 0.f, dp = 0.f;
+        float4 kk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          kk[e] = k4[e];
+          float4 t = v4[e];
+          sv = fmaf(q[4 * e], kk[e].x, sv); sv = fmaf(q[4 * e + 1], kk[e].y, sv); sv = fmaf(q[4 * e + 2], kk[e].z, sv); sv = fmaf(q[4 * e + 3], kk[e].w, sv);
+          dp = fmaf(go[4 * e], t.x, dp); dp = fmaf(go[4 * e + 1], t.y, dp); dp = fmaf(go[4 * e + 2], t.z, dp); dp = fmaf(go[4 * e + 3], t.w, dp);
+        }
+        if (brow) sv += brow[j];
+        float pj = expf(sv - m) * inv;
+        float ds = pj * (dp - delta);
+        Ps[i * n1 + j] = pj;
+        Ss[i * n1 + j] = ds;
+        if (dbias) atomicAdd(&dBs[(h * n + i) * n + j], ds);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dq[4 * e] = fmaf(ds, kk[e].x, dq[4 * e]); dq[4 * e + 1] = fmaf(ds, kk[e].y, dq[4 * e + 1]);
+          dq[4 * e + 2] = fmaf(ds, kk[e].z, dq[4 * e + 2]); dq[4 * e + 3] = fmaf(ds, kk[e].w, dq[4 * e + 3]);
+        }
+      }
+      if (rcos) rotate32(dq, rcos + i * DH, rsin + i * DH, true);
+#pragma unroll
+      for (int e = 0; e < DH; ++e) dq[e] *= p.scale;
+      store_row32(dqkv + row * p.RW + h * DH, dq);
     }
-    for (int j = half; j < n; j += 2) {
-      const int64_t row = row0 + (int64_t)j * p.d.st;
-      float dk = dKs[j * KST + dd];
-      if (rcos) dk = rot_bwd(dk, rcos[j * DH + dd], rsin[j * DH + dd], dd);
-      float* wp = dqkv + row * p.RW + h * DH + dd;
-      wp[p.HD] = dk;
-      wp[2 * p.HD] = dVs[j * KST + dd];
+    __syncthreads();
+    if (active) {   // phase B: this thread owns key/value row j = i
+      float dk[DH], dv[DH];
+#pragma unroll
+      for (int e = 0; e < DH; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+      for (int r = 0; r < n; ++r) {
+        float ds = Ss[r * n1 + i], pj = Ps[r * n1 + i];
+        const float4* q4 = reinterpret_cast<const float4*>(Qs + r * DH);
+        const float4* g4 = reinterpret_cast<const float4*>(dout + (row0 + (int64_t)r * p.d.st) * p.HD + h * DH);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float4 a = q4[e], b = g4[e];
+          dk[4 * e] = fmaf(ds, a.x, dk[4 * e]); dk[4 * e + 1] = fmaf(ds, a.y, dk[4 * e + 1]);
+          dk[4 * e + 2] = fmaf(ds, a.z, dk[4 * e + 2]); dk[4 * e + 3] = fmaf(ds, a.w, dk[4 * e + 3]);
+          dv[4 * e] = fmaf(pj, b.x, dv[4 * e]); dv[4 * e + 1] = fmaf(pj, b.y, dv[4 * e + 1]);
+          dv[4 * e + 2] = fmaf(pj, b.z, dv[4 * e + 2]); dv[4 * e + 3] = fmaf(pj, b.w, dv[4 * e + 3]);
+        }
+      }
+      if (rcos) rotate32(dk, rcos + i * DH, rsin + i * DH, true);
+      store_row32(dqkv + row * p.RW + p.HD + h * DH, dk);
+      store_row32(dqkv + row * p.RW + 2 * p.HD + h * DH, dv);
     }
   }
   if (dbias) {
     __syncthreads();
-    for (int e = lane; e < n * n; e += 64) atomicAdd(&dbias[(int64_t)h * n * n + e], dBs[e]);
+    for (int e = threadIdx.x; e < p.d.heads * n * n; e += ATT_BWD_THREADS)
+      if (dBs[e] != 0.f) atomicAdd(&dbias[e], dBs[e]);
   }
 }
 
-static int attn_check(const wdno_attn_desc* d) {
+static int attn_fill(AttnP& p, const wdno_attn_desc* d, float scale, int threads) {
   if (!d || d->n_uo <= 0 || d->n_ui <= 0 || d->n_tok <= 0 || d->heads <= 0) return WDNO_EINVAL;
+  p.d = *d; p.scale = scale; p.HD = d->heads * DH; p.RW = 3 * p.HD;
+  p.ipb = threads / d->n_tok;
+  if (p.ipb < 1) p.ipb = 1;
+  p.kst = d->n_tok * DH + 8;          // +8 floats: items start on different 32-byte LDS slots
+  p.n_items = (int64_t)d->n_uo * d->n_ui * d->heads;
   return WDNO_OK;
 }
 extern "C" int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
                              const wdno_attn_desc* d, float scale, wdno_stream_t s) {
-  int rc = attn_check(d);
-  if (rc) return rc;
-  if (d->n_tok > 64 * ATT_MAXJ) return WDNO_EUNSUPPORTED;
   AttnP p;
-  p.d = *d; p.scale = scale; p.HD = d->heads * DH; p.RW = 3 * p.HD;
-  size_t lds = ((size_t)2 * d->n_tok * KST + ((d->n_tok + 3) & ~3) + DH) * sizeof(float);
+  int rc = attn_fill(p, d, scale, ATT_THREADS);
+  if (rc) return rc;
+  if (d->n_tok > 1024) return WDNO_EUNSUPPORTED;
+  size_t lds = (size_t)p.ipb * p.kst * sizeof(float);
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;
-  int64_t blocks = (int64_t)d->n_uo * d->n_ui * d->heads;
+  int64_t blocks = (p.n_items + p.ipb - 1) / p.ipb;
   if (blocks > 0x7fffffff) return WDNO_EUNSUPPORTED;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  attn_fwd_kernel<<<(unsigned)blocks, 64, lds, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
+  attn_fwd_kernel<<<(unsigned)blocks, ATT_THREADS, lds, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
   return wdno_check_launch();
 }
-extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* dout,
-                             float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s) {
-  int rc = attn_check(d);
-  if (rc) return rc;
-  if (d->n_tok > 64 * ATT_MAXJ) return WDNO_EUNSUPPORTED;
+extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                             const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s) {
   AttnP p;
-  p.d = *d; p.scale = scale; p.HD = d->heads * DH; p.RW = 3 * p.HD;
+  int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
+  if (rc) return rc;
   const int n = d->n_tok;
-  size_t lds = ((size_t)6 * n * KST + 2 * ((n + 3) & ~3) + (dbias ? (size_t)n * n : 0)) * sizeof(float);
+  if (n > ATT_BWD_THREADS) return WDNO_EUNSUPPORTED;      // training never attends over more than 100 tokens
+  size_t lds = ((size_t)p.ipb * (2 * p.kst + 2 * n * (n + 1)) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;
-  int64_t units = (int64_t)d->n_uo * d->n_ui;
-  int64_t ub = units;
-  if (dbias && ub > 1024) ub = 1024;     // bound the number of atomic flushes
-  if (units > 0x7fffffff) return WDNO_EUNSUPPORTED;
+  int64_t groups = (p.n_items + p.ipb - 1) / p.ipb;
+  int64_t blocks = groups;
+  if (dbias && blocks > 1024) blocks = 1024;               // bound the number of global atomic flushes
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  attn_bwd_kernel<<<(unsigned)(ub * d->heads), 64, lds, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, dout, dqkv, dbias, p, (int)units);
+  attn_bwd_kernel<<<(unsigned)blocks, ATT_BWD_THREADS, lds, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p);
   return wdno_check_launch();
 }
 

@@ -62,6 +62,23 @@ __device__ __forceinline__ float group_max(float v) {
   for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// out[c] = sum_b part[b][c] for a [nb][C] partial-sum matrix: 32 columns x 8 row groups per block.
+template <typename T>
+__global__ __launch_bounds__(256) void partial_rows_sum_kernel(const T* __restrict__ part, float* __restrict__ out, int nb, int C) {
+  __shared__ double red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  double acc = 0.0;
+  if (c < C)
+    for (int b = ty; b < nb; b += 8) acc += (double)part[(int64_t)b * C + c];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    double a = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    out[c] = (float)a;
+  }
+}
+
 __device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
 __device__ __forceinline__ float silu_grad_f(float z) {
   float sg = 1.0f / (1.0f + expf(-z));

@@ -379,14 +379,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-__global__ void ln_dg_final_kernel(const float* __restrict__ part, float* __restrict__ dg, int nb, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double a = 0;
-  for (int b = 0; b < nb; ++b) a += (double)part[(int64_t)b * C + c];
-  dg[c] = (float)a;
-}
-
 static inline int ln_blocks(int64_t P, int rpb) {
   int64_t nb = cdiv64(P, rpb);
   if (nb > 1024) nb = 1024;
@@ -436,6 +428,6 @@ extern "C" int wdno_layernorm_bwd(const float* x, const float* g, const float* d
   int nb = ln_blocks(P, 256 / tpr);
   int rc = ln_launch<true>(x, g, dy, dx, (float*)ws, P, C, eps, as_stream(s));
   if (rc) return rc;
-  ln_dg_final_kernel<<<cdiv(C, 128), 128, 0, as_stream(s)>>>((const float*)ws, dg, nb, C);
+  partial_rows_sum_kernel<float><<<cdiv(C, 32), 256, 0, as_stream(s)>>>((const float*)ws, dg, nb, C);
   return wdno_check_launch();
 }

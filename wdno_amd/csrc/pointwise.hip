@@ -283,13 +283,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
   }
 }
-__global__ void colsum_final_kernel(const double* __restrict__ ws, float* __restrict__ out, int nb, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double acc = 0.0;
-  for (int b = 0; b < nb; ++b) acc += ws[(int64_t)b * C + c];
-  out[c] = (float)acc;
-}
 static inline int colsum_blocks(int64_t P) {
   int64_t nb = cdiv64(P, 64);
   if (nb > 512) nb = 512;
@@ -303,7 +296,7 @@ extern "C" int wdno_colsum(const float* in, float* out, int64_t P, int C, void* 
   int nb = colsum_blocks(P);
   int64_t rpb = cdiv64(P, nb);
   colsum_partial_kernel<<<nb, 256, 0, as_stream(s)>>>(in, (double*)ws, P, C, rpb);
-  colsum_final_kernel<<<cdiv(C, 128), 128, 0, as_stream(s)>>>((const double*)ws, out, nb, C);
+  partial_rows_sum_kernel<double><<<cdiv(C, 32), 256, 0, as_stream(s)>>>((const double*)ws, out, nb, C);
   return wdno_check_launch();
 }
 

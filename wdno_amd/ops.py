@@ -597,13 +597,13 @@ class _Attn(torch.autograd.Function):
         d = AttnDesc(*desc_args)
         bc = None if bias is None else _chk(bias, 'bias')
         _lib.check(_lib_().wdno_attn_fwd(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bc), _p(out), C.byref(d), float(scale), _stream()), 'attn_fwd')
-        ctx.save_for_backward(qkv, bc, rot_cos, rot_sin)
+        ctx.save_for_backward(qkv, bc, rot_cos, rot_sin, out)
         ctx.meta = (desc_args, scale)
         return out
 
     @staticmethod
     def backward(ctx, go):
-        qkv, bias, rot_cos, rot_sin = ctx.saved_tensors
+        qkv, bias, rot_cos, rot_sin, fout = ctx.saved_tensors
         desc_args, scale = ctx.meta
         go = _chk(go, 'grad')
         dqkv = torch.empty_like(qkv)
@@ -611,7 +611,7 @@ class _Attn(torch.autograd.Function):
         if bias is not None and ctx.needs_input_grad[1]:
             dbias = torch.zeros_like(bias)
         d = AttnDesc(*desc_args)
-        _lib.check(_lib_().wdno_attn_bwd(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(go), _p(dqkv), _p(dbias), C.byref(d),
+        _lib.check(_lib_().wdno_attn_bwd(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(dqkv), _p(dbias), C.byref(d),
                                          float(scale), _stream()), 'attn_bwd')
         return dqkv, dbias, None, None, None, None
 
