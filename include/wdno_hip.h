@@ -95,6 +95,14 @@ typedef struct {
 /* y = conv(x, wp) (+ bias[K]) (+ residual, same layout as y). bias/residual may be NULL. */
 int wdno_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                   const wdno_conv_geom* g, wdno_stream_t s);
+/* fp32-equivalent convolution on the fp16 matrix cores ("3 x fp16 split", conv_h3.hip): an fp32 tensor is pre-split by
+ * wdno_amax + wdno_split_f16 into two fp16 planes hi, lo [rows][C8] (C8 = C rounded up to 8) and a power-of-two scale;
+ * wdno_conv_fwd_f16x3 evaluates ah*bh + ah*bl + al*bh with fp32 accumulation. Same geometry contract as wdno_conv_fwd
+ * with g->C = C8; sx / sw are the device scalars written by wdno_split_f16 for the activation / packed-weight operand. */
+int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s);
+int wdno_split_f16(const float* x, const float* amax, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8, wdno_stream_t s);
+int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                        const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s);
 /* dwp[kd][kh][K][kw*C] = sum over output pixels of dy (x) shifted x. ws: caller workspace. */
 size_t wdno_conv_wgrad_ws_bytes(const wdno_conv_geom* g);
 int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_t ws_bytes,

@@ -168,6 +168,52 @@ CONV_CASES = [
 ]
 
 
+# large enough (>= 1024 output pixels, reduction >= 128) to take the 3 x fp16-split MFMA path in forward and dgrad
+CONV_CASES_H3 = [
+    ('h3_3x3x3_64', (1, 64, 8, 20, 20), (64, 64, 3, 3, 3), 1, 1),
+    ('h3_3x3x3_wide', (2, 128, 4, 16, 16), (256, 128, 3, 3, 3), 1, 1),
+    ('h3_3x3x3_oddC', (1, 36, 8, 16, 16), (20, 36, 3, 3, 3), 1, 1),
+    ('h3_7x7x7_init', (1, 42, 8, 16, 16), (64, 42, 7, 7, 7), 1, 3),
+    ('h3_1x1x1', (4, 256, 4, 16, 16), (128, 256, 1, 1, 1), 1, 0),
+    ('h3_2d_3x3', (8, 128, 16, 16), (128, 128, 3, 3), 1, 1),
+    ('h3_2d_7x7', (8, 9, 16, 16), (128, 9, 7, 7), 1, 3),
+    ('h3_down_144', (2, 64, 4, 32, 32), (64, 64, 1, 4, 4), (1, 2, 2), (0, 1, 1)),
+]
+
+
+@pytest.mark.parametrize('name,xs,ws,stride,padding', CONV_CASES_H3, ids=[c[0] for c in CONV_CASES_H3])
+def test_conv_f16x3_path(ops, name, xs, ws, stride, padding):
+    assert ops.CONV_MATH == 'f16x3'
+    n_launch = {}
+    ops.PROFILE = n_launch
+    try:
+        conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000)
+    finally:
+        ops.PROFILE = None
+    assert any('h3' in k for k in n_launch), f'fp16-split kernel was not used: {list(n_launch)}'
+
+
+def test_conv_f16x3_wide_dynamic_range(ops):
+    """Gradient-like magnitudes (1e-7) and large activations (1e3) must survive the per-tensor scaling."""
+    for scale in (1e-7, 1.0, 1e3):
+        x = g((1, 64, 8, 16, 16), 90) * scale
+        w = g((64, 64, 3, 3, 3), 91) * 0.02
+        yr = F.conv3d(x, w, None, padding=1)
+        xd = dev(to_cl(x))
+        y = ops.conv_cl(xd, dev(w), None, padding=1)
+        assert rel_l2(from_cl(y.cpu()), yr) < TOL, scale
+
+
+def test_split_f16_reconstruction(ops):
+    x = g((300, 44), 92) * torch.logspace(-6, 2, 300, dtype=torch.float64)[:, None]
+    hi, lo, s = ops.split_f16(dev(x))
+    assert hi.shape == (300, 48) and float(hi[:, 44:].abs().max()) == 0
+    rec = (hi.double() + lo.double())[:, :44].cpu() / float(s)
+    amax = x.abs().max()
+    assert ((rec - x.float().double()).abs().max() / amax) < 2 ** -21
+    assert 2 ** 14 <= float(s) * float(x.float().abs().max()) < 2 ** 15
+
+
 @pytest.mark.parametrize('name,xs,ws,stride,padding', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv(ops, name, xs, ws, stride, padding):
     conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000)

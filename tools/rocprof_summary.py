@@ -12,9 +12,9 @@ rows = list(cur.execute('select name, total_calls, total_duration, average, perc
 tot = sum(r[2] for r in rows)
 with open(out, 'w') as f:
     f.write(f'# rocprofv3 --kernel-trace --stats summary\n\ncommand: `{cmd}`\n\n')
-    f.write(f'total kernel time: {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches (durations in microseconds)\n\n')
+    f.write(f'total kernel time: {tot / 1e3:.3f} ms over {sum(r[1] for r in rows)} dispatches (durations in microseconds)\n\n')
     f.write('| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n')
     for name, calls, total, avg, pct in rows:
         short = name if len(name) < 110 else name[:107] + '...'
-        f.write(f'| `{short}` | {calls} | {total / 1e3:.1f} | {avg / 1e3:.2f} | {pct:.2f} |\n')
+        f.write(f'| `{short}` | {calls} | {total:.1f} | {avg:.2f} | {pct:.2f} |\n')
 print('wrote', out, len(rows), 'kernels')

@@ -58,6 +58,9 @@ PROTOTYPES = {
     'wdno_upsample2x_cl_fwd': (I, [P, P, L, I, I, I, P]),
     'wdno_upsample2x_cl_bwd': (I, [P, P, L, I, I, I, P]),
     'wdno_conv_fwd': (I, [P, P, P, P, P, PG, P]),
+    'wdno_amax': (I, [P, L, P, P]),
+    'wdno_split_f16': (I, [P, P, P, P, P, L, I, I, P]),
+    'wdno_conv_fwd_f16x3': (I, [P, P, P, P, P, P, P, P, P, PG, P]),
     'wdno_conv_wgrad_ws_bytes': (Z, [PG]),
     'wdno_conv_wgrad': (I, [P, P, P, P, Z, PG, P]),
     'wdno_colsum_ws_bytes': (Z, [L, I]),

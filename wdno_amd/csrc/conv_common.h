@@ -1,0 +1,56 @@
+// conv_common.h -- geometry helpers shared by the exact-fp32 and the 3xfp16-split implicit-GEMM convolution kernels.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDS_STRIDE 36   // BK + 4 floats: 144-byte rows -> 16 consecutive rows hit 16 distinct 16-B slots
+
+struct ConvP {
+  wdno_conv_geom g;
+  int R;          // kw * C
+  int nchunk;     // ceil(R / BK)
+  int nsteps;     // kd*kh*nchunk
+  int64_t P;      // N*OD*OH*OW
+  int identity_out;
+  int tiles_n;
+  int ntiles;
+};
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  // bijective remap so that each of the 8 XCDs (block b runs on XCD b % 8) gets a contiguous range of tiles
+  int q = nwg >> 3, r = nwg & 7;
+  int xcd = bid & 7, idx = bid >> 3;
+  int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+__device__ __forceinline__ int64_t out_row(const wdno_conv_geom& g, int64_t p) {
+  int ow = (int)(p % g.OW); int64_t t = p / g.OW;
+  int oh = (int)(t % g.OH); t /= g.OH;
+  int od = (int)(t % g.OD);
+  int64_t n = t / g.OD;
+  return ((n * g.YD + (od * g.osd + g.ood)) * g.YH + (oh * g.osh + g.ooh)) * g.YW + (ow * g.osw + g.oow);
+}
+
+static inline int check_geom(const wdno_conv_geom* g) {
+  if (!g) return WDNO_EINVAL;
+  if (g->N <= 0 || g->D <= 0 || g->H <= 0 || g->W <= 0 || g->C <= 0 || g->K <= 0) return WDNO_EINVAL;
+  if (g->OD <= 0 || g->OH <= 0 || g->OW <= 0 || g->kd <= 0 || g->kh <= 0 || g->kw <= 0) return WDNO_EINVAL;
+  if (g->sd <= 0 || g->sh <= 0 || g->sw <= 0 || g->osd <= 0 || g->osh <= 0 || g->osw <= 0) return WDNO_EINVAL;
+  if ((g->C & 3) || (g->K & 3)) return WDNO_EUNSUPPORTED;   // rows must be 16-byte multiples (callers pad)
+  if ((g->OD - 1) * g->osd + g->ood >= g->YD || (g->OH - 1) * g->osh + g->ooh >= g->YH || (g->OW - 1) * g->osw + g->oow >= g->YW)
+    return WDNO_EINVAL;
+  return WDNO_OK;
+}
+static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
+  p.g = *g;
+  p.R = g->kw * g->C;
+  p.nchunk = cdiv(p.R, BK);
+  p.nsteps = g->kd * g->kh * p.nchunk;
+  p.P = (int64_t)g->N * g->OD * g->OH * g->OW;
+  p.identity_out = (g->YD == g->OD && g->YH == g->OH && g->YW == g->OW && g->osd == 1 && g->osh == 1 && g->osw == 1 &&
+                    g->ood == 0 && g->ooh == 0 && g->oow == 0) ? 1 : 0;
+}
+

@@ -6,6 +6,7 @@ multiple of 4. There is no CPU path: non-CUDA tensors raise.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -308,6 +309,68 @@ def pack_transposed(w_io, cin_p, cout_p):
     return _cached(w_io, 't', cin_p, cout_p, build)
 
 
+# 'f16x3' = fp32-equivalent 3 x fp16-split MFMA for the large convolutions (forward and data gradient); 'f32' = exact-fp32
+# MFMA everywhere. Small problems always take the exact kernel.
+CONV_MATH = os.environ.get('WDNO_CONV_MATH', 'f16x3')
+H3_MIN_PIXELS = 1024
+H3_MIN_REDUCTION = 128
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def split_f16(x2d):
+    """[rows, C] fp32 -> (hi, lo) fp16 [rows, C8] and the device scalar scale (one amax pass + one split pass)."""
+    rows, c = x2d.shape
+    c8 = pad8(c)
+    lib = _lib_()
+    amax = torch.zeros(1, device=x2d.device, dtype=torch.float32)
+    hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+    lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+    scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
+    _lib.check(lib.wdno_amax(_p(x2d), x2d.numel(), _p(amax), _stream()), 'amax')
+    _lib.check(lib.wdno_split_f16(_p(x2d), _p(amax), _p(hi), _p(lo), _p(scale), rows, c, c8, _stream()), 'split_f16')
+    return hi, lo, scale
+
+
+def split_weight(w, kind, cp8, kp, pack):
+    """Packed weight (cached) -> its fp16 split planes and scale (cached with the same key)."""
+    def build():
+        wp = pack(w, cp8, kp)
+        hi, lo, sc = split_f16(wp.reshape(-1, cp8))
+        return torch.stack([hi.view(torch.int16), lo.view(torch.int16)]), sc
+    key = (w.data_ptr(), kind + '_h3', cp8, kp, tuple(w.shape), tuple(w.stride()))
+    ver = (w._version, WEIGHT_EPOCH)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        planes, sc = build()
+    _pack_cache[key] = (ver, (planes[0], planes[1], sc), w.detach())
+    return _pack_cache[key][1]
+
+
+def conv_fwd_h3(x5, w, pack, kind, bias_p, residual, ks, st, pd, kp):
+    """x5 CL fp32 [N,D,H,W,Cp]; w raw weight; pack = pack_fwd / pack_dgrad. Returns y [N,OD,OH,OW,kp] fp32."""
+    n, d, h, ww, cp = x5.shape
+    cp8 = pad8(cp)
+    wh, wl, sw = split_weight(w, kind, cp8, kp, pack)
+    xh, xl, sx = split_f16(x5.reshape(-1, cp))
+    osp = tuple(_out_size(a, k, s_, p_) for a, k, s_, p_ in zip((d, h, ww), ks, st, pd))
+    y = torch.empty((n, *osp, kp), device=x5.device, dtype=torch.float32)
+    g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp)
+    flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp
+    with _timed('conv_fwd_h3_kernel<128,..>' if kp > 64 else 'conv_fwd_h3_kernel<..,64>', flops):
+        _lib.check(_lib_().wdno_conv_fwd_f16x3(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
+                                               C.byref(g), _stream()), 'conv_fwd_f16x3')
+    return y
+
+
+def _use_h3(pixels, reduction):
+    return CONV_MATH == 'f16x3' and pixels >= H3_MIN_PIXELS and reduction >= H3_MIN_REDUCTION
+
+
 def _out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
@@ -396,7 +459,11 @@ class _Conv(torch.autograd.Function):
         if residual is not None:
             residual = _chk(residual, 'residual')
             res5 = residual
-        y = conv_fwd_raw(x5, wp, bias_p, res5, ks, stride, padding, kp)
+        osp_ = tuple(_out_size(a, kk, s_, p_) for a, kk, s_, p_ in zip(x5.shape[1:4], ks, stride, padding))
+        if _use_h3(x5.shape[0] * osp_[0] * osp_[1] * osp_[2], cp * ks[0] * ks[1] * ks[2]):
+            y = conv_fwd_h3(x5, weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp)
+        else:
+            y = conv_fwd_raw(x5, wp, bias_p, res5, ks, stride, padding, kp)
         ctx.save_for_backward(x5, weight)
         ctx.meta = (ks, stride, padding, k, c, cp, kp, bias is not None, residual is not None, lead, x.dim())
         if lead is not None:
@@ -414,9 +481,13 @@ class _Conv(torch.autograd.Function):
         gx = gw = gb = gr = None
         if ctx.needs_input_grad[0]:
             if stride == (1, 1, 1):
-                wd = pack_dgrad(weight, cp, kp)
                 pd = tuple(kk - 1 - p for kk, p in zip(ks, padding))
-                gx5 = conv_fwd_raw(gy5, wd, None, None, ks, (1, 1, 1), pd, cp)
+                if _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]):
+                    # dgrad = the same kernel on dy with flipped / transposed weights; "C" role = Kp, "K" role = Cp
+                    gx5 = conv_fwd_h3(gy5, weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, None, ks, (1, 1, 1), pd, cp)
+                else:
+                    wd = pack_dgrad(weight, cp, kp)
+                    gx5 = conv_fwd_raw(gy5, wd, None, None, ks, (1, 1, 1), pd, cp)
             elif ks == (1, 4, 4) and stride == (1, 2, 2) and padding == (0, 1, 1):
                 wt = pack_transposed(_as5(weight), kp, cp)      # "in" = K (dy channels), "out" = C
                 gx5 = conv_transpose_raw(gy5, wt, None, cp)
