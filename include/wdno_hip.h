@@ -103,6 +103,10 @@ int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s);
 int wdno_split_f16(const float* x, const float* amax, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8, wdno_stream_t s);
 int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                         const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s);
+/* weight gradient on the same split planes (g->C = C8 of x, g->K = K8 of dy); dwp [kd][kh][K8][kw*C8] fp32 */
+size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g);
+int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                          float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s);
 /* dwp[kd][kh][K][kw*C] = sum over output pixels of dy (x) shifted x. ws: caller workspace. */
 size_t wdno_conv_wgrad_ws_bytes(const wdno_conv_geom* g);
 int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_t ws_bytes,

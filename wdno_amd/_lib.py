@@ -61,6 +61,8 @@ PROTOTYPES = {
     'wdno_amax': (I, [P, L, P, P]),
     'wdno_split_f16': (I, [P, P, P, P, P, L, I, I, P]),
     'wdno_conv_fwd_f16x3': (I, [P, P, P, P, P, P, P, P, P, PG, P]),
+    'wdno_conv_wgrad_f16x3_ws_bytes': (Z, [PG]),
+    'wdno_conv_wgrad_f16x3': (I, [P, P, P, P, P, P, P, P, Z, PG, P]),
     'wdno_conv_wgrad_ws_bytes': (Z, [PG]),
     'wdno_conv_wgrad': (I, [P, P, P, P, Z, PG, P]),
     'wdno_colsum_ws_bytes': (Z, [L, I]),

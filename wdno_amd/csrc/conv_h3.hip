@@ -316,3 +316,271 @@ extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* 
   if (rc) return rc;
   return wdno_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------- weight gradient (3 x fp16 split)
+// dwp[tap][k][r] = sum_p dy[p][k] * x[p shifted by tap][r]. The reduction index (pixels) is the SLOW index of both
+// operands in memory, while v_mfma_f32_32x32x16_f16 wants 8 consecutive reduction elements per lane. The LDS tiles keep
+// the natural [pixel][channel] layout (16-byte coalesced loads / stores) and the fragments are read with the gfx950
+// transpose read ds_read_b64_tr_b16: inside a 16-lane group, lanes 4j..4j+3 point at the four 8-byte pieces of pixel
+// row j (16 channels) and lane c receives channel c of rows 0..3 (verified by tools/probes/tr_probe.hip). Two reads
+// give the 8 pixels of one MFMA operand. Rows are padded by 32 halves so the 4 pixel rows of a group fall on distinct
+// 64-byte bank quarters.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#define WH_BKP 32
+#define WH_PAD 32
+
+struct PixInfoH { int64_t yrow; int64_t xbase; int w0; int ok; };
+
+struct WgradHP {
+  ConvP c;
+  int tiles_k, tiles_r, splits;
+  int64_t pix_per_split;
+};
+
+__device__ __forceinline__ half8 tr_frag(const _Float16* tile, int stride, int pix0, int ch0, int lane) {
+  // operand fragment for channels ch0..ch0+31 (lane&31 mapping of the MFMA) and pixels pix0..pix0+15
+  const int g = lane >> 4, xl = lane & 15;
+  const _Float16* p0 = tile + (pix0 + 8 * (g >> 1) + (xl >> 2)) * stride + ch0 + 16 * (g & 1) + 4 * (xl & 3);
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef short4v __attribute__((address_space(3))) * lds_s4;
+  short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
+  short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + 4 * stride));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  short8v c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(half8, c);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                             const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
+                                                             const float* __restrict__ sx, const float* __restrict__ sdy,
+                                                             float* __restrict__ ws, WgradHP wpz) {
+  constexpr int TM = BM / (WM * 32);
+  constexpr int TN = BN / (WN * 32);
+  constexpr int SA = BM + WH_PAD, SB = BN + WH_PAD;          // LDS row strides (halves)
+  constexpr int A_C8 = BM / 8, B_C8 = BN / 8;                 // 16-byte pieces per pixel row
+  constexpr int A_RPP = 256 / A_C8, B_RPP = 256 / B_C8;       // pixel rows per pass
+  constexpr int A_PASSES = WH_BKP / A_RPP, B_PASSES = WH_BKP / B_RPP;
+  constexpr int STAGE = 2 * WH_BKP * (SA + SB);               // halves per stage: Ah, Al, Bh, Bl
+  extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
+  PixInfoH* pinfo = reinterpret_cast<PixInfoH*>(hsm + 2 * STAGE);   // [3][WH_BKP]
+
+  const ConvP& p = wpz.c;
+  const wdno_conv_geom& g = p.g;
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tile_r = b % wpz.tiles_r; b /= wpz.tiles_r;
+  const int tap = b % (g.kd * g.kh);
+  const int tile_k = b / (g.kd * g.kh);
+  const int dz = tap / g.kh, dyy = tap - dz * g.kh;
+  const int k0 = tile_k * BM, r0 = tile_r * BN;
+  const int64_t pbeg = (int64_t)blockIdx.y * wpz.pix_per_split;
+  int64_t pend = pbeg + wpz.pix_per_split;
+  if (pend > p.P) pend = p.P;
+  const int nsteps = pbeg < pend ? (int)((pend - pbeg + WH_BKP - 1) / WH_BKP) : 0;
+
+  auto decode = [&](int step) {
+    if (tid < WH_BKP) {
+      int64_t pm = pbeg + (int64_t)step * WH_BKP + tid;
+      PixInfoH pi;
+      pi.ok = 0; pi.yrow = 0; pi.xbase = 0; pi.w0 = 0;
+      if (pm < pend) {
+        int64_t q = pm;
+        int ow = (int)(q % g.OW); q /= g.OW;
+        int oh = (int)(q % g.OH); q /= g.OH;
+        int od = (int)(q % g.OD);
+        int64_t n = q / g.OD;
+        pi.yrow = ((n * g.YD + (od * g.osd + g.ood)) * g.YH + (oh * g.osh + g.ooh)) * g.YW + (ow * g.osw + g.oow);
+        int d = od * g.sd - g.pd + dz, h = oh * g.sh - g.ph + dyy;
+        pi.w0 = ow * g.sw - g.pw;
+        pi.xbase = (((n * g.D + d) * g.H + h) * (int64_t)g.W + pi.w0) * g.C;
+        pi.ok = (d >= 0 && d < g.D && h >= 0 && h < g.H) ? 3 : 1;
+      }
+      pinfo[(step % 3) * WH_BKP + tid] = pi;
+    }
+  };
+
+  const int b_row = tid / B_C8, b_c8 = (tid % B_C8) * 8;
+  const int r = r0 + b_c8;
+  const bool r_ok = r < p.R;
+  const int dx = r / g.C;
+  const int a_row = tid / A_C8, a_c8 = (tid % A_C8) * 8;
+  const int ka = k0 + a_c8;
+  const bool ka_ok = ka < g.K;
+
+  uint4 ah[A_PASSES], al[A_PASSES], bh[B_PASSES], bl[B_PASSES];
+  auto load_tile = [&](int step) {
+    const PixInfoH* ps = pinfo + (step % 3) * WH_BKP;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const PixInfoH pi = ps[a_row + i * A_RPP];
+      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+      if ((pi.ok & 1) && ka_ok) {
+        vh = *reinterpret_cast<const uint4*>(dyh + pi.yrow * g.K + ka);
+        vl = *reinterpret_cast<const uint4*>(dyl + pi.yrow * g.K + ka);
+      }
+      ah[i] = vh; al[i] = vl;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const PixInfoH pi = ps[b_row + i * B_RPP];
+      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+      int w = pi.w0 + dx;
+      if (pi.ok == 3 && r_ok && w >= 0 && w < g.W) {
+        vh = *reinterpret_cast<const uint4*>(xh + pi.xbase + r);
+        vl = *reinterpret_cast<const uint4*>(xl + pi.xbase + r);
+      }
+      bh[i] = vh; bl[i] = vl;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    _Float16* Ah = hsm + buf * STAGE;
+    _Float16* Al = Ah + WH_BKP * SA;
+    _Float16* Bh = Al + WH_BKP * SA;
+    _Float16* Bl = Bh + WH_BKP * SB;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      *reinterpret_cast<uint4*>(&Ah[(a_row + i * A_RPP) * SA + a_c8]) = ah[i];
+      *reinterpret_cast<uint4*>(&Al[(a_row + i * A_RPP) * SA + a_c8]) = al[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      *reinterpret_cast<uint4*>(&Bh[(b_row + i * B_RPP) * SB + b_c8]) = bh[i];
+      *reinterpret_cast<uint4*>(&Bl[(b_row + i * B_RPP) * SB + b_c8]) = bl[i];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 31, hh = lane >> 5;
+  const int m_base = wm * (TM * 32), n_base = wn * (TN * 32);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int bb = 0; bb < TN; ++bb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][bb][e] = 0.f;
+
+  if (nsteps > 0) {
+    decode(0);
+    if (nsteps > 1) decode(1);
+    __syncthreads();
+    load_tile(0);
+    store_tile(0);
+    if (nsteps > 2) decode(2);
+    __syncthreads();
+    if (nsteps > 1) load_tile(1);
+    for (int step = 0; step < nsteps; ++step) {
+      const _Float16* Ah = hsm + (step & 1) * STAGE;
+      const _Float16* Al = Ah + WH_BKP * SA;
+      const _Float16* Bh = Al + WH_BKP * SA;
+      const _Float16* Bl = Bh + WH_BKP * SB;
+#pragma unroll
+      for (int ks = 0; ks < WH_BKP / 16; ++ks) {
+        half8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          fah[a] = tr_frag(Ah, SA, ks * 16, m_base + a * 32, lane);
+          fal[a] = tr_frag(Al, SA, ks * 16, m_base + a * 32, lane);
+        }
+#pragma unroll
+        for (int bb = 0; bb < TN; ++bb) {
+          fbh[bb] = tr_frag(Bh, SB, ks * 16, n_base + bb * 32, lane);
+          fbl[bb] = tr_frag(Bl, SB, ks * 16, n_base + bb * 32, lane);
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int bb = 0; bb < TN; ++bb) {
+            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[bb], acc[a][bb], 0, 0, 0);
+            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[bb], acc[a][bb], 0, 0, 0);
+            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[bb], acc[a][bb], 0, 0, 0);
+          }
+      }
+      if (step + 1 < nsteps) store_tile((step + 1) & 1);
+      __syncthreads();
+      if (step + 2 < nsteps) load_tile(step + 2);
+      if (step + 3 < nsteps) decode(step + 3);
+    }
+  }
+
+  const float inv = 1.0f / (sx[0] * sdy[0]);
+  float* out = ws + ((int64_t)blockIdx.y * (g.kd * g.kh) + tap) * (int64_t)g.K * p.R;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int kk = k0 + m_base + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      if (kk >= g.K) continue;
+#pragma unroll
+      for (int bb = 0; bb < TN; ++bb) {
+        int rr = r0 + n_base + bb * 32 + li;
+        if (rr < p.R) out[(int64_t)kk * p.R + rr] = acc[a][bb][e] * inv;
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_h3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int splits) {
+  int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += ws[(int64_t)s * n + i];
+    out[i] = acc;
+  }
+}
+
+static void wgrad_h3_plan(WgradHP& w, const wdno_conv_geom* g) {
+  fill_params(w.c, g);
+  const int BM = g->K > 64 ? 128 : 64;
+  w.tiles_k = cdiv(g->K, BM);
+  w.tiles_r = cdiv(w.c.R, 128);
+  int64_t tiles = (int64_t)w.tiles_k * w.tiles_r * g->kd * g->kh;
+  int64_t want = cdiv64(1024, tiles);
+  int64_t max_splits = cdiv64(w.c.P, 16 * WH_BKP);   // at least 16 steps per block
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  if (want > 4096) want = 4096;
+  int64_t pps = cdiv64(cdiv64(w.c.P, want), WH_BKP) * WH_BKP;
+  w.pix_per_split = pps;
+  w.splits = (int)cdiv64(w.c.P, pps);
+}
+extern "C" size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g) {
+  if (check_geom(g) != WDNO_OK) return 0;
+  WgradHP w;
+  wgrad_h3_plan(w, g);
+  return (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
+}
+template <int BM, int BN, int WM, int WN>
+static void launch_wgrad_h3(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
+                            float* wsf, const WgradHP& w, dim3 grid, hipStream_t st) {
+  size_t lds = (size_t)2 * 2 * WH_BKP * (BM + WH_PAD + BN + WH_PAD) * sizeof(_Float16) + 3 * WH_BKP * sizeof(PixInfoH);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_h3_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  conv_wgrad_h3_kernel<BM, BN, WM, WN><<<grid, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh,
+                                                            (const _Float16*)dyl, sx, sdy, wsf, w);
+}
+extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                                     float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  if ((g->C & 7) || (g->K & 7)) return WDNO_EUNSUPPORTED;
+  WgradHP w;
+  wgrad_h3_plan(w, g);
+  size_t need = (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
+  if (ws_bytes < need) return WDNO_EWORKSPACE;
+  if (w.splits > 65535) return WDNO_EUNSUPPORTED;
+  dim3 grid((unsigned)(w.tiles_k * g->kd * g->kh * w.tiles_r), (unsigned)w.splits);
+  float* wsf = w.splits == 1 ? dwp : (float*)ws;
+  hipStream_t st = as_stream(s);
+  if (g->K > 64) launch_wgrad_h3<128, 128, 2, 2>(xh, xl, dyh, dyl, sx, sdy, wsf, w, grid, st);
+  else launch_wgrad_h3<64, 128, 1, 4>(xh, xl, dyh, dyl, sx, sdy, wsf, w, grid, st);
+  if (w.splits > 1) {
+    int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
+    wgrad_h3_reduce_kernel<<<stream_grid(n, 256), 256, 0, st>>>((const float*)ws, dwp, n, w.splits);
+  }
+  return wdno_check_launch();
+}

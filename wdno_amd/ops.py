@@ -351,20 +351,39 @@ def split_weight(w, kind, cp8, kp, pack):
     return _pack_cache[key][1]
 
 
-def conv_fwd_h3(x5, w, pack, kind, bias_p, residual, ks, st, pd, kp):
-    """x5 CL fp32 [N,D,H,W,Cp]; w raw weight; pack = pack_fwd / pack_dgrad. Returns y [N,OD,OH,OW,kp] fp32."""
-    n, d, h, ww, cp = x5.shape
-    cp8 = pad8(cp)
+def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp):
+    """planes = (hi, lo, scale) of a CL tensor with logical shape4 = (N, D, H, W) and C8 channels; w raw weight;
+    pack = pack_fwd / pack_dgrad. Returns y [N, OD, OH, OW, kp] fp32."""
+    xh, xl, sx = planes
+    n, d, h, ww = shape4
+    cp8 = xh.shape[-1]
     wh, wl, sw = split_weight(w, kind, cp8, kp, pack)
-    xh, xl, sx = split_f16(x5.reshape(-1, cp))
     osp = tuple(_out_size(a, k, s_, p_) for a, k, s_, p_ in zip((d, h, ww), ks, st, pd))
-    y = torch.empty((n, *osp, kp), device=x5.device, dtype=torch.float32)
+    y = torch.empty((n, *osp, kp), device=xh.device, dtype=torch.float32)
     g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp)
-    flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp
+    flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
     with _timed('conv_fwd_h3_kernel<128,..>' if kp > 64 else 'conv_fwd_h3_kernel<..,64>', flops):
         _lib.check(_lib_().wdno_conv_fwd_f16x3(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
                                                C.byref(g), _stream()), 'conv_fwd_f16x3')
     return y
+
+
+def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd):
+    """-> dwp [kd, kh, K8, kw, C8] fp32 from the split planes of x (C8 channels) and dy (K8 channels)."""
+    xh, xl, sx = xplanes
+    gh, gl, sg = gyplanes
+    n, d, h, ww = shape4
+    c8, k8 = xh.shape[-1], gh.shape[-1]
+    g = _geom((n, d, h, ww), c8, k8, ks, st, pd, osp)
+    lib = _lib_()
+    nb = lib.wdno_conv_wgrad_f16x3_ws_bytes(C.byref(g))
+    ws = _ws(nb, xh.device)
+    dwp = torch.empty((ks[0], ks[1], k8, ks[2], c8), device=xh.device, dtype=torch.float32)
+    flops = 2.0 * n * osp[0] * osp[1] * osp[2] * k8 * ks[0] * ks[1] * ks[2] * c8
+    with _timed('conv_wgrad_h3_kernel<128,..>' if k8 > 64 else 'conv_wgrad_h3_kernel<64,..>', flops):
+        _lib.check(lib.wdno_conv_wgrad_f16x3(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(dwp), _p(ws), nb, C.byref(g), _stream()),
+                   'conv_wgrad_f16x3')
+    return dwp
 
 
 def _use_h3(pixels, reduction):
@@ -460,11 +479,16 @@ class _Conv(torch.autograd.Function):
             residual = _chk(residual, 'residual')
             res5 = residual
         osp_ = tuple(_out_size(a, kk, s_, p_) for a, kk, s_, p_ in zip(x5.shape[1:4], ks, stride, padding))
-        if _use_h3(x5.shape[0] * osp_[0] * osp_[1] * osp_[2], cp * ks[0] * ks[1] * ks[2]):
-            y = conv_fwd_h3(x5, weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp)
+        h3 = _use_h3(x5.shape[0] * osp_[0] * osp_[1] * osp_[2], cp * ks[0] * ks[1] * ks[2])
+        if h3:
+            planes = split_f16(x5.reshape(-1, cp))
+            y = conv_fwd_h3(planes, tuple(x5.shape[:4]), weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp)
+            ctx.save_for_backward(planes[0], planes[1], planes[2], weight)     # the split planes replace x for wgrad
         else:
             y = conv_fwd_raw(x5, wp, bias_p, res5, ks, stride, padding, kp)
-        ctx.save_for_backward(x5, weight)
+            ctx.save_for_backward(x5, weight)
+        ctx.h3 = h3
+        ctx.xshape = tuple(x5.shape)
         ctx.meta = (ks, stride, padding, k, c, cp, kp, bias is not None, residual is not None, lead, x.dim())
         if lead is not None:
             y = y.reshape(*lead, kp) if x.dim() != 4 else y.squeeze(1)
@@ -472,10 +496,15 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x5, weight = ctx.saved_tensors
+        if ctx.h3:
+            xh, xl, sx, weight = ctx.saved_tensors
+            x5 = None
+        else:
+            x5, weight = ctx.saved_tensors
         ks, stride, padding, k, c, cp, kp, has_bias, has_res, lead, xdim = ctx.meta
         gy = _chk(gy, 'grad')
-        n, d, h, w, _ = x5.shape
+        n, d, h, w, _ = ctx.xshape
+        gyplanes = None
         osp = tuple(_out_size(a, kk, s, p) for a, kk, s, p in zip((d, h, w), ks, stride, padding))
         gy5 = gy.reshape(n, *osp, kp)
         gx = gw = gb = gr = None
@@ -484,7 +513,9 @@ class _Conv(torch.autograd.Function):
                 pd = tuple(kk - 1 - p for kk, p in zip(ks, padding))
                 if _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]):
                     # dgrad = the same kernel on dy with flipped / transposed weights; "C" role = Kp, "K" role = Cp
-                    gx5 = conv_fwd_h3(gy5, weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, None, ks, (1, 1, 1), pd, cp)
+                    gyplanes = split_f16(gy5.reshape(-1, kp))
+                    gx5 = conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, None,
+                                      ks, (1, 1, 1), pd, cp)
                 else:
                     wd = pack_dgrad(weight, cp, kp)
                     gx5 = conv_fwd_raw(gy5, wd, None, None, ks, (1, 1, 1), pd, cp)
@@ -500,7 +531,12 @@ class _Conv(torch.autograd.Function):
             if lead is not None:
                 gx = gx5.reshape(*lead, cp) if xdim != 4 else gx5.squeeze(1)
         if ctx.needs_input_grad[1]:
-            dwp = conv_wgrad_raw(x5, gy5, ks, stride, padding)
+            if ctx.h3:
+                if gyplanes is None:
+                    gyplanes = split_f16(gy5.reshape(-1, kp))
+                dwp = conv_wgrad_h3((xh, xl, sx), (n, d, h, w), gyplanes, osp, ks, stride, padding)
+            else:
+                dwp = conv_wgrad_raw(x5, gy5, ks, stride, padding)
             gw = dwp[:, :, :k, :, :c].permute(2, 4, 0, 1, 3).reshape(weight.shape).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             gb = colsum(gy5.reshape(-1, kp))[:k].contiguous()
