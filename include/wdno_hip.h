@@ -26,6 +26,8 @@ const char* wdno_strerror(int code);
 int wdno_version(void);
 /* last hip error string seen by the library on this thread (diagnostics only) */
 const char* wdno_last_hip_error(void);
+/* diagnostics only: ablation switches of the convolution kernels (0 = off) */
+int wdno_set_debug(int mode);
 
 /* ------------------------------------------------------------------------------------------------ wavelets
  * Separable single-level filter banks. mode: 0 = periodization, 1 = zero padding. Filters: 4 x L floats

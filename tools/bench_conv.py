@@ -1,5 +1,6 @@
-"""Micro-benchmark of the implicit-GEMM convolution kernels on the geometries of the smoke U-Net (batch 8)."""
-import os, sys, time
+"""Micro-benchmark of the implicit-GEMM convolution kernels on the geometries of the smoke U-Net (batch 8).
+Columns: exact-fp32 MFMA kernels and the 3 x fp16-split kernels (split pre-pass timed separately)."""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -17,9 +18,11 @@ CASES = [  # name, x [N,D,H,W,C], weight [K,C,kd,kh,kw], stride, pad
     ('l0 out 1x1 128->64', (8, 24, 40, 40, 128), (64, 128), (1, 1, 1), (0, 0, 0)),
     ('l0 down 1x4x4 64->64', (8, 24, 40, 40, 64), (64, 64, 1, 4, 4), (1, 2, 2), (0, 1, 1)),
 ]
-only = sys.argv[1:] 
+only = [a for a in sys.argv[1:] if not a.startswith('-')]
+fp32_too = '--fp32' in sys.argv
 
-def timeit(fn, iters):
+
+def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -27,6 +30,7 @@ def timeit(fn, iters):
         fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+
 
 for name, xs, ws, st, pd in CASES:
     if only and not any(o in name for o in only):
@@ -39,14 +43,30 @@ for name, xs, ws, st, pd in CASES:
     cp, kp = xs[-1], ops.pad4(k)
     wp = ops.pack_fwd(w, cp, kp)
     y = ops.conv_fwd_raw(x, wp, None, None, ks, st, pd, kp)
+    osp = tuple(y.shape[1:4])
     P = y.numel() // kp
     flops = 2.0 * P * k * c * ks[0] * ks[1] * ks[2]
-    t_f = timeit(lambda: ops.conv_fwd_raw(x, wp, None, None, ks, st, pd, kp), 10)
-    t_w = timeit(lambda: ops.conv_wgrad_raw(x, y, ks, st, pd), 10)
-    line = f'{name:24s} fwd {t_f:7.3f} ms {flops / t_f / 1e9:7.1f} TF/s | wgrad {t_w:7.3f} ms {flops / t_w / 1e9:7.1f} TF/s'
+    tf = lambda t: flops / t / 1e9
+    line = f'{name:22s}'
+    if fp32_too:
+        t_f = timeit(lambda: ops.conv_fwd_raw(x, wp, None, None, ks, st, pd, kp))
+        t_w = timeit(lambda: ops.conv_wgrad_raw(x, y, ks, st, pd))
+        line += f' f32: fwd {tf(t_f):6.1f} wgrad {tf(t_w):6.1f} |'
+    t_s = timeit(lambda: ops.split_f16(x.reshape(-1, cp)))
+    xpl = ops.split_f16(x.reshape(-1, cp))
+    ypl = ops.split_f16(y.reshape(-1, kp))
+    t_hf = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
+    if '--ablate' in sys.argv:
+        lib = ops._lib_()
+        lib.wdno_set_debug(1); t1 = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
+        t2 = float('nan')
+        lib.wdno_set_debug(0)
+        print(f'   ablation fwd: full {t_hf:.3f} ms | no global loads (all-invalid) {t1:.3f} ms | no MFMA {t2:.3f} ms')
+    t_hw = timeit(lambda: ops.conv_wgrad_h3(xpl, tuple(xs[:4]), ypl, osp, ks, st, pd))
+    line += f' h3: fwd {t_hf:6.3f} ms {tf(t_hf):6.1f} TF/s | wgrad {t_hw:6.3f} ms {tf(t_hw):6.1f} TF/s'
     if st == (1, 1, 1):
-        wd = ops.pack_dgrad(w, cp, kp)
         pdd = tuple(kk - 1 - p for kk, p in zip(ks, pd))
-        t_d = timeit(lambda: ops.conv_fwd_raw(y, wd, None, None, ks, (1, 1, 1), pdd, cp), 10)
-        line += f' | dgrad {t_d:7.3f} ms {flops / t_d / 1e9:7.1f} TF/s'
+        t_hd = timeit(lambda: ops.conv_fwd_h3(ypl, tuple(y.shape[:4]), w, lambda w_, c8_, k_: ops.pack_dgrad(w_, k_, c8_), 'd', None, None, ks, (1, 1, 1), pdd, cp))
+        line += f' | dgrad {t_hd:6.3f} ms {tf(t_hd):6.1f} TF/s'
+    line += f' | split(x) {t_s:6.3f} ms'
     print(line, flush=True)

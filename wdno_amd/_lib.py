@@ -45,6 +45,7 @@ PROTOTYPES = {
     'wdno_strerror': (C.c_char_p, [I]),
     'wdno_version': (I, []),
     'wdno_last_hip_error': (C.c_char_p, []),
+    'wdno_set_debug': (I, [I]),
     'wdno_dwt_ws_bytes': (Z, [PD]),
     'wdno_dwt_fwd': (I, [P, P, PD, PF, P, Z, P]),
     'wdno_dwt_inv': (I, [P, P, PD, PF, P, Z, P]),

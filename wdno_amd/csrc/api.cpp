@@ -16,3 +16,7 @@ extern "C" const char* wdno_strerror(int code) {
 }
 extern "C" int wdno_version(void) { return 100; }
 extern "C" const char* wdno_last_hip_error(void) { return hipGetErrorString(wdno_tls_last_hip_error); }
+
+// diagnostics hook used by tools/bench_conv.py (ablation of the convolution pipeline); 0 in production
+int wdno_debug_mode = 0;
+extern "C" int wdno_set_debug(int mode) { wdno_debug_mode = mode; return 0; }

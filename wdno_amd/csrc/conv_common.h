@@ -14,6 +14,7 @@ struct ConvP {
   int nsteps;     // kd*kh*nchunk
   int64_t P;      // N*OD*OH*OW
   int identity_out;
+  int debug;      // diagnostics only (tools/bench_conv.py): 1 = skip global loads, 2 = skip MFMAs
   int tiles_n;
   int ntiles;
 };
@@ -44,8 +45,10 @@ static inline int check_geom(const wdno_conv_geom* g) {
     return WDNO_EINVAL;
   return WDNO_OK;
 }
+extern int wdno_debug_mode;
 static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.g = *g;
+  p.debug = wdno_debug_mode;
   p.R = g->kw * g->C;
   p.nchunk = cdiv(p.R, BK);
   p.nsteps = g->kd * g->kh * p.nchunk;

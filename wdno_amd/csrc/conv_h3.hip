@@ -12,6 +12,7 @@
 // scale. The convolution kernel is the fp32 kernel's structure (conv.hip) with 16-byte loads of 8 halves, LDS planes
 // [rows][32+8] halves (80-byte rows: conflict-free ds_read_b128 / ds_write_b128) and 3 MFMAs per fragment pair.
 #include "conv_common.h"
+#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -90,113 +91,127 @@ extern "C" int wdno_split_f16(const float* x, const float* amax, void* hi, void*
 }
 
 // ---------------------------------------------------------------------------------------------- convolution
+// The fp16 MFMAs of one 32-deep step take only ~400 cycles per wave, so the per-step integer work matters as much as the
+// math. All operand fetches are raw buffer loads with 32-bit byte offsets: out-of-range pieces (zero padding, tile tails)
+// are given an offset beyond the descriptor's range and come back as zeros from the hardware bounds check, so there is
+// no branch and no select. Offsets are (per-thread constant) + (uniform per tap) + (uniform per chunk).
+typedef int int4v __attribute__((ext_vector_type(4)));
+#define OOB_OFFSET 0x7ffffff0      // > any plane size accepted by the host wrapper
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), (short)0, (int)bytes, 0x00020000);
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                            const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
                                                            const float* __restrict__ bias, const float* __restrict__ res,
-                                                           float* __restrict__ y, ConvP p) {
+                                                           float* __restrict__ y, ConvP p, unsigned x_bytes, unsigned w_bytes) {
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
   constexpr int AROWS = BM / 64;   // row passes of the 256 loader threads (64 rows x 4 column groups per pass)
   constexpr int BROWS = BN / 64;
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
-  // stage layout: [Ah | Al | Bh | Bl], two stages
-  constexpr int STAGE = 2 * (BM + BN) * HST;
+  constexpr int STAGE = 2 * (BM + BN) * HST;     // [Ah | Al | Bh | Bl]
   const wdno_conv_geom& g = p.g;
   const int tid = threadIdx.x;
   const int tile = xcd_swizzle(blockIdx.x, p.ntiles);
   const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
+  const __amdgpu_buffer_rsrc_t rxh = make_rsrc(xh, x_bytes), rxl = make_rsrc(xl, x_bytes);
+  const __amdgpu_buffer_rsrc_t rwh = make_rsrc(wh, w_bytes), rwl = make_rsrc(wl, w_bytes);
 
   const int lrow = tid >> 2;          // 0..63
   const int c8 = (tid & 3) * 8;       // element offset inside the 32-wide chunk
-  int a_d0[AROWS], a_h0[AROWS], a_w0[AROWS];
-  int64_t a_nbase[AROWS];
+  int a_d0[AROWS], a_h0[AROWS], a_w0[AROWS], a_base[AROWS];
   bool a_ok[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     int64_t pm = m0 + lrow + 64 * i;
     a_ok[i] = pm < p.P;
-    int64_t q = a_ok[i] ? pm : 0;
-    int ow = (int)(q % g.OW); q /= g.OW;
-    int oh = (int)(q % g.OH); q /= g.OH;
-    int od = (int)(q % g.OD);
-    int64_t n = q / g.OD;
+    int q = a_ok[i] ? (int)pm : 0;                 // the host wrapper guarantees P < 2^31
+    int ow = q % g.OW; q /= g.OW;
+    int oh = q % g.OH; q /= g.OH;
+    int od = q % g.OD;
+    int n = q / g.OD;
     a_d0[i] = od * g.sd - g.pd;
     a_h0[i] = oh * g.sh - g.ph;
     a_w0[i] = ow * g.sw - g.pw;
-    a_nbase[i] = n * g.D;
+    a_base[i] = (((n * g.D + a_d0[i]) * g.H + a_h0[i]) * g.W + a_w0[i]) * g.C + c8;   // element offset of (tap 0, chunk 0)
   }
-  int64_t row_off[AROWS];
-  bool row_ok[AROWS];
-  int64_t b_off[BROWS];
+  int b_base[BROWS];
   bool b_ok[BROWS];
 #pragma unroll
-  for (int i = 0; i < BROWS; ++i) b_ok[i] = (n0 + lrow + 64 * i) < g.K;
+  for (int i = 0; i < BROWS; ++i) {
+    int k = n0 + lrow + 64 * i;
+    b_ok[i] = k < g.K;
+    b_base[i] = k * p.R + c8;
+  }
 
-  int l_tap = 0, l_chunk = 0, l_dz = 0, l_dy = 0, l_r = c8, l_dx = c8 / g.C, l_cc = c8 % g.C;
+  // load cursor: (tap, chunk) uniform; (dx, cc) per thread because a chunk may straddle pixels when C % 32 != 0
+  int l_chunk = 0, l_dz = 0, l_dy = 0, l_r = c8, l_dx = c8 / g.C, l_cc = c8 % g.C;
   const int dx0 = l_dx, cc0 = l_cc;
+  int tap_off = 0, wtap_off = 0;            // uniform element offsets of the current tap row in x and in the packed weights
+  const int step_dx = HBK / g.C, step_cc = HBK % g.C;
+  bool row_ok[AROWS];
   auto refresh_tap = [&]() {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       int d = a_d0[i] + l_dz, h = a_h0[i] + l_dy;
-      row_ok[i] = a_ok[i] && d >= 0 && d < g.D && h >= 0 && h < g.H;
-      row_off[i] = (((a_nbase[i] + d) * g.H + h) * (int64_t)g.W + a_w0[i]) * g.C;
+      row_ok[i] = a_ok[i] && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H;
     }
-#pragma unroll
-    for (int i = 0; i < BROWS; ++i) b_off[i] = ((int64_t)l_tap * g.K + (n0 + lrow + 64 * i)) * p.R;
   };
   refresh_tap();
 
-  uint4 ah[AROWS], al[AROWS], bh[BROWS], bl[BROWS];
-  auto load_tile = [&]() {
-    const bool r_ok = l_r < p.R;
+  int4v ah[2][AROWS], al[2][AROWS], bh[2][BROWS], bl[2][BROWS];     // two register sets: loads run 2 steps ahead
+  auto load_tile = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const bool r_ok = l_r < p.R && p.debug != 1;
+    const int chunk_off = l_chunk * HBK;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      int w = a_w0[i] + l_dx;
-      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-      if (row_ok[i] && r_ok && w >= 0 && w < g.W) {
-        vh = *reinterpret_cast<const uint4*>(xh + row_off[i] + l_r);
-        vl = *reinterpret_cast<const uint4*>(xl + row_off[i] + l_r);
-      }
-      ah[i] = vh; al[i] = vl;
+      const bool ok = row_ok[i] && r_ok && (unsigned)(a_w0[i] + l_dx) < (unsigned)g.W;
+      const int off = ok ? (a_base[i] + tap_off + chunk_off) * 2 : OOB_OFFSET;
+      ah[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+      al[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
-      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-      if (b_ok[i] && r_ok) {
-        vh = *reinterpret_cast<const uint4*>(wh + b_off[i] + l_r);
-        vl = *reinterpret_cast<const uint4*>(wl + b_off[i] + l_r);
-      }
-      bh[i] = vh; bl[i] = vl;
+      const bool ok = b_ok[i] && r_ok;
+      const int off = ok ? (b_base[i] + wtap_off + chunk_off) * 2 : OOB_OFFSET;
+      bh[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, off, 0, 0);
+      bl[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, off, 0, 0);
     }
     ++l_chunk;
     l_r += HBK;
-    l_cc += HBK;
-    while (l_cc >= g.C) { l_cc -= g.C; ++l_dx; }
+    l_dx += step_dx;
+    l_cc += step_cc;
+    if (l_cc >= g.C) { l_cc -= g.C; ++l_dx; }
     if (l_chunk == p.nchunk) {
       l_chunk = 0; l_r = c8; l_dx = dx0; l_cc = cc0;
-      ++l_tap;
+      wtap_off += g.K * p.R;
       if (++l_dy == g.kh) { l_dy = 0; ++l_dz; }
+      tap_off = (l_dz * g.H + l_dy) * g.W * g.C;
       refresh_tap();
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](auto SET, int buf) {
+    constexpr int S = decltype(SET)::value;
     _Float16* Ah = hsm + buf * STAGE;
     _Float16* Al = Ah + BM * HST;
     _Float16* Bh = Al + BM * HST;
     _Float16* Bl = Bh + BN * HST;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      *reinterpret_cast<uint4*>(&Ah[(lrow + 64 * i) * HST + c8]) = ah[i];
-      *reinterpret_cast<uint4*>(&Al[(lrow + 64 * i) * HST + c8]) = al[i];
+      *reinterpret_cast<int4v*>(&Ah[(lrow + 64 * i) * HST + c8]) = ah[S][i];
+      *reinterpret_cast<int4v*>(&Al[(lrow + 64 * i) * HST + c8]) = al[S][i];
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
-      *reinterpret_cast<uint4*>(&Bh[(lrow + 64 * i) * HST + c8]) = bh[i];
-      *reinterpret_cast<uint4*>(&Bl[(lrow + 64 * i) * HST + c8]) = bl[i];
+      *reinterpret_cast<int4v*>(&Bh[(lrow + 64 * i) * HST + c8]) = bh[S][i];
+      *reinterpret_cast<int4v*>(&Bl[(lrow + 64 * i) * HST + c8]) = bl[S][i];
     }
   };
 
@@ -213,12 +228,12 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-  if (p.nsteps > 1) load_tile();
-  for (int step = 0; step < p.nsteps; ++step) {
-    const _Float16* Ah = hsm + (step & 1) * STAGE;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // step t lives in register set t & 1 and LDS stage t & 1
+  auto iter = [&](auto PAR, int step) {
+    constexpr int B = decltype(PAR)::value;
+    const _Float16* Ah = hsm + B * STAGE;
     const _Float16* Al = Ah + BM * HST;
     const _Float16* Bh = Al + BM * HST;
     const _Float16* Bl = Bh + BN * HST;
@@ -236,18 +251,34 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
         fbh[b] = *reinterpret_cast<const half8*>(&Bh[(n_base + b * 32 + li) * HST + col]);
         fbl[b] = *reinterpret_cast<const half8*>(&Bl[(n_base + b * 32 + li) * HST + col]);
       }
+      // the three partial products go to the same accumulator: issue them tile-interleaved so that consecutive MFMAs
+      // never depend on each other
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[b], acc[a][b], 0, 0, 0);
-        }
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[b], acc[a][b], 0, 0, 0);
     }
-    if (step + 1 < p.nsteps) store_tile((step + 1) & 1);
+    using NXT = std::integral_constant<int, 1 - B>;
+    if (step + 1 < p.nsteps) store_tile(NXT{}, 1 - B);
     __syncthreads();
-    if (step + 2 < p.nsteps) load_tile();
+    if (step + 3 < p.nsteps) load_tile(NXT{});
+  };
+  load_tile(S0{});
+  store_tile(S0{}, 0);
+  __syncthreads();
+  if (p.nsteps > 1) load_tile(S1{});
+  if (p.nsteps > 2) load_tile(S0{});
+  for (int step = 0; step < p.nsteps; step += 2) {
+    iter(S0{}, step);
+    if (step + 1 < p.nsteps) iter(S1{}, step + 1);
   }
 
   const float inv = 1.0f / (sx[0] * sw[0]);
@@ -288,8 +319,12 @@ static int launch_h3(const void* xh, const void* xl, const void* wh, const void*
     (void)hipFuncSetAttribute((const void*)conv_fwd_h3_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
+  const int64_t x_elems = (int64_t)g.N * g.D * g.H * g.W * g.C;
+  const int64_t w_elems = (int64_t)g.kd * g.kh * g.K * p.R;
+  if (x_elems * 2 >= OOB_OFFSET || w_elems * 2 >= OOB_OFFSET || p.P >= 0x7fffffff) return WDNO_EUNSUPPORTED;   // 32-bit buffer offsets
   conv_fwd_h3_kernel<BM, BN, WM, WN><<<p.ntiles, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh,
-                                                              (const _Float16*)wl, sx, sw, bias, residual, y, p);
+                                                              (const _Float16*)wl, sx, sw, bias, residual, y, p,
+                                                              (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
   return WDNO_OK;
 }
 
@@ -492,11 +527,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int bb = 0; bb < TN; ++bb) {
-            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[bb], acc[a][bb], 0, 0, 0);
-            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[bb], acc[a][bb], 0, 0, 0);
-            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[bb], acc[a][bb], 0, 0, 0);
-          }
+          for (int bb = 0; bb < TN; ++bb) acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[bb], acc[a][bb], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int bb = 0; bb < TN; ++bb) acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[bb], acc[a][bb], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int bb = 0; bb < TN; ++bb) acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[bb], acc[a][bb], 0, 0, 0);
       }
       if (step + 1 < nsteps) store_tile((step + 1) & 1);
       __syncthreads();

@@ -313,7 +313,7 @@ def pack_transposed(w_io, cin_p, cout_p):
 # MFMA everywhere. Small problems always take the exact kernel.
 CONV_MATH = os.environ.get('WDNO_CONV_MATH', 'f16x3')
 H3_MIN_PIXELS = 1024
-H3_MIN_REDUCTION = 128
+H3_MIN_REDUCTION = 64
 
 
 def pad8(c):
