@@ -107,8 +107,10 @@ int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const v
                         const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s);
 /* weight gradient on the same split planes (g->C = C8 of x, g->K = K8 of dy); dwp [kd][kh][K8][kw*C8] fp32 */
 size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g);
+/* pixel_table: [N*OD*OH*OW] 16-byte records from wdno_conv_pixel_table (depends on the geometry only; callers cache it) */
+int wdno_conv_pixel_table(void* table, const wdno_conv_geom* g, wdno_stream_t s);
 int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
-                          float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s);
+                          const void* pixel_table, float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s);
 /* dwp[kd][kh][K][kw*C] = sum over output pixels of dy (x) shifted x. ws: caller workspace. */
 size_t wdno_conv_wgrad_ws_bytes(const wdno_conv_geom* g);
 int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_t ws_bytes,

@@ -63,7 +63,8 @@ PROTOTYPES = {
     'wdno_split_f16': (I, [P, P, P, P, P, L, I, I, P]),
     'wdno_conv_fwd_f16x3': (I, [P, P, P, P, P, P, P, P, P, PG, P]),
     'wdno_conv_wgrad_f16x3_ws_bytes': (Z, [PG]),
-    'wdno_conv_wgrad_f16x3': (I, [P, P, P, P, P, P, P, P, Z, PG, P]),
+    'wdno_conv_pixel_table': (I, [P, PG, P]),
+    'wdno_conv_wgrad_f16x3': (I, [P, P, P, P, P, P, P, P, P, Z, PG, P]),
     'wdno_conv_wgrad_ws_bytes': (Z, [PG]),
     'wdno_conv_wgrad': (I, [P, P, P, P, Z, PG, P]),
     'wdno_colsum_ws_bytes': (Z, [L, I]),

@@ -364,7 +364,33 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define WH_BKP 32
 #define WH_PAD 32
 
-struct PixInfoH { int64_t yrow; int64_t xbase; int w0; int ok; };
+// pixel table: one 16-byte record per output pixel, built once per geometry (host-cached):
+//   x = physical output row (dy / y row index), y = element offset of input pixel (d0, h0, w0) (tap dz = dy = 0, may be
+//   negative), z = d0 << 16 | (h0 & 0xffff), w = w0          with d0 = od*sd - pd etc.
+__global__ __launch_bounds__(256) void pixel_table_kernel(int4v* __restrict__ tbl, wdno_conv_geom g, int P) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  int q = p;
+  int ow = q % g.OW; q /= g.OW;
+  int oh = q % g.OH; q /= g.OH;
+  int od = q % g.OD;
+  int n = q / g.OD;
+  int d0 = od * g.sd - g.pd, h0 = oh * g.sh - g.ph, w0 = ow * g.sw - g.pw;
+  int4v e;
+  e.x = ((n * g.YD + (od * g.osd + g.ood)) * g.YH + (oh * g.osh + g.ooh)) * g.YW + (ow * g.osw + g.oow);
+  e.y = (((n * g.D + d0) * g.H + h0) * g.W + w0) * g.C;
+  e.z = (d0 << 16) | (h0 & 0xffff);
+  e.w = w0;
+  tbl[p] = e;
+}
+extern "C" int wdno_conv_pixel_table(void* table, const wdno_conv_geom* g, wdno_stream_t s) {
+  int rc = check_geom(g);
+  if (rc) return rc;
+  int64_t P = (int64_t)g->N * g->OD * g->OH * g->OW;
+  if (P >= 0x7fffffff || (int64_t)g->N * g->D * g->H * g->W * g->C >= 0x3fffffff) return WDNO_EUNSUPPORTED;
+  pixel_table_kernel<<<(unsigned)cdiv64(P, 256), 256, 0, as_stream(s)>>>((int4v*)table, *g, (int)P);
+  return wdno_check_launch();
+}
 
 struct WgradHP {
   ConvP c;
@@ -385,11 +411,13 @@ __device__ __forceinline__ half8 tr_frag(const _Float16* tile, int stride, int p
   return __builtin_bit_cast(half8, c);
 }
 
+#define WH_RING 4
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                              const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
                                                              const float* __restrict__ sx, const float* __restrict__ sdy,
-                                                             float* __restrict__ ws, WgradHP wpz) {
+                                                             const int4v* __restrict__ table, float* __restrict__ ws, WgradHP wpz,
+                                                             unsigned x_bytes, unsigned dy_bytes) {
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
   constexpr int SA = BM + WH_PAD, SB = BN + WH_PAD;          // LDS row strides (halves)
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
   constexpr int A_PASSES = WH_BKP / A_RPP, B_PASSES = WH_BKP / B_RPP;
   constexpr int STAGE = 2 * WH_BKP * (SA + SB);               // halves per stage: Ah, Al, Bh, Bl
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
-  PixInfoH* pinfo = reinterpret_cast<PixInfoH*>(hsm + 2 * STAGE);   // [3][WH_BKP]
+  int4v* pinfo = reinterpret_cast<int4v*>(hsm + 2 * STAGE);   // [WH_RING][WH_BKP]
 
   const ConvP& p = wpz.c;
   const wdno_conv_geom& g = p.g;
@@ -409,30 +437,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
   const int tile_k = b / (g.kd * g.kh);
   const int dz = tap / g.kh, dyy = tap - dz * g.kh;
   const int k0 = tile_k * BM, r0 = tile_r * BN;
-  const int64_t pbeg = (int64_t)blockIdx.y * wpz.pix_per_split;
-  int64_t pend = pbeg + wpz.pix_per_split;
-  if (pend > p.P) pend = p.P;
-  const int nsteps = pbeg < pend ? (int)((pend - pbeg + WH_BKP - 1) / WH_BKP) : 0;
+  const int pbeg = (int)((int64_t)blockIdx.y * wpz.pix_per_split);
+  int pend = pbeg + (int)wpz.pix_per_split;
+  if (pend > (int)p.P) pend = (int)p.P;
+  const int nsteps = pbeg < pend ? (pend - pbeg + WH_BKP - 1) / WH_BKP : 0;
+  const __amdgpu_buffer_rsrc_t rxh = make_rsrc(xh, x_bytes), rxl = make_rsrc(xl, x_bytes);
+  const __amdgpu_buffer_rsrc_t rdh = make_rsrc(dyh, dy_bytes), rdl = make_rsrc(dyl, dy_bytes);
+  const int tap_off = (dz * g.H + dyy) * g.W * g.C;          // uniform element offset of this block's tap row
 
-  auto decode = [&](int step) {
-    if (tid < WH_BKP) {
-      int64_t pm = pbeg + (int64_t)step * WH_BKP + tid;
-      PixInfoH pi;
-      pi.ok = 0; pi.yrow = 0; pi.xbase = 0; pi.w0 = 0;
-      if (pm < pend) {
-        int64_t q = pm;
-        int ow = (int)(q % g.OW); q /= g.OW;
-        int oh = (int)(q % g.OH); q /= g.OH;
-        int od = (int)(q % g.OD);
-        int64_t n = q / g.OD;
-        pi.yrow = ((n * g.YD + (od * g.osd + g.ood)) * g.YH + (oh * g.osh + g.ooh)) * g.YW + (ow * g.osw + g.oow);
-        int d = od * g.sd - g.pd + dz, h = oh * g.sh - g.ph + dyy;
-        pi.w0 = ow * g.sw - g.pw;
-        pi.xbase = (((n * g.D + d) * g.H + h) * (int64_t)g.W + pi.w0) * g.C;
-        pi.ok = (d >= 0 && d < g.D && h >= 0 && h < g.H) ? 3 : 1;
-      }
-      pinfo[(step % 3) * WH_BKP + tid] = pi;
-    }
+  // pixel records travel table -> register -> LDS ring, several steps ahead of their use
+  auto fetch_rec = [&](int step) -> int4v {
+    int4v e;
+    e.x = 0; e.y = 0; e.z = (int)0x80008000; e.w = 0;         // d0 = h0 = -32768: never valid
+    int pm = pbeg + step * WH_BKP + tid;
+    if (tid < WH_BKP && step < nsteps && pm < pend) e = table[pm];
+    if (tid < WH_BKP && !(step < nsteps && pm < pend)) e.x = -1;
+    return e;
+  };
+  auto put_rec = [&](int step, int4v e) {
+    if (tid < WH_BKP) pinfo[(step & (WH_RING - 1)) * WH_BKP + tid] = e;
   };
 
   const int b_row = tid / B_C8, b_c8 = (tid % B_C8) * 8;
@@ -443,29 +466,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
   const int ka = k0 + a_c8;
   const bool ka_ok = ka < g.K;
 
-  uint4 ah[A_PASSES], al[A_PASSES], bh[B_PASSES], bl[B_PASSES];
+  int4v ah[A_PASSES], al[A_PASSES], bh[B_PASSES], bl[B_PASSES];
   auto load_tile = [&](int step) {
-    const PixInfoH* ps = pinfo + (step % 3) * WH_BKP;
+    const int4v* ps = pinfo + (step & (WH_RING - 1)) * WH_BKP;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      const PixInfoH pi = ps[a_row + i * A_RPP];
-      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-      if ((pi.ok & 1) && ka_ok) {
-        vh = *reinterpret_cast<const uint4*>(dyh + pi.yrow * g.K + ka);
-        vl = *reinterpret_cast<const uint4*>(dyl + pi.yrow * g.K + ka);
-      }
-      ah[i] = vh; al[i] = vl;
+      const int4v e = ps[a_row + i * A_RPP];
+      const int off = (e.x >= 0 && ka_ok) ? (e.x * g.K + ka) * 2 : OOB_OFFSET;
+      ah[i] = __builtin_amdgcn_raw_buffer_load_b128(rdh, off, 0, 0);
+      al[i] = __builtin_amdgcn_raw_buffer_load_b128(rdl, off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      const PixInfoH pi = ps[b_row + i * B_RPP];
-      uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-      int w = pi.w0 + dx;
-      if (pi.ok == 3 && r_ok && w >= 0 && w < g.W) {
-        vh = *reinterpret_cast<const uint4*>(xh + pi.xbase + r);
-        vl = *reinterpret_cast<const uint4*>(xl + pi.xbase + r);
-      }
-      bh[i] = vh; bl[i] = vl;
+      const int4v e = ps[b_row + i * B_RPP];
+      const int d = (e.z >> 16) + dz, h = (int)(short)(e.z & 0xffff) + dyy, w = e.w + dx;
+      const bool ok = e.x >= 0 && r_ok && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+      const int off = ok ? (e.y + tap_off + r) * 2 : OOB_OFFSET;
+      bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
+      bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
     }
   };
   auto store_tile = [&](int buf) {
@@ -475,13 +493,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
     _Float16* Bl = Bh + WH_BKP * SB;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      *reinterpret_cast<uint4*>(&Ah[(a_row + i * A_RPP) * SA + a_c8]) = ah[i];
-      *reinterpret_cast<uint4*>(&Al[(a_row + i * A_RPP) * SA + a_c8]) = al[i];
+      *reinterpret_cast<int4v*>(&Ah[(a_row + i * A_RPP) * SA + a_c8]) = ah[i];
+      *reinterpret_cast<int4v*>(&Al[(a_row + i * A_RPP) * SA + a_c8]) = al[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      *reinterpret_cast<uint4*>(&Bh[(b_row + i * B_RPP) * SB + b_c8]) = bh[i];
-      *reinterpret_cast<uint4*>(&Bl[(b_row + i * B_RPP) * SB + b_c8]) = bl[i];
+      *reinterpret_cast<int4v*>(&Bh[(b_row + i * B_RPP) * SB + b_c8]) = bh[i];
+      *reinterpret_cast<int4v*>(&Bl[(b_row + i * B_RPP) * SB + b_c8]) = bl[i];
     }
   };
 
@@ -498,12 +516,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
       for (int e = 0; e < 16; ++e) acc[a][bb][e] = 0.f;
 
   if (nsteps > 0) {
-    decode(0);
-    if (nsteps > 1) decode(1);
+    put_rec(0, fetch_rec(0));
+    put_rec(1, fetch_rec(1));
+    put_rec(2, fetch_rec(2));
+    int4v rec = fetch_rec(3);            // record of step s+3 is written to LDS during iteration s, loaded one iteration earlier
     __syncthreads();
     load_tile(0);
     store_tile(0);
-    if (nsteps > 2) decode(2);
     __syncthreads();
     if (nsteps > 1) load_tile(1);
     for (int step = 0; step < nsteps; ++step) {
@@ -511,6 +530,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
       const _Float16* Al = Ah + WH_BKP * SA;
       const _Float16* Bh = Al + WH_BKP * SA;
       const _Float16* Bl = Bh + WH_BKP * SB;
+      put_rec(step + 3, rec);            // slot (step+3)&3 was last read by load_tile(step-1): two barriers ago
+      rec = fetch_rec(step + 4);
 #pragma unroll
       for (int ks = 0; ks < WH_BKP / 16; ++ks) {
         half8 fah[TM], fal[TM], fbh[TN], fbl[TN];
@@ -540,7 +561,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
       if (step + 1 < nsteps) store_tile((step + 1) & 1);
       __syncthreads();
       if (step + 2 < nsteps) load_tile(step + 2);
-      if (step + 3 < nsteps) decode(step + 3);
     }
   }
 
@@ -592,21 +612,26 @@ extern "C" size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g) {
 }
 template <int BM, int BN, int WM, int WN>
 static void launch_wgrad_h3(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
-                            float* wsf, const WgradHP& w, dim3 grid, hipStream_t st) {
-  size_t lds = (size_t)2 * 2 * WH_BKP * (BM + WH_PAD + BN + WH_PAD) * sizeof(_Float16) + 3 * WH_BKP * sizeof(PixInfoH);
+                            const void* table, float* wsf, const WgradHP& w, dim3 grid, hipStream_t st) {
+  const wdno_conv_geom& g = w.c.g;
+  const unsigned x_bytes = (unsigned)((int64_t)g.N * g.D * g.H * g.W * g.C * 2);
+  const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
+  size_t lds = (size_t)2 * 2 * WH_BKP * (BM + WH_PAD + BN + WH_PAD) * sizeof(_Float16) + WH_RING * WH_BKP * sizeof(int4v);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_h3_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   conv_wgrad_h3_kernel<BM, BN, WM, WN><<<grid, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh,
-                                                            (const _Float16*)dyl, sx, sdy, wsf, w);
+                                                            (const _Float16*)dyl, sx, sdy, (const int4v*)table, wsf, w, x_bytes, dy_bytes);
 }
 extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
-                                     float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s) {
+                                     const void* pixel_table, float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s) {
   int rc = check_geom(g);
   if (rc) return rc;
-  if ((g->C & 7) || (g->K & 7)) return WDNO_EUNSUPPORTED;
+  if ((g->C & 7) || (g->K & 7) || !pixel_table) return WDNO_EUNSUPPORTED;
+  if ((int64_t)g->N * g->D * g->H * g->W * g->C * 2 >= OOB_OFFSET || (int64_t)g->N * g->YD * g->YH * g->YW * g->K * 2 >= OOB_OFFSET)
+    return WDNO_EUNSUPPORTED;        // 32-bit buffer offsets
   WgradHP w;
   wgrad_h3_plan(w, g);
   size_t need = (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
@@ -615,8 +640,8 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
   dim3 grid((unsigned)(w.tiles_k * g->kd * g->kh * w.tiles_r), (unsigned)w.splits);
   float* wsf = w.splits == 1 ? dwp : (float*)ws;
   hipStream_t st = as_stream(s);
-  if (g->K > 64) launch_wgrad_h3<128, 128, 2, 2>(xh, xl, dyh, dyl, sx, sdy, wsf, w, grid, st);
-  else launch_wgrad_h3<64, 128, 1, 4>(xh, xl, dyh, dyl, sx, sdy, wsf, w, grid, st);
+  if (g->K > 64) launch_wgrad_h3<128, 128, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
+  else launch_wgrad_h3<64, 128, 1, 4>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
   if (w.splits > 1) {
     int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
     wgrad_h3_reduce_kernel<<<stream_grid(n, 256), 256, 0, st>>>((const float*)ws, dwp, n, w.splits);

@@ -368,6 +368,9 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp)
     return y
 
 
+_pixel_tables = {}
+
+
 def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd):
     """-> dwp [kd, kh, K8, kw, C8] fp32 from the split planes of x (C8 channels) and dy (K8 channels)."""
     xh, xl, sx = xplanes
@@ -378,10 +381,16 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd):
     lib = _lib_()
     nb = lib.wdno_conv_wgrad_f16x3_ws_bytes(C.byref(g))
     ws = _ws(nb, xh.device)
+    tkey = (str(xh.device), n, d, h, ww, c8, tuple(osp), tuple(ks), tuple(st), tuple(pd))
+    table = _pixel_tables.get(tkey)
+    if table is None:                      # geometry-only: built once, reused by every later step
+        table = torch.empty((n * osp[0] * osp[1] * osp[2], 4), device=xh.device, dtype=torch.int32)
+        _lib.check(lib.wdno_conv_pixel_table(_p(table), C.byref(g), _stream()), 'conv_pixel_table')
+        _pixel_tables[tkey] = table
     dwp = torch.empty((ks[0], ks[1], k8, ks[2], c8), device=xh.device, dtype=torch.float32)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * k8 * ks[0] * ks[1] * ks[2] * c8
     with _timed('conv_wgrad_h3_kernel<128,..>' if k8 > 64 else 'conv_wgrad_h3_kernel<64,..>', flops):
-        _lib.check(lib.wdno_conv_wgrad_f16x3(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(dwp), _p(ws), nb, C.byref(g), _stream()),
+        _lib.check(lib.wdno_conv_wgrad_f16x3(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dwp), _p(ws), nb, C.byref(g), _stream()),
                    'conv_wgrad_f16x3')
     return dwp
 
