@@ -103,6 +103,10 @@ int wdno_conv_fwd(const float* x, const float* wp, const float* bias, const floa
  * with g->C = C8; sx / sw are the device scalars written by wdno_split_f16 for the activation / packed-weight operand. */
 int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s);
 int wdno_split_f16(const float* x, const float* amax, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8, wdno_stream_t s);
+/* raw weight [K][C][kd][kh][kw] -> split planes of the packed operand in one launch. mode 0: forward operand
+ * [kd][kh][A>=K][kw][B>=C]; mode 1: data-gradient operand [kd][kh][A>=C][kw][B>=K] with flipped taps. amax = max|w| (device). */
+int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh, int kw,
+                           int A, int B, int mode, wdno_stream_t s);
 int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                         const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s);
 /* weight gradient on the same split planes (g->C = C8 of x, g->K = K8 of dy); dwp [kd][kh][K8][kw*C8] fp32 */

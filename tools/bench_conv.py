@@ -59,9 +59,9 @@ for name, xs, ws, st, pd in CASES:
     if '--ablate' in sys.argv:
         lib = ops._lib_()
         lib.wdno_set_debug(1); t1 = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
-        t2 = float('nan')
+        lib.wdno_set_debug(3); t2 = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
         lib.wdno_set_debug(0)
-        print(f'   ablation fwd: full {t_hf:.3f} ms | no global loads (all-invalid) {t1:.3f} ms | no MFMA {t2:.3f} ms')
+        print(f'   ablation fwd: full {t_hf:.3f} ms | no global loads (all-invalid) {t1:.3f} ms | small-tile variant {t2:.3f} ms')
     t_hw = timeit(lambda: ops.conv_wgrad_h3(xpl, tuple(xs[:4]), ypl, osp, ks, st, pd))
     line += f' h3: fwd {t_hf:6.3f} ms {tf(t_hf):6.1f} TF/s | wgrad {t_hw:6.3f} ms {tf(t_hw):6.1f} TF/s'
     if st == (1, 1, 1):

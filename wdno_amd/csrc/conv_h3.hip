@@ -342,10 +342,10 @@ extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* 
   const int K = g->K;
   auto blocks = [&](int bm, int bn) { return cdiv64(P, bm) * cdiv(K, bn); };
   if (K > 64) {
-    if (blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) rc = launch_h3<128, 128, 2, 2>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    if ((blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) && wdno_debug_mode != 3) rc = launch_h3<128, 128, 2, 2>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
     else rc = launch_h3<64, 128, 1, 4>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
   } else {
-    if (blocks(128, 64) >= 512 || P <= 128) rc = launch_h3<128, 64, 4, 1>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    if ((blocks(128, 64) >= 512 || P <= 128) && wdno_debug_mode != 3) rc = launch_h3<128, 64, 4, 1>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
     else rc = launch_h3<64, 64, 2, 2>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
   }
   if (rc) return rc;
@@ -646,5 +646,52 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
     int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
     wgrad_h3_reduce_kernel<<<stream_grid(n, 256), 256, 0, st>>>((const float*)ws, dwp, n, w.splits);
   }
+  return wdno_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- weight pack + split
+// raw weight w[K][C][kd][kh][kw] fp32  ->  fp16 planes of the packed operand, in one launch:
+//   mode 0 (forward)  : out[dz][dy][a=k < A][dx][b=c < B]  = w[k][c][dz][dy][dx]
+//   mode 1 (data grad): out[dz][dy][a=c < A][dx][b=k < B]  = w[k][c][kd-1-dz][kh-1-dy][kw-1-dx]
+// A / B are the padded extents of the two channel roles (B % 8 == 0); entries outside K / C are zero.
+__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __restrict__ w, const float* __restrict__ amax,
+                                                                 _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                                 float* __restrict__ scale_out, int K, int C, int kd, int kh, int kw,
+                                                                 int A, int B, int mode) {
+  const float s = scale_from_amax(amax[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const int b8 = B >> 3;
+  const int64_t total = (int64_t)kd * kh * A * kw * b8;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t taps = (int64_t)kd * kh * kw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int g8 = (int)(i % b8); int64_t t = i / b8;
+    int dx = (int)(t % kw); t /= kw;
+    int a = (int)(t % A); t /= A;
+    int dy = (int)(t % kh);
+    int dz = (int)(t / kh);
+    const int z = mode ? kd - 1 - dz : dz, yy = mode ? kh - 1 - dy : dy, x = mode ? kw - 1 - dx : dx;
+    half8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int b = g8 * 8 + e;
+      int k = mode ? b : a, c = mode ? a : b;
+      float v = (k < K && c < C) ? w[((int64_t)k * C + c) * taps + ((int64_t)z * kh + yy) * kw + x] : 0.f;
+      float tv = v * s;
+      _Float16 th = (_Float16)tv;
+      h[e] = th;
+      l[e] = (_Float16)(tv - (float)th);
+    }
+    *reinterpret_cast<half8*>(hi + i * 8) = h;
+    *reinterpret_cast<half8*>(lo + i * 8) = l;
+  }
+}
+extern "C" int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh,
+                                      int kw, int A, int B, int mode, wdno_stream_t s) {
+  WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && (mode == 0 || mode == 1));
+  WDNO_REQUIRE(mode == 0 ? (A >= K && B >= C) : (A >= C && B >= K));
+  int64_t total = (int64_t)kd * kh * A * kw * (B / 8);
+  pack_split_weight_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(w, amax, (_Float16*)hi, (_Float16*)lo, scale_out, K, C, kd, kh, kw,
+                                                                            A, B, mode);
   return wdno_check_launch();
 }

@@ -320,35 +320,76 @@ def pad8(c):
     return (c + 7) // 8 * 8
 
 
+_amax_pool = {}
+
+
+def _amax_slot(device):
+    """A zeroed device scalar for wdno_amax, taken from a pool that is re-zeroed with one launch when exhausted."""
+    key = str(device)
+    st = _amax_pool.get(key)
+    if st is None or st[1] >= st[0].numel():
+        if st is None:
+            st = [torch.zeros(8192, device=device, dtype=torch.float32), 0]
+            _amax_pool[key] = st
+        else:
+            st[0].zero_()
+            st[1] = 0
+    slot = st[0][st[1]:st[1] + 1]
+    st[1] += 1
+    return slot
+
+
+def tensor_amax(x):
+    amax = _amax_slot(x.device)
+    _lib.check(_lib_().wdno_amax(_p(x), x.numel(), _p(amax), _stream()), 'amax')
+    return amax
+
+
 def split_f16(x2d):
     """[rows, C] fp32 -> (hi, lo) fp16 [rows, C8] and the device scalar scale (one amax pass + one split pass)."""
     rows, c = x2d.shape
     c8 = pad8(c)
     lib = _lib_()
-    amax = torch.zeros(1, device=x2d.device, dtype=torch.float32)
+    amax = tensor_amax(x2d)
     hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
-    _lib.check(lib.wdno_amax(_p(x2d), x2d.numel(), _p(amax), _stream()), 'amax')
     _lib.check(lib.wdno_split_f16(_p(x2d), _p(amax), _p(hi), _p(lo), _p(scale), rows, c, c8, _stream()), 'split_f16')
     return hi, lo, scale
 
 
-def split_weight(w, kind, cp8, kp, pack):
-    """Packed weight (cached) -> its fp16 split planes and scale (cached with the same key)."""
-    def build():
-        wp = pack(w, cp8, kp)
-        hi, lo, sc = split_f16(wp.reshape(-1, cp8))
-        return torch.stack([hi.view(torch.int16), lo.view(torch.int16)]), sc
+def split_weight(w, kind, cp8, kp, pack=None):
+    """Split planes of the packed weight operand (cached per weight version). kind 'f': forward operand
+    [kd,kh,kp,kw,cp8]; kind 'd': data-gradient operand [kd,kh,kp(=Cp of x),kw,cp8(=K8 of dy)] with flipped taps.
+    One amax launch per weight version (shared by both kinds) + one fused pack-and-split launch per kind."""
     key = (w.data_ptr(), kind + '_h3', cp8, kp, tuple(w.shape), tuple(w.stride()))
     ver = (w._version, WEIGHT_EPOCH)
     hit = _pack_cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
     with torch.no_grad():
-        planes, sc = build()
-    _pack_cache[key] = (ver, (planes[0], planes[1], sc), w.detach())
-    return _pack_cache[key][1]
+        wd = w.detach()
+        wc = wd if wd.is_contiguous() else wd.contiguous()
+        akey = (w.data_ptr(), 'amax', tuple(w.shape), tuple(w.stride()))
+        ah = _pack_cache.get(akey)
+        if ah is not None and ah[0] == ver:
+            amax = ah[1]
+        else:
+            amax = torch.zeros(1, device=w.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_amax(_p(wc), wc.numel(), _p(amax), _stream()), 'amax')
+            _pack_cache[akey] = (ver, amax, wd)
+        w5 = _as5(wc)
+        k, c, kd, kh, kw = w5.shape
+        rows = kd * kh * kp * kw
+        hi = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
+        lo = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
+        sc = torch.empty(1, device=w.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_pack_split_weight(_p(wc), _p(amax), _p(hi), _p(lo), _p(sc), k, c, kd, kh, kw, kp, cp8,
+                                                  0 if kind == 'f' else 1, _stream()), 'pack_split_weight')
+    if len(_pack_cache) > 8192:
+        _pack_cache.clear()
+    _pack_cache[key] = (ver, (hi, lo, sc), wd)
+    return hi, lo, sc
 
 
 def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp):
