@@ -123,7 +123,10 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
   const __amdgpu_buffer_rsrc_t rxh = make_rsrc(xh, x_bytes), rxl = make_rsrc(xl, x_bytes);
   const __amdgpu_buffer_rsrc_t rwh = make_rsrc(wh, w_bytes), rwl = make_rsrc(wl, w_bytes);
 
-  const int lrow = tid >> 2;          // 0..63
+  // 4 lanes cover one 64-byte row piece; consecutive lane quads take rows r and r+4 so that the 8 lanes of a
+  // ds_write_b128 group hit 32 distinct banks with the 80-byte row stride (r and r+1 would overlap by 16 bytes)
+  const int lq = tid >> 2;
+  const int lrow = (lq & ~7) | ((lq & 1) << 2) | ((lq >> 1) & 3);          // 0..63, bijective
   const int c8 = (tid & 3) * 8;       // element offset inside the 32-wide chunk
   int a_d0[AROWS], a_h0[AROWS], a_w0[AROWS], a_base[AROWS];
   bool a_ok[AROWS];
