@@ -164,8 +164,19 @@ def main():
             ms, fl, n = agg[dom]
             achieved = fl / (ms * 1e-3) / 1e12
             peak = PEAK_F16_MFMA_TFLOPS if 'h3' in dom else PEAK_F32_MFMA_TFLOPS
+            traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json)
+            try:
+                sym = {'conv_fwd_h3_kernel<..,64>': 'conv_fwd_h3_kernelILi128ELi64E', 'conv_fwd_h3_kernel<128,..>': 'conv_fwd_h3_kernelILi128ELi128E',
+                       'conv_wgrad_h3_kernel<64,..>': 'conv_wgrad_h3_kernelILi64ELi128E', 'conv_wgrad_h3_kernel<128,..>': 'conv_wgrad_h3_kernelILi128ELi128E'}.get(dom)
+                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+                    for kname, rec in json.load(f)['kernels'].items():
+                        if sym and sym in kname:
+                            traffic = round(rec['hbm_bytes_per_launch'])
+            except Exception:
+                traffic = None
             roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / peak, 4), 'traffic': None, 'launches_per_step': n,
+                        'frac': round(achieved / peak, 4), 'traffic': traffic, 'launches_per_step': n,
+                        'frac_of_fp32_equivalent_ceiling': round(achieved / (peak / 3), 4) if 'h3' in dom else None,
                         'note': ('fp32-equivalent 3 x fp16-split MFMA: 3 matrix flop per algorithmic flop, so frac <= 0.333; '
                                  'the exact-fp32 MFMA peak is 157.3 TFLOP/s') if 'h3' in dom else 'exact-fp32 MFMA',
                         'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
