@@ -259,3 +259,28 @@ def burgers_ddim_sample(model, buf, noise_seq, T, S, eta, *, padded_shape, flags
         x = ddim_update(buf, xs, eps, time, time_next, eta, next(it))
     burgers_apply_conditions(x, padded_shape, flags, **cond)
     return x
+
+
+# --------------------------------------------------------------------------- EMA of the weights (T1/T2 rows)
+def ema_reference_update(ema, online, state, beta=0.995, update_every=10, update_after_step=100, inv_gamma=1.0, power=2.0 / 3.0,
+                         min_value=0.0):
+    """One `ema.update()` call of ema_pytorch.EMA as configured by both Trainers (train_diffusion.py:123-125,
+    diffusion_2d.py:1165-1167). ema_pytorch is a third-party dependency that is absent from /root/reference (env.sh,
+    unpinned) -> its published rule is restated; PARITY UNPINNED for this function (no reference output available).
+    `ema`, `online`: dicts name -> tensor (ema is modified in place); `state`: {'step': int, 'initted': bool}."""
+    step = state['step']
+    state['step'] += 1
+    if step % update_every != 0:
+        return
+    if step <= update_after_step:
+        for k in ema:
+            ema[k].copy_(online[k])
+        return
+    if not state['initted']:
+        for k in ema:
+            ema[k].copy_(online[k])
+        state['initted'] = True
+    epoch = max(state['step'] - update_after_step - 1, 0)
+    decay = 0.0 if epoch <= 0 else min(max(1 - (1 + epoch / inv_gamma) ** -power, min_value), beta)
+    for k in ema:
+        ema[k].lerp_(online[k], 1 - decay)

@@ -202,10 +202,82 @@ def idwt3(lll, details, wave, mode='zero'):
     return s(lvl2['a'], lvl2['d'], rl, rh, -3)
 
 
+# --------------------------------------------------------------------------- multi-level (J > 1) transforms
+def _crop_like(ll, ref_shape, naxes):
+    """pytorch_wavelets.DWTInverse / pywt.waverec*: an approximation one sample longer than the next detail band
+    (odd length one level up) loses its last sample before the synthesis."""
+    sl = [slice(None)] * ll.ndim
+    for ax in range(-naxes, 0):
+        if ll.shape[ax] == ref_shape[ax] + 1:
+            sl[ax] = slice(0, -1)
+    return ll[tuple(sl)]
+
+
+def wavedec1(x, wave, mode, J):
+    """pytorch_wavelets.DWT1DForward(J): (x0, [x1 finest, ..., coarsest])."""
+    highs = []
+    for _ in range(J):
+        x, hi = dwt1d(x, wave, mode)
+        highs.append(hi)
+    return x, highs
+
+
+def waverec1(lo, highs, wave, mode):
+    for hi in highs[::-1]:
+        lo = idwt1d(_crop_like(lo, hi.shape, 1), hi, wave, mode)
+    return lo
+
+
+def wavedec2(x, wave, mode, J):
+    """pytorch_wavelets.DWTForward(J): (Yl, [Yh finest, ..., Yh coarsest]); each level re-analyses the LL band
+    (burgers/wave_trans.py:94 builds J = dwt_max_level; data uses J = 1)."""
+    yh = []
+    for _ in range(J):
+        x, h = dwt2(x, wave, mode)
+        yh.append(h)
+    return x, yh
+
+
+def waverec2(yl, yh, wave, mode):
+    for h in yh[::-1]:
+        yl = idwt2(_crop_like(yl, h.shape, 2), h, wave, mode)
+    return yl
+
+
+def wavedec3(x, wave, mode='zero', level=1):
+    """ptwt.wavedec3: [lll, {coarsest details}, ..., {finest details}]."""
+    dicts = []
+    for _ in range(level):
+        x, det = dwt3(x, wave, mode)
+        dicts.append(det)
+    return [x] + dicts[::-1]
+
+
+def waverec3(coeffs, wave, mode='zero'):
+    lll = coeffs[0]
+    for det in coeffs[1:]:
+        lll = idwt3(_crop_like(lll, det['aad'].shape, 3), det, wave, mode)
+    return lll
+
+
 # --------------------------------------------------------------------------- packing helpers
 def burgers_coef_to_tensor(yl, yh, pad=False):
-    """burgers/wave_trans.py:43-62 for J=1: stack (Yl, Yh[0]) -> [N, C, 4, H', W'] (optionally zero-pad to 64x64 multiples)."""
-    t = np.concatenate([yl[:, :, None], yh], axis=2)
+    """burgers/wave_trans.py:43-62: J = 1 -> stack (Yl, Yh[0]) -> [N, C, 4, H', W'] (optionally zero-pad to 64x64
+    multiples). J > 1 (yh a list, finest first): every band is nearest-repeated to the finest grid (Yl and Yh[i] by
+    2^(J-1) / 2^i) and the row deficit of Yh[i] is filled by replicating its last row (wave_trans.py:50-57)."""
+    if isinstance(yh, (list, tuple)) and len(yh) > 1:
+        J = len(yh)
+        rows = yh[0].shape[-2] + 2 ** (J - 1) - 1
+        t = np.zeros((yl.shape[0], yl.shape[1], 1 + 3 * J, rows, yh[0].shape[-1]), dtype=yl.dtype)
+        t[:, :, 0] = np.repeat(np.repeat(yl, 2 ** (J - 1), axis=-2), 2 ** (J - 1), axis=-1)
+        for i in range(J):
+            r = np.repeat(np.repeat(yh[i], 2 ** i, axis=-2), 2 ** i, axis=-1)
+            fill = np.repeat(r[:, :, :, -1:], 2 ** (J - 1) - 2 ** i, axis=3)
+            t[:, :, 1 + 3 * i:1 + 3 * (i + 1)] = np.concatenate([r, fill], axis=3)
+    else:
+        if isinstance(yh, (list, tuple)):
+            yh = yh[0]
+        t = np.concatenate([yl[:, :, None], yh], axis=2)
     if pad:
         up_t = int(t.shape[-2] / 40)
         up_x = int(t.shape[-1] / 60)

@@ -72,6 +72,46 @@ for tag, wave, shape in [('mid', 'bior1.3', (2, 16, 20, 24)), ('odd', 'bior1.3',
     put(f'idwt3_{tag}_coef', np.stack([r[k] for k in KEYS], axis=1))
     put(f'idwt3_{tag}_x', pywt.idwtn(r, wave, mode='zero', axes=(1, 2, 3)))
 
+# ---- multi-level (J > 1): pywt.wavedec2 / wavedec / wavedecn return coarsest first
+for tag, wave, shape, J in [('ref3', 'bior2.4', (1, 2, 81, 120), 3), ('even2', 'bior2.4', (2, 1, 32, 48), 2), ('db4odd', 'db4', (1, 1, 37, 26), 2)]:
+    x = rng.standard_normal(shape)
+    c = pywt.wavedec2(x, wave, mode='periodization', level=J, axes=(-2, -1))
+    put(f'wavedec2_{tag}_x', x)
+    put(f'wavedec2_{tag}_yl', c[0])
+    for lvl in range(J):                      # store finest first (pytorch_wavelets order)
+        cH, cV, cD = c[J - lvl]
+        put(f'wavedec2_{tag}_yh{lvl}', np.stack([cH, cV, cD], axis=2))
+    out[f'wavedec2_{tag}_wave'] = np.array(wave)
+    out[f'wavedec2_{tag}_J'] = np.array(J)
+    r = [rng.standard_normal(c[0].shape)] + [tuple(rng.standard_normal(b.shape) for b in lv) for lv in c[1:]]
+    put(f'waverec2_{tag}_yl', r[0])
+    for lvl in range(J):
+        put(f'waverec2_{tag}_yh{lvl}', np.stack(r[J - lvl], axis=2))
+    put(f'waverec2_{tag}_x', pywt.waverec2(r, wave, mode='periodization', axes=(-2, -1)))
+
+for tag, wave, mode, shape, J in [('per3', 'bior2.4', 'periodization', (2, 2, 81), 3), ('zero2', 'bior1.3', 'zero', (1, 2, 33), 2)]:
+    x = rng.standard_normal(shape)
+    c = pywt.wavedec(x, wave, mode=mode, level=J, axis=-1)
+    put(f'wavedec1_{tag}_x', x)
+    put(f'wavedec1_{tag}_lo', c[0])
+    for lvl in range(J):
+        put(f'wavedec1_{tag}_hi{lvl}', c[J - lvl])
+    out[f'wavedec1_{tag}_wave'] = np.array(wave)
+    out[f'wavedec1_{tag}_mode'] = np.array(mode)
+    out[f'wavedec1_{tag}_J'] = np.array(J)
+    put(f'waverec1_{tag}_x', pywt.waverec(c, wave, mode=mode, axis=-1))
+
+for tag, wave, shape, J in [('l2', 'bior1.3', (2, 16, 20, 24), 2), ('l2odd', 'bior1.3', (1, 13, 18, 15), 2)]:
+    x = rng.standard_normal(shape)
+    c = pywt.wavedecn(x, wave, mode='zero', level=J, axes=(1, 2, 3))
+    put(f'wavedec3_{tag}_x', x)
+    put(f'wavedec3_{tag}_lll', c[0])
+    for lvl in range(J):                      # ptwt order: coarsest first, like pywt
+        put(f'wavedec3_{tag}_d{lvl}', np.stack([c[1 + lvl][k] for k in KEYS[1:]], axis=1))
+    out[f'wavedec3_{tag}_wave'] = np.array(wave)
+    out[f'wavedec3_{tag}_J'] = np.array(J)
+    put(f'waverec3_{tag}_x', pywt.waverecn(c, wave, mode='zero', axes=(1, 2, 3)))
+
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dwt_pywt.npz')
 np.savez_compressed(dst, **out)
 print('wrote', dst, os.path.getsize(dst), 'bytes,', len(out), 'arrays')

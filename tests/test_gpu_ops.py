@@ -394,6 +394,69 @@ def test_dwt3_vs_pywt(ops, tag):
     assert (rec.cpu().double() - torch.from_numpy(G[f'idwt3_{tag}_x'])).abs().max() < 3e-6
 
 
+@pytest.mark.parametrize('tag', ['ref3', 'even2', 'db4odd'])
+def test_wavedec2_multilevel_vs_pywt(ops, tag):
+    """J > 1 (burgers/wave_trans.py:94 builds DWTForward(J=dwt_max_level)); bands finest first, odd sizes cropped on the way back."""
+    W = _dw()
+    wave, J = str(G[f'wavedec2_{tag}_wave']), int(G[f'wavedec2_{tag}_J'])
+    yl, yh = W.DWTForward(J=J, wave=wave, mode='periodization')(dev(torch.from_numpy(G[f'wavedec2_{tag}_x'])))
+    assert len(yh) == J
+    assert (yl.cpu().double() - torch.from_numpy(G[f'wavedec2_{tag}_yl'])).abs().max() < 5e-6
+    for lvl in range(J):
+        assert (yh[lvl].cpu().double() - torch.from_numpy(G[f'wavedec2_{tag}_yh{lvl}'])).abs().max() < 5e-6
+    rec = W.DWTInverse(wave=wave, mode='periodization')((dev(torch.from_numpy(G[f'waverec2_{tag}_yl'])),
+                                                         [dev(torch.from_numpy(G[f'waverec2_{tag}_yh{lvl}'])) for lvl in range(J)]))
+    assert (rec.cpu().double() - torch.from_numpy(G[f'waverec2_{tag}_x'])).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['per3', 'zero2'])
+def test_wavedec1_multilevel_vs_pywt(ops, tag):
+    W = _dw()
+    wave, mode, J = str(G[f'wavedec1_{tag}_wave']), str(G[f'wavedec1_{tag}_mode']), int(G[f'wavedec1_{tag}_J'])
+    lo, his = W.DWT1DForward(J=J, wave=wave, mode=mode)(dev(torch.from_numpy(G[f'wavedec1_{tag}_x'])))
+    assert (lo.cpu().double() - torch.from_numpy(G[f'wavedec1_{tag}_lo'])).abs().max() < 5e-6
+    for lvl in range(J):
+        assert (his[lvl].cpu().double() - torch.from_numpy(G[f'wavedec1_{tag}_hi{lvl}'])).abs().max() < 5e-6
+    rec = W.DWT1DInverse(wave=wave, mode=mode)((lo, his))
+    assert (rec.cpu().double() - torch.from_numpy(G[f'waverec1_{tag}_x'])).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['l2', 'l2odd'])
+def test_wavedec3_multilevel_vs_pywt(ops, tag):
+    W = _dw()
+    wave, J = str(G[f'wavedec3_{tag}_wave']), int(G[f'wavedec3_{tag}_J'])
+    c = W.wavedec3(dev(torch.from_numpy(G[f'wavedec3_{tag}_x'])), wave, mode='zero', level=J)
+    assert len(c) == J + 1
+    assert (c[0].cpu().double() - torch.from_numpy(G[f'wavedec3_{tag}_lll'])).abs().max() < 5e-6
+    for lvl in range(J):
+        d = torch.from_numpy(G[f'wavedec3_{tag}_d{lvl}'])
+        assert list(c[1 + lvl].keys()) == list(W.BANDS3[1:])
+        for i, k in enumerate(W.BANDS3[1:]):
+            assert (c[1 + lvl][k].cpu().double() - d[:, i]).abs().max() < 5e-6
+    rec = W.waverec3(c, wave)
+    assert (rec.cpu().double() - torch.from_numpy(G[f'waverec3_{tag}_x'])).abs().max() < 1e-5
+
+
+def test_multilevel_gradients_are_adjoints(ops):
+    """<DWT_J x, c> == <x, DWT_J^T c> through autograd over two levels (guidance back-propagates through the IDWT)."""
+    W = _dw()
+    x = dev(torch.randn(2, 2, 32, 48)).requires_grad_(True)
+    yl, yh = W.DWTForward(J=2, wave='bior2.4', mode='periodization')(x)
+    cl, ch = torch.randn_like(yl), [torch.randn_like(h) for h in yh]
+    lhs = (yl * cl).sum() + sum((h * c).sum() for h, c in zip(yh, ch))
+    lhs.backward()
+    cl.requires_grad_(True)
+    rec = W.DWTInverse(wave='bior2.4', mode='periodization')((cl, ch))
+    # bior2.4 is biorthogonal: analysis^T != synthesis, so check the adjoint identity numerically instead
+    v = torch.randn_like(x)
+    num = ((W.DWTForward(J=2, wave='bior2.4', mode='periodization')(v)[0] * cl).sum()
+           + sum((h * c).sum() for h, c in zip(W.DWTForward(J=2, wave='bior2.4', mode='periodization')(v)[1], ch)))
+    assert abs(float((x.grad * v).sum()) - float(num)) < 2e-3 * max(1.0, abs(float(num)))
+    g = torch.randn_like(rec)
+    (rec * g).sum().backward()
+    assert cl.grad is not None and torch.isfinite(cl.grad).all()
+
+
 @pytest.mark.parametrize('nd,mode,wave,shape', [(2, 'periodization', 'bior2.4', (3, 2, 81, 120)), (2, 'periodization', 'bior2.4', (2, 2, 160, 128)),
                                                 (3, 'zero', 'bior1.3', (4, 32, 64, 64)), (3, 'zero', 'bior1.3', (2, 9, 11, 13)),
                                                 (1, 'zero', 'bior1.3', (5, 33)), (1, 'periodization', 'db4', (4, 31)), (2, 'zero', 'bior1.3', (2, 17, 20))])

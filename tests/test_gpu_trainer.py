@@ -1,0 +1,153 @@
+"""Rows T1-T3: the drop-in Trainer classes (ddpm_burgers.train_diffusion.Trainer, ddpm.diffusion_2d.Trainer) on the GPU.
+
+The optimiser arithmetic itself is pinned against the reference in test_gpu_models.py::test_three_optimizer_steps_vs_reference;
+here: the Trainer loop reproduces that arithmetic (same trajectory as a torch.optim.Adam run on the same batches), the EMA
+follows the restated ema_pytorch rule (oracle), and checkpoints have the reference's file names / keys and round-trip."""
+import os
+import sys
+
+import pytest
+import torch
+
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def trees():
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion as GD1
+    from ddpm_burgers.train_diffusion import Trainer as TB
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion as GD2, Trainer as TS
+    return dict(Unet2D=Unet2D, GD1=GD1, TB=TB, Unet3D=Unet3D_with_Conv3D, GD2=GD2, TS=TS)
+
+
+def _burgers(trees, seed=0):
+    torch.manual_seed(seed)
+    net = trees['Unet2D'](dim=8, dim_mults=(1, 2), channels=9, resnet_block_groups=1)
+    return trees['GD1'](net, seq_length=(8, 8), padded_shape=[6, 7], ori_shape=[10, 14], loss_layer_weight=torch.ones(1, 9, 1, 1),
+                        is_condition_pad=True, is_condition_u0=True, is_condition_f=True)
+
+
+class _Fixed(torch.utils.data.Dataset):
+    def __init__(self, data, as_tuple=False):
+        self.data, self.as_tuple = data, as_tuple
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def __getitem__(self, i):
+        return (self.data[i], [1], [1], i) if self.as_tuple else self.data[i]
+
+
+def test_burgers_trainer_loop_checkpoint_and_ema(trees, tmp_path):
+    from oracle import diffusion_ref as D
+    dif = _burgers(trees)
+    data = torch.randn(4, 9, 8, 8) * 0.5
+    tr = trees['TB'](dif, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=23, save_and_sample_every=10,
+                     test_every=1000, results_folder=str(tmp_path / 'res'), ema_update_every=2, num_workers=0)
+    tr.ema.update_after_step = 6                      # exercise copy phase, init and the decayed phase within 23 steps
+    ema_ref = {k: v.detach().cpu().clone() for k, v in dif.state_dict().items() if v.is_floating_point()}
+    st = {'step': 0, 'initted': False}
+    names = [k for k, p in dif.named_parameters() if p.requires_grad]
+    # run the loop by hand (what train() does), mirroring the EMA with the oracle on the CPU
+    while tr.step < tr.train_num_steps:
+        tr.optimisation_step(lambda: next(tr.dl).to(tr.device))
+        tr.ema.update()
+        online = {k: v.detach().cpu() for k, v in dif.state_dict().items()}
+        D.ema_reference_update({k: ema_ref[k] for k in names}, online, st, beta=0.995, update_every=2, update_after_step=6)
+        tr.step += 1
+    esd = tr.ema.ema_model.state_dict()
+    for k in names:
+        assert rel_l2(esd[k].cpu(), ema_ref[k]) < 1e-6, k
+    assert tr.ema.step == 23 and tr.ema.initted
+    # learning rate follows CosineAnnealingLR(T_max = 10000)
+    import math
+    assert abs(tr.lr_schedule(tr.train_lr, 5000) - 0.5e-4) < 1e-12 and abs(tr.lr_schedule(tr.train_lr, 10000)) < 1e-12
+    # checkpoint: reference file name and keys
+    tr.save(2)
+    path = tmp_path / 'res' / 'True-cos10000-model-2.pt'
+    assert path.exists()
+    ck = torch.load(str(path), map_location='cpu', weights_only=False)
+    assert list(ck.keys()) == ['step', 'model', 'opt', 'ema', 'scaler', 'loss']
+    assert list(ck['model'].keys()) == list(dif.state_dict().keys())
+    assert {'initted', 'step'} <= set(ck['ema'].keys()) and f'ema_model.{names[0]}' in ck['ema'] and f'online_model.{names[0]}' in ck['ema']
+    ref_opt = torch.optim.Adam(_burgers(trees, 1).parameters())
+    ref_opt.load_state_dict(ck['opt'])                # loadable by the optimiser the reference uses
+    # round trip into a fresh trainer, then both take the same next step
+    dif2 = _burgers(trees, seed=5)
+    tr2 = trees['TB'](dif2, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=30, results_folder=str(tmp_path / 'res'),
+                      ema_update_every=2, num_workers=0)
+    tr2.load(2)
+    assert tr2.step == 23 and tr2.opt.step_count == tr.opt.step_count
+    for (k, a), b in zip(dif.state_dict().items(), dif2.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert torch.equal(tr.opt.exp_avg, tr2.opt.exp_avg) and torch.equal(tr.opt.exp_avg_sq, tr2.opt.exp_avg_sq)
+    assert torch.equal(tr.ema.flat, tr2.ema.flat)
+    x0, t, noise = data.to(DEV), torch.tensor([3, 500, 999, 0], device=DEV), torch.randn(4, 9, 8, 8, device=DEV)
+    outs = []
+    for trn, d in ((tr, dif), (tr2, dif2)):
+        trn.opt.zero_grad()
+        d.p_losses(x0.clone(), t, noise=noise.clone()).backward()
+        trn.opt.step(lr=trn.lr_schedule(trn.train_lr, trn.step))
+        outs.append(trn.opt.buf.flat_param.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_burgers_trainer_matches_torch_adam_trajectory(trees, tmp_path):
+    """The same batches through (a) Trainer.optimisation_step and (b) autograd + clip_grad_norm_ + torch.optim.Adam +
+    CosineAnnealingLR on a second copy of the module: weights after 4 steps agree."""
+    difa, difb = _burgers(trees, 3), _burgers(trees, 3)
+    data = torch.randn(4, 9, 8, 8) * 0.5
+    tr = trees['TB'](difa, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=4, results_folder=str(tmp_path / 'a'), num_workers=0)
+    difb = difb.to(DEV)
+    w0 = {k: v.detach().clone() for k, v in difb.named_parameters()}
+    opt = torch.optim.Adam(difb.parameters(), lr=1e-4, betas=(0.9, 0.99))
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10000, eta_min=0)
+    x0 = data.to(DEV)
+    for step in range(4):
+        t = torch.tensor([10 + step, 400, 999 - step, 0], device=DEV)
+        noise = torch.randn(4, 9, 8, 8, device=DEV)
+        tr.opt.zero_grad()
+        difa.p_losses(x0.clone(), t, noise=noise.clone()).backward()
+        tr.opt.step(lr=tr.lr_schedule(tr.train_lr, step))
+        difb.p_losses(x0.clone(), t, noise=noise.clone()).backward()
+        torch.nn.utils.clip_grad_norm_(difb.parameters(), 1.0)
+        opt.step(); opt.zero_grad(); sch.step()
+    for (k, a), b in zip(difa.named_parameters(), difb.parameters()):
+        if a.requires_grad and (b - w0[k]).abs().max() > 0:
+            assert rel_l2(a.detach() - w0[k], b.detach() - w0[k]) < 2e-3, k
+
+
+def test_smoke_trainer_runs_and_saves(trees, tmp_path):
+    torch.manual_seed(0)
+    net = trees['Unet3D'](dim=8, dim_mults=(1, 2), channels=42)
+    dif = trees['GD2'](net, torch.ones(1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero', (3, 6, 6), (4, 8, 8), image_size=8, frames=4,
+                       timesteps=1000, sampling_timesteps=10, loss_type='l2')
+    data = torch.randn(4, 4, 42, 8, 8) * 0.3
+    tr = trees['TS'](dif, _Fixed(data, as_tuple=True), None, train_batch_size=2, train_lr=1e-3, train_num_steps=3, save_and_sample_every=3,
+                     results_path=str(tmp_path / 'smoke'), calculate_fid=False, num_workers=0)
+    w0 = tr.opt.buf.flat_param.clone()
+    tr.train()
+    assert tr.step == 3 and (tr.opt.buf.flat_param - w0).abs().max() > 0 and torch.isfinite(tr.opt.buf.flat_param).all()
+    ck = torch.load(str(tmp_path / 'smoke' / 'model-1.pt'), map_location='cpu', weights_only=False)
+    assert list(ck.keys()) == ['step', 'model', 'opt', 'ema', 'scaler'] and ck['step'] == 3
+    assert abs(tr.lr_schedule(1e-3, 49999) - 1e-3) < 1e-15 and abs(tr.lr_schedule(1e-3, 50000) - 1e-4) < 1e-15
+    dif2 = trees['GD2'](trees['Unet3D'](dim=8, dim_mults=(1, 2), channels=42), torch.ones(1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero',
+                        (3, 6, 6), (4, 8, 8), image_size=8, frames=4, timesteps=1000, sampling_timesteps=10, loss_type='l2')
+    tr2 = trees['TS'](dif2, _Fixed(data, as_tuple=True), None, train_batch_size=2, results_path=str(tmp_path / 'smoke'), num_workers=0)
+    tr2.load(1)
+    assert tr2.step == 3 and torch.equal(tr2.opt.buf.flat_param, tr.opt.buf.flat_param)
+    # the EMA copy is a usable module whose parameters live in the flat EMA buffer
+    with torch.no_grad():
+        assert torch.isfinite(tr2.ema.ema_model(data[:2].to(DEV)))
+    p_first = next(p for p in tr2.ema.ema_model.parameters() if p.dtype == torch.float32 and p.numel() > 1)
+    assert tr2.ema.flat.data_ptr() <= p_first.data_ptr() < tr2.ema.flat.data_ptr() + 4 * tr2.ema.flat.numel()

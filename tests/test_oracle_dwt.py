@@ -83,3 +83,49 @@ def test_upsample_coef():
     assert R.upsample_coef_3d(b, 'time').shape == (1, 4, 3, 2, 2)
     assert R.upsample_coef_3d(b, 'space').shape == (1, 2, 3, 4, 4)
     assert np.array_equal(R.upsample_coef_3d(b, 'time')[0, 1], b[0, 0])
+
+
+# ----------------------------------------------------------------------------- multi-level (J > 1)
+@pytest.mark.parametrize('tag', ['ref3', 'even2', 'db4odd'])
+def test_wavedec2_multilevel(tag):
+    w, J = str(G[f'wavedec2_{tag}_wave']), int(G[f'wavedec2_{tag}_J'])
+    yl, yh = R.wavedec2(G[f'wavedec2_{tag}_x'], w, 'periodization', J)
+    assert _err(yl, G[f'wavedec2_{tag}_yl']) < TOL
+    for lvl in range(J):
+        assert _err(yh[lvl], G[f'wavedec2_{tag}_yh{lvl}']) < TOL
+    rec = R.waverec2(G[f'waverec2_{tag}_yl'], [G[f'waverec2_{tag}_yh{lvl}'] for lvl in range(J)], w, 'periodization')
+    assert _err(rec, G[f'waverec2_{tag}_x']) < TOL
+
+
+@pytest.mark.parametrize('tag', ['per3', 'zero2'])
+def test_wavedec1_multilevel(tag):
+    w, m, J = str(G[f'wavedec1_{tag}_wave']), str(G[f'wavedec1_{tag}_mode']), int(G[f'wavedec1_{tag}_J'])
+    lo, his = R.wavedec1(G[f'wavedec1_{tag}_x'], w, m, J)
+    assert _err(lo, G[f'wavedec1_{tag}_lo']) < TOL
+    for lvl in range(J):
+        assert _err(his[lvl], G[f'wavedec1_{tag}_hi{lvl}']) < TOL
+    assert _err(R.waverec1(lo, his, w, m), G[f'waverec1_{tag}_x']) < TOL
+
+
+@pytest.mark.parametrize('tag', ['l2', 'l2odd'])
+def test_wavedec3_multilevel(tag):
+    w, J = str(G[f'wavedec3_{tag}_wave']), int(G[f'wavedec3_{tag}_J'])
+    c = R.wavedec3(G[f'wavedec3_{tag}_x'], w, 'zero', J)
+    assert _err(c[0], G[f'wavedec3_{tag}_lll']) < TOL
+    for lvl in range(J):
+        d = G[f'wavedec3_{tag}_d{lvl}']
+        for i, k in enumerate(R.BANDS3[1:]):
+            assert _err(c[1 + lvl][k], d[:, i]) < TOL
+    assert _err(R.waverec3(c, w, 'zero'), G[f'waverec3_{tag}_x']) < TOL
+
+
+def test_multilevel_packing_reference_sizes():
+    """burgers/wave_trans.py:43-62 with J = 3 at the reference size 81 x 120: bands live on a 44 x 60 grid."""
+    yl, yh = R.wavedec2(G['wavedec2_ref3_x'], 'bior2.4', 'periodization', 3)
+    assert [h.shape[-2:] for h in yh] == [(41, 60), (21, 30), (11, 15)] and yl.shape[-2:] == (11, 15)
+    t = R.burgers_coef_to_tensor(yl, yh)
+    assert t.shape == (1, 2, 10, 44, 60)
+    assert np.array_equal(t[:, :, 0, ::4, ::4], yl) and np.array_equal(t[:, :, 0, 3::4, 3::4], yl)
+    assert np.array_equal(t[:, :, 1:4, :41], yh[0]) and np.array_equal(t[:, :, 1:4, 43], yh[0][:, :, :, 40])
+    assert np.array_equal(t[:, :, 4:7, :42:2, ::2], yh[1]) and np.array_equal(t[:, :, 4:7, 43, 1::2], yh[1][:, :, :, 20])
+    assert np.array_equal(t[:, :, 7:10, ::4, ::4], yh[2])

@@ -22,3 +22,37 @@ def tree_path(name):
     if not os.path.isdir(p):
         raise ValueError(name)
     return p
+
+
+def reference_fallthrough(module_name, this_file):
+    """Module-level __getattr__ for a drop-in module: names the MI355X module does not define (classes that are not on
+    the WDNO path, e.g. the 2-D `Unet` of smoke/ddpm/diffusion_2d.py) are looked up in the *reference's* module of the
+    same name, if the reference tree is on sys.path behind this one. Nothing is loaded until such a name is asked for."""
+    import importlib.util
+    import sys
+    state = {}
+
+    def _load():
+        if 'mod' in state:
+            return state['mod']
+        rel = module_name.replace('.', os.sep) + '.py'
+        mod = None
+        for d in sys.path:
+            cand = os.path.join(d or '.', rel)
+            if os.path.isfile(cand) and os.path.abspath(cand) != os.path.abspath(this_file):
+                spec = importlib.util.spec_from_file_location('_reference_' + module_name.replace('.', '_'), cand)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                break
+        state['mod'] = mod
+        return mod
+
+    def __getattr__(name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        mod = _load()
+        if mod is None or not hasattr(mod, name):
+            raise AttributeError(f"module '{module_name}' (wdno_amd drop-in) has no attribute '{name}' and no reference module "
+                                 f"providing it was found on sys.path")
+        return getattr(mod, name)
+    return __getattr__

@@ -1,4 +1,4 @@
-"""Coefficient <-> tensor packing helpers of burgers/wave_trans.py:18-62 (single-level J = 1 path).
+"""Coefficient <-> tensor packing helpers of burgers/wave_trans.py:18-62.
 
 With the HIP transform the packed tensor is produced directly (wdno_amd.wavelets.DWTForward.packed); these helpers
 keep the reference's names and argument order for callers that hold (Yl, Yh) pairs. They are views / concatenations
@@ -23,10 +23,22 @@ tensor_to_coef_super = tensor_to_coef
 
 
 def coef_to_tensor(Yl, Yh, pad=False):
-    """(Yl [N,C,h,w], [Yh [N,C,3,h,w]]) -> [N, C, 4, h, w]; pad=True zero-pads to multiples of 64 x 64 like the reference."""
-    if len(Yh) != 1:
-        raise NotImplementedError('single-level (J = 1) packing only; WDNO never uses J > 1 (wave_trans.py:107)')
-    t = torch.cat((Yl.unsqueeze(2), Yh[0]), dim=2)
+    """(Yl [N,C,h,w], [Yh [N,C,3,h,w]]) -> [N, C, 1+3J, h, w]; pad=True zero-pads to multiples of 64 x 64 like the
+    reference. For J > 1 every band is nearest-repeated to the finest grid (Yl by 2^(J-1), Yh[i] by 2^i) and the
+    row deficit of the coarser bands is filled by replicating their last row (wave_trans.py:50-57)."""
+    J = len(Yh)
+    if J == 1:
+        t = torch.cat((Yl.unsqueeze(2), Yh[0]), dim=2)
+    else:
+        top = 2 ** (J - 1)
+        rows, cols = Yh[0].shape[-2] + top - 1, Yh[0].shape[-1]
+        t = torch.zeros(Yl.shape[0], Yl.shape[1], 1 + 3 * J, rows, cols, device=Yl.device, dtype=Yl.dtype)
+        t[:, :, 0] = Yl.repeat_interleave(top, dim=-2).repeat_interleave(top, dim=-1)
+        for i in range(J):
+            r = Yh[i].repeat_interleave(2 ** i, dim=-2).repeat_interleave(2 ** i, dim=-1)
+            t[:, :, 1 + 3 * i:4 + 3 * i, :r.shape[-2]] = r
+            if top - 2 ** i:
+                t[:, :, 1 + 3 * i:4 + 3 * i, r.shape[-2]:] = r[:, :, :, -1:]
     if pad:
         up_t = int(t.shape[-2] / 40)
         up_x = int(t.shape[-1] / 60)

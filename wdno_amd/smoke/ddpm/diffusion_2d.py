@@ -18,7 +18,11 @@ from collections import namedtuple
 import torch
 from torch import nn
 
+import wdno_amd
 from wdno_amd import diffusion_core as K
+from wdno_amd.trainer import TrainerCore as _TrainerCore, multistep_lr as _multistep_lr
+
+_reference_getattr = wdno_amd.reference_fallthrough('ddpm.diffusion_2d', __file__)
 
 ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
 
@@ -294,3 +298,132 @@ class GaussianDiffusion(nn.Module):
         b, device = state.shape[0], state.device
         t = torch.randint(0, self.num_timesteps, (b,), device=device).long()
         return self.p_losses(state, t, *args, **kwargs)
+
+
+# ======================================================================================================================
+# Trainer -- drop-in for smoke/ddpm/diffusion_2d.py:1060-1307
+# ======================================================================================================================
+def has_int_squareroot(num):
+    return (math.sqrt(num) ** 2) == num
+
+
+def cycle(dl):
+    while True:
+        for data in dl:
+            yield data
+
+
+class Trainer(_TrainerCore):
+    """Same constructor keywords, attributes (`model`, `opt`, `ema`, `step`, `results_path`, `ds`, `device`), checkpoint
+    naming (`model-{milestone}.pt`) and checkpoint keys (`step / model / opt / ema / scaler`) as the reference Trainer.
+    The step itself is wdno_amd.trainer's flat-buffer path (one RCCL all-reduce, clip + Adam in two launches);
+    `accelerate` is replaced by one process per GPU under torchrun.
+
+    `dataset` is the string "Smoke" like in train_2d.py:123-126 (the dataset class is then taken from `ddpm.data_2d`,
+    i.e. from whichever tree provides it), or -- an extension -- any map-style dataset object yielding
+    `(state [F, C, H, W], shape, ori_shape, sim_id)` tuples."""
+
+    def __init__(
+        self,
+        diffusion_model,
+        dataset,
+        dataset_path=None,
+        *,
+        N_downsample=0,
+        train_batch_size=16,
+        gradient_accumulate_every=1,
+        augment_horizontal_flip=True,
+        train_lr=1e-4,
+        train_num_steps=100000,
+        ema_update_every=10,
+        ema_decay=0.995,
+        adam_betas=(0.9, 0.99),
+        save_and_sample_every=1000,
+        num_samples=25,
+        results_path='./results',
+        amp=False,
+        fp16=False,
+        split_batches=True,
+        convert_image_to=None,
+        calculate_fid=True,
+        inception_block_idx=2048,
+        is_schedule=True,
+        resume=False,
+        resume_step=0,
+        num_workers=None,
+    ):
+        if amp or fp16:
+            raise ValueError('mixed precision is not part of the fp32 WDNO path (train_2d.py passes amp=False)')
+        assert has_int_squareroot(num_samples), 'number of samples must have an integer square root'
+        schedule = (lambda base, step: _multistep_lr(base, step, (50000, 150000, 300000), 0.1)) if is_schedule else (lambda base, step: base)
+        super().__init__(diffusion_model, train_batch_size=train_batch_size, gradient_accumulate_every=gradient_accumulate_every,
+                         train_lr=train_lr, train_num_steps=train_num_steps, ema_update_every=ema_update_every, ema_decay=ema_decay,
+                         adam_betas=adam_betas, save_and_sample_every=save_and_sample_every, split_batches=split_batches,
+                         max_grad_norm=1.0, results_dir=results_path, lr_schedule=schedule)
+        self.dataset = dataset
+        self.num_samples = num_samples
+        self.image_size = diffusion_model.image_size
+        self.resume, self.resume_step = resume, resume_step
+        from pathlib import Path
+        self.results_path = Path(results_path)
+        if isinstance(dataset, str):
+            if dataset != 'Smoke':
+                raise AssertionError(dataset)
+            from ddpm.data_2d import Smoke_wave, SuperDataLoader                       # diffusion_2d.py:1117-1145
+            if not self.model.is_wavelet:
+                raise NotImplementedError('only the wavelet parametrisation is on the WDNO path')
+            if not self.model.is_super_model:
+                self.ds = Smoke_wave(dataset_path, self.model.wave_type, self.model.pad_mode, is_super_model=False, N_downsample=0)
+            else:
+                self.ds = [Smoke_wave(dataset_path, self.model.wave_type, self.model.pad_mode, is_super_model=True,
+                                      downsample_type='space' if self.model.is_condition_control else 'time', N_downsample=i)
+                           for i in range(N_downsample)]
+        else:
+            self.ds = dataset
+        if isinstance(self.ds, (list, tuple)):
+            from ddpm.data_2d import SuperDataLoader
+            workers = 4 if num_workers is None else num_workers
+            dl = SuperDataLoader(self.ds, batch_size=self.local_batch_size, shuffle=True, pin_memory=True, num_workers=workers)
+        else:
+            workers = 16 if num_workers is None else num_workers
+            dl = self.make_loader(self.ds, self.local_batch_size, workers)
+        self.dl = cycle(dl)
+
+    def save(self, milestone):
+        if not self.is_main_process:
+            return
+        torch.save(self.checkpoint_dict(), str(self.results_path / f'model-{milestone}.pt'))
+
+    def load(self, milestone):
+        path = str(self.results_path / f'model-{milestone}.pt')
+        print('model path: ', path)
+        data = torch.load(path, map_location=self.device, weights_only=False)
+        self.load_checkpoint_dict(data)
+        print('model loaded: ', path)
+
+    def _next_state(self):
+        state = next(self.dl)[0]                                   # (state, shape, ori_shape, sim_id)
+        return state.to(self.device, non_blocking=True)
+
+    def train(self):
+        import logging
+        import os
+        logging.basicConfig(filename=os.path.join(self.results_path, 'info.log'), level=logging.INFO,
+                            format='%(asctime)s - %(levelname)s - %(message)s')
+        while self.step < self.train_num_steps:
+            lr = self.lr_schedule(self.train_lr, self.step)
+            total_loss = self.optimisation_step(self._next_state)
+            if self.step != 0 and self.step % 10 == 0 and self.is_main_process:
+                logging.info(f'step: {self.step}, loss: {total_loss:.4f}, LR: {lr}')
+            self.step += 1
+            if self.is_main_process:
+                self.ema.update()
+                if self.step != 0 and self.step % self.save_and_sample_every == 0:
+                    self.ema.ema_model.eval()
+                    self.save(self.step // self.save_and_sample_every)
+        if self.is_main_process:
+            print('training complete')
+
+
+def __getattr__(name):          # names that are not on the WDNO path (e.g. the 2-D `Unet`) come from the reference module, if present
+    return _reference_getattr(name)

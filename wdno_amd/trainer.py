@@ -208,3 +208,198 @@ class TrainStep:
             self.ema.flat.copy_(sd['ema']['flat'])
             self.ema.calls = int(sd['ema']['calls'])
         ops.bump_weight_epoch()
+
+
+# ======================================================================================================================
+# Reference-compatible checkpoint formats and the Trainer core (rows T1-T3 of SURVEY.md section 8a)
+# ======================================================================================================================
+def adam_state_to_torch(model, opt):
+    """FlatAdam state -> the dictionary `torch.optim.Adam(model.parameters()).state_dict()` would hold
+    (the 'opt' entry of the reference checkpoints, train_diffusion.py:155, diffusion_2d.py:1195): parameter indices
+    count *every* parameter of model.parameters() (frozen ones included, they simply own no state)."""
+    params = list(model.parameters())
+    spans = {id(p): span for p, span in zip(opt.buf.params, opt.buf._spans())}
+    state = {}
+    for i, p in enumerate(params):
+        if id(p) in spans and opt.step_count > 0:
+            o, n = spans[id(p)]
+            state[i] = {'step': torch.tensor(float(opt.step_count)), 'exp_avg': opt.exp_avg[o:o + n].view(p.shape).clone(),
+                        'exp_avg_sq': opt.exp_avg_sq[o:o + n].view(p.shape).clone()}
+    group = {'lr': opt.lr, 'betas': tuple(opt.betas), 'eps': opt.eps, 'weight_decay': 0, 'amsgrad': False, 'maximize': False,
+             'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(params)))}
+    return {'state': state, 'param_groups': [group]}
+
+
+def adam_state_from_torch(model, opt, sd):
+    """Inverse of adam_state_to_torch; accepts checkpoints written by the reference's torch.optim.Adam."""
+    params = list(model.parameters())
+    spans = {id(p): span for p, span in zip(opt.buf.params, opt.buf._spans())}
+    steps = set()
+    opt.exp_avg.zero_()
+    opt.exp_avg_sq.zero_()
+    for i, st in sd['state'].items():
+        p = params[int(i)]
+        if id(p) not in spans:
+            continue
+        o, n = spans[id(p)]
+        opt.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+        opt.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+        steps.add(int(float(st['step'])))
+    if len(steps) > 1:
+        raise ValueError(f'per-parameter Adam step counters differ ({sorted(steps)}); the flat optimiser keeps one')
+    opt.step_count = steps.pop() if steps else 0
+    g = sd['param_groups'][0]
+    opt.lr, opt.betas, opt.eps = float(g['lr']), tuple(g['betas']), float(g['eps'])
+
+
+class ModelEMA:
+    """ema_pytorch.EMA(model, beta, update_every) as the reference configures it (train_diffusion.py:123-125,
+    diffusion_2d.py:1165-1167), on a flat buffer with one HIP launch per update.
+
+    ema_pytorch is a third-party package that is not part of the reference tree (unpinned in env.sh); its published
+    update rule is restated here: calls are counted in `step`; only every `update_every`-th call does work; until
+    `update_after_step` (100) the online weights are copied; afterwards
+        ema <- ema + (1 - d) * (online - ema),   d = clamp(1 - (1 + (step - update_after_step - 1) / inv_gamma)^-power, min_value, beta)
+    with inv_gamma = 1, power = 2/3, min_value = 0. `ema_model` is a structural copy of the diffusion module whose
+    parameters are views of the flat EMA buffer (so `trainer.ema.ema_model.sample(...)` works like in the reference).
+    """
+
+    def __init__(self, model, flat_online, beta=0.995, update_every=10, update_after_step=100, inv_gamma=1.0, power=2.0 / 3.0,
+                 min_value=0.0):
+        import copy
+        self.online_model = model
+        self.ema_model = copy.deepcopy(model)
+        self.ema_model.requires_grad_(False)
+        self.flat_online = flat_online
+        self.flat = flat_online.detach().clone()
+        off = 0
+        for p_on, p_ema in zip(model.parameters(), self.ema_model.parameters()):
+            if p_on.requires_grad:                       # same traversal order as FlatBuffers
+                n = p_on.numel()
+                p_ema.data = self.flat[off:off + n].view(p_on.shape)
+                off += n
+        assert off == self.flat.numel()
+        self.beta, self.update_every, self.update_after_step = beta, update_every, update_after_step
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self.step, self.initted = 0, False
+
+    def to(self, device):
+        return self
+
+    def current_decay(self):
+        epoch = max(self.step - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        return min(max(1 - (1 + epoch / self.inv_gamma) ** -self.power, self.min_value), self.beta)
+
+    def copy_params_from_model_to_ema(self):
+        self.flat.copy_(self.flat_online)
+        ops.bump_weight_epoch()
+
+    def update(self):
+        step = self.step
+        self.step += 1
+        if step % self.update_every:
+            return
+        if step <= self.update_after_step:
+            self.copy_params_from_model_to_ema()
+            return
+        if not self.initted:
+            self.copy_params_from_model_to_ema()
+            self.initted = True
+        n = self.flat.numel()
+        _lib.check(_lib_().wdno_ema_update(_p(self.flat), _p(self.flat_online), n, float(self.current_decay()), _stream()), 'ema_update')
+        ops.bump_weight_epoch()
+
+    def state_dict(self):
+        """Keys of ema_pytorch.EMA.state_dict(): initted, step, ema_model.*, online_model.*"""
+        sd = {'initted': torch.tensor(self.initted), 'step': torch.tensor(self.step)}
+        sd.update({f'online_model.{k}': v for k, v in self.online_model.state_dict().items()})
+        sd.update({f'ema_model.{k}': v.clone() for k, v in self.ema_model.state_dict().items()})
+        return sd
+
+    def load_state_dict(self, sd):
+        self.initted = bool(sd['initted'])
+        self.step = int(sd['step'])
+        self.ema_model.load_state_dict({k[len('ema_model.'):]: v for k, v in sd.items() if k.startswith('ema_model.')})
+        ops.bump_weight_epoch()
+
+
+class TrainerCore:
+    """What both reference Trainers do, once (train_diffusion.py:40-237, diffusion_2d.py:1060-1307): data loader with
+    split-batch semantics, Adam + LR schedule + global-norm clip, EMA on the main process, checkpoint dictionary
+    {'step','model','opt','ema','scaler'}. `accelerate` is replaced by one process per GPU + torch.distributed
+    (RCCL): if a process group is initialised (torchrun) the flat gradient is all-reduced once per step."""
+
+    def __init__(self, diffusion_model, *, train_batch_size, gradient_accumulate_every, train_lr, train_num_steps, ema_update_every,
+                 ema_decay, adam_betas, save_and_sample_every, split_batches, max_grad_norm, lr_schedule, results_dir):
+        from pathlib import Path
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        import os
+        self._device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+        if not torch.cuda.is_available():
+            raise RuntimeError('wdno_amd Trainer needs an MI355X (no CPU fallback on the hot path)')
+        self.model = diffusion_model.to(self._device)
+        self.channels = diffusion_model.channels
+        self.batch_size = train_batch_size
+        self.local_batch_size = train_batch_size // self.world if split_batches else train_batch_size
+        assert self.local_batch_size >= 1, 'train_batch_size smaller than the number of processes'
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.max_grad_norm = max_grad_norm
+        self.train_num_steps = train_num_steps
+        self.save_and_sample_every = save_and_sample_every
+        self.train_lr = train_lr
+        self.lr_schedule = lr_schedule
+        self.opt = FlatAdam(self.model.parameters(), lr=train_lr, betas=adam_betas, max_grad_norm=max_grad_norm)
+        if self.is_main_process:
+            self.ema = ModelEMA(self.model, self.opt.buf.flat_param, beta=ema_decay, update_every=ema_update_every)
+        self.results_dir = Path(results_dir)
+        self.results_dir.mkdir(parents=True, exist_ok=True)
+        self.step = 0
+        self.total_loss = 0.0
+
+    # ------------------------------------------------------------------ accelerate-like surface the scripts touch
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def is_main_process(self):
+        return self.rank == 0
+
+    def make_loader(self, dataset, batch_size, num_workers, shuffle=True):
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=self.world, rank=self.rank, shuffle=shuffle) if self.world > 1 else None
+        return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler, pin_memory=True,
+                          num_workers=num_workers, drop_last=False)
+
+    # ------------------------------------------------------------------ one optimisation step (T1 / T2)
+    def optimisation_step(self, next_batch):
+        """next_batch() -> device tensor. Returns the python float loss of this rank (the reference logs it per rank)."""
+        self.opt.zero_grad()
+        total = 0.0
+        for _ in range(self.gradient_accumulate_every):
+            loss = self.model(next_batch()) / self.gradient_accumulate_every
+            loss.backward()
+            total += float(loss.detach())
+        self.opt.buf.gather_grads()
+        if self.world > 1:
+            allreduce_mean_(self.opt.buf.flat_grad, self.world)
+        self.last_grad_norm = self.opt.step(lr=self.lr_schedule(self.train_lr, self.step), grad_scale=1.0 / self.world)
+        self.total_loss = total
+        return total
+
+    # ------------------------------------------------------------------ checkpoints (T3)
+    def checkpoint_dict(self):
+        return {'step': self.step, 'model': self.model.state_dict(), 'opt': adam_state_to_torch(self.model, self.opt),
+                'ema': self.ema.state_dict(), 'scaler': None}
+
+    def load_checkpoint_dict(self, data):
+        self.model.load_state_dict(data['model'])
+        self.step = data['step']
+        adam_state_from_torch(self.model, self.opt, data['opt'])
+        if self.is_main_process:
+            self.ema.load_state_dict(data['ema'])
+        ops.bump_weight_epoch()

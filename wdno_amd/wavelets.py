@@ -1,4 +1,4 @@
-"""Single-level DWT / IDWT operators on MI355X (autograd-aware), behind the call signatures the reference uses.
+"""DWT / IDWT operators on MI355X (autograd-aware), behind the call signatures the reference uses.
 
 The reference calls three third-party packages that are not dependencies of this repo:
   pytorch_wavelets.DWTForward / DWTInverse / DWT1DForward / DWT1DInverse   (burgers/wave_trans.py:94-98,
@@ -7,7 +7,7 @@ The reference calls three third-party packages that are not dependencies of this
   pywt.Wavelet(name)                                                        (filter taps only)
 wdno_amd/third_party/ re-exports the classes / functions below under those module names.
 
-Every transform is one C-ABI call (wdno_dwt_fwd / wdno_dwt_inv) which writes / reads the sub-bands *already stacked*
+Every transform level is one C-ABI call (wdno_dwt_fwd / wdno_dwt_inv) which writes / reads the sub-bands *already stacked*
 in coef_to_tensor order, so `dwt2_packed` / `dwt3_packed` give the packed training tensor with no extra copies.
 Gradients use the exact adjoint kernels (wdno_dwt_*_adjoint), which is what guidance back-propagation through the
 IDWT needs in every sampling step (smoke/inference_2d.py:41,65).
@@ -112,19 +112,33 @@ def idwt_packed(coef, wave, mode, nd):
     return out.reshape(*lead, *out.shape[1:])
 
 
+def _crop_like(ll, ref_shape, nd):
+    """An approximation band one sample longer than the next-finer detail band (odd length one level up) drops its
+    last sample before the synthesis (pytorch_wavelets DWTInverse.forward; ptwt waverec3 padding removal)."""
+    for ax in range(-nd, 0):
+        if ll.shape[ax] == ref_shape[ax] + 1:
+            ll = ll.narrow(ax, 0, ref_shape[ax])
+    return ll
+
+
 # ----------------------------------------------------------------------------------------------------- pytorch_wavelets look-alikes
 class DWTForward(nn.Module):
-    """pytorch_wavelets.DWTForward(J=1, wave, mode): x [N, C, H, W] -> (Yl [N,C,H',W'], [Yh [N,C,3,H',W']])."""
+    """pytorch_wavelets.DWTForward(J, wave, mode): x [N, C, H, W] -> (Yl, [Yh_1 (finest) ... Yh_J]) with
+    Yh_j [N, C, 3, H_j, W_j]; every level re-analyses the LL band of the previous one (burgers/wave_trans.py:94-98)."""
 
     def __init__(self, J=1, wave='db1', mode='zero'):
         super().__init__()
-        if J != 1:
-            raise NotImplementedError('WDNO uses single-level transforms only (burgers/wave_trans.py:107, smoke/wave_trans_2d.py:79)')
-        self.J, self.wave, self.mode = J, _wave_name(wave), mode
+        if int(J) < 1:
+            raise ValueError('J must be >= 1')
+        self.J, self.wave, self.mode = int(J), _wave_name(wave), mode
 
     def forward(self, x):
-        packed = dwt_packed(x, self.wave, self.mode, 2)         # [N, C, 4, H', W']
-        return packed[:, :, 0], [packed[:, :, 1:]]
+        yh = []
+        for _ in range(self.J):
+            packed = dwt_packed(x, self.wave, self.mode, 2)     # [N, C, 4, H', W']
+            x = packed[:, :, 0]
+            yh.append(packed[:, :, 1:])
+        return x, yh
 
     def packed(self, x):
         """The same transform returned as the coef_to_tensor tensor [N, C, 4, H', W'] (no stacking copy)."""
@@ -140,23 +154,29 @@ class DWTInverse(nn.Module):
 
     def forward(self, coeffs):
         yl, yh = coeffs
-        assert len(yh) == 1, 'single-level only'
-        packed = torch.cat([yl.unsqueeze(2), yh[0]], dim=2)
-        return idwt_packed(packed, self.wave, self.mode, 2)
+        for h in yh[::-1]:
+            if h is None:
+                h = torch.zeros(yl.shape[0], yl.shape[1], 3, yl.shape[-2], yl.shape[-1], device=yl.device, dtype=yl.dtype)
+            yl = idwt_packed(torch.cat([_crop_like(yl, h.shape, 2).unsqueeze(2), h], dim=2), self.wave, self.mode, 2)
+        return yl
 
 
 class DWT1DForward(nn.Module):
-    """pytorch_wavelets.DWT1DForward(J=1): x [N, C, L] -> (lo, [hi])"""
+    """pytorch_wavelets.DWT1DForward(J): x [N, C, L] -> (lo, [hi_1 (finest) ... hi_J])"""
 
     def __init__(self, J=1, wave='db1', mode='zero'):
         super().__init__()
-        if J != 1:
-            raise NotImplementedError('single-level only')
-        self.J, self.wave, self.mode = J, _wave_name(wave), mode
+        if int(J) < 1:
+            raise ValueError('J must be >= 1')
+        self.J, self.wave, self.mode = int(J), _wave_name(wave), mode
 
     def forward(self, x):
-        packed = dwt_packed(x, self.wave, self.mode, 1)         # [N, C, 2, L']
-        return packed[:, :, 0], [packed[:, :, 1]]
+        highs = []
+        for _ in range(self.J):
+            packed = dwt_packed(x, self.wave, self.mode, 1)     # [N, C, 2, L']
+            x = packed[:, :, 0]
+            highs.append(packed[:, :, 1])
+        return x, highs
 
 
 class DWT1DInverse(nn.Module):
@@ -165,18 +185,25 @@ class DWT1DInverse(nn.Module):
         self.wave, self.mode = _wave_name(wave), mode
 
     def forward(self, coeffs):
-        lo, hi = coeffs
-        assert len(hi) == 1
-        return idwt_packed(torch.stack([lo, hi[0]], dim=2), self.wave, self.mode, 1)
+        lo, highs = coeffs
+        for hi in highs[::-1]:
+            if hi is None:
+                hi = torch.zeros_like(lo)
+            lo = idwt_packed(torch.stack([_crop_like(lo, hi.shape, 1), hi], dim=2), self.wave, self.mode, 1)
+        return lo
 
 
 # ----------------------------------------------------------------------------------------------------- ptwt look-alikes
 def wavedec3(data, wavelet, mode='zero', level=1):
-    """ptwt.wavedec3(level=1): [N, T, H, W] -> [lll, {'aad': ..., ..., 'ddd': ...}] (dict in BANDS3 order)."""
-    if level != 1:
-        raise NotImplementedError('single-level only (smoke/wave_trans_2d.py:129)')
-    packed = dwt_packed(data, _wave_name(wavelet), mode, 3)     # [N, 8, T', H', W']
-    return [packed[:, 0], {k: packed[:, i + 1] for i, k in enumerate(BANDS3[1:])}]
+    """ptwt.wavedec3: [N, T, H, W] -> [lll, {coarsest 'aad'..'ddd'}, ..., {finest}] (dicts in BANDS3 order)."""
+    if level is None or int(level) < 1:
+        raise ValueError('level must be >= 1')
+    dicts = []
+    for _ in range(int(level)):
+        packed = dwt_packed(data, _wave_name(wavelet), mode, 3)     # [N, 8, T', H', W']
+        data = packed[:, 0]
+        dicts.append({k: packed[:, i + 1] for i, k in enumerate(BANDS3[1:])})
+    return [data] + dicts[::-1]
 
 
 def wavedec3_packed(data, wavelet, mode='zero'):
@@ -185,7 +212,9 @@ def wavedec3_packed(data, wavelet, mode='zero'):
 
 
 def waverec3(coeffs, wavelet, mode='zero'):
-    """ptwt.waverec3 for a level-1 coefficient list."""
-    lll, det = coeffs[0], coeffs[1]
-    packed = torch.stack([lll] + [det[k] for k in BANDS3[1:]], dim=1)
-    return idwt_packed(packed, _wave_name(wavelet), mode, 3)
+    """ptwt.waverec3: coefficient list [lll, {coarsest}, ..., {finest}] -> [N, T, H, W]."""
+    lll = coeffs[0]
+    for det in coeffs[1:]:
+        packed = torch.stack([_crop_like(lll, det['aad'].shape, 3)] + [det[k] for k in BANDS3[1:]], dim=1)
+        lll = idwt_packed(packed, _wave_name(wavelet), mode, 3)
+    return lll
