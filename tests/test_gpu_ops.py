@@ -193,6 +193,19 @@ def test_conv_f16x3_path(ops, name, xs, ws, stride, padding):
     assert any('h3' in k for k in n_launch), f'fp16-split kernel was not used: {list(n_launch)}'
 
 
+@pytest.mark.parametrize('mode', [7], ids=['dma'])
+@pytest.mark.parametrize('name,xs,ws,stride,padding', CONV_CASES_H3, ids=[c[0] for c in CONV_CASES_H3])
+def test_conv_f16x3_dma_kernels(ops, name, xs, ws, stride, padding, mode):
+    """The LDS-DMA forward / dgrad kernels (normally picked for >= 256 tiles) forced on the small parity cases:
+    ragged M / N tiles, C % 32 != 0 (per-lane dx), 7-wide taps, strided and 1x1 geometries; several tiles per persistent block."""
+    lib = ops._lib_()
+    lib.wdno_set_debug(mode)
+    try:
+        conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000)
+    finally:
+        lib.wdno_set_debug(0)
+
+
 def test_conv_f16x3_wide_dynamic_range(ops):
     """Gradient-like magnitudes (1e-7) and large activations (1e3) must survive the per-tensor scaling."""
     for scale in (1e-7, 1.0, 1e3):

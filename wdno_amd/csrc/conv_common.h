@@ -46,6 +46,9 @@ static inline int check_geom(const wdno_conv_geom* g) {
   return WDNO_OK;
 }
 extern int wdno_debug_mode;
+// conv_h3d.hip: LDS-DMA variant of the split-fp16 forward / data-gradient kernel (WDNO_EUNSUPPORTED -> use conv_h3.hip's)
+int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
+                         const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st, int stages);
 static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.g = *g;
   p.debug = wdno_debug_mode;

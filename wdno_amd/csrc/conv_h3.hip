@@ -22,14 +22,24 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------------------------------------- amax / split
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
   __shared__ float red[4];
-  int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t n4 = n >> 2;
+  const int64_t n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
   float m = 0.f;
-  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += stride) {
-    float4 v = reinterpret_cast<const float4*>(x)[k];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  // four independent 16-byte loads in flight per thread: a bandwidth-bound sweep needs ~8 MB outstanding chip-wide
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t k0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; k0 < n4; k0 += stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int64_t k = k0 + u * 256;
+      v[u] = k < n4 ? x4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
   }
-  for (int64_t k = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) m = fmaxf(m, fabsf(x[k]));
+  if (blockIdx.x == 0)
+    for (int64_t k = (n4 << 2) + threadIdx.x; k < n; k += 256) m = fmaxf(m, fabsf(x[k]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -40,7 +50,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 }
 extern "C" int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s) {
   WDNO_REQUIRE(n > 0);
-  amax_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, as_stream(s)>>>(x, n, reinterpret_cast<unsigned*>(amax_zeroed));
+  amax_kernel<<<stream_grid(n / 16 + 1, 256), 256, 0, as_stream(s)>>>(x, n, reinterpret_cast<unsigned*>(amax_zeroed));
   return wdno_check_launch();
 }
 
@@ -101,6 +111,24 @@ typedef int int4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), (short)0, (int)bytes, 0x00020000);
 }
+// The same descriptor as four SGPR words for the hand-counted loads below (raw buffer, stride 0, bounds = bytes).
+__device__ __forceinline__ int4v make_rsrc_words(const void* ptr, unsigned bytes) {
+  uint64_t a = reinterpret_cast<uint64_t>(ptr);
+  int4v r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+// hipcc turns every counted prefetch of compiler-visible loads into s_waitcnt vmcnt(0) at the next use, which drains the
+// queue once per step and leaves the kernel latency bound. These loads are therefore invisible to its bookkeeping: the
+// destination counts as written at issue, and the kernel waits for them itself with vm_wait<N>() naming the registers.
+__device__ __forceinline__ int4v asm_buffer_load_b128(int4v rsrc, int byte_off) {
+  int4v v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(byte_off), "s"(rsrc) : "memory");
+  return v;
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
@@ -120,8 +148,9 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
   const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
-  const __amdgpu_buffer_rsrc_t rxh = make_rsrc(xh, x_bytes), rxl = make_rsrc(xl, x_bytes);
-  const __amdgpu_buffer_rsrc_t rwh = make_rsrc(wh, w_bytes), rwl = make_rsrc(wl, w_bytes);
+  int4v rxh = make_rsrc_words(xh, x_bytes), rxl = make_rsrc_words(xl, x_bytes);
+  int4v rwh = make_rsrc_words(wh, w_bytes), rwl = make_rsrc_words(wl, w_bytes);
+  asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rwh), "+s"(rwl));      // SGPR write -> VMEM descriptor read wait states
 
   // 4 lanes cover one 64-byte row piece; consecutive lane quads take rows r and r+4 so that the 8 lanes of a
   // ds_write_b128 group hit 32 distinct banks with the 80-byte row stride (r and r+1 would overlap by 16 bytes)
@@ -177,15 +206,15 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
     for (int i = 0; i < AROWS; ++i) {
       const bool ok = row_ok[i] && r_ok && (unsigned)(a_w0[i] + l_dx) < (unsigned)g.W;
       const int off = ok ? (a_base[i] + tap_off + chunk_off) * 2 : OOB_OFFSET;
-      ah[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
-      al[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+      ah[S][i] = asm_buffer_load_b128(rxh, off);
+      al[S][i] = asm_buffer_load_b128(rxl, off);
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
       const bool ok = b_ok[i] && r_ok;
       const int off = ok ? (b_base[i] + wtap_off + chunk_off) * 2 : OOB_OFFSET;
-      bh[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rwh, off, 0, 0);
-      bl[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rwl, off, 0, 0);
+      bh[S][i] = asm_buffer_load_b128(rwh, off);
+      bl[S][i] = asm_buffer_load_b128(rwl, off);
     }
     ++l_chunk;
     l_r += HBK;
@@ -198,6 +227,24 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
       if (++l_dy == g.kh) { l_dy = 0; ++l_dz; }
       tap_off = (l_dz * g.H + l_dy) * g.W * g.C;
       refresh_tap();
+    }
+  };
+  // wait until at most `newer` younger loads are outstanding; names every register of the set so that no consumer of
+  // them can be scheduled above the wait
+  constexpr int NLOADS = 2 * (AROWS + BROWS);
+  auto wait_set = [&](auto SET, bool newer_in_flight) {
+    constexpr int S = decltype(SET)::value;
+    if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NLOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      int4v &r0 = ah[S][i], &r1 = al[S][i];
+      asm volatile("" : "+v"(r0), "+v"(r1));
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      int4v &r0 = bh[S][i], &r1 = bl[S][i];
+      asm volatile("" : "+v"(r0), "+v"(r1));
     }
   };
   auto store_tile = [&](auto SET, int buf) {
@@ -270,11 +317,15 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[b], acc[a][b], 0, 0, 0);
     }
     using NXT = std::integral_constant<int, 1 - B>;
-    if (step + 1 < p.nsteps) store_tile(NXT{}, 1 - B);
+    if (step + 1 < p.nsteps) {
+      wait_set(NXT{}, step + 2 < p.nsteps);      // the set of step+2 (issued one iteration later) may stay in flight
+      store_tile(NXT{}, 1 - B);
+    }
     __syncthreads();
     if (step + 3 < p.nsteps) load_tile(NXT{});
   };
   load_tile(S0{});
+  wait_set(S0{}, false);
   store_tile(S0{}, 0);
   __syncthreads();
   if (p.nsteps > 1) load_tile(S1{});
@@ -344,6 +395,13 @@ extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* 
   const int64_t P = p.P;
   const int K = g->K;
   auto blocks = [&](int bm, int bn) { return cdiv64(P, bm) * cdiv(K, bn); };
+  // large problems: persistent LDS-DMA kernels (256x64 / 128x128 tiles, 64x64 per compute wave). debug: 5 = never, 7 = always
+  const int dbg = wdno_debug_mode;
+  if (dbg != 5 && dbg != 3 && dbg != 1 && (dbg == 7 || (K > 64 ? blocks(128, 128) : blocks(256, 64)) >= 256)) {
+    rc = wdno_conv_fwd_h3_dma(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st, 3);
+    if (rc == WDNO_OK) return wdno_check_launch();
+    if (rc != WDNO_EUNSUPPORTED) return rc;
+  }
   if (K > 64) {
     if ((blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) && wdno_debug_mode != 3) rc = launch_h3<128, 128, 2, 2>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
     else rc = launch_h3<64, 128, 1, 4>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
