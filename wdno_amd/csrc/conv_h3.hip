@@ -455,7 +455,7 @@ extern "C" int wdno_conv_pixel_table(void* table, const wdno_conv_geom* g, wdno_
 
 struct WgradHP {
   ConvP c;
-  int tiles_k, tiles_r, splits;
+  int tiles_k, tiles_r, splits, bn;
   int64_t pix_per_split;
 };
 
@@ -483,8 +483,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
   constexpr int TN = BN / (WN * 32);
   constexpr int SA = BM + WH_PAD, SB = BN + WH_PAD;          // LDS row strides (halves)
   constexpr int A_C8 = BM / 8, B_C8 = BN / 8;                 // 16-byte pieces per pixel row
-  constexpr int A_RPP = 256 / A_C8, B_RPP = 256 / B_C8;       // pixel rows per pass
-  constexpr int A_PASSES = WH_BKP / A_RPP, B_PASSES = WH_BKP / B_RPP;
+  constexpr int A_RPP = 256 / A_C8;                           // pixel rows per pass
+  constexpr int A_PASSES = WH_BKP / A_RPP, B_PASSES = WH_BKP * B_C8 / 256;
+  static_assert(256 % A_C8 == 0 && (WH_BKP * B_C8) % 256 == 0, "loader mapping");
   constexpr int STAGE = 2 * WH_BKP * (SA + SB);               // halves per stage: Ah, Al, Bh, Bl
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
   int4v* pinfo = reinterpret_cast<int4v*>(hsm + 2 * STAGE);   // [WH_RING][WH_BKP]
@@ -519,10 +520,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
     if (tid < WH_BKP) pinfo[(step & (WH_RING - 1)) * WH_BKP + tid] = e;
   };
 
-  const int b_row = tid / B_C8, b_c8 = (tid % B_C8) * 8;
-  const int r = r0 + b_c8;
-  const bool r_ok = r < p.R;
-  const int dx = r / g.C;
+  // B pieces: piece index tid + 256*i -> (pixel row, 8-channel group); BN need not divide 256 (192-wide tiles)
+  int b_row[B_PASSES], b_c8[B_PASSES], r[B_PASSES], dx[B_PASSES];
+  bool r_ok[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int idx = tid + 256 * i;
+    b_row[i] = idx / B_C8;
+    b_c8[i] = (idx - b_row[i] * B_C8) * 8;
+    r[i] = r0 + b_c8[i];
+    r_ok[i] = r[i] < p.R;
+    dx[i] = r[i] / g.C;
+  }
   const int a_row = tid / A_C8, a_c8 = (tid % A_C8) * 8;
   const int ka = k0 + a_c8;
   const bool ka_ok = ka < g.K;
@@ -539,10 +548,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      const int4v e = ps[b_row + i * B_RPP];
-      const int d = (e.z >> 16) + dz, h = (int)(short)(e.z & 0xffff) + dyy, w = e.w + dx;
-      const bool ok = e.x >= 0 && r_ok && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-      const int off = ok ? (e.y + tap_off + r) * 2 : OOB_OFFSET;
+      const int4v e = ps[b_row[i]];
+      const int d = (e.z >> 16) + dz, h = (int)(short)(e.z & 0xffff) + dyy, w = e.w + dx[i];
+      const bool ok = e.x >= 0 && r_ok[i] && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+      const int off = ok ? (e.y + tap_off + r[i]) * 2 : OOB_OFFSET;
       bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
       bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
     }
@@ -559,8 +568,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      *reinterpret_cast<int4v*>(&Bh[(b_row + i * B_RPP) * SB + b_c8]) = bh[i];
-      *reinterpret_cast<int4v*>(&Bl[(b_row + i * B_RPP) * SB + b_c8]) = bl[i];
+      *reinterpret_cast<int4v*>(&Bh[b_row[i] * SB + b_c8[i]]) = bh[i];
+      *reinterpret_cast<int4v*>(&Bl[b_row[i] * SB + b_c8[i]]) = bl[i];
     }
   };
 
@@ -654,9 +663,13 @@ static void wgrad_h3_plan(WgradHP& w, const wdno_conv_geom* g) {
   fill_params(w.c, g);
   const int BM = g->K > 64 ? 128 : 64;
   w.tiles_k = cdiv(g->K, BM);
-  w.tiles_r = cdiv(w.c.R, 128);
+  // column tile of the kw*C run: 192 for the wide-K kernel (64 x 96 per wave beats 64 x 64), and for K <= 64 only when it
+  // removes a half-empty tile (kw*C = 192: the 3-wide taps of the 64-channel layers)
+  w.bn = (g->K > 64 || (w.c.R % 128 != 0 && w.c.R % 192 == 0)) ? 192 : 128;
+  w.tiles_r = cdiv(w.c.R, w.bn);
   int64_t tiles = (int64_t)w.tiles_k * w.tiles_r * g->kd * g->kh;
-  int64_t want = cdiv64(1024, tiles);
+  int64_t want = 512 / tiles;       // at most 512 blocks (floor): whole rounds of the 256 CUs, never a short extra round
+  if (want < 1) want = 1;
   int64_t max_splits = cdiv64(w.c.P, 16 * WH_BKP);   // at least 16 steps per block
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
@@ -701,7 +714,8 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
   dim3 grid((unsigned)(w.tiles_k * g->kd * g->kh * w.tiles_r), (unsigned)w.splits);
   float* wsf = w.splits == 1 ? dwp : (float*)ws;
   hipStream_t st = as_stream(s);
-  if (g->K > 64) launch_wgrad_h3<128, 128, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
+  if (g->K > 64) launch_wgrad_h3<128, 192, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
+  else if (w.bn == 192) launch_wgrad_h3<64, 192, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
   else launch_wgrad_h3<64, 128, 1, 4>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
   if (w.splits > 1) {
     int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
