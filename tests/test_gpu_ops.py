@@ -246,6 +246,19 @@ def test_conv_transpose(ops, c):
     conv_case(ops, (2, c, 3, 5, 6), (c, c, 1, 4, 4), (1, 2, 2), (0, 1, 1), seed=14 + c, transposed=True)
 
 
+@pytest.mark.parametrize('cin,cout,sp', [(64, 64, (4, 16, 16)), (128, 72, (3, 20, 20))])
+def test_conv_transpose_f16x3_path(ops, cin, cout, sp):
+    """Large enough for the split-fp16 kernels: 4 parity-class launches with interleaved output placement, the strided
+    data gradient and the weight gradient (operand roles swapped) all on the fp32-equivalent MFMA path."""
+    n_launch = {}
+    ops.PROFILE = n_launch
+    try:
+        conv_case(ops, (2, cin, *sp), (cin, cout, 1, 4, 4), (1, 2, 2), (0, 1, 1), seed=200 + cin, transposed=True)
+    finally:
+        ops.PROFILE = None
+    assert any('h3' in k for k in n_launch) and not any(k.startswith('conv_fwd_kernel') for k in n_launch), list(n_launch)
+
+
 # ----------------------------------------------------------------------------------------------------- normalisation
 @pytest.mark.parametrize('shape,groups,use_ss,act', [((2, 64, 3, 10, 10), 8, True, True), ((2, 16, 5, 5), 1, True, True),
                                                       ((1, 8, 2, 4, 4), 4, False, True), ((3, 128, 8, 8), 1, False, False),

@@ -294,14 +294,24 @@ extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float
 }
 
 // ================================================================================================ linear attention
-// pass 1: per (unit, column = head*32+d): max over tokens and sum of exp -> kstats[unit][col][2]
-__global__ __launch_bounds__(256) void linattn_kstats_kernel(const float* __restrict__ qkv, float* __restrict__ kstats, int n, int HD) {
+// pass 1: per (unit, column = head*32+d): max over tokens and sum of exp -> kstats[unit][col][2].
+// A unit has up to 1600 tokens but there are only ~200 units: the token range is cut into `chunks` pieces (one block each,
+// online-softmax partials into a scratch area) and a second tiny launch merges them, so the sweep fills the chip.
+__device__ __forceinline__ void softmax_merge(float& m, float& l, float m2, float l2) {
+  float mn = fmaxf(m, m2);
+  float a = (m == -INFINITY) ? 0.f : l * expf(m - mn);
+  float b = (m2 == -INFINITY) ? 0.f : l2 * expf(m2 - mn);
+  l = a + b; m = mn;
+}
+__global__ __launch_bounds__(256) void linattn_kstats_kernel(const float* __restrict__ qkv, float* __restrict__ part, int n, int HD, int chunks) {
   __shared__ float rm[256], rl[256];
-  const int unit = blockIdx.x;
+  const int unit = blockIdx.x / chunks, chunk = blockIdx.x - unit * chunks;
+  const int per = (n + chunks - 1) / chunks;
+  const int jb = chunk * per, je = min(n, jb + per);
   const int col = threadIdx.x % HD, rg = threadIdx.x / HD, nrg = 256 / HD;
   const float* kp = qkv + ((int64_t)unit * n) * (3 * HD) + HD + col;
   float m = -INFINITY, l = 0.f;
-  for (int j = rg; j < n; j += nrg) {
+  for (int j = jb + rg; j < je; j += nrg) {
     float v = kp[(int64_t)j * 3 * HD];
     float mn = fmaxf(m, v);
     l = l * expf(m - mn) + expf(v - mn);
@@ -310,16 +320,23 @@ __global__ __launch_bounds__(256) void linattn_kstats_kernel(const float* __rest
   rm[threadIdx.x] = m; rl[threadIdx.x] = l;
   __syncthreads();
   if (rg == 0) {
-    for (int t = 1; t < nrg; ++t) {
-      float m2 = rm[t * HD + col], l2 = rl[t * HD + col];
-      float mn = fmaxf(m, m2);
-      float a = (m == -INFINITY) ? 0.f : l * expf(m - mn);
-      float b = (m2 == -INFINITY) ? 0.f : l2 * expf(m2 - mn);
-      l = a + b; m = mn;
-    }
-    kstats[((int64_t)unit * HD + col) * 2 + 0] = m;
-    kstats[((int64_t)unit * HD + col) * 2 + 1] = l;
+    for (int t = 1; t < nrg; ++t) softmax_merge(m, l, rm[t * HD + col], rl[t * HD + col]);
+    part[((int64_t)blockIdx.x * HD + col) * 2 + 0] = m;
+    part[((int64_t)blockIdx.x * HD + col) * 2 + 1] = l;
   }
+}
+__global__ __launch_bounds__(256) void linattn_kstats_merge_kernel(const float* __restrict__ part, float* __restrict__ kstats, int64_t cols, int HD, int chunks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (unit, col)
+  if (i >= cols) return;
+  const int64_t unit = i / HD;
+  const int col = (int)(i - unit * HD);
+  float m = -INFINITY, l = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float* q = part + (((unit * chunks + c) * HD) + col) * 2;
+    softmax_merge(m, l, q[0], q[1]);
+  }
+  kstats[i * 2] = m;
+  kstats[i * 2 + 1] = l;
 }
 
 // pass 2 (MODE 0): ctx[d][e]  = sum_n softmax_n(k)[n][d] * v[n][e]        A = exp(k - m)/l, B = v
@@ -536,7 +553,16 @@ extern "C" int wdno_linattn_fwd(const float* qkv, float* out, float* kstats, flo
   int rc = la_check(units, n_tok, heads);
   if (rc) return rc;
   hipStream_t st = as_stream(s);
-  linattn_kstats_kernel<<<(unsigned)units, 256, 0, st>>>(qkv, kstats, n_tok, heads * DH);
+  // partial statistics go through `ctx` (written only afterwards by the context kernel): chunks * HD * 2 <= 32 * HD floats per unit
+  int chunks = n_tok / 64;
+  chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
+  if (chunks == 1) {
+    linattn_kstats_kernel<<<(unsigned)units, 256, 0, st>>>(qkv, kstats, n_tok, heads * DH, 1);
+  } else {
+    linattn_kstats_kernel<<<(unsigned)(units * chunks), 256, 0, st>>>(qkv, ctx, n_tok, heads * DH, chunks);
+    const int64_t cols = units * heads * DH;
+    linattn_kstats_merge_kernel<<<(unsigned)cdiv64(cols, 256), 256, 0, st>>>(ctx, kstats, cols, heads * DH, chunks);
+  }
   linattn_ctx_kernel<0><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, nullptr, kstats, nullptr, ctx, nullptr, n_tok, heads, scale);
   size_t lds = (size_t)heads * DH * DH * sizeof(float);
   linattn_out_kernel<<<dim3((unsigned)units, (unsigned)cdiv(n_tok, 64)), 64 * heads, lds, st>>>(qkv, ctx, out, n_tok, heads, scale);

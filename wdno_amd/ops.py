@@ -392,16 +392,22 @@ def split_weight(w, kind, cp8, kp, pack=None):
     return hi, lo, sc
 
 
-def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp):
+def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp, out=None, osp=None, ostride=(1, 1, 1), ooff=(0, 0, 0)):
     """planes = (hi, lo, scale) of a CL tensor with logical shape4 = (N, D, H, W) and C8 channels; w raw weight;
-    pack = pack_fwd / pack_dgrad. Returns y [N, OD, OH, OW, kp] fp32."""
+    pack = pack_fwd / pack_dgrad. Returns y [N, OD, OH, OW, kp] fp32. With `out` ([N, YD, YH, YW, kp]) the osp output
+    pixels are placed at ooff + ostride * index (parity classes of the transposed convolution)."""
     xh, xl, sx = planes
     n, d, h, ww = shape4
     cp8 = xh.shape[-1]
     wh, wl, sw = split_weight(w, kind, cp8, kp, pack)
-    osp = tuple(_out_size(a, k, s_, p_) for a, k, s_, p_ in zip((d, h, ww), ks, st, pd))
-    y = torch.empty((n, *osp, kp), device=xh.device, dtype=torch.float32)
-    g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp)
+    if osp is None:
+        osp = tuple(_out_size(a, k, s_, p_) for a, k, s_, p_ in zip((d, h, ww), ks, st, pd))
+    if out is None:
+        y = torch.empty((n, *osp, kp), device=xh.device, dtype=torch.float32)
+        g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp)
+    else:
+        y = out
+        g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp, y_sp=tuple(out.shape[1:4]), ostride=ostride, ooff=ooff)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
     with _timed('conv_fwd_h3_kernel<128,..>' if kp > 64 else 'conv_fwd_h3_kernel<..,64>', flops):
         _lib.check(_lib_().wdno_conv_fwd_f16x3(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
@@ -638,21 +644,40 @@ class _ConvT(torch.autograd.Function):
         cin, cout = weight.shape[0], weight.shape[1]
         cin_p, cout_p = x.shape[-1], pad4(cout)
         assert cin_p == pad4(cin) and tuple(weight.shape[2:]) == (1, 4, 4)
-        wt = pack_transposed(weight, cin_p, cout_p)
         with torch.no_grad():
             bias_p = _pad_vec(bias.detach() if bias is not None else None, cout_p)
-        y = conv_transpose_raw(x, wt, bias_p, cout_p)
-        ctx.save_for_backward(x, weight)
-        ctx.meta = (cin, cout, cin_p, cout_p, bias is not None)
+        n, d, h, w = x.shape[:4]
+        h3 = _use_h3(n * d * h * w, 4 * cin_p) and cout_p % 8 == 0
+        if h3:
+            planes = split_f16(x.reshape(-1, cin_p))
+            y = conv_transpose_h3(planes, (n, d, h, w), weight, bias_p, cout_p)
+            ctx.save_for_backward(weight, *planes)
+        else:
+            y = conv_transpose_raw(x, pack_transposed(weight, cin_p, cout_p), bias_p, cout_p)
+            ctx.save_for_backward(x, weight)
+        ctx.meta = (cin, cout, cin_p, cout_p, bias is not None, h3, (n, d, h, w))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
-        cin, cout, cin_p, cout_p, has_bias = ctx.meta
+        cin, cout, cin_p, cout_p, has_bias, h3, xshape4 = ctx.meta
         gy = _chk(gy, 'grad')
         ks, st, pd = (1, 4, 4), (1, 2, 2), (0, 1, 1)
         gx = gw = gb = None
+        if h3:
+            # dx = conv_s2(dy, W) with W read as a conv weight [K' = in, C' = out, 1, 4, 4]; dW from the same two operands
+            weight, xh, xl, sx = ctx.saved_tensors
+            gyplanes = split_f16(gy.reshape(-1, cout_p))
+            gshape4 = tuple(gy.shape[:4])
+            if ctx.needs_input_grad[0]:
+                gx = conv_fwd_h3(gyplanes, gshape4, weight, pack_fwd, 'f', None, None, ks, st, pd, cin_p)
+            if ctx.needs_input_grad[1]:
+                dwp = conv_wgrad_h3(gyplanes, gshape4, (xh, xl, sx), xshape4[1:], ks, st, pd)      # [1, 4, Cin8, 4, Cout8]
+                gw = dwp[:, :, :cin, :, :cout].permute(2, 4, 0, 1, 3).contiguous()
+            if has_bias and ctx.needs_input_grad[2]:
+                gb = colsum(gy.reshape(-1, cout_p))[:cout].contiguous()
+            return gx, gw, gb
+        x, weight = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
             # dx = conv_s2(dy, W) with W read as a conv weight [K' = in, C' = out, 1, 4, 4]
             wp = pack_fwd(weight, cout_p, cin_p)
@@ -663,6 +688,28 @@ class _ConvT(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             gb = colsum(gy.reshape(-1, cout_p))[:cout].contiguous()
         return gx, gw, gb
+
+
+def _parity_weight(w_io, py, px):
+    """The (1,2,2) stride-1 convolution weight [out, in, 1, 2, 2] of parity class (py, px) of the (1,4,4)/(1,2,2)/(0,1,1)
+    transposed convolution with weight [in, out, 1, 4, 4]: W[o][i][0][dy][dx] = w[i][o][0][3 - py - 2 dy][3 - px - 2 dx]."""
+    def build():
+        w = w_io.detach()
+        ys = [3 - py, 1 - py]
+        xs = [3 - px, 1 - px]
+        return w[:, :, :, ys][:, :, :, :, xs].permute(1, 0, 2, 3, 4).contiguous()
+    return _cached(w_io, f'par{py}{px}', 0, 0, build)
+
+
+def conv_transpose_h3(xplanes, shape4, weight, bias_p, cout_p):
+    """Parity-class form of the transposed convolution on the split-fp16 kernels: 4 launches writing interleaved outputs."""
+    n, d, h, w = shape4
+    y = torch.empty((n, d, 2 * h, 2 * w, cout_p), device=xplanes[0].device, dtype=torch.float32)
+    for py in range(2):
+        for px in range(2):
+            conv_fwd_h3(xplanes, shape4, _parity_weight(weight, py, px), pack_fwd, 'f', bias_p, None, (1, 2, 2), (1, 1, 1), (0, 1 - py, 1 - px),
+                        cout_p, out=y, osp=(d, h, w), ostride=(1, 2, 2), ooff=(0, py, px))
+    return y
 
 
 def conv_transpose_cl(x, weight, bias=None):
