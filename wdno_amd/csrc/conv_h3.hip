@@ -682,6 +682,9 @@ extern "C" size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g) {
   if (check_geom(g) != WDNO_OK) return 0;
   WgradHP w;
   wgrad_h3_plan(w, g);
+  int bm, bn, splits, pps;
+  wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps);                 // the DMA kernel's plan may use a different split count
+  if (splits > w.splits) w.splits = splits;
   return (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
 }
 template <int BM, int BN, int WM, int WN>
@@ -708,6 +711,26 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
     return WDNO_EUNSUPPORTED;        // 32-bit buffer offsets
   WgradHP w;
   wgrad_h3_plan(w, g);
+  hipStream_t st0 = as_stream(s);
+  // persistent LDS-DMA kernel, except for 64 output channels with a long 128-multiple run (kw*C >= 384), where its 32-row
+  // wave tiles carry too few MFMAs per barrier and the register-staged 64 x 128 kernel below measures ~8 % faster.
+  // debug 5 = never, 7 = always
+  const bool dma_ok = !(g->K <= 64 && w.c.R >= 384 && w.c.R % 128 == 0) || wdno_debug_mode == 7;
+  if (wdno_debug_mode != 5 && dma_ok) {
+    int bm, bn, splits, pps;
+    wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps);
+    size_t need_d = (size_t)splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
+    if (splits > 1 && ws_bytes < need_d) return WDNO_EWORKSPACE;
+    rc = wdno_conv_wgrad_h3_dma(xh, xl, dyh, dyl, sx, sdy, pixel_table, splits == 1 ? dwp : (float*)ws, g, st0);
+    if (rc == WDNO_OK) {
+      if (splits > 1) {
+        int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
+        wgrad_h3_reduce_kernel<<<stream_grid(n, 256), 256, 0, st0>>>((const float*)ws, dwp, n, splits);
+      }
+      return wdno_check_launch();
+    }
+    if (rc != WDNO_EUNSUPPORTED) return rc;
+  }
   size_t need = (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
   if (ws_bytes < need) return WDNO_EWORKSPACE;
   if (w.splits > 65535) return WDNO_EUNSUPPORTED;

@@ -1,0 +1,380 @@
+// conv_wgrad_h3d.hip -- weight gradient, 3 x fp16 split, operands streamed by LDS-DMA (gfx950).
+//
+// dwp[tap][k][r] = sum_p dy[p][k] * x[p shifted by tap][r]  (r = dx*C + c), same arithmetic and workspace contract as
+// conv_wgrad_h3_kernel (conv_h3.hip). Structure = the forward DMA kernel's (conv_h3d.hip):
+//   * persistent 512-thread blocks, one per CU: waves 0-3 compute (2 x 2 over the BM x BN tile), waves 4-7 produce;
+//   * NS-stage LDS ring, one barrier per 32-pixel step, hand-counted vmcnt so the pieces of later steps stay in flight;
+//   * work items (k tile, tap row, r tile, pixel split) are walked in a fixed order, every item has the same number of
+//     steps (pixels past the end contribute zeros), so producers and consumers count steps without talking.
+// What is specific to the weight gradient:
+//   * both operands are pixel-major in memory while the MFMA wants 8 consecutive pixels per lane -> fragments are read
+//     with ds_read_b64_tr_b16 (see conv_h3.hip). The LDS plane layout is [4-pixel group][16-byte channel chunk][pixel
+//     in group][16 B]: a DMA piece (64 lanes x 16 B, lane-linear) covers 16 chunks x 4 pixels, and the 32 lanes that one
+//     transpose read serves together touch 4 consecutive chunks x 4 pixels = 256 contiguous bytes: conflict-free without
+//     padding (which lane-linear DMA could not produce).
+//   * the per-pixel geometry comes from the host-cached pixel table (wdno_conv_pixel_table). Producer lanes fetch the
+//     records of the pixels they serve two steps before they need them, with loads that are part of the same counted
+//     queue as the pieces.
+//   * the accumulator tile is kept as [r][k] (x fragment as the MFMA row operand), so a lane owns one k and runs of four
+//     consecutive r: 16-byte stores into dwp / the split workspace.
+#include "conv_common.h"
+#include <type_traits>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+#define WD_OOB 0x7ffffff0
+
+struct WgradDP {
+  ConvP c;
+  int tiles_k, tiles_r, splits, nsteps;     // nsteps per item (same for all)
+  int items;                                // tiles_k * ntap * tiles_r * splits
+  int pix_per_split;
+};
+
+__device__ __forceinline__ int4v wd_rsrc(const void* ptr, unsigned bytes) {
+  uint64_t a = reinterpret_cast<uint64_t>(ptr);
+  int4v r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void wd_piece(int4v rsrc, int off, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(off), "s"(lds_dst), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ int4v wd_load_rec(int4v rsrc, int off) {
+  int4v v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(rsrc) : "memory");
+  return v;
+}
+// transpose-read fragment: channels ch0..ch0+31 (MFMA row/column index = lane & 31) x pixels pix0..pix0+15 (k index) of a
+// plane laid out [pixel / 4][chunk16][pixel % 4][16 B] with NCH chunks per pixel
+template <int NCH>
+__device__ __forceinline__ half8 wd_frag(const char* plane, int lane_off, int pix0, int ch0) {
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef short4v __attribute__((address_space(3))) * lds_s4;
+  const char* p0 = plane + lane_off + (pix0 / 4) * (NCH * 64) + (ch0 / 8) * 64;
+  short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
+  short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + NCH * 64));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  short8v c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(half8, c);
+}
+
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                              const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
+                                                              const float* __restrict__ sx, const float* __restrict__ sdy,
+                                                              const int4v* __restrict__ table, float* __restrict__ ws, WgradDP wp,
+                                                              unsigned x_bytes, unsigned dy_bytes, unsigned tbl_bytes) {
+  constexpr int TM = BM / 64, TN = BN / 64;              // 32-wide MFMA tiles per compute wave (2 x 2 waves)
+  constexpr int ACH = BM / 8, BCH = BN / 8;              // 16-byte chunks per pixel row
+  constexpr int A_PLANE = 32 * ACH * 16, B_PLANE = 32 * BCH * 16;
+  constexpr int A_LO = A_PLANE, B_HI = 2 * A_PLANE, B_LO = B_HI + B_PLANE;
+  constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+  constexpr int APC = A_PLANE / 1024, BPC = B_PLANE / 1024;      // pieces per plane
+  constexpr int NPAIR = APC + BPC;                                // (hi, lo) piece pairs per step
+  static_assert(NPAIR % 4 == 0, "pieces are dealt to four producer waves");
+  constexpr int R = NPAIR / 4;                                    // pairs (= pixel records) per producer lane and step
+  constexpr int PW = 2 * R;
+  constexpr int LA = 2;                                           // records are fetched LA steps ahead of their pieces
+  static_assert(R + (NS - 2) * (R + PW) <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const ConvP& p = wp.c;
+  const wdno_conv_geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int my_items = (wp.items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int ntap = g.kd * g.kh;
+  auto decode_item = [&](int t, int& tile_k, int& tap, int& tile_r, int& split) {
+    int id = (int)blockIdx.x + t * (int)gridDim.x;
+    tile_r = id % wp.tiles_r; id /= wp.tiles_r;
+    tap = id % ntap; id /= ntap;
+    tile_k = id % wp.tiles_k;
+    split = id / wp.tiles_k;
+  };
+
+  if (wave >= 4) {
+    // ================================================================== producer waves
+    const int pq = wave - 4;
+    int4v rxh = wd_rsrc(xh, x_bytes), rxl = wd_rsrc(xl, x_bytes), rdh = wd_rsrc(dyh, dy_bytes), rdl = wd_rsrc(dyl, dy_bytes);
+    int4v rtb = wd_rsrc(table, tbl_bytes);
+    asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rdh), "+s"(rdl), "+s"(rtb));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    // pair j of this producer = global pair pq + 4*j: pairs [0, APC) are dy pieces, [APC, NPAIR) are x pieces.
+    // lane L of piece q covers flat position f = 64*q + L of the plane: pixel = 4*(f / (4*NCH)) + f % 4, chunk = (f / 4) % NCH
+    int row[R], chk[R];            // pixel inside the step, channel offset (elements)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int gp = pq + 4 * j;
+      const bool isA = gp < APC;
+      const int f = 64 * (isA ? gp : gp - APC) + lane;
+      const int nch = isA ? ACH : BCH;
+      row[j] = 4 * (f / (4 * nch)) + (f & 3);
+      chk[j] = ((f >> 2) % nch) * 8;
+    }
+    // cursors over the global step stream of this block: (item slot, step)
+    struct Cur { int t, s; };
+    Cur rc{0, 0}, pc{0, 0};          // record cursor, piece cursor
+    int r_pbeg = 0;                  // first pixel of the record cursor's item
+    int c_k0 = 0, c_r0 = 0, c_dz = 0, c_dy = 0, c_tap = 0;      // piece cursor's item
+    auto load_item_r = [&]() {
+      int tk, tap, tr, sp;
+      decode_item(rc.t, tk, tap, tr, sp);
+      r_pbeg = sp * wp.pix_per_split;
+    };
+    auto load_item_p = [&]() {
+      int tk, tap, tr, sp;
+      decode_item(pc.t, tk, tap, tr, sp);
+      c_k0 = tk * BM; c_r0 = tr * BN; c_tap = tap;
+      c_dz = tap / g.kh; c_dy = tap - c_dz * g.kh;
+    };
+    if (my_items > 0) { load_item_r(); load_item_p(); }
+    int4v rec[LA + 1][R];
+    bool rok[LA + 1][R];
+    auto fetch = [&](auto SLOT) {
+      constexpr int S = decltype(SLOT)::value;
+      const bool live = rc.t < my_items;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int pm = r_pbeg + rc.s * 32 + row[j];
+        rok[S][j] = live && pm < (int)p.P;
+        rec[S][j] = wd_load_rec(rtb, rok[S][j] ? pm * 16 : WD_OOB);
+      }
+      if (live && ++rc.s == wp.nsteps) { rc.s = 0; if (++rc.t < my_items) load_item_r(); }
+    };
+    auto issue = [&](auto SLOT, int stage) {
+      constexpr int S = decltype(SLOT)::value;
+      const bool live = pc.t < my_items;
+      const unsigned sb = lds0 + stage * STAGE;
+      const int tap_off = (c_dz * g.H + c_dy) * g.W * g.C;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        int4v e = rec[S][j];
+        asm volatile("" : "+v"(e));                                   // consumers of the record stay below the counted wait
+        const int gp = pq + 4 * j;                                    // compile-time after unrolling (pq is wave-uniform: branchy but cheap)
+        const bool ok0 = live && rok[S][j];
+        if (gp < APC) {
+          const int k = c_k0 + chk[j];
+          const int off = (ok0 && k < g.K) ? (e.x * g.K + k) * 2 : WD_OOB;
+          wd_piece(rdh, off, sb + gp * 1024);
+          wd_piece(rdl, off, sb + A_LO + gp * 1024);
+        } else {
+          const int r = c_r0 + chk[j];
+          const int dx = r / g.C;
+          const int d = (e.z >> 16) + c_dz, h = (int)(short)(e.z & 0xffff) + c_dy, w = e.w + dx;
+          const bool ok = ok0 && r < p.R && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+          const int off = ok ? (e.y + tap_off + r) * 2 : WD_OOB;
+          wd_piece(rxh, off, sb + B_HI + (gp - APC) * 1024);
+          wd_piece(rxl, off, sb + B_LO + (gp - APC) * 1024);
+        }
+      }
+      if (live && ++pc.s == wp.nsteps) { pc.s = 0; if (++pc.t < my_items) load_item_p(); }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // counted wait that names the record registers of slot S, so that no reader of them can be scheduled above it
+    auto wait_pin = [&](auto SLOT, auto COUNT, auto BAR) {
+      constexpr int S = decltype(SLOT)::value;
+      constexpr int N = decltype(COUNT)::value;
+      constexpr bool WITH_BARRIER = decltype(BAR)::value;
+      static_assert(R >= 3 && R <= 5, "record count");
+      int4v &r0 = rec[S][0], &r1 = rec[S][1], &r2 = rec[S][2], &r3 = rec[S][R > 3 ? 3 : 0], &r4 = rec[S][R > 4 ? 4 : 0];
+      if (WITH_BARRIER) {
+        if (R == 3) asm volatile("s_waitcnt vmcnt(%3)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
+        else if (R == 4) asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%5)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "n"(N) : "memory");
+      } else {
+        if (R == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
+        else if (R == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "n"(N) : "memory");
+      }
+    };
+    using YES = std::true_type;
+    using NO = std::false_type;
+    using ZERO = std::integral_constant<int, 0>;
+    using WSTEADY = std::integral_constant<int, R + (NS - 2) * (R + PW)>;
+    // prologue: records of steps 0..LA-1+NS-1 ..., pieces of steps 0..NS-2. Slot of step q = q % 3.
+    static_assert(NS == 3 && LA == 2, "slot schedule below is written for a 3-stage ring and 2 steps of record look-ahead");
+    fetch(S0{}); fetch(S1{}); fetch(S2{});          // records of steps 0, 1, 2
+    wait_pin(S0{}, ZERO{}, NO{});
+    wait_pin(S1{}, ZERO{}, NO{});
+    wait_pin(S2{}, ZERO{}, NO{});
+    issue(S0{}, 0);                                 // pieces of step 0
+    fetch(S0{});                                    // records of step 3 (slot 0 is free again)
+    issue(S1{}, 1);                                 // pieces of step 1
+    // steady state, iteration gs: fetch records of step gs+4 | wait pieces(gs) | barrier | issue pieces of step gs+2
+    const int total = my_items * wp.nsteps;
+    int stage = 0;
+    auto iter = [&](auto FS, auto IS) {
+      fetch(FS);
+      wait_pin(IS, WSTEADY{}, YES{});               // pieces of step gs and the records in slot IS have landed
+      int nstage = stage + NS - 1;
+      if (nstage >= NS) nstage -= NS;
+      issue(IS, nstage);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+    };
+    for (int gs = 0; gs < total; gs += 3) {
+      iter(S1{}, S2{});                              // gs % 3 == 0: fetch step gs+4 -> slot 1, issue step gs+2 from slot 2
+      if (gs + 1 < total) iter(S2{}, S0{});
+      if (gs + 2 < total) iter(S0{}, S1{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    return;
+  }
+
+  // ================================================================== compute waves
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31;
+  const int gq = lane >> 4, xq = lane & 15;
+  const int m_base = wm * (TM * 32), n_base = wn * (TN * 32);
+  // per-lane part of the transpose-read address (see wd_frag): pixel group 2*(gq>>1), chunk 2*(gq&1) + ((xq&3)>>1), pixel xq>>2 (xq = lane & 15)
+  const int offA = (2 * (gq >> 1)) * (ACH * 64) + (2 * (gq & 1) + ((xq & 3) >> 1)) * 64 + (xq >> 2) * 16 + 8 * (xq & 1);
+  const int offB = (2 * (gq >> 1)) * (BCH * 64) + (2 * (gq & 1) + ((xq & 3) >> 1)) * 64 + (xq >> 2) * 16 + 8 * (xq & 1);
+  half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+  auto read_frags = [&](auto SET, int stage, int ks) {
+    constexpr int B = decltype(SET)::value;
+    const char* st = smem + stage * STAGE;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      fah[B][a] = wd_frag<ACH>(st, offA, ks * 16, m_base + a * 32);
+      fal[B][a] = wd_frag<ACH>(st + A_LO, offA, ks * 16, m_base + a * 32);
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      fbh[B][b] = wd_frag<BCH>(st + B_HI, offB, ks * 16, n_base + b * 32);
+      fbl[B][b] = wd_frag<BCH>(st + B_LO, offB, ks * 16, n_base + b * 32);
+    }
+  };
+  f32x16 acc[TM][TN];
+  auto mfma_set = [&](auto SET) {          // row operand = x fragment (r), column operand = dy fragment (k): acc is [r][k]
+    constexpr int B = decltype(SET)::value;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[B][b], fal[B][a], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[B][b], fah[B][a], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[B][b], fah[B][a], acc[a][b], 0, 0, 0);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  const float inv = 1.0f / (sx[0] * sdy[0]);
+  const int hh = lane >> 5;
+  int stage = 0;
+  for (int t = 0; t < my_items; ++t) {
+    int tile_k, tap, tile_r, split;
+    decode_item(t, tile_k, tap, tile_r, split);
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+    read_frags(B0{}, stage, 0);
+    for (int step = 0; step < wp.nsteps; ++step) {
+      read_frags(B1{}, stage, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(B0{});
+      __builtin_amdgcn_sched_barrier(0);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      if (step + 1 < wp.nsteps) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+        read_frags(B0{}, stage, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(B1{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // acc[a][b]: rows = r (n_base + b*32 + 8*(e>>2) + 4*hh + (e&3)), column = k (m_base + a*32 + li)
+    float* out = ws + ((int64_t)split * ntap + tap) * (int64_t)g.K * p.R;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int kk = tile_k * BM + m_base + a * 32 + li;
+      if (kk >= g.K) continue;
+      float* orow = out + (int64_t)kk * p.R;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int rr = tile_r * BN + n_base + b * 32 + 8 * e4 + 4 * hh;
+          if (rr < p.R)                           // R = kw*C is a multiple of 8
+            *reinterpret_cast<float4*>(orow + rr) = make_float4(acc[a][b][4 * e4] * inv, acc[a][b][4 * e4 + 1] * inv, acc[a][b][4 * e4 + 2] * inv, acc[a][b][4 * e4 + 3] * inv);
+        }
+      }
+    }
+  }
+}
+
+static int wd_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+// plan shared by the workspace query and the launch (conv_h3.hip calls both)
+void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits, int* pix_per_split) {
+  ConvP c;
+  fill_params(c, g);
+  *bm = g->K > 64 ? 128 : 64;
+  // column tile of the kw*C run: the width that pads the run least; 192 on a tie (more MFMAs per step and barrier)
+  *bn = cdiv(c.R, 192) * 192 <= cdiv(c.R, 128) * 128 ? 192 : 128;
+  const int tiles = cdiv(g->K, *bm) * cdiv(c.R, *bn) * g->kd * g->kh;
+  int64_t want = 512 / tiles;                              // two items per persistent block
+  int64_t max_splits = cdiv64(c.P, 16 * 32);               // at least 16 steps per item
+  if (want > max_splits) want = max_splits;
+  if (want < 1) want = 1;
+  int64_t pps = cdiv64(cdiv64(c.P, want), 32) * 32;
+  *pix_per_split = (int)pps;
+  *splits = (int)cdiv64(c.P, pps);
+}
+
+template <int BM, int BN>
+static void launch_wd(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
+                      const void* table, float* wsf, const WgradDP& w, hipStream_t st) {
+  const wdno_conv_geom& g = w.c.g;
+  const unsigned x_bytes = (unsigned)((int64_t)g.N * g.D * g.H * g.W * g.C * 2);
+  const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
+  const unsigned tbl_bytes = (unsigned)(w.c.P * 16);
+  constexpr int NS = 3;
+  const size_t lds = (size_t)NS * 2 * (32 * (BM / 8) * 16 + 32 * (BN / 8) * 16);
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_h3d_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  int grid = wd_num_cus();
+  if (w.items < grid) grid = w.items;
+  conv_wgrad_h3d_kernel<BM, BN, NS><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh, (const _Float16*)dyl,
+                                                         sx, sdy, (const int4v*)table, wsf, w, x_bytes, dy_bytes, tbl_bytes);
+}
+
+// wsf: split workspace [splits][ntap][K][R] (or dwp itself when splits == 1). Returns WDNO_EUNSUPPORTED for geometries the
+// DMA kernel does not take.
+int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
+                           const void* table, float* wsf, const wdno_conv_geom* g, hipStream_t st) {
+  WgradDP w;
+  fill_params(w.c, g);
+  int bm, bn;
+  wdno_wgrad_h3d_plan(g, &bm, &bn, &w.splits, &w.pix_per_split);
+  if (w.c.P * 16 >= WD_OOB) return WDNO_EUNSUPPORTED;
+  w.tiles_k = cdiv(g->K, bm);
+  w.tiles_r = cdiv(w.c.R, bn);
+  w.nsteps = w.pix_per_split / 32;
+  w.items = w.tiles_k * w.tiles_r * g->kd * g->kh * w.splits;
+  if (bm == 128 && bn == 192) launch_wd<128, 192>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  else if (bm == 128) launch_wd<128, 128>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  else if (bn == 192) launch_wd<64, 192>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  else launch_wd<64, 128>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  return WDNO_OK;
+}
