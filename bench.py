@@ -166,8 +166,10 @@ def main():
             peak = PEAK_F16_MFMA_TFLOPS if 'h3' in dom else PEAK_F32_MFMA_TFLOPS
             traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json)
             try:
-                sym = {'conv_fwd_h3_kernel<..,64>': 'conv_fwd_h3_kernelILi128ELi64E', 'conv_fwd_h3_kernel<128,..>': 'conv_fwd_h3_kernelILi128ELi128E',
-                       'conv_wgrad_h3_kernel<64,..>': 'conv_wgrad_h3_kernelILi64ELi128E', 'conv_wgrad_h3_kernel<128,..>': 'conv_wgrad_h3_kernelILi128ELi128E'}.get(dom)
+                # profiling key 'conv_fwd_h3d_kernel<256,64>' -> mangled symbol prefix 'conv_fwd_h3d_kernelILi256ELi64E'
+                fam, dims = dom.split('<')
+                dims = dims.rstrip('>').split(',')
+                sym = fam + 'I' + ''.join(f'Li{d}E' for d in dims) if all(d.isdigit() for d in dims) else None
                 with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
                     for kname, rec in json.load(f)['kernels'].items():
                         if sym and sym in kname:

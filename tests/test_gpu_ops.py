@@ -304,6 +304,17 @@ def test_layernorm(ops, rows, c):
 
 
 # ----------------------------------------------------------------------------------------------------- attention
+def test_softmax_attention_mfma_backward(ops):
+    """The one-wave-per-item MFMA backward (n_tok <= 32; not the default yet) against the same fp64 reference."""
+    lib = ops._lib_()
+    lib.wdno_set_debug(8)
+    try:
+        test_softmax_attention(ops, 'temporal', 2, 24, 3, 5)
+        test_softmax_attention(ops, 'temporal', 1, 7, 2, 2)
+    finally:
+        lib.wdno_set_debug(0)
+
+
 @pytest.mark.parametrize('kind,b,f,h,w', [('temporal', 2, 24, 3, 5), ('temporal', 1, 7, 2, 2), ('spatial', 2, 3, 10, 10), ('spatial', 1, 1, 8, 8)])
 def test_softmax_attention(ops, kind, b, f, h, w):
     from oracle import unet_ref as U

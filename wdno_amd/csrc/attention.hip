@@ -8,6 +8,7 @@
 //    global memory (each lane supplies one k and one v element per MFMA); the per-token 32x32 mat-vecs run
 //    on the vector ALU with the context broadcast from LDS.
 #include "common.h"
+extern int wdno_debug_mode;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define DH 32
@@ -253,6 +254,311 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_kernel(const float* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ n_tok <= 32: one wave per item
+// With at most 32 tokens the score matrix is ONE 32x32 MFMA tile (v_mfma_f32_32x32x2_f32: exact fp32 products and sums).
+// Everything is kept transposed so that the softmax axis lies inside a lane:
+//   S^T[j][i] = sum_d K[j][d] Q[i][d]     row operand K (lane = key j), column operand Q (lane = query i)
+//   -> accumulator: lane (i, hh) holds keys j = 8*(e>>2) + 4*hh + (e&3), e = 0..15: max / sum over e and the partner lane.
+//   O^T[d][i] = sum_j V[j][d] P[i][j]     the reduction index runs over the keys in exactly the order the accumulator holds
+//   them (step m <-> e = m), so P^T feeds the second MFMA without moving data; V is read as coalesced 128-byte rows.
+// The backward needs P and dS with the roles of the lanes swapped (lane = key) for dK / dV: two 32x33 tiles per wave in LDS.
+#define AM_WAVES 4
+// wave-uniform pointer in SGPRs: the per-lane part of an address stays a 32-bit offset (global_load saddr + voffset)
+__device__ __forceinline__ const float* am_uniform(const float* p) {
+  uint64_t a = reinterpret_cast<uint64_t>(p);
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int am_key(int m, int hh) { return 8 * (m >> 2) + 4 * hh + (m & 3); }
+
+// Rows of one operand ([n][32] floats: q, k, v or dO of one head) -> LDS tile [32][AM_TS], loaded cooperatively (8 lanes
+// per 128-byte row, three passes for 24 rows), optionally scaled and rotated on the way; rows >= n are zero-filled.
+#define AM_TS 36
+__device__ __forceinline__ void am_stage_rows(float* __restrict__ tile, const float* __restrict__ base, int64_t row0, int64_t st, int64_t rw,
+                                              const float* __restrict__ rc, const float* __restrict__ rs, float scale, int n, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = lane + 64 * k;
+    const int r = idx >> 3, c4 = (idx & 7) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n) {
+      x = *reinterpret_cast<const float4*>(base + (row0 + (int64_t)r * st) * rw + c4);
+      x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+      if (rc) {
+        const float4 c = *reinterpret_cast<const float4*>(rc + r * DH + c4), sn = *reinterpret_cast<const float4*>(rs + r * DH + c4);
+        x = make_float4(x.x * c.x - x.y * sn.x, x.y * c.y + x.x * sn.y, x.z * c.z - x.w * sn.z, x.w * c.w + x.z * sn.w);
+      }
+    }
+    *reinterpret_cast<float4*>(tile + r * AM_TS + c4) = x;
+  }
+}
+// the 16 values of row `li` this lane feeds to the MFMA: channels d = 2m + hh
+__device__ __forceinline__ void am_sel(const float* __restrict__ tile, int li, int hh, float* sel) {
+#pragma unroll
+  for (int m = 0; m < 16; ++m) sel[m] = tile[li * AM_TS + 2 * m + hh];
+}
+// softmax over the keys of query `li` from the transposed score tile (masked beyond n); returns P^T in place
+__device__ __forceinline__ void am_softmax(f32x16& sT, const float* __restrict__ brow, int n, int hh, bool tok) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int j = am_key(e, hh);
+    float v = sT[e];
+    if (brow && tok && j < n) v += brow[j];
+    v = j < n ? v : -INFINITY;
+    sT[e] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float l = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { sT[e] = expf(sT[e] - mx); l += sT[e]; }
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sT[e] *= inv;
+}
+
+__global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+                                                                          const float* __restrict__ rsin, const float* __restrict__ bias,
+                                                                          float* __restrict__ out, AttnP p) {
+  __shared__ __attribute__((aligned(16))) float tiles[AM_WAVES][2][32 * AM_TS];
+  const int n = p.d.n_tok;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+  const bool tok = li < n;
+  float* Tq = tiles[wave][0];
+  float* Tk = tiles[wave][1];
+  for (int64_t item = (int64_t)blockIdx.x * AM_WAVES + wave; item < p.n_items; item += (int64_t)gridDim.x * AM_WAVES) {
+    const int h = (int)(item % p.d.heads);
+    const int64_t unit = item / p.d.heads;
+    const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
+    const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
+    const int64_t rowl = row0 + (int64_t)(tok ? li : 0) * p.d.st;
+    am_stage_rows(Tq, qkv + h * DH, row0, p.d.st, p.RW, rcos, rsin, p.scale, n, lane);
+    am_stage_rows(Tk, qkv + p.HD + h * DH, row0, p.d.st, p.RW, rcos, rsin, 1.0f, n, lane);
+    // V elements for the second product: step m needs V[key(m, hh)][d = li] (coalesced 128-byte rows)
+    float va[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int j = am_key(m, hh);
+      va[m] = j < n ? qkv[(row0 + (int64_t)j * p.d.st) * p.RW + 2 * p.HD + h * DH + li] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float qs[16], ks[16];
+    am_sel(Tq, li, hh, qs);
+    am_sel(Tk, li, hh, ks);
+    f32x16 sT;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sT[e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[m], qs[m], sT, 0, 0, 0);
+    am_softmax(sT, bias ? bias + ((int64_t)h * n + (tok ? li : 0)) * n : nullptr, n, hh, tok);
+    f32x16 oT;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oT[e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) oT = __builtin_amdgcn_mfma_f32_32x32x2f32(va[m], sT[m], oT, 0, 0, 0);
+    if (tok) {
+      float* orow = out + rowl * p.HD + h * DH;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4)
+        *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = make_float4(oT[4 * e4], oT[4 * e4 + 1], oT[4 * e4 + 2], oT[4 * e4 + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();      // the next item overwrites the tiles
+  }
+}
+
+// element (row j, channel li) of a rotated q / k row, read column-wise (coalesced 128-byte rows): the rotation partner sits in
+// the neighbouring lane
+__device__ __forceinline__ float am_rot_elem(float x, const float* __restrict__ rc, const float* __restrict__ rs, int j, int li, bool ok) {
+  if (!rc) return x;
+  const float partner = __shfl_xor(x, 1);
+  const float c = ok ? rc[j * DH + li] : 1.f, sn = ok ? rs[j * DH + li] : 0.f;
+  return (li & 1) ? x * c + partner * sn : x * c - partner * sn;
+}
+// gradient of the rotation on a run of four consecutive channels d0..d0+3 held by one lane (pairs are inside the run)
+__device__ __forceinline__ float4 am_unrotate4(float4 g, const float* __restrict__ rc, const float* __restrict__ rs, int d0) {
+  if (!rc) return g;
+  const float4 c = *reinterpret_cast<const float4*>(rc + d0), s = *reinterpret_cast<const float4*>(rs + d0);
+  return make_float4(g.x * c.x + g.y * s.x, g.y * c.y - g.x * s.y, g.z * c.z + g.w * s.z, g.w * c.w - g.z * s.w);
+}
+
+__global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+                                                                       const float* __restrict__ rsin, const float* __restrict__ bias,
+                                                                       const float* __restrict__ fout, const float* __restrict__ dout,
+                                                                       float* __restrict__ dqkv, float* __restrict__ dbias, AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = p.d.n_tok;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+  constexpr int WAVE_LDS = 2 * 32 * KST + 2 * 32 * AM_TS + 32;
+  float* Pt = smem + wave * WAVE_LDS;                // [j][i] (+1 pad): P^T and dS^T of this wave's item
+  float* St = Pt + 32 * KST;
+  float* Ta = St + 32 * KST;                         // two staged operand tiles (q, k then v, dO) and delta[32]
+  float* Tb = Ta + 32 * AM_TS;
+  float* dl = Tb + 32 * AM_TS;
+  float* dBs = smem + AM_WAVES * WAVE_LDS;            // [heads][n][n] when dbias
+  if (dbias) {
+    for (int e = threadIdx.x; e < p.d.heads * n * n; e += 64 * AM_WAVES) dBs[e] = 0.f;
+    __syncthreads();
+  }
+  const bool tok = li < n;
+  for (int64_t item = (int64_t)blockIdx.x * AM_WAVES + wave; item < p.n_items; item += (int64_t)gridDim.x * AM_WAVES) {
+    const int h = (int)(item % p.d.heads);
+    const int64_t unit = item / p.d.heads;
+    const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
+    const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
+    const int64_t rowl = row0 + (int64_t)(tok ? li : 0) * p.d.st;
+    const float* rcl = rcos ? rcos + li * DH : nullptr;
+    const float* rsl = rsin ? rsin + li * DH : nullptr;
+    const float* qb = am_uniform(qkv + row0 * p.RW + h * DH);          // q of token 0 of this item; k at + HD, v at + 2 HD
+    const float* gb = am_uniform(dout + row0 * p.HD + h * DH);
+    const unsigned tstride = (unsigned)(p.d.st * p.RW), gstride = (unsigned)(p.d.st * p.HD);
+    f32x16 pT, dsT;
+    {
+      am_stage_rows(Ta, qkv + h * DH, row0, p.d.st, p.RW, rcos, rsin, p.scale, n, lane);
+      am_stage_rows(Tb, qkv + p.HD + h * DH, row0, p.d.st, p.RW, rcos, rsin, 1.0f, n, lane);
+      __builtin_amdgcn_wave_barrier();
+      float qs[16], ks[16];
+      am_sel(Ta, li, hh, qs);
+      am_sel(Tb, li, hh, ks);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pT[e] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) pT = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[m], qs[m], pT, 0, 0, 0);
+      am_softmax(pT, bias ? bias + ((int64_t)h * n + (tok ? li : 0)) * n : nullptr, n, hh, tok);
+    }
+    {
+      // dP^T[j][i] = sum_d V[j][d] dO[i][d]; delta_i = <dO_i, O_i> (8 lanes per row, reduced with three shuffles)
+      __builtin_amdgcn_wave_barrier();
+      am_stage_rows(Ta, qkv + 2 * p.HD + h * DH, row0, p.d.st, p.RW, nullptr, nullptr, 1.0f, n, lane);
+      am_stage_rows(Tb, dout + h * DH, row0, p.d.st, p.HD, nullptr, nullptr, 1.0f, n, lane);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = lane + 64 * k;
+        const int r = idx >> 3, c4 = (idx & 7) * 4;
+        float part = 0.f;
+        if (r < n) {
+          const float4 o = *reinterpret_cast<const float4*>(fout + (row0 + (int64_t)r * p.d.st) * p.HD + h * DH + c4);
+          const float4 gg = *reinterpret_cast<const float4*>(Tb + r * AM_TS + c4);      // this lane wrote it
+          part = gg.x * o.x + gg.y * o.y + gg.z * o.z + gg.w * o.w;
+        }
+        part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
+        if ((lane & 7) == 0) dl[r] = part;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float vs[16], gs[16];
+      am_sel(Ta, li, hh, vs);
+      am_sel(Tb, li, hh, gs);
+      const float delta = dl[li];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dsT[e] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[m], gs[m], dsT, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dsT[e] = pT[e] * (dsT[e] - delta);
+    }
+    // the two tiles with the lane roles swapped (lane = key) go through LDS; the relative-position-bias gradient is dS itself
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int j = am_key(e, hh);
+      Pt[j * KST + li] = pT[e];
+      St[j * KST + li] = dsT[e];
+      if (dbias && tok && j < n) atomicAdd(&dBs[(h * n + li) * n + j], dsT[e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]  (K rotated, read as rows): lane i gets runs of four channels
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {          // four steps at a time: bounded live registers, the other waves hide the latency
+        float ka[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = 4 * g4 + q, j = am_key(m, hh);
+          const float x = j < n ? qb[(unsigned)j * tstride + (unsigned)(p.HD + li)] : 0.f;
+          ka[q] = am_rot_elem(x, rcos, rsin, j, li, j < n);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[q], dsT[4 * g4 + q], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tok) {
+        float* drow = dqkv + rowl * p.RW + h * DH;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int d0 = 8 * e4 + 4 * hh;
+          float4 gq = am_unrotate4(make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]), rcl, rsl, d0);
+          *reinterpret_cast<float4*>(drow + d0) = make_float4(gq.x * p.scale, gq.y * p.scale, gq.z * p.scale, gq.w * p.scale);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dK^T[d][j] = sum_i Q[i][d] dS[i][j],  dV^T[d][j] = sum_i dO[i][d] P[i][j]: lane j, reduction over the queries
+    // (one after the other: 48 live registers each instead of 96)
+    {
+      f32x16 dk;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dk[e] = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float qa[4], sb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = am_key(4 * g4 + q, hh);
+          const bool ok = i < n;
+          const float x = ok ? qb[(unsigned)i * tstride + (unsigned)li] * p.scale : 0.f;
+          qa[q] = am_rot_elem(x, rcos, rsin, i, li, ok);
+          sb[q] = St[li * KST + i];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q], sb[q], dk, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tok) {
+        float* drow = dqkv + rowl * p.RW + p.HD + h * DH;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int d0 = 8 * e4 + 4 * hh;
+          *reinterpret_cast<float4*>(drow + d0) = am_unrotate4(make_float4(dk[4 * e4], dk[4 * e4 + 1], dk[4 * e4 + 2], dk[4 * e4 + 3]), rcl, rsl, d0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      f32x16 dv;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dv[e] = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float ga[4], pb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = am_key(4 * g4 + q, hh);
+          ga[q] = i < n ? gb[(unsigned)i * gstride + (unsigned)li] : 0.f;
+          pb[q] = Pt[li * KST + i];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dv = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[q], pb[q], dv, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tok) {
+        float* drow = dqkv + rowl * p.RW + 2 * p.HD + h * DH;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4)
+          *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = make_float4(dv[4 * e4], dv[4 * e4 + 1], dv[4 * e4 + 2], dv[4 * e4 + 3]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();      // the next item overwrites this wave's tiles
+  }
+  if (dbias) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < p.d.heads * n * n; e += 64 * AM_WAVES)
+      if (dBs[e] != 0.f) atomicAdd(&dbias[e], dBs[e]);
+  }
+}
+
 static int attn_fill(AttnP& p, const wdno_attn_desc* d, float scale, int threads) {
   if (!d || d->n_uo <= 0 || d->n_ui <= 0 || d->n_tok <= 0 || d->heads <= 0) return WDNO_EINVAL;
   p.d = *d; p.scale = scale; p.HD = d->heads * DH; p.RW = 3 * p.HD;
@@ -268,6 +574,12 @@ extern "C" int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float
   int rc = attn_fill(p, d, scale, ATT_THREADS);
   if (rc) return rc;
   if (d->n_tok > 1024) return WDNO_EUNSUPPORTED;
+  if (d->n_tok <= 32 && wdno_debug_mode != 5) {                  // one 32x32 MFMA tile per (unit, head): one wave per item
+    int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
+    if (nb > 4096) nb = 4096;
+    attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
+    return wdno_check_launch();
+  }
   size_t lds = (size_t)p.ipb * p.kst * sizeof(float);
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;
   int64_t blocks = (p.n_items + p.ipb - 1) / p.ipb;
@@ -282,6 +594,15 @@ extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float
   int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
   if (rc) return rc;
   const int n = d->n_tok;
+  // the one-wave-per-item MFMA backward (debug 8) measures no faster than the thread-per-row kernel yet: it needs ~300
+  // registers and LDS for two transposes, so only two waves per SIMD hide its five dependent load phases
+  if (n <= 32 && wdno_debug_mode == 8) {
+    size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * KST + 2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
+    int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
+    if (nb > 2048) nb = 2048;                                // also bounds the number of global dbias flushes
+    attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p);
+    return wdno_check_launch();
+  }
   if (n > ATT_BWD_THREADS) return WDNO_EUNSUPPORTED;      // training never attends over more than 100 tokens
   size_t lds = ((size_t)p.ipb * (2 * p.kst + 2 * n * (n + 1)) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;

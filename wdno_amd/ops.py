@@ -409,13 +409,31 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
         y = out
         g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp, y_sp=tuple(out.shape[1:4]), ostride=ostride, ooff=ooff)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
-    with _timed('conv_fwd_h3_kernel<128,..>' if kp > 64 else 'conv_fwd_h3_kernel<..,64>', flops):
+    with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks), flops):
         _lib.check(_lib_().wdno_conv_fwd_f16x3(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
                                                C.byref(g), _stream()), 'conv_fwd_f16x3')
     return y
 
 
 _pixel_tables = {}
+
+
+def _fwd_h3_kernel_name(pixels, k, ks):
+    """Kernel family wdno_conv_fwd_f16x3 picks (mirrors the dispatch in csrc/conv_h3.hip; used as the profiling key)."""
+    cdiv = lambda a, b: -(-a // b)
+    tiles = cdiv(pixels, 128) * cdiv(k, 128) if k > 64 else cdiv(pixels, 256)
+    if tiles >= 256 and max(ks) <= 8:
+        return 'conv_fwd_h3d_kernel<128,128>' if k > 64 else 'conv_fwd_h3d_kernel<256,64>'
+    return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
+
+
+def _wgrad_h3_kernel_name(k, run):
+    """Same for wdno_conv_wgrad_f16x3 (run = kw * C8)."""
+    cdiv = lambda a, b: -(-a // b)
+    if k <= 64 and run >= 384 and run % 128 == 0:
+        return 'conv_wgrad_h3_kernel<64,128>'
+    bn = 192 if cdiv(run, 192) * 192 <= cdiv(run, 128) * 128 else 128
+    return f'conv_wgrad_h3d_kernel<{128 if k > 64 else 64},{bn}>'
 
 
 def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd):
@@ -436,7 +454,7 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd):
         _pixel_tables[tkey] = table
     dwp = torch.empty((ks[0], ks[1], k8, ks[2], c8), device=xh.device, dtype=torch.float32)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * k8 * ks[0] * ks[1] * ks[2] * c8
-    with _timed('conv_wgrad_h3_kernel<128,..>' if k8 > 64 else 'conv_wgrad_h3_kernel<64,..>', flops):
+    with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8), flops):
         _lib.check(lib.wdno_conv_wgrad_f16x3(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dwp), _p(ws), nb, C.byref(g), _stream()),
                    'conv_wgrad_f16x3')
     return dwp
