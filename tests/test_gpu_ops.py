@@ -181,6 +181,20 @@ CONV_CASES_H3 = [
 ]
 
 
+# more tiles / work items than CUs: every persistent block of the LDS-DMA kernels walks over several tiles (forward, dgrad)
+# and several (tap, split) items (wgrad), with the producers prefetching across the tile boundary
+CONV_CASES_PERSISTENT = [
+    ('persist_k32', (2, 16, 24, 40, 40), (32, 16, 3, 3, 3), 1, 1),        # 300 tiles of 256 x 64
+    ('persist_k96', (1, 16, 24, 40, 40), (96, 16, 3, 3, 3), 1, 1),        # 300 tiles of 128 x 128
+    ('persist_1x1', (2, 64, 24, 40, 40), (24, 64, 1, 1, 1), 1, 0),        # one step per tile
+]
+
+
+@pytest.mark.parametrize('name,xs,ws,stride,padding', CONV_CASES_PERSISTENT, ids=[c[0] for c in CONV_CASES_PERSISTENT])
+def test_conv_f16x3_persistent_blocks(ops, name, xs, ws, stride, padding):
+    conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000)
+
+
 @pytest.mark.parametrize('name,xs,ws,stride,padding', CONV_CASES_H3, ids=[c[0] for c in CONV_CASES_H3])
 def test_conv_f16x3_path(ops, name, xs, ws, stride, padding):
     assert ops.CONV_MATH == 'f16x3'

@@ -713,9 +713,9 @@ def _parity_weight(w_io, py, px):
     transposed convolution with weight [in, out, 1, 4, 4]: W[o][i][0][dy][dx] = w[i][o][0][3 - py - 2 dy][3 - px - 2 dx]."""
     def build():
         w = w_io.detach()
-        ys = [3 - py, 1 - py]
-        xs = [3 - px, 1 - px]
-        return w[:, :, :, ys][:, :, :, :, xs].permute(1, 0, 2, 3, 4).contiguous()
+        rows = torch.stack((w[:, :, :, 3 - py], w[:, :, :, 1 - py]), dim=3)                  # [in, out, 1, 2(dy), 4]
+        sub = torch.stack((rows[..., 3 - px], rows[..., 1 - px]), dim=4)                     # [in, out, 1, 2(dy), 2(dx)]
+        return sub.permute(1, 0, 2, 3, 4).contiguous()
     return _cached(w_io, f'par{py}{px}', 0, 0, build)
 
 
