@@ -103,6 +103,11 @@ int wdno_conv_fwd(const float* x, const float* wp, const float* bias, const floa
  * with g->C = C8; sx / sw are the device scalars written by wdno_split_f16 for the activation / packed-weight operand. */
 int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s);
 int wdno_split_f16(const float* x, const float* amax, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8, wdno_stream_t s);
+/* wdno_split_f16 that also returns colsum_out[C8] = sum over rows (the bias gradient when x is dy), in the same pass.
+ * WDNO_EUNSUPPORTED unless C8 / 8 is a power of two <= 256 (use wdno_split_f16 + wdno_colsum then). */
+size_t wdno_split_colsum_ws_bytes(int64_t rows, int C8);
+int wdno_split_f16_colsum(const float* x, const float* amax, void* hi, void* lo, float* scale_out, float* colsum_out,
+                          void* ws, size_t ws_bytes, int64_t rows, int C, int C8, wdno_stream_t s);
 /* raw weight [K][C][kd][kh][kw] -> split planes of the packed operand in one launch. mode 0: forward operand
  * [kd][kh][A>=K][kw][B>=C]; mode 1: data-gradient operand [kd][kh][A>=C][kw][B>=K] with flipped taps. amax = max|w| (device). */
 int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh, int kw,

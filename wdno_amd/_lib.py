@@ -61,6 +61,8 @@ PROTOTYPES = {
     'wdno_conv_fwd': (I, [P, P, P, P, P, PG, P]),
     'wdno_amax': (I, [P, L, P, P]),
     'wdno_split_f16': (I, [P, P, P, P, P, L, I, I, P]),
+    'wdno_split_colsum_ws_bytes': (Z, [L, I]),
+    'wdno_split_f16_colsum': (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),
     'wdno_pack_split_weight': (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     'wdno_conv_fwd_f16x3': (I, [P, P, P, P, P, P, P, P, P, PG, P]),
     'wdno_conv_wgrad_f16x3_ws_bytes': (Z, [PG]),

@@ -100,6 +100,73 @@ extern "C" int wdno_split_f16(const float* x, const float* amax, void* hi, void*
   return wdno_check_launch();
 }
 
+// split + per-channel column sums in one pass (the bias gradient of a convolution is the column sum of the same dy that is
+// being split for the data / weight gradient kernels). Every thread always works on the same 8-channel group (the host
+// only calls this for power-of-two group counts <= 256), accumulates its rows in fp32 and the block folds them to one
+// double row of partials; partial_rows_sum_kernel<double> finishes, as for wdno_colsum.
+__global__ __launch_bounds__(256) void split_colsum_kernel(const float* __restrict__ x, const float* __restrict__ amax,
+                                                            _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ scale_out,
+                                                            double* __restrict__ part, int64_t rows, int C, int C8) {
+  __shared__ float red[256][9];
+  const float s = scale_from_amax(amax[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const int g8 = C8 >> 3;
+  const int64_t total = rows * g8;
+  const int64_t stride = (int64_t)gridDim.x * 256;            // a multiple of g8: the channel group of a thread never changes
+  float cs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    int64_t r = i / g8;
+    int c0 = (int)(i - r * g8) * 8;
+    float v[8];
+    const float* xp = x + r * C + c0;
+    if (c0 + 8 <= C) {
+      float4 a = *reinterpret_cast<const float4*>(xp), b = *reinterpret_cast<const float4*>(xp + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? xp[e] : 0.f;
+    }
+    half8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      cs[e] += v[e];
+      float t = v[e] * s;
+      _Float16 th = (_Float16)t;
+      h[e] = th;
+      l[e] = (_Float16)(t - (float)th);
+    }
+    *reinterpret_cast<half8*>(hi + r * C8 + c0) = h;
+    *reinterpret_cast<half8*>(lo + r * C8 + c0) = l;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = cs[e];
+  __syncthreads();
+  // threads t, t + g8, t + 2 g8, ... share the group t % g8
+  for (int idx = threadIdx.x; idx < C8; idx += 256) {
+    const int grp = idx >> 3, e = idx & 7;
+    double acc = 0.0;
+    for (int t = grp; t < 256; t += g8) acc += (double)red[t][e];
+    part[(int64_t)blockIdx.x * C8 + idx] = acc;
+  }
+}
+// ws: doubles [wdno_split_colsum_ws_bytes / 8]; colsum_out[C8] fp32. WDNO_EUNSUPPORTED unless C8/8 is a power of two <= 256.
+extern "C" size_t wdno_split_colsum_ws_bytes(int64_t rows, int C8) {
+  return (size_t)stream_grid(rows * (C8 / 8), 256) * (size_t)C8 * sizeof(double);
+}
+extern "C" int wdno_split_f16_colsum(const float* x, const float* amax, void* hi, void* lo, float* scale_out, float* colsum_out,
+                                     void* ws, size_t ws_bytes, int64_t rows, int C, int C8, wdno_stream_t s) {
+  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 8);
+  const int g8 = C8 / 8;
+  if (g8 > 256 || (g8 & (g8 - 1))) return WDNO_EUNSUPPORTED;
+  if (ws_bytes < wdno_split_colsum_ws_bytes(rows, C8)) return WDNO_EWORKSPACE;
+  const int grid = stream_grid(rows * g8, 256);
+  split_colsum_kernel<<<grid, 256, 0, as_stream(s)>>>(x, amax, (_Float16*)hi, (_Float16*)lo, scale_out, (double*)ws, rows, C, C8);
+  partial_rows_sum_kernel<double><<<cdiv(C8, 32), 256, 0, as_stream(s)>>>((const double*)ws, colsum_out, grid, C8);
+  return wdno_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------- convolution
 // The fp16 MFMAs of one 32-deep step take only ~400 cycles per wave, so the per-step integer work matters as much as the
 // math. All operand fetches are raw buffer loads with 32-bit byte offsets: out-of-range pieces (zero padding, tile tails)

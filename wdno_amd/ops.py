@@ -358,6 +358,26 @@ def split_f16(x2d):
     return hi, lo, scale
 
 
+def split_f16_colsum(x2d):
+    """split_f16 that also returns the column sums [C] of x2d from the same pass (bias gradient of a convolution whose dy
+    is being split anyway); falls back to split_f16 + colsum for channel counts the fused kernel does not take."""
+    rows, c = x2d.shape
+    c8 = pad8(c)
+    g8 = c8 // 8
+    if g8 > 256 or (g8 & (g8 - 1)):
+        return split_f16(x2d), colsum(x2d)
+    lib = _lib_()
+    amax = tensor_amax(x2d)
+    hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+    lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+    scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
+    cs = torch.empty(c8, device=x2d.device, dtype=torch.float32)
+    nb = lib.wdno_split_colsum_ws_bytes(rows, c8)
+    ws = _ws(nb, x2d.device)
+    _lib.check(lib.wdno_split_f16_colsum(_p(x2d), _p(amax), _p(hi), _p(lo), _p(scale), _p(cs), _p(ws), nb, rows, c, c8, _stream()), 'split_f16_colsum')
+    return (hi, lo, scale), cs[:c]
+
+
 def split_weight(w, kind, cp8, kp, pack=None):
     """Split planes of the packed weight operand (cached per weight version). kind 'f': forward operand
     [kd,kh,kp,kw,cp8]; kind 'd': data-gradient operand [kd,kh,kp(=Cp of x),kw,cp8(=K8 of dy)] with flipped taps.
@@ -582,12 +602,19 @@ class _Conv(torch.autograd.Function):
         osp = tuple(_out_size(a, kk, s, p) for a, kk, s, p in zip((d, h, w), ks, stride, padding))
         gy5 = gy.reshape(n, *osp, kp)
         gx = gw = gb = gr = None
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        will_split = (ctx.needs_input_grad[1] and ctx.h3) or (ctx.needs_input_grad[0] and stride == (1, 1, 1)
+                                                              and _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]))
+        if want_gb and will_split:               # dy is split for the gradient kernels anyway: column sums from the same pass
+            gyplanes, gbs = split_f16_colsum(gy5.reshape(-1, kp))
+            gb = gbs[:k].contiguous()
         if ctx.needs_input_grad[0]:
             if stride == (1, 1, 1):
                 pd = tuple(kk - 1 - p for kk, p in zip(ks, padding))
                 if _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]):
                     # dgrad = the same kernel on dy with flipped / transposed weights; "C" role = Kp, "K" role = Cp
-                    gyplanes = split_f16(gy5.reshape(-1, kp))
+                    if gyplanes is None:
+                        gyplanes = split_f16(gy5.reshape(-1, kp))
                     gx5 = conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, None,
                                       ks, (1, 1, 1), pd, cp)
                 else:
@@ -612,7 +639,7 @@ class _Conv(torch.autograd.Function):
             else:
                 dwp = conv_wgrad_raw(x5, gy5, ks, stride, padding)
             gw = dwp[:, :, :k, :, :c].permute(2, 4, 0, 1, 3).reshape(weight.shape).contiguous()
-        if has_bias and ctx.needs_input_grad[2]:
+        if want_gb and gb is None:
             gb = colsum(gy5.reshape(-1, kp))[:k].contiguous()
         if has_res and ctx.needs_input_grad[3]:
             gr = gy
