@@ -1,0 +1,90 @@
+"""SURVEY 8f rank 1 on the GPU: the offline transforms (field -> coefficient file) and the Burgers packer, whose condition
+channel needs the HIP IDWT / DWT. Smoke_wave (pure indexing) is covered on the CPU in test_host.py."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def trees():
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    return True
+
+
+def test_burgers_packer_matches_reference_golden(trees):
+    """get_wavelet_super_preprocess against the reference function (run on the oracle DWT): base, u0-only condition, and both
+    super-resolution levels. Packed coefficients are copies (bit-exact); the condition stripes go through IDWT + DWT (1e-5)."""
+    import ddpm_burgers.data_burgers_1d as DB
+    G = load_npz('ref_data_burgers.npz')
+    coef = [torch.from_numpy(G[f'coef{i}']) for i in range(4)]
+    db = lambda: {'coef': [c.clone() for c in coef], 'shape': [c.shape[2:] for c in coef], 'ori_shape': torch.Size((81, 120))}
+    resc = torch.tensor([10, 3, 3, 1, 21, 5, 5, 1, 10]).view(1, 9, 1, 1).float()
+    resc2 = torch.cat((resc[:, :8].repeat(1, 2, 1, 1), resc[:, 8:]), dim=1)
+    for tag, kw in (('base', dict(rescaler=resc)), ('base_u0only', dict(rescaler=resc, is_condition_uT=False)),
+                    ('super0', dict(rescaler=resc2, is_super_model=True, N_downsample=0)), ('super1', dict(rescaler=resc2, is_super_model=True, N_downsample=1))):
+        pre = DB.get_wavelet_super_preprocess(mode='periodization', wave_type='bior2.4', **kw)
+        data, shape, ori_shape = pre(db())
+        ref = G[f'out_{tag}_data']
+        assert data.device.type == 'cpu' and tuple(data.shape) == ref.shape, tag
+        assert list(shape) == G[f'out_{tag}_shape'].tolist() and list(ori_shape) == G[f'out_{tag}_ori_shape'].tolist()
+        assert np.array_equal(data[:, :-1].numpy(), ref[:, :-1]), tag                       # coefficient channels: pure copies
+        err = np.abs(data[:, -1].numpy() - ref[:, -1]).max() / np.abs(ref[:, -1]).max()
+        assert err < 1e-5, (tag, err)
+    ds = DB.DiffusionDataset(db(), preprocess=DB.get_wavelet_super_preprocess(rescaler=resc, mode='periodization', wave_type='bior2.4'))
+    assert len(ds) == 3 and ds[1].shape == (9, 64, 64) and ds.shape == [41, 60] and ds.ori_shape == [81, 120]
+
+
+def test_burgers_offline_transform_vs_oracle(trees):
+    import wave_trans
+    from oracle import dwt_ref as R
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal((2, 2, 81, 120)).astype(np.float32)
+    out = wave_trans.transform_dataset(torch.from_numpy(u).to(DEV), 'bior2.4', 'periodization', N_downsample=4)
+    assert [tuple(s) for s in out['shape']] == [(4, 41, 60), (4, 21, 30), (4, 11, 15), (4, 6, 8)] and tuple(out['ori_shape']) == (81, 120)
+    for i in range(4):
+        yl, yh = R.dwt2(u[:, :, ::2 ** i, ::2 ** i].astype(np.float64), 'bior2.4', 'periodization')
+        ref = R.burgers_coef_to_tensor(yl, yh)
+        assert out['coef'][i].device.type == 'cpu' and np.abs(out['coef'][i].numpy() - ref).max() < 5e-6
+
+
+def test_smoke_offline_transform_vs_oracle_and_dataset_roundtrip(trees, tmp_path):
+    """transform_simulation -> files -> Smoke_wave: the whole preprocessing chain of the smoke task, against the oracle."""
+    import wave_trans_2d
+    from ddpm.data_2d import Smoke_wave
+    from oracle import dwt_ref as R
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((5, 32, 64, 64)).astype(np.float32)
+    s = rng.random(32).astype(np.float32)
+    ft, fs = wave_trans_2d.transform_simulation(torch.from_numpy(X).to(DEV), torch.from_numpy(s).to(DEV), N_downsample=3)
+    assert [tuple(v) for v in ft['shape']] == [(18, 34, 34), (10, 34, 34), (6, 34, 34)]
+    assert [tuple(v) for v in fs['shape']] == [(18, 34, 34), (18, 18, 18), (18, 10, 10)] and tuple(ft['ori_shape']) == (32, 64, 64)
+    for kind, f in (('time', ft), ('space', fs)):
+        for i in range(3):
+            xs = X[:, ::2 ** i] if kind == 'time' else X[:, :, ::2 ** i, ::2 ** i]
+            lll, det = R.dwt3(xs.astype(np.float64), 'bior1.3')
+            assert np.abs(f['coef'][i].numpy() - R.smoke_coef_to_tensor(lll, det)).max() < 5e-6
+            yl, yh = R.dwt2(xs[:, None, 0].astype(np.float64), 'bior1.3', 'zero')
+            assert np.abs(f['init_coef'][i].numpy() - np.concatenate([yl, yh[:, 0]], axis=1)).max() < 5e-6
+            ss = s.reshape(1, 1, -1)[:, :, ::2 ** i] if kind == 'time' else s.reshape(1, 1, -1)
+            lo, hi = R.dwt1d(ss.astype(np.float64), 'bior1.3', 'zero')
+            assert np.abs(f['smokeout'][i].numpy() - np.concatenate([lo, hi], axis=1)[0]).max() < 5e-6
+    for kind, f in (('time', ft), ('space', fs)):
+        d = tmp_path / 'train' / 'bior1.3_zero' / f'{kind}_downsample'
+        d.mkdir(parents=True)
+        torch.save(f, str(d / '000003'))
+    state, shape, ori_shape, sim_id = Smoke_wave(str(tmp_path), 'bior1.3', 'zero')[3]
+    assert state.shape == (24, 42, 40, 40) and shape == [18, 34, 34] and ori_shape == [32, 64, 64] and sim_id == 3
+    assert float(state[18:, :40].abs().max()) == 0 and float(state[:, :40, 34:].abs().max()) == 0     # zero padding of the coefficient channels
+    st_sr, _, _, _ = Smoke_wave(str(tmp_path), 'bior1.3', 'zero', is_super_model=True, downsample_type='space', N_downsample=0)[3]
+    assert st_sr.shape == (24, 82, 40, 40)

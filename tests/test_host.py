@@ -234,12 +234,13 @@ def test_trainer_checkpoint_layout_matches_torch_adam():
 
 def test_package_fallthrough_to_reference_modules(tmp_path):
     """Modules / names that are not on the WDNO path resolve to the reference tree when it sits behind ours on sys.path
-    (ddpm.data_2d, ddpm_burgers.result_io, the 2-D `Unet` of ddpm.diffusion_2d ...). A stand-in tree is used here."""
+    (ddpm.utils, ddpm_burgers.result_io, the 2-D `Unet` of ddpm.diffusion_2d, the raw-field `Smoke` dataset ...). A stand-in tree is used here."""
     import subprocess
     from wdno_amd import tree_path
     fake = tmp_path / 'ref_smoke'
     (fake / 'ddpm').mkdir(parents=True)                      # namespace package, like smoke/ddpm in the reference
-    (fake / 'ddpm' / 'data_2d.py').write_text('Smoke_wave = "reference dataset"\n')
+    (fake / 'ddpm' / 'utils.py').write_text('load_data = "reference utils"\n')
+    (fake / 'ddpm' / 'data_2d.py').write_text('Smoke = "reference raw dataset"\nSmoke_wave = "must not win"\n')
     (fake / 'ddpm' / 'diffusion_2d.py').write_text('Unet = "reference 2-D Unet"\nGaussianDiffusion = "must not win"\n')
     fakeb = tmp_path / 'ref_burgers'
     (fakeb / 'ddpm_burgers').mkdir(parents=True)
@@ -249,11 +250,13 @@ def test_package_fallthrough_to_reference_modules(tmp_path):
         'import sys\n'
         f'sys.path[:0] = [{tree_path("third_party")!r}, {tree_path("smoke")!r}, {tree_path("burgers")!r}, {str(fake)!r}, {str(fakeb)!r}]\n'
         'from ddpm.diffusion_2d import Unet, GaussianDiffusion, Trainer\n'
-        'from ddpm.data_2d import Smoke_wave\n'
+        'from ddpm.data_2d import Smoke, Smoke_wave\n'
+        'from ddpm.utils import load_data\n'
         'from ddpm_burgers.result_io import merge_save_dict\n'
         'from ddpm_burgers.unet import Unet2D\n'
         'import ddpm.diffusion_2d as m\n'
-        'assert Unet == "reference 2-D Unet" and Smoke_wave == "reference dataset" and merge_save_dict() == "reference io"\n'
+        'assert Unet == "reference 2-D Unet" and load_data == "reference utils" and merge_save_dict() == "reference io"\n'
+        'assert Smoke == "reference raw dataset" and isinstance(Smoke_wave, type)\n'
         'assert isinstance(GaussianDiffusion, type) and "wdno_amd" in m.__file__ and "wdno_amd" in sys.modules[Unet2D.__module__].__file__\n'
         'try:\n'
         '    m.DoesNotExist\n'
@@ -283,3 +286,29 @@ def test_trainer_signatures_match_reference(trees):
     for T in (TB, TS):
         for m in ('save', 'load', 'train', 'device'):
             assert hasattr(T, m)
+
+
+def test_smoke_dataset_matches_reference_golden(trees, tmp_path):
+    """ddpm.data_2d.Smoke_wave (file-per-simulation coefficient format -> U-Net state, base and both
+    super-resolution variants) against the outputs of the reference class on the same synthetic files."""
+    from ddpm.data_2d import Smoke_wave, SuperDataLoader, pack_smoke_state
+    from tests.helpers import load_npz
+    G = load_npz('ref_data_smoke.npz')
+    T = torch.from_numpy
+    for kind in ('time', 'space'):
+        d = tmp_path / 'train' / 'bior1.3_zero' / f'{kind}_downsample'
+        d.mkdir(parents=True)
+        torch.save({'coef': [T(G[f'{kind}_coef{i}']) for i in range(2)], 'init_coef': [T(G[f'{kind}_init{i}']) for i in range(2)],
+                    'smokeout': [T(G[f'{kind}_smokeout{i}']) for i in range(2)], 'shape': [G[f'{kind}_coef{i}'].shape[-3:] for i in range(2)],
+                    'ori_shape': torch.Size(G[f'{kind}_ori_shape'].tolist())}, str(d / '000000'))
+    for tag, kw in (('base', dict(is_super_model=False)), ('super_time', dict(is_super_model=True, downsample_type='time', N_downsample=0)),
+                    ('super_space', dict(is_super_model=True, downsample_type='space', N_downsample=0))):
+        ds = Smoke_wave(str(tmp_path), 'bior1.3', 'zero', **kw)
+        state, shape, ori_shape, sim_id = ds[0]
+        assert np.array_equal(ds.RESCALER.numpy(), G[f'out_{tag}_rescaler'])
+        assert state.shape == G[f'out_{tag}_state'].shape and np.array_equal(state.numpy(), G[f'out_{tag}_state']), tag
+        assert list(shape) == G[f'out_{tag}_shape'].tolist() and list(ori_shape) == G[f'out_{tag}_ori_shape'].tolist() and sim_id == 0
+    assert len(ds) == 20000 and hasattr(SuperDataLoader, '__iter__')
+    # the packer itself is device-agnostic: same result when called directly
+    st = pack_smoke_state(T(G['time_coef0']), T(G['time_init0']), T(G['time_smokeout0']), torch.from_numpy(G['out_base_rescaler']))
+    assert np.array_equal(st.numpy(), G['out_base_state'])

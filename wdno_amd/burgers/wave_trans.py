@@ -44,3 +44,12 @@ def coef_to_tensor(Yl, Yh, pad=False):
         up_x = int(t.shape[-1] / 60)
         t = nn.functional.pad(t, (0, 64 * up_x - t.shape[-1], 0, 64 * up_t - t.shape[-2]), 'constant', 0)
     return t
+
+
+def transform_dataset(data, wave_type='bior2.4', mode='periodization', N_downsample=4):
+    """The body of the offline transform (wave_trans.py:99-123) on the GPU: data [N, 2, nt, nx] = (u, f with its last row
+    zero-filled) -> {'coef': [level][N, 2, 4, h, w], 'shape', 'ori_shape'} with level i the single-level 2-D DWT of the
+    fields sub-sampled by 2^i in t and x (the file train_ddpm_burgers.py reads as coef_<wave>_<mode>_super)."""
+    from wdno_amd import wavelets as W
+    coef = [W.dwt_packed(data[:, :, ::2 ** i, ::2 ** i].contiguous(), wave_type, mode, 2).cpu() for i in range(N_downsample)]
+    return {'coef': coef, 'shape': [c.shape[2:] for c in coef], 'ori_shape': data.shape[2:]}

@@ -1,0 +1,130 @@
+"""Wavelet-coefficient dataset of the 2-D smoke task -- drop-in for smoke/ddpm/data_2d.py:119-232 (Smoke_wave, SuperDataLoader).
+
+A simulation is stored by the offline transform (wave_trans_2d.py, here: wave_trans_2d.transform_simulation) as
+    {'coef': [level][5, 8, T', H', W'], 'init_coef': [level][5, 4, H', W'], 'smokeout': [level][2, T'], 'shape', 'ori_shape'}
+and becomes one U-Net input [frames, channels, 40, 40]:
+    channels 0..39   the 5 fields x 8 sub-bands, zero-padded to 24 x 40 x 40
+    (super-resolution models: 40 more channels with the next-coarser level, nearest-upsampled in time or in space, the fine
+     level carrying one replicated border coefficient so that both grids line up)
+    channel -2       initial-density condition: the 4 sub-bands of the 2-D DWT of rho(t=0), each repeated over frames/4 frames
+    channel -1       smoke-out condition: the 2 sub-bands of its 1-D DWT painted over the upper / lower half of the image
+all divided by the per-channel RESCALER. `pack_smoke_state` is the packing itself and works on tensors of any device, so a
+batch can be packed on the GPU straight from transform_simulation's output; `Smoke_wave` keeps the reference's file-per-item
+interface. The raw-field dataset `Smoke` is not on the WDNO path: it resolves to the reference module when that is present.
+"""
+import math
+import os
+import random
+
+import torch
+import torch.nn.functional as F
+from torch.utils.data import DataLoader, Dataset
+
+import wdno_amd
+
+_RESCALERS = {
+    'bior2.2': [4, 2, 2, 1, 2, 2, 1, 1, 42, 10, 21, 8, 15, 3, 5, 2, 51, 18, 8, 5, 16, 6, 4, 2,
+                42, 8, 17, 6, 15, 3, 5, 2, 51, 18, 9, 5, 13, 5, 3, 2, 3, 2],
+    'bior1.3': [4, 2, 2, 2, 2, 2, 1, 1, 37, 12, 15, 11, 19, 6, 11, 5, 44, 24, 9, 10, 16, 9, 6, 6,
+                37, 10, 15, 8, 19, 5, 11, 5, 43, 24, 9, 10, 16, 9, 5, 5, 3, 2],
+}
+
+
+def cycle(dl):
+    while True:
+        for data in dl:
+            yield data
+
+
+def pack_smoke_state(coef, init_coef, smokeout, rescaler, coef_sub=None, downsample_type='time', pad_t=24, pad_x=40):
+    """coef [5, 8, t, x, x] (+ coef_sub: the next-coarser level for super-resolution models), init_coef [5, 4, x, x],
+    smokeout [2, t]  ->  state [pad_t, C, pad_x, pad_x] / rescaler, C = 42 (or 82)."""
+    nt, nx = coef.shape[-3], coef.shape[-1]
+    w = coef.reshape(40, nt, nx, nx)
+    data = F.pad(w, (0, pad_x - nx, 0, pad_x - nx, 0, pad_t - nt))
+    if coef_sub is not None:
+        w_sub = coef_sub.reshape(40, *coef_sub.shape[-3:])
+        kind = 'space' if downsample_type == 'space' else 'time'
+        # nearest x2 of the coarse level (ddpm/wave_utils.upsample_coef): pure indexing, valid on host and device tensors
+        w_sub = w_sub.repeat_interleave(2, dim=1) if kind == 'time' else w_sub.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        if kind == 'space':
+            fine = F.pad(w, (1, 1, 1, 1), mode='replicate')
+        else:
+            fine = torch.cat((w[:, :1], w, w[:, -1:]), dim=1)
+        assert fine.shape == w_sub.shape, (fine.shape, w_sub.shape)
+        both = torch.cat((fine, w_sub), dim=0)
+        data = F.pad(both, (0, pad_x - both.shape[-1], 0, pad_x - both.shape[-2], 0, pad_t - both.shape[-3]))
+    # initial density: its 4 sub-bands, each shown for pad_t / 4 consecutive frames
+    rho0 = init_coef[0]
+    cond = rho0.unsqueeze(1).expand(rho0.shape[0], pad_t // 4, nx, nx).reshape(-1, nx, nx)
+    cond = F.pad(cond, (0, pad_x - nx, 0, pad_x - nx))
+    # smoke-out: approximation band over the upper half of the image, detail band over the lower half
+    assert pad_x % 2 == 0
+    so = smokeout.permute(1, 0)                                            # [t, 2]
+    so = so.reshape(1, so.shape[0], 2, 1, 1).expand(1, so.shape[0], 2, pad_x // 2, pad_x).reshape(1, so.shape[0], pad_x, pad_x)
+    so = F.pad(so, (0, 0, 0, 0, 0, pad_t - nt))
+    state = torch.cat((data, cond.unsqueeze(0), so), dim=0)
+    return state.permute(1, 0, 2, 3) / rescaler
+
+
+class Smoke_wave(Dataset):
+    def __init__(self, dataset_path, wave_type, pad_mode, is_train=True, is_super_model=False, downsample_type='time', N_downsample=0):
+        super().__init__()
+        assert is_train
+        if wave_type not in _RESCALERS:
+            raise ValueError(f'no RESCALER for wavelet {wave_type!r}')
+        self.root, self.wave_type, self.pad_mode = dataset_path, wave_type, pad_mode
+        self.is_train, self.is_super_model = is_train, is_super_model
+        self.dirname = 'train'
+        self.downsample_type = downsample_type
+        self.N_downsample = N_downsample if is_super_model else 0
+        self.n_simu = 20000
+        r = torch.tensor(_RESCALERS[wave_type]).reshape(1, 42, 1, 1)
+        if is_super_model:                                   # coefficient channels twice (fine, coarse), conditions once
+            r = torch.cat((r[:, :40].repeat(1, 2, 1, 1), r[:, -2:]), dim=1)
+        self.RESCALER = r
+
+    def __len__(self):
+        return self.n_simu
+
+    def path(self, sim_id):
+        return os.path.join(self.root, self.dirname, f'{self.wave_type}_{self.pad_mode}', f'{self.downsample_type}_downsample', f'{sim_id:06d}')
+
+    def __getitem__(self, sim_id):
+        db = torch.load(self.path(sim_id), weights_only=False)
+        lvl = self.N_downsample
+        coef = db['coef'][lvl]
+        ori_shape = list(db['ori_shape'])
+        if self.downsample_type == 'time':
+            ori_shape[0] = math.ceil(ori_shape[0] / 2 ** lvl)
+            pad_t, pad_x = int(24 / 2 ** lvl), 40
+        else:
+            ori_shape[1] = math.ceil(ori_shape[1] / 2 ** lvl)
+            ori_shape[2] = math.ceil(ori_shape[2] / 2 ** lvl)
+            pad_t, pad_x = 24, int(40 / 2 ** lvl)
+        state = pack_smoke_state(coef, db['init_coef'][lvl], db['smokeout'][lvl], self.RESCALER,
+                                 coef_sub=db['coef'][lvl + 1] if self.is_super_model else None,
+                                 downsample_type=self.downsample_type, pad_t=pad_t, pad_x=pad_x)
+        return state, list(coef.shape[2:]), ori_shape, sim_id
+
+
+class SuperDataLoader:
+    """One batch per iteration, drawn from a randomly chosen dataset of the list (super-resolution levels)."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=True, pin_memory=True, num_workers=1):
+        self.dataset = dataset
+        self.dl = [cycle(DataLoader(ds, batch_size=batch_size, shuffle=shuffle, pin_memory=pin_memory, num_workers=num_workers)) for ds in dataset]
+        self.num_batches = len(dataset) * ((len(dataset[0]) + batch_size - 1) // batch_size)
+
+    def __iter__(self):
+        yield next(self.dl[random.randint(0, len(self.dl) - 1)])
+
+    def __len__(self):
+        return self.num_batches
+
+
+_reference_getattr = wdno_amd.reference_fallthrough('ddpm.data_2d', __file__)
+
+
+def __getattr__(name):           # `Smoke` (raw fields, not on the WDNO path) and anything else come from the reference module
+    return _reference_getattr(name)
