@@ -88,3 +88,38 @@ def test_smoke_offline_transform_vs_oracle_and_dataset_roundtrip(trees, tmp_path
     assert float(state[18:, :40].abs().max()) == 0 and float(state[:, :40, 34:].abs().max()) == 0     # zero padding of the coefficient channels
     st_sr, _, _, _ = Smoke_wave(str(tmp_path), 'bior1.3', 'zero', is_super_model=True, downsample_type='space', N_downsample=0)[3]
     assert st_sr.shape == (24, 82, 40, 40)
+
+
+def test_smoke_guidance_gradient_vs_oracle_finite_difference(trees):
+    """dJ/dx of the control objective (inference_2d.py:30-66) through the HIP IDWT adjoints, checked against
+    central differences of the same objective evaluated with the numpy oracle in fp64 (J is quadratic: the difference is exact)."""
+    from wdno_amd.smoke import guidance as Gd
+    from oracle import dwt_ref as R
+    rng = np.random.default_rng(9)
+    shape, ori = (18, 34, 34), (32, 64, 64)
+    x = np.zeros((1, 24, 42, 40, 40))
+    x[:, :18, :, :34, :34] = rng.standard_normal((1, 18, 42, 34, 34)) * 0.3
+    x[:, :18, -1] = rng.standard_normal((1, 18, 40, 40)) * 0.3
+    resc = np.linspace(1.0, 9.0, 42).reshape(1, 1, 42, 1, 1)
+    init_u = rng.standard_normal((1, 64, 64))
+    w_e, w_i = 0.7, 1.3
+
+    def J(xs):                       # xs = x * RESCALER, numpy fp64
+        lll, det = R.smoke_tensor_to_coef(np.transpose(xs[:, :, :-2], (0, 2, 1, 3, 4)), shape)
+        state = R.idwt3(lll, det, 'bior1.3')[:, :32, :64, :64].reshape(-1, 5, 32, 64, 64)
+        lo = xs[:, :18, -1, :20].mean((-2, -1))[:, None]
+        hi = xs[:, :18, -1, 20:].mean((-2, -1))[:, None]
+        so = R.idwt1d(lo, hi, 'bior1.3', 'zero')[:, 0]
+        return -so[:, 31].sum() + w_e * (state[:, 3:5] ** 2).mean((1, 2, 3, 4)).sum() + w_i * ((state[:, 0, 0] - init_u) ** 2).mean((-1, -2)).sum()
+
+    g = Gd.guidance_fn(torch.from_numpy(x).float().to(DEV), shape, ori, torch.from_numpy(resc).float().to(DEV), w_energy=w_e, w_init=w_i,
+                       init_u=torch.from_numpy(init_u).float().to(DEV)).double().cpu().numpy()
+    xs = x * resc
+    for seed in range(3):
+        v = np.random.default_rng(100 + seed).standard_normal(xs.shape)
+        fd = (J(xs + 0.5 * v) - J(xs - 0.5 * v))
+        assert abs((g * v).sum() - fd) < 2e-5 * max(1.0, abs(fd)), (seed, (g * v).sum(), fd)
+    # conditioned on the control: only the initial-density term remains
+    g2 = Gd.guidance_fn(torch.from_numpy(x).float().to(DEV), shape, ori, torch.from_numpy(resc).float().to(DEV), is_condition_control=True,
+                        w_energy=w_e, w_init=w_i, init_u=torch.from_numpy(init_u).float().to(DEV))
+    assert float(g2[:, :, 8:].abs().max()) == 0 and float(g2[:, :, :8].abs().max()) > 0
