@@ -172,8 +172,9 @@ def main():
                 sym = fam + 'I' + ''.join(f'Li{d}E' for d in dims) if all(d.isdigit() for d in dims) else None
                 with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
                     for kname, rec in json.load(f)['kernels'].items():
-                        if sym and sym in kname:
+                        if sym and sym in kname:          # entries are ordered by total time: the first match is the main instantiation
                             traffic = round(rec['hbm_bytes_per_launch'])
+                            break
             except Exception:
                 traffic = None
             roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
