@@ -118,7 +118,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
     struct Cur { int t, s; };
     Cur rc{0, 0}, pc{0, 0};          // record cursor, piece cursor
     int r_pbeg = 0;                  // first pixel of the record cursor's item
-    int c_k0 = 0, c_r0 = 0, c_dz = 0, c_dy = 0, c_tap = 0;      // piece cursor's item
+    int c_dz = 0, c_dy = 0, c_tapoff = 0;                     // piece cursor's item: tap row and its element offset in x
+    int i_off[R], i_dx[R];                                     // per pair: channel byte offset (dy) / run element offset and dx (x)
+    bool i_ok[R];
     auto load_item_r = [&]() {
       int tk, tap, tr, sp;
       decode_item(rc.t, tk, tap, tr, sp);
@@ -127,8 +129,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
     auto load_item_p = [&]() {
       int tk, tap, tr, sp;
       decode_item(pc.t, tk, tap, tr, sp);
-      c_k0 = tk * BM; c_r0 = tr * BN; c_tap = tap;
       c_dz = tap / g.kh; c_dy = tap - c_dz * g.kh;
+      c_tapoff = (c_dz * g.H + c_dy) * g.W * g.C;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {                            // everything that only depends on the item, once per item
+        if (pq + 4 * j < APC) {
+          const int k = tk * BM + chk[j];
+          i_ok[j] = k < g.K;
+          i_off[j] = k * 2;
+          i_dx[j] = 0;
+        } else {
+          const int r = tr * BN + chk[j];
+          i_ok[j] = r < p.R;
+          i_off[j] = r;
+          i_dx[j] = r / g.C;
+        }
+      }
     };
     if (my_items > 0) { load_item_r(); load_item_p(); }
     int4v rec[LA + 1][R];
@@ -148,24 +164,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
       constexpr int S = decltype(SLOT)::value;
       const bool live = pc.t < my_items;
       const unsigned sb = lds0 + stage * STAGE;
-      const int tap_off = (c_dz * g.H + c_dy) * g.W * g.C;
+      const int k2 = g.K * 2;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         int4v e = rec[S][j];
         asm volatile("" : "+v"(e));                                   // consumers of the record stay below the counted wait
-        const int gp = pq + 4 * j;                                    // compile-time after unrolling (pq is wave-uniform: branchy but cheap)
-        const bool ok0 = live && rok[S][j];
+        const int gp = pq + 4 * j;                                    // pq is wave-uniform: a scalar branch
+        const bool ok0 = live && rok[S][j] && i_ok[j];
         if (gp < APC) {
-          const int k = c_k0 + chk[j];
-          const int off = (ok0 && k < g.K) ? (e.x * g.K + k) * 2 : WD_OOB;
+          const int off = ok0 ? e.x * k2 + i_off[j] : WD_OOB;
           wd_piece(rdh, off, sb + gp * 1024);
           wd_piece(rdl, off, sb + A_LO + gp * 1024);
         } else {
-          const int r = c_r0 + chk[j];
-          const int dx = r / g.C;
-          const int d = (e.z >> 16) + c_dz, h = (int)(short)(e.z & 0xffff) + c_dy, w = e.w + dx;
-          const bool ok = ok0 && r < p.R && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-          const int off = ok ? (e.y + tap_off + r) * 2 : WD_OOB;
+          const int d = (e.z >> 16) + c_dz, h = (int)(short)(e.z & 0xffff) + c_dy, w = e.w + i_dx[j];
+          const bool ok = ok0 && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+          const int off = ok ? (e.y + c_tapoff + i_off[j]) * 2 : WD_OOB;
           wd_piece(rxh, off, sb + B_HI + (gp - APC) * 1024);
           wd_piece(rxl, off, sb + B_LO + (gp - APC) * 1024);
         }
