@@ -442,7 +442,7 @@ def _fwd_h3_kernel_name(pixels, k, ks):
     """Kernel family wdno_conv_fwd_f16x3 picks (mirrors the dispatch in csrc/conv_h3.hip; used as the profiling key)."""
     cdiv = lambda a, b: -(-a // b)
     tiles = cdiv(pixels, 128) * cdiv(k, 128) if k > 64 else cdiv(pixels, 256)
-    if tiles >= 256 and max(ks) <= 8:
+    if tiles >= 100 and max(ks) <= 8:
         return 'conv_fwd_h3d_kernel<128,128>' if k > 64 else 'conv_fwd_h3d_kernel<256,64>'
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
 
