@@ -69,8 +69,19 @@ __global__ __launch_bounds__(256) void partial_rows_sum_kernel(const T* __restri
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + tx;
   double acc = 0.0;
-  if (c < C)
-    for (int b = ty; b < nb; b += 8) acc += (double)part[(int64_t)b * C + c];
+  if (c < C) {
+    // four independent partial sums: the loads of a column are 8 rows apart and would otherwise form one dependent chain
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = ty;
+    for (; b + 24 < nb; b += 32) {
+      a0 += (double)part[(int64_t)b * C + c];
+      a1 += (double)part[(int64_t)(b + 8) * C + c];
+      a2 += (double)part[(int64_t)(b + 16) * C + c];
+      a3 += (double)part[(int64_t)(b + 24) * C + c];
+    }
+    for (; b < nb; b += 8) a0 += (double)part[(int64_t)b * C + c];
+    acc = (a0 + a1) + (a2 + a3);
+  }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && c < C) {

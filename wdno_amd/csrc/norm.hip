@@ -94,17 +94,40 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   const int n = blockIdx.x, cg = C / G;
   if (part) {
     for (int c = threadIdx.x; c < C; c += 256) {
-      double a = 0, b = 0;
-      for (int k = 0; k < nchunk; ++k) {
-        const double* q = part + (((int64_t)n * nchunk + k) * C + c) * 2;
-        a += q[0]; b += q[1];
+      double a0 = 0, b0 = 0, a1 = 0, b1 = 0;             // two independent chains over the chunk partials
+      int k = 0;
+      for (; k + 1 < nchunk; k += 2) {
+        const double* q0 = part + (((int64_t)n * nchunk + k) * C + c) * 2;
+        const double* q1 = q0 + (int64_t)C * 2;
+        a0 += q0[0]; b0 += q0[1]; a1 += q1[0]; b1 += q1[1];
       }
-      chs[c] = a; chq[c] = b;
+      if (k < nchunk) {
+        const double* q0 = part + (((int64_t)n * nchunk + k) * C + c) * 2;
+        a0 += q0[0]; b0 += q0[1];
+      }
+      chs[c] = a0 + a1; chq[c] = b0 + b1;
     }
     __syncthreads();
+    if (cg > 64) {
+      // few, wide groups (GroupNorm(1, C) of the Burgers U-Net): the whole block reduces each group
+      __shared__ double ra[256], rb[256];
+      for (int g = 0; g < G; ++g) {
+        double a = 0, b = 0;
+        for (int c = g * cg + threadIdx.x; c < (g + 1) * cg; c += 256) { a += chs[c]; b += chq[c]; }
+        ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+          if (threadIdx.x < o) { ra[threadIdx.x] += ra[threadIdx.x + o]; rb[threadIdx.x] += rb[threadIdx.x + o]; }
+          __syncthreads();
+        }
+        if (threadIdx.x == 0) { chs[g * cg] = ra[0]; chq[g * cg] = rb[0]; }      // group totals parked in the first channel slot
+        __syncthreads();
+      }
+    }
     for (int g = threadIdx.x; g < G; g += 256) {
       double a = 0, b = 0;
-      for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chs[c]; b += chq[c]; }
+      if (cg > 64) { a = chs[g * cg]; b = chq[g * cg]; }
+      else for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chs[c]; b += chq[c]; }
       double m = (double)cg * (double)S;
       double mean = a / m;
       double var = b / m - mean * mean;
@@ -182,9 +205,25 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
     chA[c] = w * a; chB[c] = w * b;
   }
   __syncthreads();
+  if (cg > 64) {                       // few, wide groups: block-wide reduction per group (see gn_finalize_kernel)
+    __shared__ double ra[256], rb[256];
+    for (int g = 0; g < G; ++g) {
+      double a = 0, b = 0;
+      for (int c = g * cg + threadIdx.x; c < (g + 1) * cg; c += 256) { a += chA[c]; b += chB[c]; }
+      ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { ra[threadIdx.x] += ra[threadIdx.x + o]; rb[threadIdx.x] += rb[threadIdx.x + o]; }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) { chA[g * cg] = ra[0]; chB[g * cg] = rb[0]; }
+      __syncthreads();
+    }
+  }
   for (int g = threadIdx.x; g < G; g += 256) {
     double a = 0, b = 0;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chA[c]; b += chB[c]; }
+    if (cg > 64) { a = chA[g * cg]; b = chB[g * cg]; }
+    else for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chA[c]; b += chB[c]; }
     double m = (double)cg * (double)S;
     float* o = gb + ((int64_t)n * G + g) * 4;
     float rstd = o[1];
