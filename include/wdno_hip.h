@@ -112,6 +112,15 @@ int wdno_split_f16_colsum(const float* x, const float* amax, void* hi, void* lo,
  * [kd][kh][A>=K][kw][B>=C]; mode 1: data-gradient operand [kd][kh][A>=C][kw][B>=K] with flipped taps. amax = max|w| (device). */
 int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh, int kw,
                            int A, int B, int mode, wdno_stream_t s);
+/* Multi-tensor forms of wdno_amax and wdno_pack_split_weight for the per-step refresh of all weights: one launch for any
+ * number of items, arguments in a device-resident table (all pointers are device pointers). amax outputs must be zeroed. */
+typedef struct { const void* x; int64_t n; void* out; } wdno_amax_item;
+typedef struct {
+  const void* w; const void* amax; void* hi; void* lo; void* scale_out;
+  int K, C, kd, kh, kw, A, B, mode;
+} wdno_wsplit_item;
+int wdno_amax_multi(const void* table, int n_items, int blocks_per_item, wdno_stream_t s);
+int wdno_pack_split_weight_multi(const void* table, int n_items, int blocks_per_item, wdno_stream_t s);
 int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                         const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s);
 /* weight gradient on the same split planes (g->C = C8 of x, g->K = K8 of dy); dwp [kd][kh][K8][kw*C8] fp32 */

@@ -64,6 +64,8 @@ PROTOTYPES = {
     'wdno_split_colsum_ws_bytes': (Z, [L, I]),
     'wdno_split_f16_colsum': (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),
     'wdno_pack_split_weight': (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    'wdno_amax_multi': (I, [P, I, I, P]),
+    'wdno_pack_split_weight_multi': (I, [P, I, I, P]),
     'wdno_conv_fwd_f16x3': (I, [P, P, P, P, P, P, P, P, P, PG, P]),
     'wdno_conv_wgrad_f16x3_ws_bytes': (Z, [PG]),
     'wdno_conv_pixel_table': (I, [P, PG, P]),

@@ -820,17 +820,17 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
 //   mode 0 (forward)  : out[dz][dy][a=k < A][dx][b=c < B]  = w[k][c][dz][dy][dx]
 //   mode 1 (data grad): out[dz][dy][a=c < A][dx][b=k < B]  = w[k][c][kd-1-dz][kh-1-dy][kw-1-dx]
 // A / B are the padded extents of the two channel roles (B % 8 == 0); entries outside K / C are zero.
-__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __restrict__ w, const float* __restrict__ amax,
-                                                                 _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                                 float* __restrict__ scale_out, int K, int C, int kd, int kh, int kw,
-                                                                 int A, int B, int mode) {
+__device__ __forceinline__ void pack_split_body(const float* __restrict__ w, const float* __restrict__ amax,
+                                                _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                float* __restrict__ scale_out, int K, int C, int kd, int kh, int kw,
+                                                int A, int B, int mode, int block, int nblocks) {
   const float s = scale_from_amax(amax[0]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+  if (block == 0 && threadIdx.x == 0) scale_out[0] = s;
   const int b8 = B >> 3;
   const int64_t total = (int64_t)kd * kh * A * kw * b8;
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t stride = (int64_t)nblocks * 256;
   const int64_t taps = (int64_t)kd * kh * kw;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+  for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < total; i += stride) {
     int g8 = (int)(i % b8); int64_t t = i / b8;
     int dx = (int)(t % kw); t /= kw;
     int a = (int)(t % A); t /= A;
@@ -851,6 +851,46 @@ __global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __r
     *reinterpret_cast<half8*>(hi + i * 8) = h;
     *reinterpret_cast<half8*>(lo + i * 8) = l;
   }
+}
+__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float* __restrict__ w, const float* __restrict__ amax,
+                                                                 _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                                 float* __restrict__ scale_out, int K, int C, int kd, int kh, int kw,
+                                                                 int A, int B, int mode) {
+  pack_split_body(w, amax, hi, lo, scale_out, K, C, kd, kh, kw, A, B, mode, (int)blockIdx.x, (int)gridDim.x);
+}
+// Multi-tensor forms: after an optimiser step EVERY weight needs a fresh amax and fresh packed planes; with ~100 (smoke) to
+// ~300 (Burgers) operands that is hundreds of 5-microsecond launches. One launch each, grid = (blocks per item, items), the
+// per-item arguments come from a device-resident table (wdno_amax_item / wdno_wsplit_item in wdno_hip.h).
+__global__ __launch_bounds__(256) void amax_multi_kernel(const wdno_amax_item* __restrict__ tab) {
+  __shared__ float red[4];
+  const wdno_amax_item it = tab[blockIdx.y];
+  const float* x = (const float*)it.x;
+  const int64_t n = it.n;
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) m = fmaxf(m, fabsf(x[k]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.f) atomicMax((unsigned*)it.out, __float_as_uint(m));
+  }
+}
+extern "C" int wdno_amax_multi(const void* table, int n_items, int blocks_per_item, wdno_stream_t s) {
+  WDNO_REQUIRE(table && n_items > 0 && n_items <= 65535 && blocks_per_item > 0);
+  amax_multi_kernel<<<dim3((unsigned)blocks_per_item, (unsigned)n_items), 256, 0, as_stream(s)>>>((const wdno_amax_item*)table);
+  return wdno_check_launch();
+}
+__global__ __launch_bounds__(256) void pack_split_weight_multi_kernel(const wdno_wsplit_item* __restrict__ tab) {
+  const wdno_wsplit_item it = tab[blockIdx.y];
+  pack_split_body((const float*)it.w, (const float*)it.amax, (_Float16*)it.hi, (_Float16*)it.lo, (float*)it.scale_out, it.K, it.C, it.kd, it.kh,
+                  it.kw, it.A, it.B, it.mode, (int)blockIdx.x, (int)gridDim.x);
+}
+extern "C" int wdno_pack_split_weight_multi(const void* table, int n_items, int blocks_per_item, wdno_stream_t s) {
+  WDNO_REQUIRE(table && n_items > 0 && n_items <= 65535 && blocks_per_item > 0);
+  pack_split_weight_multi_kernel<<<dim3((unsigned)blocks_per_item, (unsigned)n_items), 256, 0, as_stream(s)>>>((const wdno_wsplit_item*)table);
+  return wdno_check_launch();
 }
 extern "C" int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh,
                                       int kw, int A, int B, int mode, wdno_stream_t s) {

@@ -378,38 +378,108 @@ def split_f16_colsum(x2d):
     return (hi, lo, scale), cs[:c]
 
 
+class _WPlan:
+    """One packed split-fp16 weight operand that is refreshed every optimiser step: persistent output planes, so the refresh of
+    all of them is two multi-tensor launches (wdno_amax_multi, wdno_pack_split_weight_multi) instead of two launches each."""
+    __slots__ = ('w', 'wd', 'kind', 'cp8', 'kp', 'hi', 'lo', 'sc', 'ver', 'used')
+
+
+_wplans = {}            # key -> _WPlan
+_wtables = {}           # tuple of plan keys -> (amax buffer, amax table, split table, keep-alive list)
+WEIGHT_BATCH = os.environ.get('WDNO_WEIGHT_BATCH', '1') != '0'
+
+
+class _AmaxItem(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('n', C.c_int64), ('out', C.c_void_p)]
+
+
+class _WsplitItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('amax', C.c_void_p), ('hi', C.c_void_p), ('lo', C.c_void_p), ('scale_out', C.c_void_p),
+                ('K', C.c_int), ('C', C.c_int), ('kd', C.c_int), ('kh', C.c_int), ('kw', C.c_int), ('A', C.c_int), ('B', C.c_int), ('mode', C.c_int)]
+
+
+def _refresh_weight_plans(epoch_used):
+    """Refresh every registered plan that was used in one of the last few weight epochs (they will all be needed again; an
+    EMA update also counts as an epoch)."""
+    keys = tuple(k for k, pl in _wplans.items() if pl.used >= epoch_used - 3 and pl.wd.is_contiguous())
+    if len(keys) < 2:
+        return
+    dev = _wplans[keys[0]].wd.device
+    tabs = _wtables.get(keys)
+    if tabs is None:
+        _wtables.clear()
+        wptrs = []
+        for k in keys:
+            pl = _wplans[k]
+            if pl.wd.data_ptr() not in wptrs:
+                wptrs.append(pl.wd.data_ptr())
+        amax = torch.zeros(len(wptrs), device=dev, dtype=torch.float32)
+        seen = {}
+        aitems = (_AmaxItem * len(wptrs))()
+        for k in keys:
+            pl = _wplans[k]
+            i = wptrs.index(pl.wd.data_ptr())
+            if i not in seen:
+                seen[i] = True
+                aitems[i] = _AmaxItem(pl.wd.data_ptr(), pl.wd.numel(), amax.data_ptr() + 4 * i)
+        sitems = (_WsplitItem * len(keys))()
+        for j, k in enumerate(keys):
+            pl = _wplans[k]
+            w5 = _as5(pl.wd)
+            kk, cc, kd, kh, kw = w5.shape
+            i = wptrs.index(pl.wd.data_ptr())
+            sitems[j] = _WsplitItem(pl.wd.data_ptr(), amax.data_ptr() + 4 * i, pl.hi.data_ptr(), pl.lo.data_ptr(), pl.sc.data_ptr(),
+                                    kk, cc, kd, kh, kw, pl.kp, pl.cp8, 0 if pl.kind == 'f' else 1)
+        at = torch.frombuffer(bytearray(bytes(aitems)), dtype=torch.uint8).to(dev)
+        stt = torch.frombuffer(bytearray(bytes(sitems)), dtype=torch.uint8).to(dev)
+        tabs = (amax, at, stt, len(wptrs))
+        _wtables[keys] = tabs
+    amax, at, stt, nw = tabs
+    lib = _lib_()
+    with torch.no_grad():
+        amax.zero_()
+        _lib.check(lib.wdno_amax_multi(_p(at), nw, 256, _stream()), 'amax_multi')
+        _lib.check(lib.wdno_pack_split_weight_multi(_p(stt), len(keys), 256, _stream()), 'pack_split_weight_multi')
+    for k in keys:
+        pl = _wplans[k]
+        pl.ver = (pl.w._version, WEIGHT_EPOCH)
+
+
 def split_weight(w, kind, cp8, kp, pack=None):
     """Split planes of the packed weight operand (cached per weight version). kind 'f': forward operand
     [kd,kh,kp,kw,cp8]; kind 'd': data-gradient operand [kd,kh,kp(=Cp of x),kw,cp8(=K8 of dy)] with flipped taps.
-    One amax launch per weight version (shared by both kinds) + one fused pack-and-split launch per kind."""
-    key = (w.data_ptr(), kind + '_h3', cp8, kp, tuple(w.shape), tuple(w.stride()))
+    The first stale operand met after an optimiser step refreshes ALL operands of the previous step in two launches."""
+    key = (w.data_ptr(), kind, cp8, kp, tuple(w.shape), tuple(w.stride()))
     ver = (w._version, WEIGHT_EPOCH)
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
+    pl = _wplans.get(key)
+    if pl is not None:
+        if pl.ver != ver and WEIGHT_BATCH:
+            _refresh_weight_plans(WEIGHT_EPOCH)
+        if pl.ver == ver:
+            pl.used = WEIGHT_EPOCH
+            return pl.hi, pl.lo, pl.sc
     with torch.no_grad():
         wd = w.detach()
         wc = wd if wd.is_contiguous() else wd.contiguous()
-        akey = (w.data_ptr(), 'amax', tuple(w.shape), tuple(w.stride()))
-        ah = _pack_cache.get(akey)
-        if ah is not None and ah[0] == ver:
-            amax = ah[1]
-        else:
-            amax = torch.zeros(1, device=w.device, dtype=torch.float32)
-            _lib.check(_lib_().wdno_amax(_p(wc), wc.numel(), _p(amax), _stream()), 'amax')
-            _pack_cache[akey] = (ver, amax, wd)
+        amax = torch.zeros(1, device=w.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_amax(_p(wc), wc.numel(), _p(amax), _stream()), 'amax')
         w5 = _as5(wc)
         k, c, kd, kh, kw = w5.shape
         rows = kd * kh * kp * kw
-        hi = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
-        lo = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
-        sc = torch.empty(1, device=w.device, dtype=torch.float32)
-        _lib.check(_lib_().wdno_pack_split_weight(_p(wc), _p(amax), _p(hi), _p(lo), _p(sc), k, c, kd, kh, kw, kp, cp8,
+        if pl is None:
+            pl = _WPlan()
+            pl.w, pl.wd, pl.kind, pl.cp8, pl.kp = w, wd, kind, cp8, kp
+            pl.hi = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
+            pl.lo = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
+            pl.sc = torch.empty(1, device=w.device, dtype=torch.float32)
+            if len(_wplans) > 4096:
+                _wplans.clear(); _wtables.clear()
+            _wplans[key] = pl
+        _lib.check(_lib_().wdno_pack_split_weight(_p(wc), _p(amax), _p(pl.hi), _p(pl.lo), _p(pl.sc), k, c, kd, kh, kw, kp, cp8,
                                                   0 if kind == 'f' else 1, _stream()), 'pack_split_weight')
-    if len(_pack_cache) > 8192:
-        _pack_cache.clear()
-    _pack_cache[key] = (ver, (hi, lo, sc), wd)
-    return hi, lo, sc
+    pl.ver = ver
+    pl.used = WEIGHT_EPOCH
+    return pl.hi, pl.lo, pl.sc
 
 
 def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp, out=None, osp=None, ostride=(1, 1, 1), ooff=(0, 0, 0)):
