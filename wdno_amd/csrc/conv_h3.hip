@@ -719,12 +719,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
 }
 
 __global__ __launch_bounds__(256) void wgrad_h3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int splits) {
-  int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    float acc = 0.f;
-    for (int s = 0; s < splits; ++s) acc += ws[(int64_t)s * n + i];
-    out[i] = acc;
+  // one float4 column per thread, four independent chains over the splits (a fixed order: the result is deterministic)
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)(s + u) * n + 4 * i);
+        a[u].x += v.x; a[u].y += v.y; a[u].z += v.z; a[u].w += v.w;
+      }
+    }
+    for (; s < splits; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)s * n + 4 * i);
+      a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + 4 * i) = make_float4((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y),
+                                                          (a[0].z + a[1].z) + (a[2].z + a[3].z), (a[0].w + a[1].w) + (a[2].w + a[3].w));
   }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+      float acc = 0.f;
+      for (int s = 0; s < splits; ++s) acc += ws[(int64_t)s * n + i];
+      out[i] = acc;
+    }
 }
 
 static void wgrad_h3_plan(WgradHP& w, const wdno_conv_geom* g) {
@@ -793,7 +815,7 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
     if (rc == WDNO_OK) {
       if (splits > 1) {
         int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
-        wgrad_h3_reduce_kernel<<<stream_grid(n, 256), 256, 0, st0>>>((const float*)ws, dwp, n, splits);
+        wgrad_h3_reduce_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, st0>>>((const float*)ws, dwp, n, splits);
       }
       return wdno_check_launch();
     }
@@ -810,7 +832,7 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
   else launch_wgrad_h3<64, 128, 1, 4>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
   if (w.splits > 1) {
     int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
-    wgrad_h3_reduce_kernel<<<stream_grid(n, 256), 256, 0, st>>>((const float*)ws, dwp, n, w.splits);
+    wgrad_h3_reduce_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, st>>>((const float*)ws, dwp, n, w.splits);
   }
   return wdno_check_launch();
 }
