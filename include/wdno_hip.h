@@ -129,6 +129,11 @@ size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g);
 int wdno_conv_pixel_table(void* table, const wdno_conv_geom* g, wdno_stream_t s);
 int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
                           const void* pixel_table, float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s);
+/* Same, with the result in the layout of the parameter: dw[Kn][Cn][kd][kh][kw] (Kn <= g->K, Cn <= g->C; channel padding dropped),
+ * written by the split reduction itself. ws >= wdno_conv_wgrad_f16x3_ws_bytes(g) always (also when there is one split). */
+int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                                const void* pixel_table, float* dw, int Kn, int Cn, void* ws, size_t ws_bytes,
+                                const wdno_conv_geom* g, wdno_stream_t s);
 /* dwp[kd][kh][K][kw*C] = sum over output pixels of dy (x) shifted x. ws: caller workspace. */
 size_t wdno_conv_wgrad_ws_bytes(const wdno_conv_geom* g);
 int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_t ws_bytes,

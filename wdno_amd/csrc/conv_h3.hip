@@ -792,8 +792,11 @@ static void launch_wgrad_h3(const void* xh, const void* xl, const void* dyh, con
   conv_wgrad_h3_kernel<BM, BN, WM, WN><<<grid, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh,
                                                             (const _Float16*)dyl, sx, sdy, (const int4v*)table, wsf, w, x_bytes, dy_bytes);
 }
-extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
-                                     const void* pixel_table, float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s) {
+// Runs the weight-gradient kernels; the per-split partial results go to `ws` ([splits][ntap][K][R]; with one split `single`
+// may name the final packed destination instead). Returns the split count through *splits_out.
+static int wgrad_h3_partials(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                             const void* pixel_table, float* single, void* ws, size_t ws_bytes, const wdno_conv_geom* g, hipStream_t st,
+                             int* splits_out) {
   int rc = check_geom(g);
   if (rc) return rc;
   if ((g->C & 7) || (g->K & 7) || !pixel_table) return WDNO_EUNSUPPORTED;
@@ -801,7 +804,6 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
     return WDNO_EUNSUPPORTED;        // 32-bit buffer offsets
   WgradHP w;
   wgrad_h3_plan(w, g);
-  hipStream_t st0 = as_stream(s);
   // persistent LDS-DMA kernel, except for 64 output channels with a long 128-multiple run (kw*C >= 384), where its 32-row
   // wave tiles carry too few MFMAs per barrier and the register-staged 64 x 128 kernel below measures ~8 % faster.
   // debug 5 = never, 7 = always
@@ -810,30 +812,68 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
     int bm, bn, splits, pps;
     wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps);
     size_t need_d = (size_t)splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
-    if (splits > 1 && ws_bytes < need_d) return WDNO_EWORKSPACE;
-    rc = wdno_conv_wgrad_h3_dma(xh, xl, dyh, dyl, sx, sdy, pixel_table, splits == 1 ? dwp : (float*)ws, g, st0);
-    if (rc == WDNO_OK) {
-      if (splits > 1) {
-        int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
-        wgrad_h3_reduce_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, st0>>>((const float*)ws, dwp, n, splits);
-      }
-      return wdno_check_launch();
-    }
+    float* dst = (splits == 1 && single) ? single : (float*)ws;
+    if (dst == (float*)ws && ws_bytes < need_d) return WDNO_EWORKSPACE;
+    rc = wdno_conv_wgrad_h3_dma(xh, xl, dyh, dyl, sx, sdy, pixel_table, dst, g, st);
+    if (rc == WDNO_OK) { *splits_out = splits; return WDNO_OK; }
     if (rc != WDNO_EUNSUPPORTED) return rc;
   }
   size_t need = (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
-  if (ws_bytes < need) return WDNO_EWORKSPACE;
+  float* wsf = (w.splits == 1 && single) ? single : (float*)ws;
+  if (wsf == (float*)ws && ws_bytes < need) return WDNO_EWORKSPACE;
   if (w.splits > 65535) return WDNO_EUNSUPPORTED;
   dim3 grid((unsigned)(w.tiles_k * g->kd * g->kh * w.tiles_r), (unsigned)w.splits);
-  float* wsf = w.splits == 1 ? dwp : (float*)ws;
-  hipStream_t st = as_stream(s);
   if (g->K > 64) launch_wgrad_h3<128, 192, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
   else if (w.bn == 192) launch_wgrad_h3<64, 192, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
   else launch_wgrad_h3<64, 128, 1, 4>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
-  if (w.splits > 1) {
-    int64_t n = (int64_t)g->kd * g->kh * g->K * w.c.R;
-    wgrad_h3_reduce_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, st>>>((const float*)ws, dwp, n, w.splits);
+  *splits_out = w.splits;
+  return WDNO_OK;
+}
+extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                                     const void* pixel_table, float* dwp, void* ws, size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s) {
+  hipStream_t st = as_stream(s);
+  int splits = 0;
+  int rc = wgrad_h3_partials(xh, xl, sx, dyh, dyl, sdy, pixel_table, dwp, ws, ws_bytes, g, st, &splits);
+  if (rc) return rc;
+  if (splits > 1) {
+    int64_t n = (int64_t)g->kd * g->kh * g->K * (int64_t)g->kw * g->C;
+    wgrad_h3_reduce_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, st>>>((const float*)ws, dwp, n, splits);
   }
+  return wdno_check_launch();
+}
+// Same, but the gradient is delivered in the layout of the parameter, dw[Kn][Cn][kd][kh][kw] (Kn <= g->K, Cn <= g->C: the
+// channel padding is dropped), by the split reduction itself -- no packed intermediate, no permute / slice copy afterwards.
+__global__ __launch_bounds__(256) void wgrad_h3_reduce_nat_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
+                                                                   int K8, int C8, int kw, int ntap, int Kn, int Cn) {
+  const int R = kw * C8;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int r = (int)(i % R);
+    int64_t t = i / R;
+    const int k = (int)(t % K8);
+    const int tap = (int)(t / K8);
+    const int dx = r / C8, c = r - dx * C8;
+    if (k >= Kn || c >= Cn) continue;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+      a0 += ws[(int64_t)s * n + i]; a1 += ws[(int64_t)(s + 1) * n + i];
+      a2 += ws[(int64_t)(s + 2) * n + i]; a3 += ws[(int64_t)(s + 3) * n + i];
+    }
+    for (; s < splits; ++s) a0 += ws[(int64_t)s * n + i];
+    dw[(((int64_t)k * Cn + c) * ntap + tap) * kw + dx] = (a0 + a1) + (a2 + a3);
+  }
+}
+extern "C" int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                                           const void* pixel_table, float* dw, int Kn, int Cn, void* ws, size_t ws_bytes,
+                                           const wdno_conv_geom* g, wdno_stream_t s) {
+  WDNO_REQUIRE(g && Kn > 0 && Cn > 0 && Kn <= g->K && Cn <= g->C);
+  hipStream_t st = as_stream(s);
+  int splits = 0;
+  int rc = wgrad_h3_partials(xh, xl, sx, dyh, dyl, sdy, pixel_table, nullptr, ws, ws_bytes, g, st, &splits);
+  if (rc) return rc;
+  const int64_t n = (int64_t)g->kd * g->kh * g->K * (int64_t)g->kw * g->C;
+  wgrad_h3_reduce_nat_kernel<<<stream_grid(n, 256), 256, 0, st>>>((const float*)ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
   return wdno_check_launch();
 }
 

@@ -526,8 +526,9 @@ def _wgrad_h3_kernel_name(k, run):
     return f'conv_wgrad_h3d_kernel<{128 if k > 64 else 64},{bn}>'
 
 
-def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd):
-    """-> dwp [kd, kh, K8, kw, C8] fp32 from the split planes of x (C8 channels) and dy (K8 channels)."""
+def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None):
+    """-> dwp [kd, kh, K8, kw, C8] fp32 from the split planes of x (C8 channels) and dy (K8 channels); with param_kc = (K, C)
+    the result comes back as [K, C, kd, kh, kw] (the parameter's layout, padding dropped) straight from the split reduction."""
     xh, xl, sx = xplanes
     gh, gl, sg = gyplanes
     n, d, h, ww = shape4
@@ -542,8 +543,15 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd):
         table = torch.empty((n * osp[0] * osp[1] * osp[2], 4), device=xh.device, dtype=torch.int32)
         _lib.check(lib.wdno_conv_pixel_table(_p(table), C.byref(g), _stream()), 'conv_pixel_table')
         _pixel_tables[tkey] = table
-    dwp = torch.empty((ks[0], ks[1], k8, ks[2], c8), device=xh.device, dtype=torch.float32)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * k8 * ks[0] * ks[1] * ks[2] * c8
+    if param_kc is not None:
+        kn, cn = param_kc
+        dw = torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
+        with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8), flops):
+            _lib.check(lib.wdno_conv_wgrad_f16x3_param(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dw), kn, cn, _p(ws), nb,
+                                                       C.byref(g), _stream()), 'conv_wgrad_f16x3_param')
+        return dw
+    dwp = torch.empty((ks[0], ks[1], k8, ks[2], c8), device=xh.device, dtype=torch.float32)
     with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8), flops):
         _lib.check(lib.wdno_conv_wgrad_f16x3(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dwp), _p(ws), nb, C.byref(g), _stream()),
                    'conv_wgrad_f16x3')
@@ -705,10 +713,10 @@ class _Conv(torch.autograd.Function):
             if ctx.h3:
                 if gyplanes is None:
                     gyplanes = split_f16(gy5.reshape(-1, kp))
-                dwp = conv_wgrad_h3((xh, xl, sx), (n, d, h, w), gyplanes, osp, ks, stride, padding)
+                gw = conv_wgrad_h3((xh, xl, sx), (n, d, h, w), gyplanes, osp, ks, stride, padding, param_kc=(k, c)).reshape(weight.shape)
             else:
                 dwp = conv_wgrad_raw(x5, gy5, ks, stride, padding)
-            gw = dwp[:, :, :k, :, :c].permute(2, 4, 0, 1, 3).reshape(weight.shape).contiguous()
+                gw = dwp[:, :, :k, :, :c].permute(2, 4, 0, 1, 3).reshape(weight.shape).contiguous()
         if want_gb and gb is None:
             gb = colsum(gy5.reshape(-1, kp))[:k].contiguous()
         if has_res and ctx.needs_input_grad[3]:
@@ -787,8 +795,7 @@ class _ConvT(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = conv_fwd_h3(gyplanes, gshape4, weight, pack_fwd, 'f', None, None, ks, st, pd, cin_p)
             if ctx.needs_input_grad[1]:
-                dwp = conv_wgrad_h3(gyplanes, gshape4, (xh, xl, sx), xshape4[1:], ks, st, pd)      # [1, 4, Cin8, 4, Cout8]
-                gw = dwp[:, :, :cin, :, :cout].permute(2, 4, 0, 1, 3).contiguous()
+                gw = conv_wgrad_h3(gyplanes, gshape4, (xh, xl, sx), xshape4[1:], ks, st, pd, param_kc=(cin, cout))    # [in, out, 1, 4, 4]
             if has_bias and ctx.needs_input_grad[2]:
                 gb = colsum(gy.reshape(-1, cout_p))[:cout].contiguous()
             return gx, gw, gb
