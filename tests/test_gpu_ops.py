@@ -318,10 +318,11 @@ def test_layernorm(ops, rows, c):
 
 
 # ----------------------------------------------------------------------------------------------------- attention
-def test_softmax_attention_mfma_backward(ops):
-    """The one-wave-per-item MFMA backward (n_tok <= 32; not the default yet) against the same fp64 reference."""
+def test_softmax_attention_thread_per_row_kernels(ops):
+    """n_tok <= 32 normally takes the one-wave-per-item MFMA kernels; debug 5 forces the thread-per-row kernels (used for the
+    mid-block spatial attention) on the same temporal cases."""
     lib = ops._lib_()
-    lib.wdno_set_debug(8)
+    lib.wdno_set_debug(5)
     try:
         test_softmax_attention(ops, 'temporal', 2, 24, 3, 5)
         test_softmax_attention(ops, 'temporal', 1, 7, 2, 2)

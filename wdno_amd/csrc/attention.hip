@@ -274,15 +274,17 @@ __device__ __forceinline__ int am_key(int m, int hh) { return 8 * (m >> 2) + 4 *
 // Rows of one operand ([n][32] floats: q, k, v or dO of one head) -> LDS tile [32][AM_TS], loaded cooperatively (8 lanes
 // per 128-byte row, three passes for 24 rows), optionally scaled and rotated on the way; rows >= n are zero-filled.
 #define AM_TS 36
-__device__ __forceinline__ void am_stage_rows(float* __restrict__ tile, const float* __restrict__ base, int64_t row0, int64_t st, int64_t rw,
+__device__ __forceinline__ void am_stage_rows(float* __restrict__ tile, const float* __restrict__ ubase, unsigned row_stride,
                                               const float* __restrict__ rc, const float* __restrict__ rs, float scale, int n, int lane) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  // ubase: wave-uniform pointer to row 0 of the operand (am_uniform); the per-lane part of every address is a 32-bit offset,
+  // so nothing 64-bit per lane has to stay live across the item loop
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {          // not unrolled: the four passes would otherwise keep 48 registers of loads in flight per call
     const int idx = lane + 64 * k;
     const int r = idx >> 3, c4 = (idx & 7) * 4;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < n) {
-      x = *reinterpret_cast<const float4*>(base + (row0 + (int64_t)r * st) * rw + c4);
+      x = *reinterpret_cast<const float4*>(ubase + ((unsigned)r * row_stride + (unsigned)c4));
       x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
       if (rc) {
         const float4 c = *reinterpret_cast<const float4*>(rc + r * DH + c4), sn = *reinterpret_cast<const float4*>(rs + r * DH + c4);
@@ -334,14 +336,16 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
     const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
     const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
     const int64_t rowl = row0 + (int64_t)(tok ? li : 0) * p.d.st;
-    am_stage_rows(Tq, qkv + h * DH, row0, p.d.st, p.RW, rcos, rsin, p.scale, n, lane);
-    am_stage_rows(Tk, qkv + p.HD + h * DH, row0, p.d.st, p.RW, rcos, rsin, 1.0f, n, lane);
+    const float* qb = am_uniform(qkv + row0 * p.RW + h * DH);          // q of token 0 of this item; k at + HD, v at + 2 HD
+    const unsigned tstride = (unsigned)(p.d.st * p.RW);
+    am_stage_rows(Tq, qb, tstride, rcos, rsin, p.scale, n, lane);
+    am_stage_rows(Tk, qb + p.HD, tstride, rcos, rsin, 1.0f, n, lane);
     // V elements for the second product: step m needs V[key(m, hh)][d = li] (coalesced 128-byte rows)
     float va[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const int j = am_key(m, hh);
-      va[m] = j < n ? qkv[(row0 + (int64_t)j * p.d.st) * p.RW + 2 * p.HD + h * DH + li] : 0.f;
+      va[m] = j < n ? qb[(unsigned)j * tstride + (unsigned)(2 * p.HD + li)] : 0.f;
     }
     __builtin_amdgcn_wave_barrier();
     float qs[16], ks[16];
@@ -383,19 +387,19 @@ __device__ __forceinline__ float4 am_unrotate4(float4 g, const float* __restrict
   return make_float4(g.x * c.x + g.y * s.x, g.y * c.y - g.x * s.y, g.z * c.z + g.w * s.z, g.w * c.w - g.z * s.w);
 }
 
-__global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+__global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
                                                                        const float* __restrict__ rsin, const float* __restrict__ bias,
                                                                        const float* __restrict__ fout, const float* __restrict__ dout,
                                                                        float* __restrict__ dqkv, float* __restrict__ dbias, AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = p.d.n_tok;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
-  constexpr int WAVE_LDS = 2 * 32 * KST + 2 * 32 * AM_TS + 32;
-  float* Pt = smem + wave * WAVE_LDS;                // [j][i] (+1 pad): P^T and dS^T of this wave's item
-  float* St = Pt + 32 * KST;
-  float* Ta = St + 32 * KST;                         // two staged operand tiles (q, k then v, dO) and delta[32]
-  float* Tb = Ta + 32 * AM_TS;
+  constexpr int WAVE_LDS = 2 * 32 * AM_TS + 32;
+  float* Ta = smem + wave * WAVE_LDS;                // two staged operand tiles (q, k then v, dO), then P^T / dS^T ([j][i]) in the same
+  float* Tb = Ta + 32 * AM_TS;                       // storage once the staged operands have been consumed; delta[32]
   float* dl = Tb + 32 * AM_TS;
+  float* Pt = Ta;
+  float* St = Tb;
   float* dBs = smem + AM_WAVES * WAVE_LDS;            // [heads][n][n] when dbias
   if (dbias) {
     for (int e = threadIdx.x; e < p.d.heads * n * n; e += 64 * AM_WAVES) dBs[e] = 0.f;
@@ -412,11 +416,18 @@ __global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const f
     const float* rsl = rsin ? rsin + li * DH : nullptr;
     const float* qb = am_uniform(qkv + row0 * p.RW + h * DH);          // q of token 0 of this item; k at + HD, v at + 2 HD
     const float* gb = am_uniform(dout + row0 * p.HD + h * DH);
+    const float* fb = am_uniform(fout + row0 * p.HD + h * DH);
+    float* db = const_cast<float*>(am_uniform(dqkv + row0 * p.RW + h * DH));
+    const unsigned lrow = (unsigned)(tok ? li : 0);
+    // key / query index of step m for this lane = 8*(m>>2) + (m&3) + hz with hz = 4*hh, made opaque per item: otherwise the
+    // compiler hoists all 48 per-lane row offsets (as 64-bit pairs) out of the item loop and the kernel needs 270 registers
+    unsigned hz = 4u * (unsigned)hh;
+    asm volatile("" : "+v"(hz));
     const unsigned tstride = (unsigned)(p.d.st * p.RW), gstride = (unsigned)(p.d.st * p.HD);
     f32x16 pT, dsT;
     {
-      am_stage_rows(Ta, qkv + h * DH, row0, p.d.st, p.RW, rcos, rsin, p.scale, n, lane);
-      am_stage_rows(Tb, qkv + p.HD + h * DH, row0, p.d.st, p.RW, rcos, rsin, 1.0f, n, lane);
+      am_stage_rows(Ta, qb, tstride, rcos, rsin, p.scale, n, lane);
+      am_stage_rows(Tb, qb + p.HD, tstride, rcos, rsin, 1.0f, n, lane);
       __builtin_amdgcn_wave_barrier();
       float qs[16], ks[16];
       am_sel(Ta, li, hh, qs);
@@ -430,15 +441,15 @@ __global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const f
     {
       // dP^T[j][i] = sum_d V[j][d] dO[i][d]; delta_i = <dO_i, O_i> (8 lanes per row, reduced with three shuffles)
       __builtin_amdgcn_wave_barrier();
-      am_stage_rows(Ta, qkv + 2 * p.HD + h * DH, row0, p.d.st, p.RW, nullptr, nullptr, 1.0f, n, lane);
-      am_stage_rows(Tb, dout + h * DH, row0, p.d.st, p.HD, nullptr, nullptr, 1.0f, n, lane);
-#pragma unroll
+      am_stage_rows(Ta, qb + 2 * p.HD, tstride, nullptr, nullptr, 1.0f, n, lane);
+      am_stage_rows(Tb, gb, gstride, nullptr, nullptr, 1.0f, n, lane);
+#pragma unroll 1
       for (int k = 0; k < 4; ++k) {
         const int idx = lane + 64 * k;
         const int r = idx >> 3, c4 = (idx & 7) * 4;
         float part = 0.f;
         if (r < n) {
-          const float4 o = *reinterpret_cast<const float4*>(fout + (row0 + (int64_t)r * p.d.st) * p.HD + h * DH + c4);
+          const float4 o = *reinterpret_cast<const float4*>(fb + ((unsigned)r * gstride + (unsigned)c4));
           const float4 gg = *reinterpret_cast<const float4*>(Tb + r * AM_TS + c4);      // this lane wrote it
           part = gg.x * o.x + gg.y * o.y + gg.z * o.z + gg.w * o.w;
         }
@@ -457,12 +468,14 @@ __global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const f
 #pragma unroll
       for (int e = 0; e < 16; ++e) dsT[e] = pT[e] * (dsT[e] - delta);
     }
-    // the two tiles with the lane roles swapped (lane = key) go through LDS; the relative-position-bias gradient is dS itself
+    // the two tiles with the lane roles swapped (lane = key) go through LDS (over the staged operands, which every lane has
+    // consumed by now); the relative-position-bias gradient is dS itself
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int j = am_key(e, hh);
-      Pt[j * KST + li] = pT[e];
-      St[j * KST + li] = dsT[e];
+      Pt[j * AM_TS + li] = pT[e];
+      St[j * AM_TS + li] = dsT[e];
       if (dbias && tok && j < n) atomicAdd(&dBs[(h * n + li) * n + j], dsT[e]);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -476,16 +489,17 @@ __global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const f
         float ka[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int m = 4 * g4 + q, j = am_key(m, hh);
-          const float x = j < n ? qb[(unsigned)j * tstride + (unsigned)(p.HD + li)] : 0.f;
-          ka[q] = am_rot_elem(x, rcos, rsin, j, li, j < n);
+          const int m = 4 * g4 + q;
+          const unsigned j = (unsigned)(8 * (m >> 2) + (m & 3)) + hz;
+          const float x = j < (unsigned)n ? qb[j * tstride + (unsigned)(p.HD + li)] : 0.f;
+          ka[q] = am_rot_elem(x, rcos, rsin, (int)j, li, j < (unsigned)n);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[q], dsT[4 * g4 + q], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (tok) {
-        float* drow = dqkv + rowl * p.RW + h * DH;
+        float* drow = db + lrow * tstride;
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
@@ -506,18 +520,19 @@ __global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const f
         float qa[4], sb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = am_key(4 * g4 + q, hh);
-          const bool ok = i < n;
-          const float x = ok ? qb[(unsigned)i * tstride + (unsigned)li] * p.scale : 0.f;
-          qa[q] = am_rot_elem(x, rcos, rsin, i, li, ok);
-          sb[q] = St[li * KST + i];
+          const int m = 4 * g4 + q;
+          const unsigned i = (unsigned)(8 * (m >> 2) + (m & 3)) + hz;
+          const bool ok = i < (unsigned)n;
+          const float x = ok ? qb[i * tstride + (unsigned)li] * p.scale : 0.f;
+          qa[q] = am_rot_elem(x, rcos, rsin, (int)i, li, ok);
+          sb[q] = St[li * AM_TS + i];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q], sb[q], dk, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (tok) {
-        float* drow = dqkv + rowl * p.RW + p.HD + h * DH;
+        float* drow = db + (lrow * tstride + (unsigned)p.HD);
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
@@ -535,16 +550,17 @@ __global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_kernel(const f
         float ga[4], pb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = am_key(4 * g4 + q, hh);
-          ga[q] = i < n ? gb[(unsigned)i * gstride + (unsigned)li] : 0.f;
-          pb[q] = Pt[li * KST + i];
+          const int m = 4 * g4 + q;
+          const unsigned i = (unsigned)(8 * (m >> 2) + (m & 3)) + hz;
+          ga[q] = i < (unsigned)n ? gb[i * gstride + (unsigned)li] : 0.f;
+          pb[q] = Pt[li * AM_TS + i];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) dv = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[q], pb[q], dv, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (tok) {
-        float* drow = dqkv + rowl * p.RW + 2 * p.HD + h * DH;
+        float* drow = db + (lrow * tstride + (unsigned)(2 * p.HD));
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4)
           *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = make_float4(dv[4 * e4], dv[4 * e4 + 1], dv[4 * e4 + 2], dv[4 * e4 + 3]);
@@ -594,10 +610,10 @@ extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float
   int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
   if (rc) return rc;
   const int n = d->n_tok;
-  // the one-wave-per-item MFMA backward (debug 8) measures no faster than the thread-per-row kernel yet: it needs ~300
-  // registers and LDS for two transposes, so only two waves per SIMD hide its five dependent load phases
-  if (n <= 32 && wdno_debug_mode == 8) {
-    size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * KST + 2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
+  // one wave per item on MFMA tiles (debug 5: thread-per-row kernel below); 116 registers and 9 KB of LDS per wave, so four
+  // waves per SIMD hide its five dependent load phases (0.94 vs 1.17 ms at the 40 x 40 level)
+  if (n <= 32 && wdno_debug_mode != 5) {
+    size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
     int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
     if (nb > 2048) nb = 2048;                                // also bounds the number of global dbias flushes
     attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p);
