@@ -22,6 +22,15 @@ extern "C" {
 typedef void* wdno_stream_t; /* hipStream_t */
 
 enum { WDNO_OK = 0, WDNO_EINVAL = -1, WDNO_ELAUNCH = -2, WDNO_EUNSUPPORTED = -3, WDNO_EWORKSPACE = -4 };
+
+/* "amax record": WDNO_AMAX_FLOATS floats in device memory (WDNO_AMAX_SLOTS slots, one per 64-byte line so that the atomic
+ * updates of a launch do not serialise), zeroed by the caller, whose maximum is max|x| of one tensor. The
+ * fp32-equivalent convolutions scale their fp16 split by it. wdno_amax_record fills one with a sweep over x; the *_amax
+ * forms of the kernels that WRITE activation tensors (group norm, layer norm, concat, add) fill one for their output on
+ * the way (amax_rec may be NULL: not wanted), which saves that sweep. */
+#define WDNO_AMAX_SLOTS 64
+#define WDNO_AMAX_STRIDE 16
+#define WDNO_AMAX_FLOATS (WDNO_AMAX_SLOTS * WDNO_AMAX_STRIDE)
 const char* wdno_strerror(int code);
 int wdno_version(void);
 /* last hip error string seen by the library on this thread (diagnostics only) */
@@ -68,6 +77,7 @@ int wdno_upsample_coef(const float* in, float* out, int64_t outer, int a, int mi
 int wdno_nc_to_cl(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s);
 int wdno_cl_to_nc(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s);
 int wdno_concat2_cl(const float* a, int Ca, const float* b, int Cb, float* out, int64_t P, wdno_stream_t s);
+int wdno_concat2_cl_amax(const float* a, int Ca, const float* b, int Cb, float* out, float* amax_rec, int64_t P, wdno_stream_t s);
 int wdno_split2_cl(const float* in, float* a, int Ca, float* b, int Cb, int64_t P, wdno_stream_t s);
 /* nearest x2 in H and W of CL [N, H, W, C] (nn.Upsample, burgers/ddpm_burgers/unet.py:35-39) and its adjoint */
 int wdno_upsample2x_cl_fwd(const float* in, float* out, int64_t N, int H, int W, int C, wdno_stream_t s);
@@ -98,15 +108,17 @@ typedef struct {
 int wdno_conv_fwd(const float* x, const float* wp, const float* bias, const float* residual, float* y,
                   const wdno_conv_geom* g, wdno_stream_t s);
 /* fp32-equivalent convolution on the fp16 matrix cores ("3 x fp16 split", conv_h3.hip): an fp32 tensor is pre-split by
- * wdno_amax + wdno_split_f16 into two fp16 planes hi, lo [rows][C8] (C8 = C rounded up to 8) and a power-of-two scale;
+ * wdno_amax_record + wdno_split_f16 into two fp16 planes hi, lo [rows][C8] (C8 = C rounded up to 8) and a power-of-two scale;
  * wdno_conv_fwd_f16x3 evaluates ah*bh + ah*bl + al*bh with fp32 accumulation. Same geometry contract as wdno_conv_fwd
  * with g->C = C8; sx / sw are the device scalars written by wdno_split_f16 for the activation / packed-weight operand. */
-int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s);
-int wdno_split_f16(const float* x, const float* amax, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8, wdno_stream_t s);
+int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s);            /* one float (weights) */
+int wdno_amax_record(const float* x, int64_t n, float* rec_zeroed, wdno_stream_t s);     /* an amax record (activations) */
+/* amax_rec: the amax record of x (from wdno_amax_record or from the kernel that produced x) */
+int wdno_split_f16(const float* x, const float* amax_rec, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8, wdno_stream_t s);
 /* wdno_split_f16 that also returns colsum_out[C8] = sum over rows (the bias gradient when x is dy), in the same pass.
  * WDNO_EUNSUPPORTED unless C8 / 8 is a power of two <= 256 (use wdno_split_f16 + wdno_colsum then). */
 size_t wdno_split_colsum_ws_bytes(int64_t rows, int C8);
-int wdno_split_f16_colsum(const float* x, const float* amax, void* hi, void* lo, float* scale_out, float* colsum_out,
+int wdno_split_f16_colsum(const float* x, const float* amax_rec, void* hi, void* lo, float* scale_out, float* colsum_out,
                           void* ws, size_t ws_bytes, int64_t rows, int C, int C8, wdno_stream_t s);
 /* raw weight [K][C][kd][kh][kw] -> split planes of the packed operand in one launch. mode 0: forward operand
  * [kd][kh][A>=K][kw][B>=C]; mode 1: data-gradient operand [kd][kh][A>=C][kw][B>=K] with flipped taps. amax = max|w| (device). */
@@ -123,6 +135,10 @@ int wdno_amax_multi(const void* table, int n_items, int blocks_per_item, wdno_st
 int wdno_pack_split_weight_multi(const void* table, int n_items, int blocks_per_item, wdno_stream_t s);
 int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                         const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s);
+/* the same, and max|y| over the outputs this launch wrote is merged into amax_rec (an amax record, or NULL) */
+int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                             const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
+                             wdno_stream_t s);
 /* weight gradient on the same split planes (g->C = C8 of x, g->K = K8 of dy); dwp [kd][kh][K8][kw*C8] fp32 */
 size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g);
 /* pixel_table: [N*OD*OH*OW] 16-byte records from wdno_conv_pixel_table (depends on the geometry only; callers cache it) */
@@ -152,12 +168,19 @@ size_t wdno_groupnorm_ws_bytes(int64_t N, int64_t S, int C, int G);
 int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
                            float* stats, int64_t N, int64_t S, int C, int G, float eps, int silu,
                            void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+                                float* stats, float* amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                void* ws, size_t ws_bytes, wdno_stream_t s);
 /* dx, dgamma_beta_partial [N, 2, C] (per-sample; caller sums over N), dss [N, 2C] or NULL */
 int wdno_groupnorm_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
                            const float* stats, float* dx, float* dgb_partial, float* dss,
                            int64_t N, int64_t S, int C, int G, int silu, void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                                const float* stats, float* dx, float* dgb_partial, float* dss, float* amax_rec,
+                                int64_t N, int64_t S, int C, int G, int silu, void* ws, size_t ws_bytes, wdno_stream_t s);
 /* Channel LayerNorm over C of CL rows [P, C], gain only (unet.py:55-65, conv3d.py:165-174) */
 int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s);
+int wdno_layernorm_fwd_amax(const float* x, const float* g, float* y, float* amax_rec, int64_t P, int C, float eps, wdno_stream_t s);
 size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C);
 int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
                        float eps, void* ws, size_t ws_bytes, wdno_stream_t s);
@@ -192,6 +215,7 @@ int wdno_linattn_bwd(const float* qkv, const float* dout, const float* kstats, c
 int wdno_act_fwd(const float* x, float* y, int64_t n, int act, wdno_stream_t s);
 int wdno_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, wdno_stream_t s);
 int wdno_add(const float* a, const float* b, float* out, int64_t n, wdno_stream_t s);
+int wdno_add_amax(const float* a, const float* b, float* out, float* amax_rec, int64_t n, wdno_stream_t s);
 /* out[b, :] = cat(sin(t_b f_k), cos(t_b f_k)); freqs[dim/2] = exp(-k ln(theta)/(dim/2-1)) is a device table built by
  * the caller with the reference's own host arithmetic (unet.py:88-96, conv3d.py:144-151) */
 int wdno_sinusoidal_emb(const int64_t* t, const float* freqs, float* out, int B, int dim, wdno_stream_t s);

@@ -273,6 +273,62 @@ def test_conv_transpose_f16x3_path(ops, cin, cout, sp):
     assert any('h3' in k for k in n_launch) and not any(k.startswith('conv_fwd_kernel') for k in n_launch), list(n_launch)
 
 
+# ----------------------------------------------------------------------------------------------------- amax records
+def _amax_chain(ops, hints, poison=False):
+    """layer norm -> 1x1 conv -> group norm + SiLU -> 3x3x3 conv (residual) -> concat -> conv -> add -> conv: every producer that
+    can leave an amax record on its output, each followed by a split-fp16 convolution that would use it."""
+    ops.AMAX_HINTS = hints
+    torch.manual_seed(5)
+    n, d, h, w, c = 2, 6, 20, 20, 64
+    x = dev(torch.randn(n, d, h, w, c) * 3, True)
+    gl = dev(torch.rand(1, c, 1, 1, 1) + 0.5, True)
+    w1, w2, w3, w4 = (dev(torch.randn(*s) * 0.05, True) for s in ((c, c, 1, 1, 1), (c, c, 3, 3, 3), (c, 2 * c, 1, 3, 3), (c, c, 1, 3, 3)))
+    b2 = dev(torch.randn(c) * 0.1, True)
+    gam, bet = dev(torch.rand(c) + 0.5, True), dev(torch.randn(c) * 0.1, True)
+    t = ops.layernorm_cl(x, gl)
+    t = ops.conv_cl(t, w1)
+    t = ops.groupnorm_act(t, gam, bet, 8)
+    if poison:
+        with torch.no_grad():
+            t.mul_(4096.0)                 # an in-place change after the record was left: the record must not be used
+    t = ops.conv_cl(t, w2, b2, padding=1, residual=x)
+    t = ops.concat_cl(t, x)
+    t = ops.conv_cl(t, w3, padding=(0, 1, 1))
+    t = ops.add(t, x)
+    y = ops.conv_cl(t, w4, padding=(0, 1, 1))
+    if not poison:
+        y.backward(dev(torch.randn(n, d, h, w, c)))
+    ops.AMAX_HINTS = True
+    return [y.detach()] + ([] if poison else [v.grad for v in (x, gl, w1, w2, w3, w4, b2, gam, bet)])
+
+
+def test_amax_records_match_the_sweep(ops):
+    """The amax a producer kernel leaves behind is the same number the separate sweep finds, so everything downstream
+    (scale, fp16 planes, convolution outputs and all gradients) is bit-identical with and without the records."""
+    calls = {}
+    orig = ops.tensor_amax
+    def counting(x):
+        calls['n'] = calls.get('n', 0) + 1
+        return orig(x)
+    ops.tensor_amax = counting
+    try:
+        with_rec = _amax_chain(ops, True)
+        n_with = calls.pop('n', 0)
+        without = _amax_chain(ops, False)
+        n_without = calls.pop('n', 0)
+    finally:
+        ops.tensor_amax = orig
+    for a, b in zip(with_rec, without):
+        assert torch.equal(a, b)
+    assert n_with < n_without and n_with <= n_without - 5, (n_with, n_without)      # the forward chain alone drops 5 sweeps
+
+
+def test_amax_record_is_void_after_an_in_place_change(ops):
+    a = _amax_chain(ops, True, poison=True)[0]
+    b = _amax_chain(ops, False, poison=True)[0]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 # ----------------------------------------------------------------------------------------------------- normalisation
 @pytest.mark.parametrize('shape,groups,use_ss,act', [((2, 64, 3, 10, 10), 8, True, True), ((2, 16, 5, 5), 1, True, True),
                                                       ((1, 8, 2, 4, 4), 4, False, True), ((3, 128, 8, 8), 1, False, False),

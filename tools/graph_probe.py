@@ -16,7 +16,7 @@ params = [p for p in dif.parameters() if p.requires_grad]
 _orig_slot = ops._amax_slot
 def slot(device, n=1):
     if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(n, device=device, dtype=torch.float32)
+        return torch.zeros(ops.AMAX_FLOATS, device=device, dtype=torch.float32)
     return _orig_slot(device) if n == 1 else _orig_slot(device, n)
 ops._amax_slot = slot
 

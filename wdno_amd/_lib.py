@@ -55,11 +55,13 @@ PROTOTYPES = {
     'wdno_nc_to_cl': (I, [P, P, L, I, L, I, P]),
     'wdno_cl_to_nc': (I, [P, P, L, I, L, I, P]),
     'wdno_concat2_cl': (I, [P, I, P, I, P, L, P]),
+    'wdno_concat2_cl_amax': (I, [P, I, P, I, P, P, L, P]),
     'wdno_split2_cl': (I, [P, P, I, P, I, L, P]),
     'wdno_upsample2x_cl_fwd': (I, [P, P, L, I, I, I, P]),
     'wdno_upsample2x_cl_bwd': (I, [P, P, L, I, I, I, P]),
     'wdno_conv_fwd': (I, [P, P, P, P, P, PG, P]),
     'wdno_amax': (I, [P, L, P, P]),
+    'wdno_amax_record': (I, [P, L, P, P]),
     'wdno_split_f16': (I, [P, P, P, P, P, L, I, I, P]),
     'wdno_split_colsum_ws_bytes': (Z, [L, I]),
     'wdno_split_f16_colsum': (I, [P, P, P, P, P, P, P, Z, L, I, I, P]),
@@ -67,6 +69,7 @@ PROTOTYPES = {
     'wdno_amax_multi': (I, [P, I, I, P]),
     'wdno_pack_split_weight_multi': (I, [P, I, I, P]),
     'wdno_conv_fwd_f16x3': (I, [P, P, P, P, P, P, P, P, P, PG, P]),
+    'wdno_conv_fwd_f16x3_amax': (I, [P, P, P, P, P, P, P, P, P, P, PG, P]),
     'wdno_conv_wgrad_f16x3_ws_bytes': (Z, [PG]),
     'wdno_conv_pixel_table': (I, [P, PG, P]),
     'wdno_conv_wgrad_f16x3': (I, [P, P, P, P, P, P, P, P, P, Z, PG, P]),
@@ -77,8 +80,11 @@ PROTOTYPES = {
     'wdno_colsum': (I, [P, P, L, I, P, Z, P]),
     'wdno_groupnorm_ws_bytes': (Z, [L, L, I, I]),
     'wdno_groupnorm_act_fwd': (I, [P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
+    'wdno_groupnorm_act_fwd_amax': (I, [P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_groupnorm_act_bwd': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
+    'wdno_groupnorm_act_bwd_amax': (I, [P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_layernorm_fwd': (I, [P, P, P, L, I, F, P]),
+    'wdno_layernorm_fwd_amax': (I, [P, P, P, P, L, I, F, P]),
     'wdno_layernorm_bwd_ws_bytes': (Z, [L, I]),
     'wdno_layernorm_bwd': (I, [P, P, P, P, P, L, I, F, P, Z, P]),
     'wdno_attn_fwd': (I, [P, P, P, P, P, PA, F, P]),
@@ -89,6 +95,7 @@ PROTOTYPES = {
     'wdno_act_fwd': (I, [P, P, L, I, P]),
     'wdno_act_bwd': (I, [P, P, P, L, I, P]),
     'wdno_add': (I, [P, P, P, L, P]),
+    'wdno_add_amax': (I, [P, P, P, P, L, P]),
     'wdno_sinusoidal_emb': (I, [P, P, P, I, I, P]),
     'wdno_q_sample_cond': (I, [P, P, P, P, P, P, P, PC, P]),
     'wdno_apply_cond': (I, [P, P, PC, P]),

@@ -49,6 +49,28 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// "amax record": WDNO_AMAX_SLOTS slots of WDNO_AMAX_STRIDE floats (one used float per 64-byte line), zeroed by the host,
+// whose maximum is max|x| of a tensor. The kernel that writes a tensor can leave the record behind (one atomicMax per
+// block), which saves the separate sweep the fp16 split would otherwise need to find its scale. The spread matters:
+// atomics serialise per cache line at ~10 ns each -- 2048 blocks on ONE word cost a 78 MB sweep +19 us (12 -> 31 us), on
+// 64 words of four lines +6 us, on 64 separate lines nothing measurable (tools/probes/atomic_probe.hip).
+// Non-negative floats order like their bit patterns. Every thread of a 256-thread block calls amax_record_emit.
+__device__ __forceinline__ void amax_record_emit(float m, float* __restrict__ rec, unsigned block_linear) {
+  __shared__ float amax_red[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) amax_red[(threadIdx.x >> 6) & 3] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
+    atomicMax(reinterpret_cast<unsigned*>(rec) + (block_linear & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE, __float_as_uint(m));
+  }
+}
+__device__ __forceinline__ float amax_record_read(const float* __restrict__ rec) {      // whole wave
+  return wave_max(rec[(threadIdx.x & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE]);
+}
+__device__ __forceinline__ float amax4(float m, float4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
 // reductions inside aligned lane groups of width W (power of two <= 64)
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {

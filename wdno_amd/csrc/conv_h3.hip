@@ -20,6 +20,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define HST 40   // LDS row stride in halves
 
 // ---------------------------------------------------------------------------------------------- amax / split
+template <bool RECORD>
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
   __shared__ float red[4];
   const int64_t n4 = n >> 2;
@@ -40,6 +41,10 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
   if (blockIdx.x == 0)
     for (int64_t k = (n4 << 2) + threadIdx.x; k < n; k += 256) m = fmaxf(m, fabsf(x[k]));
+  if (RECORD) {
+    amax_record_emit(m, reinterpret_cast<float*>(out), blockIdx.x);
+    return;
+  }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -48,9 +53,15 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     atomicMax(out, __float_as_uint(m));      // non-negative floats order like their bit patterns
   }
 }
+extern "C" int wdno_amax_record(const float* x, int64_t n, float* rec_zeroed, wdno_stream_t s) {
+  WDNO_REQUIRE(n >= 0);
+  if (n == 0) return WDNO_OK;
+  amax_kernel<true><<<stream_grid(n / 16 + 1, 256), 256, 0, as_stream(s)>>>(x, n, reinterpret_cast<unsigned*>(rec_zeroed));
+  return wdno_check_launch();
+}
 extern "C" int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_stream_t s) {
   WDNO_REQUIRE(n > 0);
-  amax_kernel<<<stream_grid(n / 16 + 1, 256), 256, 0, as_stream(s)>>>(x, n, reinterpret_cast<unsigned*>(amax_zeroed));
+  amax_kernel<false><<<stream_grid(n / 16 + 1, 256), 256, 0, as_stream(s)>>>(x, n, reinterpret_cast<unsigned*>(amax_zeroed));
   return wdno_check_launch();
 }
 
@@ -63,7 +74,7 @@ __device__ __forceinline__ float scale_from_amax(float amax) {
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, const float* __restrict__ amax,
                                                      _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ scale_out,
                                                      int64_t rows, int C, int C8) {
-  const float s = scale_from_amax(amax[0]);
+  const float s = scale_from_amax(amax_record_read(amax));
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
   const int g8 = C8 >> 3;
   const int64_t total = rows * g8;
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(256) void split_colsum_kernel(const float* __restri
                                                             _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ scale_out,
                                                             double* __restrict__ part, int64_t rows, int C, int C8) {
   __shared__ float red[256][9];
-  const float s = scale_from_amax(amax[0]);
+  const float s = scale_from_amax(amax_record_read(amax));
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
   const int g8 = C8 >> 3;
   const int64_t total = rows * g8;
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
   }
 
   const float inv = 1.0f / (sx[0] * sw[0]);
+  float am = 0.f;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -419,10 +431,12 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
           if (bias) v += bias[kc];
           if (res) v += res[yr * g.K + kc];
           y[yr * g.K + kc] = v;
+          am = fmaxf(am, fabsf(v));
         }
       }
     }
   }
+  if (p.amax_rec) conv_amax_emit(am, p.amax_rec, (int)blockIdx.x * 4 + wave);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -451,11 +465,17 @@ static int launch_h3(const void* xh, const void* xl, const void* wh, const void*
 
 extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                                    const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s) {
+  return wdno_conv_fwd_f16x3_amax(xh, xl, sx, wph, wpl, sw, bias, residual, y, nullptr, g, s);
+}
+extern "C" int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                                        const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
+                                        wdno_stream_t s) {
   int rc = check_geom(g);
   if (rc) return rc;
   if (g->C & 7) return WDNO_EUNSUPPORTED;       // fp16 rows must be 16-byte multiples
   ConvP p;
   fill_params(p, g);
+  p.amax_rec = amax_rec;
   p.nchunk = cdiv(p.R, HBK);
   p.nsteps = g->kd * g->kh * p.nchunk;
   hipStream_t st = as_stream(s);

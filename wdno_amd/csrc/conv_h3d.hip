@@ -169,6 +169,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
   }
 
   // ================================================================== compute waves
+  float am = 0.f;                                                // max |y| this lane has stored (amax record of the output)
   const int wm = wave / WN, wn = wave - wm * WN;
   const int li = lane & 31, hh = lane >> 5;
   const int m_base = wm * (TM * 32), n_base = wn * (TN * 32);
@@ -262,11 +263,13 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
             if (bias) { const float4 t = *reinterpret_cast<const float4*>(bias + kc); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             if (rrow) { const float4 t = *reinterpret_cast<const float4*>(rrow + kc); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             *reinterpret_cast<float4*>(yrow + kc) = v;
+            am = amax4(am, v);
           }
         }
       }
     }
   }
+  if (p.amax_rec) conv_amax_emit(am, p.amax_rec, (int)blockIdx.x * (WM * WN) + wave);
 }
 
 static int num_cus() {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ cb, float* __restrict__ y,
-                                                        int64_t S, int C, int silu) {
+                                                        int64_t S, int C, int silu, float* __restrict__ amax_rec) {
   const int n = blockIdx.y;
   const int C4 = C >> 2;
   const int64_t total4 = S * C4;
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   float4* yp = reinterpret_cast<float4*>(y + (int64_t)n * S * C);
   const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
   const int64_t stride = (int64_t)gridDim.x * 256;
+  float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     int c4 = (int)(i % C4);
     float4 v = xp[i];
@@ -177,7 +178,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     o.x = k0.x * v.x + k0.y; o.y = k1.x * v.y + k1.y; o.z = k2.x * v.z + k2.y; o.w = k3.x * v.w + k3.y;
     if (silu) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
     yp[i] = o;
+    am = amax4(am, o);
   }
+  if (amax_rec) amax_record_emit(am, amax_rec, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------- backward finalize / apply
@@ -234,7 +237,8 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ cb, const float* __restrict__ gb,
-                                                            float* __restrict__ dx, int64_t S, int C, int cg, int G, int silu) {
+                                                            float* __restrict__ dx, int64_t S, int C, int cg, int G, int silu,
+                                                            float* __restrict__ amax_rec) {
   const int n = blockIdx.y;
   const int C4 = C >> 2;
   const int64_t total4 = S * C4;
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
   const float4* gbp = reinterpret_cast<const float4*>(gb + (int64_t)n * G * 4);
   const int64_t stride = (int64_t)gridDim.x * 256;
+  float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     int c4 = (int)(i % C4);
     float4 v = xp[i], d = dp[i];
@@ -259,7 +264,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       o[j] = k.z * dz - gq.z - xh * gq.w;
     }
     op[i] = make_float4(o[0], o[1], o[2], o[3]);
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
+  if (amax_rec) amax_record_emit(am, amax_rec, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -273,8 +280,8 @@ static int gn_check(int64_t N, int64_t S, int C, int G) {
   if ((C & 3) || C > GN_MAXC || (C % G) != 0) return WDNO_EUNSUPPORTED;
   return WDNO_OK;
 }
-extern "C" int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
-                                      float* stats, int64_t N, int64_t S, int C, int G, float eps, int silu,
+extern "C" int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+                                      float* stats, float* amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
                                       void* ws, size_t ws_bytes, wdno_stream_t s) {
   int rc = gn_check(N, S, C, G);
   if (rc) return rc;
@@ -290,11 +297,16 @@ extern "C" int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const 
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps);
   int gx = stream_grid(S * (C / 4), 256);
   if (gx > 512) gx = 512;
-  gn_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, y, S, C, silu);
+  gn_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, y, S, C, silu, amax_rec);
   return wdno_check_launch();
 }
-extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
-                                      const float* stats, float* dx, float* dgb_partial, float* dss,
+extern "C" int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+                                      float* stats, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                      void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_groupnorm_act_fwd_amax(x, gamma, beta, ss, y, stats, nullptr, N, S, C, G, eps, silu, ws, ws_bytes, s);
+}
+extern "C" int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                                      const float* stats, float* dx, float* dgb_partial, float* dss, float* amax_rec,
                                       int64_t N, int64_t S, int C, int G, int silu, void* ws, size_t ws_bytes, wdno_stream_t s) {
   int rc = gn_check(N, S, C, G);
   if (rc) return rc;
@@ -311,8 +323,13 @@ extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const flo
   gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk);
   int gx = stream_grid(S * (C / 4), 256);
   if (gx > 512) gx = 512;
-  gn_bwd_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, dx, S, C, C / G, G, silu);
+  gn_bwd_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, dx, S, C, C / G, G, silu, amax_rec);
   return wdno_check_launch();
+}
+extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                                      const float* stats, float* dx, float* dgb_partial, float* dss,
+                                      int64_t N, int64_t S, int C, int G, int silu, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_groupnorm_act_bwd_amax(x, dy, gamma, beta, ss, stats, dx, dgb_partial, dss, nullptr, N, S, C, G, silu, ws, ws_bytes, s);
 }
 
 // ---------------------------------------------------------------------------------------------- channel LayerNorm
@@ -340,6 +357,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) dgacc[v][j] = 0.f;
   const float invC = 1.0f / (float)C;
   const int64_t rstride = (int64_t)gridDim.x * RPB;
+  float am = 0.f;       // forward only: max|y| of this thread's outputs, left in the amax record dg_part points to (if any)
   // all lanes of a row group iterate together (uniform trip count per group)
   for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < P; r0 += rstride) {
     int64_t r = r0 + rloc;
@@ -370,6 +388,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           o.x = xv[v].x * rstd * gv[v].x; o.y = xv[v].y * rstd * gv[v].y;
           o.z = xv[v].z * rstd * gv[v].z; o.w = xv[v].w * rstd * gv[v].w;
           reinterpret_cast<float4*>(out + r * C)[lane + v * TPR] = o;
+          am = amax4(am, o);
         }
     } else {
       float4 dv[VPL];
@@ -397,6 +416,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
   }
+  if (!BWD && dg_part) amax_record_emit(am, dg_part, blockIdx.x);
   if (BWD) {
     // reduce dg over the RPB row groups of the block, write one partial row per block
 #pragma unroll
@@ -449,12 +469,16 @@ static int ln_launch(const float* x, const float* g, const float* dy, float* out
 #undef LN_CASE
   return WDNO_OK;
 }
-extern "C" int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s) {
+extern "C" int wdno_layernorm_fwd_amax(const float* x, const float* g, float* y, float* amax_rec, int64_t P, int C, float eps,
+                                       wdno_stream_t s) {
   WDNO_REQUIRE(P > 0 && C >= 4);
   if ((C & 3) || C > 1024) return WDNO_EUNSUPPORTED;
-  int rc = ln_launch<false>(x, g, nullptr, y, nullptr, P, C, eps, as_stream(s));
+  int rc = ln_launch<false>(x, g, nullptr, y, amax_rec, P, C, eps, as_stream(s));
   if (rc) return rc;
   return wdno_check_launch();
+}
+extern "C" int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s) {
+  return wdno_layernorm_fwd_amax(x, g, y, nullptr, P, C, eps, s);
 }
 extern "C" size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C) { return (size_t)1024 * C * sizeof(float); }
 extern "C" int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,

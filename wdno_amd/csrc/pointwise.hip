@@ -61,23 +61,33 @@ extern "C" int wdno_act_bwd(const float* x, const float* dy, float* dx, int64_t 
 }
 
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                   float* __restrict__ o, int64_t n) {
+                                                   float* __restrict__ o, int64_t n, float* __restrict__ amax_rec) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * 256;
   int64_t n4 = n >> 2;
+  float am = 0.f;
   for (int64_t k = i; k < n4; k += stride) {
     float4 u = reinterpret_cast<const float4*>(a)[k];
     float4 v = reinterpret_cast<const float4*>(b)[k];
     u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
     reinterpret_cast<float4*>(o)[k] = u;
+    am = amax4(am, u);
   }
-  for (int64_t k = (n4 << 2) + i; k < n; k += stride) o[k] = a[k] + b[k];
+  for (int64_t k = (n4 << 2) + i; k < n; k += stride) {
+    float r = a[k] + b[k];
+    o[k] = r;
+    am = fmaxf(am, fabsf(r));
+  }
+  if (amax_rec) amax_record_emit(am, amax_rec, blockIdx.x);
 }
-extern "C" int wdno_add(const float* a, const float* b, float* out, int64_t n, wdno_stream_t s) {
+extern "C" int wdno_add_amax(const float* a, const float* b, float* out, float* amax_rec, int64_t n, wdno_stream_t s) {
   WDNO_REQUIRE(n >= 0);
   if (n == 0) return WDNO_OK;
-  add_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, as_stream(s)>>>(a, b, out, n);
+  add_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, as_stream(s)>>>(a, b, out, n, amax_rec);
   return wdno_check_launch();
+}
+extern "C" int wdno_add(const float* a, const float* b, float* out, int64_t n, wdno_stream_t s) {
+  return wdno_add_amax(a, b, out, nullptr, n, s);
 }
 
 // ---------------------------------------------------------------------------------------------- time embedding
@@ -160,14 +170,18 @@ extern "C" int wdno_cl_to_nc(const float* src, float* dst, int64_t N, int C, int
 
 // out[p] = (a[p] | b[p]) ; Ca, Cb multiples of 4
 __global__ __launch_bounds__(256) void concat2_kernel(const float4* __restrict__ a, int Ca4, const float4* __restrict__ b, int Cb4,
-                                                       float4* __restrict__ out, int64_t total4) {
+                                                       float4* __restrict__ out, int64_t total4, float* __restrict__ amax_rec) {
   int Ct4 = Ca4 + Cb4;
   int64_t stride = (int64_t)gridDim.x * 256;
+  float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     int64_t p = i / Ct4;
     int c = (int)(i - p * Ct4);
-    out[i] = (c < Ca4) ? a[p * Ca4 + c] : b[p * Cb4 + (c - Ca4)];
+    float4 v = (c < Ca4) ? a[p * Ca4 + c] : b[p * Cb4 + (c - Ca4)];
+    out[i] = v;
+    am = amax4(am, v);
   }
+  if (amax_rec) amax_record_emit(am, amax_rec, blockIdx.x);
 }
 __global__ __launch_bounds__(256) void split2_kernel(const float4* __restrict__ in, float4* __restrict__ a, int Ca4,
                                                       float4* __restrict__ b, int Cb4, int64_t total4) {
@@ -180,11 +194,16 @@ __global__ __launch_bounds__(256) void split2_kernel(const float4* __restrict__ 
     if (c < Ca4) a[p * Ca4 + c] = v; else b[p * Cb4 + (c - Ca4)] = v;
   }
 }
-extern "C" int wdno_concat2_cl(const float* a, int Ca, const float* b, int Cb, float* out, int64_t P, wdno_stream_t s) {
+extern "C" int wdno_concat2_cl_amax(const float* a, int Ca, const float* b, int Cb, float* out, float* amax_rec, int64_t P,
+                                    wdno_stream_t s) {
   WDNO_REQUIRE(P > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0);
   int64_t total4 = P * ((Ca + Cb) / 4);
-  concat2_kernel<<<stream_grid(total4, 256), 256, 0, as_stream(s)>>>((const float4*)a, Ca / 4, (const float4*)b, Cb / 4, (float4*)out, total4);
+  concat2_kernel<<<stream_grid(total4, 256), 256, 0, as_stream(s)>>>((const float4*)a, Ca / 4, (const float4*)b, Cb / 4, (float4*)out,
+                                                                     total4, amax_rec);
   return wdno_check_launch();
+}
+extern "C" int wdno_concat2_cl(const float* a, int Ca, const float* b, int Cb, float* out, int64_t P, wdno_stream_t s) {
+  return wdno_concat2_cl_amax(a, Ca, b, Cb, out, nullptr, P, s);
 }
 extern "C" int wdno_split2_cl(const float* in, float* a, int Ca, float* b, int Cb, int64_t P, wdno_stream_t s) {
   WDNO_REQUIRE(P > 0 && Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0);

@@ -134,9 +134,10 @@ class _Concat(torch.autograd.Function):
         ca, cb = a.shape[-1], b.shape[-1]
         p = a.numel() // ca
         out = torch.empty((*a.shape[:-1], ca + cb), device=a.device, dtype=torch.float32)
-        _lib.check(_lib_().wdno_concat2_cl(_p(a), ca, _p(b), cb, _p(out), p, _stream()), 'concat2_cl')
+        rec = _new_amax_record(a.device)
+        _lib.check(_lib_().wdno_concat2_cl_amax(_p(a), ca, _p(b), cb, _p(out), _p(rec), p, _stream()), 'concat2_cl')
         ctx.ca, ctx.cb = ca, cb
-        return out
+        return _leave_amax(out, rec)
 
     @staticmethod
     def backward(ctx, g):
@@ -209,8 +210,9 @@ class _Add(torch.autograd.Function):
         a, b = _chk(a, 'a'), _chk(b, 'b')
         assert a.shape == b.shape
         out = torch.empty_like(a)
-        _lib.check(_lib_().wdno_add(_p(a), _p(b), _p(out), a.numel(), _stream()), 'add')
-        return out
+        rec = _new_amax_record(a.device)
+        _lib.check(_lib_().wdno_add_amax(_p(a), _p(b), _p(out), _p(rec), a.numel(), _stream()), 'add')
+        return _leave_amax(out, rec)
 
     @staticmethod
     def backward(ctx, g):
@@ -321,36 +323,54 @@ def pad8(c):
 
 
 _amax_pool = {}
+AMAX_FLOATS = 64 * 16    # WDNO_AMAX_FLOATS
+AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 
 def _amax_slot(device):
-    """A zeroed device scalar for wdno_amax, taken from a pool that is re-zeroed with one launch when exhausted."""
+    """A zeroed amax record (AMAX_FLOATS floats whose maximum will be max|x|, include/wdno_hip.h) from a pool. An exhausted
+    pool is replaced, never re-zeroed: records left on tensors by their producers (_leave_amax) may still be read."""
     key = str(device)
     st = _amax_pool.get(key)
-    if st is None or st[1] >= st[0].numel():
-        if st is None:
-            st = [torch.zeros(8192, device=device, dtype=torch.float32), 0]
-            _amax_pool[key] = st
-        else:
-            st[0].zero_()
-            st[1] = 0
-    slot = st[0][st[1]:st[1] + 1]
+    if st is None or st[1] >= st[0].shape[0]:
+        st = [torch.zeros((1024, AMAX_FLOATS), device=device, dtype=torch.float32), 0]
+        _amax_pool[key] = st
+    rec = st[0][st[1]]
     st[1] += 1
-    return slot
+    return rec
+
+
+def _new_amax_record(device):
+    return _amax_slot(device) if AMAX_HINTS else None
+
+
+def _leave_amax(t, rec):
+    """The kernel that wrote t also filled `rec` with its amax: remember it on the tensor object together with the tensor's
+    version, so that a later in-place change (autograd accumulating another gradient into it) voids the record."""
+    if rec is not None:
+        t._wdno_amax = (rec, t._version)
+    return t
+
+
+def _known_amax(t):
+    h = getattr(t, '_wdno_amax', None)
+    return h[0] if h is not None and h[1] == t._version and AMAX_HINTS else None
 
 
 def tensor_amax(x):
     amax = _amax_slot(x.device)
-    _lib.check(_lib_().wdno_amax(_p(x), x.numel(), _p(amax), _stream()), 'amax')
+    _lib.check(_lib_().wdno_amax_record(_p(x), x.numel(), _p(amax), _stream()), 'amax')
     return amax
 
 
-def split_f16(x2d):
-    """[rows, C] fp32 -> (hi, lo) fp16 [rows, C8] and the device scalar scale (one amax pass + one split pass)."""
+def split_f16(x2d, amax=None):
+    """[rows, C] fp32 -> (hi, lo) fp16 [rows, C8] and the device scalar scale: one amax sweep (unless the producer of the
+    tensor left its amax record, `amax`) + one split pass."""
     rows, c = x2d.shape
     c8 = pad8(c)
     lib = _lib_()
-    amax = tensor_amax(x2d)
+    if amax is None:
+        amax = tensor_amax(x2d)
     hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
@@ -358,16 +378,17 @@ def split_f16(x2d):
     return hi, lo, scale
 
 
-def split_f16_colsum(x2d):
+def split_f16_colsum(x2d, amax=None):
     """split_f16 that also returns the column sums [C] of x2d from the same pass (bias gradient of a convolution whose dy
     is being split anyway); falls back to split_f16 + colsum for channel counts the fused kernel does not take."""
     rows, c = x2d.shape
     c8 = pad8(c)
     g8 = c8 // 8
     if g8 > 256 or (g8 & (g8 - 1)):
-        return split_f16(x2d), colsum(x2d)
+        return split_f16(x2d, amax), colsum(x2d)
     lib = _lib_()
-    amax = tensor_amax(x2d)
+    if amax is None:
+        amax = tensor_amax(x2d)
     hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
@@ -482,7 +503,8 @@ def split_weight(w, kind, cp8, kp, pack=None):
     return pl.hi, pl.lo, pl.sc
 
 
-def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp, out=None, osp=None, ostride=(1, 1, 1), ooff=(0, 0, 0)):
+def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp, out=None, osp=None, ostride=(1, 1, 1), ooff=(0, 0, 0),
+                amax_rec=None):
     """planes = (hi, lo, scale) of a CL tensor with logical shape4 = (N, D, H, W) and C8 channels; w raw weight;
     pack = pack_fwd / pack_dgrad. Returns y [N, OD, OH, OW, kp] fp32. With `out` ([N, YD, YH, YW, kp]) the osp output
     pixels are placed at ooff + ostride * index (parity classes of the transposed convolution)."""
@@ -500,8 +522,8 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
         g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp, y_sp=tuple(out.shape[1:4]), ostride=ostride, ooff=ooff)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
     with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks), flops):
-        _lib.check(_lib_().wdno_conv_fwd_f16x3(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
-                                               C.byref(g), _stream()), 'conv_fwd_f16x3')
+        _lib.check(_lib_().wdno_conv_fwd_f16x3_amax(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
+                                                    _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_f16x3')
     return y
 
 
@@ -631,6 +653,7 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, padding):
+        xrec = _known_amax(x)
         x = _chk(x, 'x')
         lead = None
         if x.dim() != 5:       # [P, C] rows (nn.Linear) or [N, H, W, C]
@@ -653,8 +676,10 @@ class _Conv(torch.autograd.Function):
         osp_ = tuple(_out_size(a, kk, s_, p_) for a, kk, s_, p_ in zip(x5.shape[1:4], ks, stride, padding))
         h3 = _use_h3(x5.shape[0] * osp_[0] * osp_[1] * osp_[2], cp * ks[0] * ks[1] * ks[2])
         if h3:
-            planes = split_f16(x5.reshape(-1, cp))
-            y = conv_fwd_h3(planes, tuple(x5.shape[:4]), weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp)
+            planes = split_f16(x5.reshape(-1, cp), xrec)
+            yrec = _new_amax_record(x5.device)
+            y = _leave_amax(conv_fwd_h3(planes, tuple(x5.shape[:4]), weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp,
+                                        amax_rec=yrec), yrec)
             ctx.save_for_backward(planes[0], planes[1], planes[2], weight)     # the split planes replace x for wgrad
         else:
             y = conv_fwd_raw(x5, wp, bias_p, res5, ks, stride, padding, kp)
@@ -674,6 +699,7 @@ class _Conv(torch.autograd.Function):
         else:
             x5, weight = ctx.saved_tensors
         ks, stride, padding, k, c, cp, kp, has_bias, has_res, lead, xdim = ctx.meta
+        grec = _known_amax(gy)
         gy = _chk(gy, 'grad')
         n, d, h, w, _ = ctx.xshape
         gyplanes = None
@@ -684,7 +710,7 @@ class _Conv(torch.autograd.Function):
         will_split = (ctx.needs_input_grad[1] and ctx.h3) or (ctx.needs_input_grad[0] and stride == (1, 1, 1)
                                                               and _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]))
         if want_gb and will_split:               # dy is split for the gradient kernels anyway: column sums from the same pass
-            gyplanes, gbs = split_f16_colsum(gy5.reshape(-1, kp))
+            gyplanes, gbs = split_f16_colsum(gy5.reshape(-1, kp), grec)
             gb = gbs[:k].contiguous()
         if ctx.needs_input_grad[0]:
             if stride == (1, 1, 1):
@@ -692,7 +718,7 @@ class _Conv(torch.autograd.Function):
                 if _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]):
                     # dgrad = the same kernel on dy with flipped / transposed weights; "C" role = Kp, "K" role = Cp
                     if gyplanes is None:
-                        gyplanes = split_f16(gy5.reshape(-1, kp))
+                        gyplanes = split_f16(gy5.reshape(-1, kp), grec)
                     gx5 = conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, None,
                                       ks, (1, 1, 1), pd, cp)
                 else:
@@ -712,7 +738,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if ctx.h3:
                 if gyplanes is None:
-                    gyplanes = split_f16(gy5.reshape(-1, kp))
+                    gyplanes = split_f16(gy5.reshape(-1, kp), grec)
                 gw = conv_wgrad_h3((xh, xl, sx), (n, d, h, w), gyplanes, osp, ks, stride, padding, param_kc=(k, c)).reshape(weight.shape)
             else:
                 dwp = conv_wgrad_raw(x5, gy5, ks, stride, padding)
@@ -763,6 +789,7 @@ class _ConvT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        xrec = _known_amax(x)
         x = _chk(x, 'x')
         cin, cout = weight.shape[0], weight.shape[1]
         cin_p, cout_p = x.shape[-1], pad4(cout)
@@ -772,8 +799,9 @@ class _ConvT(torch.autograd.Function):
         n, d, h, w = x.shape[:4]
         h3 = _use_h3(n * d * h * w, 4 * cin_p) and cout_p % 8 == 0
         if h3:
-            planes = split_f16(x.reshape(-1, cin_p))
-            y = conv_transpose_h3(planes, (n, d, h, w), weight, bias_p, cout_p)
+            planes = split_f16(x.reshape(-1, cin_p), xrec)
+            yrec = _new_amax_record(x.device)
+            y = _leave_amax(conv_transpose_h3(planes, (n, d, h, w), weight, bias_p, cout_p, yrec), yrec)
             ctx.save_for_backward(weight, *planes)
         else:
             y = conv_transpose_raw(x, pack_transposed(weight, cin_p, cout_p), bias_p, cout_p)
@@ -784,13 +812,14 @@ class _ConvT(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         cin, cout, cin_p, cout_p, has_bias, h3, xshape4 = ctx.meta
+        grec = _known_amax(gy)
         gy = _chk(gy, 'grad')
         ks, st, pd = (1, 4, 4), (1, 2, 2), (0, 1, 1)
         gx = gw = gb = None
         if h3:
             # dx = conv_s2(dy, W) with W read as a conv weight [K' = in, C' = out, 1, 4, 4]; dW from the same two operands
             weight, xh, xl, sx = ctx.saved_tensors
-            gyplanes = split_f16(gy.reshape(-1, cout_p))
+            gyplanes = split_f16(gy.reshape(-1, cout_p), grec)
             gshape4 = tuple(gy.shape[:4])
             if ctx.needs_input_grad[0]:
                 gx = conv_fwd_h3(gyplanes, gshape4, weight, pack_fwd, 'f', None, None, ks, st, pd, cin_p)
@@ -823,14 +852,14 @@ def _parity_weight(w_io, py, px):
     return _cached(w_io, f'par{py}{px}', 0, 0, build)
 
 
-def conv_transpose_h3(xplanes, shape4, weight, bias_p, cout_p):
+def conv_transpose_h3(xplanes, shape4, weight, bias_p, cout_p, amax_rec=None):
     """Parity-class form of the transposed convolution on the split-fp16 kernels: 4 launches writing interleaved outputs."""
     n, d, h, w = shape4
     y = torch.empty((n, d, 2 * h, 2 * w, cout_p), device=xplanes[0].device, dtype=torch.float32)
     for py in range(2):
         for px in range(2):
             conv_fwd_h3(xplanes, shape4, _parity_weight(weight, py, px), pack_fwd, 'f', bias_p, None, (1, 2, 2), (1, 1, 1), (0, 1 - py, 1 - px),
-                        cout_p, out=y, osp=(d, h, w), ostride=(1, 2, 2), ooff=(0, py, px))
+                        cout_p, out=y, osp=(d, h, w), ostride=(1, 2, 2), ooff=(0, py, px), amax_rec=amax_rec)      # the 4 classes merge into one record
     return y
 
 
@@ -851,11 +880,12 @@ class _GroupNormAct(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
         ssc = None if ss is None else _chk(ss, 'scale_shift')
-        _lib.check(lib.wdno_groupnorm_act_fwd(_p(x), _p(gamma), _p(beta), _p(ssc), _p(y), _p(stats), n, s, c, groups,
-                                              float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
+        rec = _new_amax_record(x.device)
+        _lib.check(lib.wdno_groupnorm_act_fwd_amax(_p(x), _p(gamma), _p(beta), _p(ssc), _p(y), _p(stats), _p(rec), n, s, c, groups,
+                                                   float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (n, s, c, groups, int(act_silu))
-        return y
+        return _leave_amax(y, rec)
 
     @staticmethod
     def backward(ctx, gy):
@@ -868,10 +898,11 @@ class _GroupNormAct(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
         dss = None if ss is None else torch.empty_like(ss)
-        _lib.check(lib.wdno_groupnorm_act_bwd(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(dx), _p(dgb), _p(dss),
-                                              n, s, c, groups, act_silu, _p(ws), nb, _stream()), 'groupnorm_bwd')
+        rec = _new_amax_record(x.device)          # dx is the dy of the convolution in front of this norm
+        _lib.check(lib.wdno_groupnorm_act_bwd_amax(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(dx), _p(dgb), _p(dss), _p(rec),
+                                                   n, s, c, groups, act_silu, _p(ws), nb, _stream()), 'groupnorm_bwd')
         red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
-        return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None
+        return _leave_amax(dx, rec), red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None
 
 
 def groupnorm_act(x, gamma, beta, groups, scale_shift=None, act=True, eps=1e-5):
@@ -887,10 +918,11 @@ class _LayerNorm(torch.autograd.Function):
         p = x.numel() // c
         y = torch.empty_like(x)
         gf = g.reshape(-1)
-        _lib.check(_lib_().wdno_layernorm_fwd(_p(x), _p(gf), _p(y), p, c, float(eps), _stream()), 'layernorm_fwd')
+        rec = _new_amax_record(x.device)
+        _lib.check(_lib_().wdno_layernorm_fwd_amax(_p(x), _p(gf), _p(y), _p(rec), p, c, float(eps), _stream()), 'layernorm_fwd')
         ctx.save_for_backward(x, g)
         ctx.eps = eps
-        return y
+        return _leave_amax(y, rec)
 
     @staticmethod
     def backward(ctx, gy):
