@@ -202,6 +202,12 @@ int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float* rot_sin, 
  * the caller) or NULL. n_tok <= 128. */
 int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                   const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s);
+/* the same with an amax record (or NULL) for the tensor written: out / dqkv */
+int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, float* amax_rec,
+                       const wdno_attn_desc* d, float scale, wdno_stream_t s);
+int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                       const float* dout, float* dqkv, float* dbias, float* amax_rec, const wdno_attn_desc* d, float scale,
+                       wdno_stream_t s);
 /* Linear attention (unet.py:203-223 ; conv3d.py:241-258): q softmax over the 32 head channels, k softmax over
  * tokens, ctx = k^T v, out = ctx^T q * scale. units x n_tok rows, contiguous. ws holds k statistics and ctx. */
 size_t wdno_linattn_ws_bytes(int64_t units, int heads);
@@ -209,6 +215,10 @@ int wdno_linattn_fwd(const float* qkv, float* out, float* kstats /*[units,heads,
                      int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 int wdno_linattn_bwd(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv,
                      void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
+int wdno_linattn_fwd_amax(const float* qkv, float* out, float* kstats, float* ctx, float* amax_rec, int64_t units, int n_tok, int heads,
+                          float scale, wdno_stream_t s);
+int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv, float* amax_rec,
+                          void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ pointwise
  * act: 0 = SiLU, 1 = GELU(erf). */

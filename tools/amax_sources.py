@@ -50,11 +50,11 @@ for fn in ('split_f16', 'split_f16_colsum'):
     o = getattr(ops, fn)
 
     def mk2(o):
-        def w(x2d):
-            s = stats[cur[0]]
+        def w(x2d, amax=None):
+            s = stats[cur[0] + (' (record)' if amax is not None else '')]
             s[0] += 1
             s[1] += x2d.numel() * 4
-            return o(x2d)
+            return o(x2d, amax)
         return w
     setattr(ops, fn, mk2(o))
 

@@ -117,8 +117,8 @@ class LinearAttention(nn.Module):
     def forward(self, x, residual=None):
         b, h, w, _ = x.shape
         qkv = ops.conv_cl(x, self.to_qkv.weight)
-        out = ops.linear_attention(qkv.reshape(-1, qkv.shape[-1]), b, h * w, self.heads, self.scale)
-        out = ops.conv_cl(out.reshape(b, h, w, -1), self.to_out[0].weight, self.to_out[0].bias)
+        out = ops.linear_attention(qkv, b, h * w, self.heads, self.scale)
+        out = ops.conv_cl(out, self.to_out[0].weight, self.to_out[0].bias)
         out = self.to_out[1](out)
         return out if residual is None else ops.add(out, residual)
 
@@ -137,8 +137,8 @@ class Attention(nn.Module):
     def forward(self, x, residual=None):
         b, h, w, _ = x.shape
         qkv = ops.conv_cl(x, self.to_qkv.weight)
-        out = ops.softmax_attention(qkv.reshape(-1, qkv.shape[-1]), self.heads, b, 1, h * w, h * w, 0, 1, self.scale)
-        return ops.conv_cl(out.reshape(b, h, w, -1), self.to_out.weight, self.to_out.bias, residual=residual)
+        out = ops.softmax_attention(qkv, self.heads, b, 1, h * w, h * w, 0, 1, self.scale)
+        return ops.conv_cl(out, self.to_out.weight, self.to_out.bias, residual=residual)
 
 
 class Unet2D(nn.Module):

@@ -27,6 +27,7 @@ struct AttnP {
   int ipb;  // items (unit, head) per block
   int kst;  // LDS floats per item for one [n][32] matrix (padded)
   int64_t n_items;
+  float* amax_rec;   // optional amax record (common.h) of the tensor the kernel writes: out (forward), dqkv (backward)
 };
 
 #define ATT_THREADS 256
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
   const int n = p.d.n_tok;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
   const bool tok = li < n;
+  float am = 0.f;
   float* Tq = tiles[wave][0];
   float* Tk = tiles[wave][1];
   for (int64_t item = (int64_t)blockIdx.x * AM_WAVES + wave; item < p.n_items; item += (int64_t)gridDim.x * AM_WAVES) {
@@ -365,11 +367,15 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
     if (tok) {
       float* orow = out + rowl * p.HD + h * DH;
 #pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4)
-        *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = make_float4(oT[4 * e4], oT[4 * e4 + 1], oT[4 * e4 + 2], oT[4 * e4 + 3]);
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const float4 v = make_float4(oT[4 * e4], oT[4 * e4 + 1], oT[4 * e4 + 2], oT[4 * e4 + 3]);
+        *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;
+        am = amax4(am, v);
+      }
     }
     __builtin_amdgcn_wave_barrier();      // the next item overwrites the tiles
   }
+  if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * AM_WAVES + wave);
 }
 
 // element (row j, channel li) of a rotated q / k row, read column-wise (coalesced 128-byte rows): the rotation partner sits in
@@ -406,6 +412,7 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
     __syncthreads();
   }
   const bool tok = li < n;
+  float am = 0.f;                                    // max |dqkv| this lane has stored
   for (int64_t item = (int64_t)blockIdx.x * AM_WAVES + wave; item < p.n_items; item += (int64_t)gridDim.x * AM_WAVES) {
     const int h = (int)(item % p.d.heads);
     const int64_t unit = item / p.d.heads;
@@ -504,7 +511,9 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
           float4 gq = am_unrotate4(make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]), rcl, rsl, d0);
-          *reinterpret_cast<float4*>(drow + d0) = make_float4(gq.x * p.scale, gq.y * p.scale, gq.z * p.scale, gq.w * p.scale);
+          gq = make_float4(gq.x * p.scale, gq.y * p.scale, gq.z * p.scale, gq.w * p.scale);
+          *reinterpret_cast<float4*>(drow + d0) = gq;
+          am = amax4(am, gq);
         }
       }
     }
@@ -536,7 +545,9 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
-          *reinterpret_cast<float4*>(drow + d0) = am_unrotate4(make_float4(dk[4 * e4], dk[4 * e4 + 1], dk[4 * e4 + 2], dk[4 * e4 + 3]), rcl, rsl, d0);
+          const float4 gk = am_unrotate4(make_float4(dk[4 * e4], dk[4 * e4 + 1], dk[4 * e4 + 2], dk[4 * e4 + 3]), rcl, rsl, d0);
+          *reinterpret_cast<float4*>(drow + d0) = gk;
+          am = amax4(am, gk);
         }
       }
     }
@@ -562,12 +573,16 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
       if (tok) {
         float* drow = db + (lrow * tstride + (unsigned)(2 * p.HD));
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4)
-          *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = make_float4(dv[4 * e4], dv[4 * e4 + 1], dv[4 * e4 + 2], dv[4 * e4 + 3]);
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const float4 gv = make_float4(dv[4 * e4], dv[4 * e4 + 1], dv[4 * e4 + 2], dv[4 * e4 + 3]);
+          *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = gv;
+          am = amax4(am, gv);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();      // the next item overwrites this wave's tiles
   }
+  if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * AM_WAVES + wave);
   if (dbias) {
     __syncthreads();
     for (int e = threadIdx.x; e < p.d.heads * n * n; e += 64 * AM_WAVES)
@@ -582,10 +597,22 @@ static int attn_fill(AttnP& p, const wdno_attn_desc* d, float scale, int threads
   if (p.ipb < 1) p.ipb = 1;
   p.kst = d->n_tok * DH + 8;          // +8 floats: items start on different 32-byte LDS slots
   p.n_items = (int64_t)d->n_uo * d->n_ui * d->heads;
+  p.amax_rec = nullptr;
   return WDNO_OK;
 }
 extern "C" int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
                              const wdno_attn_desc* d, float scale, wdno_stream_t s) {
+  return wdno_attn_fwd_amax(qkv, rot_cos, rot_sin, bias, out, nullptr, d, scale, s);
+}
+// the thread-per-row kernels do not track the amax of what they write: a sweep over the result fills the record instead
+static int attn_amax_sweep(int rc, const float* t, const wdno_attn_desc* d, int width, float* amax_rec, wdno_stream_t s) {
+  if (rc != WDNO_OK || !amax_rec) return rc;
+  return wdno_amax_record(t, (int64_t)d->n_uo * d->n_ui * d->n_tok * width, amax_rec, s);
+}
+static int attn_fwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, AttnP& p,
+                         const wdno_attn_desc* d, wdno_stream_t s);
+extern "C" int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
+                                  float* amax_rec, const wdno_attn_desc* d, float scale, wdno_stream_t s) {
   AttnP p;
   int rc = attn_fill(p, d, scale, ATT_THREADS);
   if (rc) return rc;
@@ -593,9 +620,14 @@ extern "C" int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float
   if (d->n_tok <= 32 && wdno_debug_mode != 5) {                  // one 32x32 MFMA tile per (unit, head): one wave per item
     int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
     if (nb > 4096) nb = 4096;
+    p.amax_rec = amax_rec;
     attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
     return wdno_check_launch();
   }
+  return attn_amax_sweep(attn_fwd_rows(qkv, rot_cos, rot_sin, bias, out, p, d, s), out, d, p.HD, amax_rec, s);
+}
+static int attn_fwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, AttnP& p,
+                         const wdno_attn_desc* d, wdno_stream_t s) {
   size_t lds = (size_t)p.ipb * p.kst * sizeof(float);
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;
   int64_t blocks = (p.n_items + p.ipb - 1) / p.ipb;
@@ -606,6 +638,13 @@ extern "C" int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float
 }
 extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                              const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s) {
+  return wdno_attn_bwd_amax(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, nullptr, d, scale, s);
+}
+static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                         const float* dout, float* dqkv, float* dbias, AttnP& p, const wdno_attn_desc* d, wdno_stream_t s);
+extern "C" int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                                  const float* dout, float* dqkv, float* dbias, float* amax_rec, const wdno_attn_desc* d, float scale,
+                                  wdno_stream_t s) {
   AttnP p;
   int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
   if (rc) return rc;
@@ -616,9 +655,15 @@ extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float
     size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
     int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
     if (nb > 2048) nb = 2048;                                // also bounds the number of global dbias flushes
+    p.amax_rec = amax_rec;
     attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p);
     return wdno_check_launch();
   }
+  return attn_amax_sweep(attn_bwd_rows(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p, d, s), dqkv, d, p.RW, amax_rec, s);
+}
+static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                         const float* dout, float* dqkv, float* dbias, AttnP& p, const wdno_attn_desc* d, wdno_stream_t s) {
+  const int n = d->n_tok;
   if (n > ATT_BWD_THREADS) return WDNO_EUNSUPPORTED;      // training never attends over more than 100 tokens
   size_t lds = ((size_t)p.ipb * (2 * p.kst + 2 * n * (n + 1)) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;
@@ -740,15 +785,16 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
 
 // pass 3: out[n][e] = scale * sum_d ctx[d][e] * softmax_d(q[n])[d]; one thread per (token, head)
 __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx, float* __restrict__ out,
-                                   int n, int heads, float scale) {
+                                   int n, int heads, float scale, float* __restrict__ amax_rec) {
   extern __shared__ __attribute__((aligned(16))) float cs[];   // [heads][32][32]
   const int HD = heads * DH, RW = 3 * HD;
   const int unit = blockIdx.x;
   const int h = threadIdx.x >> 6;
   for (int e = threadIdx.x; e < heads * DH * DH; e += blockDim.x) cs[e] = ctx[(int64_t)unit * heads * DH * DH + e];
   __syncthreads();
-  const int j = blockIdx.y * 64 + (threadIdx.x & 63);
-  if (j >= n) return;
+  const int jt = blockIdx.y * 64 + (threadIdx.x & 63);
+  const bool ok = jt < n;
+  const int j = ok ? jt : n - 1;           // lanes past the last token redo it (all lanes stay active for the amax reduction) and store nothing
   const float4* qp = reinterpret_cast<const float4*>(qkv + ((int64_t)unit * n + j) * RW + h * DH);
   float q[DH];
 #pragma unroll
@@ -775,8 +821,14 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
     }
   }
   float4* op = reinterpret_cast<float4*>(out + ((int64_t)unit * n + j) * HD + h * DH);
+  float am = 0.f;
+  if (ok) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) op[e] = make_float4(o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]);
+  }
+#pragma unroll
+  for (int e = 0; e < DH; ++e) am = fmaxf(am, fabsf(o[e]));
+  if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * heads + h));
 }
 
 // backward pass B2: one thread per (token, head):
@@ -784,7 +836,7 @@ __global__ __launch_bounds__(256) void linattn_out_kernel(const float* __restric
 //   dv[e] = sum_d ks[d] dctx[d][e] ; dk[d] = ks[d] * (sum_e v[e] dctx[d][e] - T[d])
 __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ kstats,
                                        const float* __restrict__ ctx, const float* __restrict__ dctx, const float* __restrict__ tvec,
-                                       float* __restrict__ dqkv, int n, int heads, float scale) {
+                                       float* __restrict__ dqkv, int n, int heads, float scale, float* __restrict__ amax_rec) {
   extern __shared__ __attribute__((aligned(16))) float sm_[];
   const int HD = heads * DH, RW = 3 * HD;
   float* cs = sm_;                       // [heads][32][32]
@@ -804,8 +856,10 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
     tv[e] = tvec[(int64_t)unit * HD + e];
   }
   __syncthreads();
-  const int j = blockIdx.y * 64 + (threadIdx.x & 63);
-  if (j >= n) return;
+  const int jt = blockIdx.y * 64 + (threadIdx.x & 63);
+  const bool ok = jt < n;
+  const int j = ok ? jt : n - 1;           // as in linattn_out_kernel
+  float am = 0.f;
   const int64_t row = (int64_t)unit * n + j;
   const float4* cp = reinterpret_cast<const float4*>(cs + h * DH * DH);
   const float4* dp = reinterpret_cast<const float4*>(ds + h * DH * DH);
@@ -840,9 +894,12 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
       dot = fmaf(q[d], a, dot);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      reinterpret_cast<float4*>(wq)[e] = make_float4(scale * q[4 * e] * (dqs[4 * e] - dot), scale * q[4 * e + 1] * (dqs[4 * e + 1] - dot),
-                                                     scale * q[4 * e + 2] * (dqs[4 * e + 2] - dot), scale * q[4 * e + 3] * (dqs[4 * e + 3] - dot));
+    for (int e = 0; e < 8; ++e) {
+      const float4 v = make_float4(scale * q[4 * e] * (dqs[4 * e] - dot), scale * q[4 * e + 1] * (dqs[4 * e + 1] - dot),
+                                   scale * q[4 * e + 2] * (dqs[4 * e + 2] - dot), scale * q[4 * e + 3] * (dqs[4 * e + 3] - dot));
+      if (ok) reinterpret_cast<float4*>(wq)[e] = v;
+      am = amax4(am, v);
+    }
   }
   {  // ---- dk, dv
     float ks[DH], vv[DH], dv[DH];
@@ -870,10 +927,16 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      reinterpret_cast<float4*>(wq + HD)[e] = make_float4(dk[4 * e], dk[4 * e + 1], dk[4 * e + 2], dk[4 * e + 3]);
-      reinterpret_cast<float4*>(wq + 2 * HD)[e] = make_float4(dv[4 * e], dv[4 * e + 1], dv[4 * e + 2], dv[4 * e + 3]);
+      const float4 gk = make_float4(dk[4 * e], dk[4 * e + 1], dk[4 * e + 2], dk[4 * e + 3]);
+      const float4 gv = make_float4(dv[4 * e], dv[4 * e + 1], dv[4 * e + 2], dv[4 * e + 3]);
+      if (ok) {
+        reinterpret_cast<float4*>(wq + HD)[e] = gk;
+        reinterpret_cast<float4*>(wq + 2 * HD)[e] = gv;
+      }
+      am = amax4(amax4(am, gk), gv);
     }
   }
+  if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * heads + h));
 }
 
 static int la_check(int64_t units, int n, int heads) {
@@ -887,6 +950,10 @@ extern "C" size_t wdno_linattn_ws_bytes(int64_t units, int heads) {
 }
 extern "C" int wdno_linattn_fwd(const float* qkv, float* out, float* kstats, float* ctx, int64_t units, int n_tok, int heads,
                                 float scale, wdno_stream_t s) {
+  return wdno_linattn_fwd_amax(qkv, out, kstats, ctx, nullptr, units, n_tok, heads, scale, s);
+}
+extern "C" int wdno_linattn_fwd_amax(const float* qkv, float* out, float* kstats, float* ctx, float* amax_rec, int64_t units, int n_tok,
+                                     int heads, float scale, wdno_stream_t s) {
   int rc = la_check(units, n_tok, heads);
   if (rc) return rc;
   hipStream_t st = as_stream(s);
@@ -902,11 +969,16 @@ extern "C" int wdno_linattn_fwd(const float* qkv, float* out, float* kstats, flo
   }
   linattn_ctx_kernel<0><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, nullptr, kstats, nullptr, ctx, nullptr, n_tok, heads, scale);
   size_t lds = (size_t)heads * DH * DH * sizeof(float);
-  linattn_out_kernel<<<dim3((unsigned)units, (unsigned)cdiv(n_tok, 64)), 64 * heads, lds, st>>>(qkv, ctx, out, n_tok, heads, scale);
+  linattn_out_kernel<<<dim3((unsigned)units, (unsigned)cdiv(n_tok, 64)), 64 * heads, lds, st>>>(qkv, ctx, out, n_tok, heads, scale, amax_rec);
   return wdno_check_launch();
 }
 extern "C" int wdno_linattn_bwd(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv,
                                 void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s) {
+  return wdno_linattn_bwd_amax(qkv, dout, kstats, ctx, dqkv, nullptr, ws, ws_bytes, units, n_tok, heads, scale, s);
+}
+extern "C" int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv,
+                                     float* amax_rec, void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale,
+                                     wdno_stream_t s) {
   int rc = la_check(units, n_tok, heads);
   if (rc) return rc;
   if (ws_bytes < wdno_linattn_ws_bytes(units, heads)) return WDNO_EWORKSPACE;
@@ -917,6 +989,6 @@ extern "C" int wdno_linattn_bwd(const float* qkv, const float* dout, const float
   size_t lds = ((size_t)2 * heads * DH * DH + 3 * heads * DH) * sizeof(float);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)linattn_bwd_tok_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   linattn_bwd_tok_kernel<<<dim3((unsigned)units, (unsigned)cdiv(n_tok, 64)), 64 * heads, lds, st>>>(qkv, dout, kstats, ctx, dctx, tvec, dqkv,
-                                                                                                n_tok, heads, scale);
+                                                                                                n_tok, heads, scale, amax_rec);
   return wdno_check_launch();
 }

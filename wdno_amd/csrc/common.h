@@ -65,6 +65,13 @@ __device__ __forceinline__ void amax_record_emit(float m, float* __restrict__ re
     atomicMax(reinterpret_cast<unsigned*>(rec) + (block_linear & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE, __float_as_uint(m));
   }
 }
+// the same for kernels whose waves work independently (convolution epilogues, one-wave-per-item attention): one atomic per
+// wave; all 64 lanes must be active
+__device__ __forceinline__ void wave_amax_emit(float am, float* rec, int wave_linear) {
+  am = wave_max(am);
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned*>(rec) + (wave_linear & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE, __float_as_uint(am));
+}
 __device__ __forceinline__ float amax_record_read(const float* __restrict__ rec) {      // whole wave
   return wave_max(rec[(threadIdx.x & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE]);
 }

@@ -54,15 +54,6 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
 // conv_h3d.hip: LDS-DMA variant of the split-fp16 forward / data-gradient kernel (WDNO_EUNSUPPORTED -> use conv_h3.hip's)
 int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st, int stages);
-#ifdef __HIPCC__
-// epilogue side of an amax record: one atomic per wave (at most ~1000 per launch, spread over the record's 64 lines)
-__device__ __forceinline__ void conv_amax_emit(float am, float* rec, int wave_linear) {
-  am = wave_max(am);
-  if ((threadIdx.x & 63) == 0)
-    atomicMax(reinterpret_cast<unsigned*>(rec) + (wave_linear & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE, __float_as_uint(am));
-}
-#endif
-
 static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.g = *g;
   p.amax_rec = nullptr;

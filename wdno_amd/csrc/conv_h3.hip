@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
       }
     }
   }
-  if (p.amax_rec) conv_amax_emit(am, p.amax_rec, (int)blockIdx.x * 4 + wave);
+  if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * 4 + wave);
 }
 
 template <int BM, int BN, int WM, int WN>

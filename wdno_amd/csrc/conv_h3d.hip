@@ -269,7 +269,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
       }
     }
   }
-  if (p.amax_rec) conv_amax_emit(am, p.amax_rec, (int)blockIdx.x * (WM * WN) + wave);
+  if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * (WM * WN) + wave);
 }
 
 static int num_cus() {

@@ -954,10 +954,12 @@ class _Attn(torch.autograd.Function):
         out = torch.empty((*qkv.shape[:-1], heads * 32), device=qkv.device, dtype=torch.float32)
         d = AttnDesc(*desc_args)
         bc = None if bias is None else _chk(bias, 'bias')
-        _lib.check(_lib_().wdno_attn_fwd(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bc), _p(out), C.byref(d), float(scale), _stream()), 'attn_fwd')
+        rec = _new_amax_record(qkv.device)
+        _lib.check(_lib_().wdno_attn_fwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bc), _p(out), _p(rec), C.byref(d), float(scale), _stream()),
+                   'attn_fwd')
         ctx.save_for_backward(qkv, bc, rot_cos, rot_sin, out)
         ctx.meta = (desc_args, scale)
-        return out
+        return _leave_amax(out, rec)
 
     @staticmethod
     def backward(ctx, go):
@@ -969,13 +971,16 @@ class _Attn(torch.autograd.Function):
         if bias is not None and ctx.needs_input_grad[1]:
             dbias = torch.zeros_like(bias)
         d = AttnDesc(*desc_args)
-        _lib.check(_lib_().wdno_attn_bwd(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(dqkv), _p(dbias), C.byref(d),
-                                         float(scale), _stream()), 'attn_bwd')
-        return dqkv, dbias, None, None, None, None
+        rec = _new_amax_record(qkv.device)        # dqkv is the dy of the qkv projection
+        _lib.check(_lib_().wdno_attn_bwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(dqkv), _p(dbias), _p(rec),
+                                              C.byref(d), float(scale), _stream()), 'attn_bwd')
+        return _leave_amax(dqkv, rec), dbias, None, None, None, None
 
 
 def softmax_attention(qkv, heads, n_uo, n_ui, n_tok, so, si, st, scale, bias=None, rot=None):
-    """qkv rows [R, 3*heads*32]; unit (uo, ui), token j -> row uo*so + ui*si + j*st. Returns [R, heads*32]."""
+    """qkv rows [R, 3*heads*32] (any leading shape with R rows); unit (uo, ui), token j -> row uo*so + ui*si + j*st. Returns
+    [..., heads*32] with the same leading shape (pass the CL tensor itself rather than a reshaped view: tensors and gradients
+    then keep the amax records their kernels leave for the neighbouring projections)."""
     rc, rs = (None, None) if rot is None else rot
     return _Attn.apply(qkv, bias, rc, rs, (n_uo, n_ui, n_tok, heads, so, si, st), scale)
 
@@ -988,10 +993,12 @@ class _LinAttn(torch.autograd.Function):
         out = torch.empty((*qkv.shape[:-1], hd), device=qkv.device, dtype=torch.float32)
         kstats = torch.empty((units, hd, 2), device=qkv.device, dtype=torch.float32)
         cx = torch.empty((units, heads, 32, 32), device=qkv.device, dtype=torch.float32)
-        _lib.check(_lib_().wdno_linattn_fwd(_p(qkv), _p(out), _p(kstats), _p(cx), units, n_tok, heads, float(scale), _stream()), 'linattn_fwd')
+        rec = _new_amax_record(qkv.device)
+        _lib.check(_lib_().wdno_linattn_fwd_amax(_p(qkv), _p(out), _p(kstats), _p(cx), _p(rec), units, n_tok, heads, float(scale), _stream()),
+                   'linattn_fwd')
         ctx.save_for_backward(qkv, kstats, cx)
         ctx.meta = (units, n_tok, heads, scale)
-        return out
+        return _leave_amax(out, rec)
 
     @staticmethod
     def backward(ctx, go):
@@ -1002,13 +1009,14 @@ class _LinAttn(torch.autograd.Function):
         nb = lib.wdno_linattn_ws_bytes(units, heads)
         ws = _ws(nb, qkv.device)
         dqkv = torch.empty_like(qkv)
-        _lib.check(lib.wdno_linattn_bwd(_p(qkv), _p(go), _p(kstats), _p(cx), _p(dqkv), _p(ws), nb, units, n_tok, heads, float(scale), _stream()),
-                   'linattn_bwd')
-        return dqkv, None, None, None, None
+        rec = _new_amax_record(qkv.device)
+        _lib.check(lib.wdno_linattn_bwd_amax(_p(qkv), _p(go), _p(kstats), _p(cx), _p(dqkv), _p(rec), _p(ws), nb, units, n_tok, heads,
+                                             float(scale), _stream()), 'linattn_bwd')
+        return _leave_amax(dqkv, rec), None, None, None, None
 
 
 def linear_attention(qkv, units, n_tok, heads, scale):
-    """qkv [units*n_tok, 3*heads*32] (contiguous units) -> [units*n_tok, heads*32]."""
+    """qkv [units*n_tok, 3*heads*32] rows (contiguous units; any leading shape) -> [..., heads*32], same leading shape."""
     return _LinAttn.apply(qkv, units, n_tok, heads, scale)
 
 

@@ -149,8 +149,8 @@ class SpatialLinearAttention(nn.Module):
     def forward(self, x, residual=None):
         b, f, h, w, _ = x.shape
         qkv = ops.conv_cl(x, self.to_qkv.weight)
-        out = ops.linear_attention(qkv.reshape(-1, qkv.shape[-1]), b * f, h * w, self.heads, self.scale)
-        return ops.conv_cl(out.reshape(b, f, h, w, -1), self.to_out.weight, self.to_out.bias, residual=residual)
+        out = ops.linear_attention(qkv, b * f, h * w, self.heads, self.scale)         # rows in CL order; same leading shape out
+        return ops.conv_cl(out, self.to_out.weight, self.to_out.bias, residual=residual)
 
 
 class Attention(nn.Module):
@@ -186,14 +186,13 @@ class EinopsToAndFrom(nn.Module):
             raise NotImplementedError('focus_present_mask is always all-False on the WDNO path (conv3d.py:304,332)')
         att = self.fn
         b, f, h, w, _ = x.shape
-        qkv = ops.conv_cl(x, att.to_qkv.weight)
-        rows = qkv.reshape(-1, qkv.shape[-1])
+        rows = ops.conv_cl(x, att.to_qkv.weight)           # [b, f, h, w, 3*hidden]: the attention kernels index its rows in place
         if self.token_axis == 'frames':
             rot = ops.rotary_tables(att.rotary_emb.freqs, f) if exists(att.rotary_emb) else None
             out = ops.softmax_attention(rows, att.heads, b, h * w, f, f * h * w, 1, h * w, att.scale, bias=pos_bias, rot=rot)
         else:
             out = ops.softmax_attention(rows, att.heads, b * f, 1, h * w, h * w, 0, 1, att.scale, bias=pos_bias, rot=None)
-        return ops.conv_cl(out.reshape(b, f, h, w, -1), att.to_out.weight, None, residual=residual)
+        return ops.conv_cl(out, att.to_out.weight, None, residual=residual)
 
 
 def Upsample(dim):
