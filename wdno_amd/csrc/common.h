@@ -92,30 +92,36 @@ __device__ __forceinline__ float group_max(float v) {
   return v;
 }
 // out[c] = sum_b part[b][c] for a [nb][C] partial-sum matrix: 32 columns x 8 row groups per block.
+// Launch with PRS_THREADS threads: the partial matrices have up to 2048 rows (one per block of the producing sweep) but only a
+// few dozen columns, so the few blocks of this kernel are latency chains -- 32 row groups x 4 independent sums keep a
+// chain at nb/128 loads (256 threads x 1 sum: 12.9 us per launch at nb = 2048, ~90 launches per train step).
+#define PRS_GROUPS 32
+#define PRS_THREADS (32 * PRS_GROUPS)
 template <typename T>
-__global__ __launch_bounds__(256) void partial_rows_sum_kernel(const T* __restrict__ part, float* __restrict__ out, int nb, int C) {
-  __shared__ double red[8][33];
+__global__ __launch_bounds__(PRS_THREADS) void partial_rows_sum_kernel(const T* __restrict__ part, float* __restrict__ out, int nb, int C) {
+  __shared__ double red[PRS_GROUPS][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + tx;
   double acc = 0.0;
   if (c < C) {
-    // four independent partial sums: the loads of a column are 8 rows apart and would otherwise form one dependent chain
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int b = ty;
-    for (; b + 24 < nb; b += 32) {
+    for (; b + 3 * PRS_GROUPS < nb; b += 4 * PRS_GROUPS) {
       a0 += (double)part[(int64_t)b * C + c];
-      a1 += (double)part[(int64_t)(b + 8) * C + c];
-      a2 += (double)part[(int64_t)(b + 16) * C + c];
-      a3 += (double)part[(int64_t)(b + 24) * C + c];
+      a1 += (double)part[(int64_t)(b + PRS_GROUPS) * C + c];
+      a2 += (double)part[(int64_t)(b + 2 * PRS_GROUPS) * C + c];
+      a3 += (double)part[(int64_t)(b + 3 * PRS_GROUPS) * C + c];
     }
-    for (; b < nb; b += 8) a0 += (double)part[(int64_t)b * C + c];
+    for (; b < nb; b += PRS_GROUPS) a0 += (double)part[(int64_t)b * C + c];
     acc = (a0 + a1) + (a2 + a3);
   }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && c < C) {
-    double a = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
-    out[c] = (float)a;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < PRS_GROUPS; ++g) a[g & 3] += red[g][tx];
+    out[c] = (float)((a[0] + a[1]) + (a[2] + a[3]));
   }
 }
 

@@ -491,6 +491,6 @@ extern "C" int wdno_layernorm_bwd(const float* x, const float* g, const float* d
   int nb = ln_blocks(P, 256 / tpr);
   int rc = ln_launch<true>(x, g, dy, dx, (float*)ws, P, C, eps, as_stream(s));
   if (rc) return rc;
-  partial_rows_sum_kernel<float><<<cdiv(C, 32), 256, 0, as_stream(s)>>>((const float*)ws, dg, nb, C);
+  partial_rows_sum_kernel<float><<<cdiv(C, 32), PRS_THREADS, 0, as_stream(s)>>>((const float*)ws, dg, nb, C);
   return wdno_check_launch();
 }

@@ -315,7 +315,7 @@ extern "C" int wdno_colsum(const float* in, float* out, int64_t P, int C, void* 
   int nb = colsum_blocks(P);
   int64_t rpb = cdiv64(P, nb);
   colsum_partial_kernel<<<nb, 256, 0, as_stream(s)>>>(in, (double*)ws, P, C, rpb);
-  partial_rows_sum_kernel<double><<<cdiv(C, 32), 256, 0, as_stream(s)>>>((const double*)ws, out, nb, C);
+  partial_rows_sum_kernel<double><<<cdiv(C, 32), PRS_THREADS, 0, as_stream(s)>>>((const double*)ws, out, nb, C);
   return wdno_check_launch();
 }
 
