@@ -131,6 +131,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    if os.environ.get('WDNO_DEBUG'):          # kernel-selection switches for A/B measurements (see the `debug` notes in csrc/)
+        lib.wdno_set_debug(int(os.environ['WDNO_DEBUG']))
     return lib
 
 

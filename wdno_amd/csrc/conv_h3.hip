@@ -545,6 +545,7 @@ struct WgradHP {
   ConvP c;
   int tiles_k, tiles_r, splits, bn;
   int64_t pix_per_split;
+  int xcd_group;      // blocks renumbered so that each XCD owns a contiguous range of (split, tile) pairs
 };
 
 __device__ __forceinline__ half8 tr_frag(const _Float16* tile, int stride, int pix0, int ch0, int lane) {
@@ -581,13 +582,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
   const ConvP& p = wpz.c;
   const wdno_conv_geom& g = p.g;
   const int tid = threadIdx.x;
-  int b = blockIdx.x;
+  // (pixel split, k tile, tap row, r tile) from the block number, r tile fastest -- after xcd_swizzle, so that every XCD
+  // (block b runs on XCD b % 8) works on one contiguous range of them: the tiles of a pixel split then pull that split's dy
+  // and x rows through ONE L2. Unswizzled, the 27 tiles of a split of the 128 -> 64 level-0 layer sit on all eight XCDs and the
+  // launch moves 4.6 GB over the fabric for 236 MB of operands.
+  int b = wpz.xcd_group ? xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y))
+                        : (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int split = b / (int)gridDim.x;
+  b -= split * (int)gridDim.x;
   const int tile_r = b % wpz.tiles_r; b /= wpz.tiles_r;
   const int tap = b % (g.kd * g.kh);
   const int tile_k = b / (g.kd * g.kh);
   const int dz = tap / g.kh, dyy = tap - dz * g.kh;
   const int k0 = tile_k * BM, r0 = tile_r * BN;
-  const int pbeg = (int)((int64_t)blockIdx.y * wpz.pix_per_split);
+  const int pbeg = (int)((int64_t)split * wpz.pix_per_split);
   int pend = pbeg + (int)wpz.pix_per_split;
   if (pend > (int)p.P) pend = (int)p.P;
   const int nsteps = pbeg < pend ? (pend - pbeg + WH_BKP - 1) / WH_BKP : 0;
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
   }
 
   const float inv = 1.0f / (sx[0] * sdy[0]);
-  float* out = ws + ((int64_t)blockIdx.y * (g.kd * g.kh) + tap) * (int64_t)g.K * p.R;
+  float* out = ws + ((int64_t)split * (g.kd * g.kh) + tap) * (int64_t)g.K * p.R;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -771,6 +779,7 @@ __global__ __launch_bounds__(256) void wgrad_h3_reduce_kernel(const float* __res
 
 static void wgrad_h3_plan(WgradHP& w, const wdno_conv_geom* g) {
   fill_params(w.c, g);
+  w.xcd_group = wdno_debug_mode != 6;      // debug 6: plain block order (the A/B)
   const int BM = g->K > 64 ? 128 : 64;
   w.tiles_k = cdiv(g->K, BM);
   // column tile of the kw*C run: 192 for the wide-K kernel (64 x 96 per wave beats 64 x 64), and for K <= 64 only when it

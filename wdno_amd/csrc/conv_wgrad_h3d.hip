@@ -29,6 +29,7 @@ struct WgradDP {
   int tiles_k, tiles_r, splits, nsteps;     // nsteps per item (same for all)
   int items;                                // tiles_k * ntap * tiles_r * splits
   int pix_per_split;
+  int xcd_chunk;                            // items per XCD (grid is a multiple of 8), or 0: items dealt round-robin over the blocks
 };
 
 __device__ __forceinline__ int4v wd_rsrc(const void* ptr, unsigned bytes) {
@@ -85,10 +86,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
   const wdno_conv_geom& g = p.g;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int my_items = (wp.items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // Items are numbered (split, k tile, tap row, r tile) with the r tile running fastest, and every XCD (block b runs on XCD
+  // b % 8) owns one CONTIGUOUS range of them: all tap rows of a pixel split then stream the same dy rows and (shifted) x rows
+  // through the same L2 at the same time. Dealt round-robin, the nine taps of a split land on all eight XCDs and each L2
+  // fetches the whole of x and dy: 1.34 GB of fabric traffic per launch on the 64 -> 64 level-0 layer for 157 MB of operands.
+  int it_first, it_stride, my_items;
+  if (wp.xcd_chunk > 0) {
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int beg = xcd * wp.xcd_chunk, end = min(beg + wp.xcd_chunk, wp.items);
+    it_stride = (int)gridDim.x >> 3;
+    it_first = beg + idx;
+    my_items = it_first < end ? (end - it_first + it_stride - 1) / it_stride : 0;
+  } else {
+    it_first = (int)blockIdx.x; it_stride = (int)gridDim.x;
+    my_items = (wp.items - it_first + it_stride - 1) / it_stride;
+  }
   const int ntap = g.kd * g.kh;
   auto decode_item = [&](int t, int& tile_k, int& tap, int& tile_r, int& split) {
-    int id = (int)blockIdx.x + t * (int)gridDim.x;
+    int id = it_first + t * it_stride;
     tile_r = id % wp.tiles_r; id /= wp.tiles_r;
     tap = id % ntap; id /= ntap;
     tile_k = id % wp.tiles_k;
@@ -368,8 +383,14 @@ static void launch_wd(const void* xh, const void* xl, const void* dyh, const voi
   if (!done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_h3d_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
   int grid = wd_num_cus();
   if (w.items < grid) grid = w.items;
+  WgradDP wl = w;
+  wl.xcd_chunk = 0;
+  if (grid >= 64 && wdno_debug_mode != 6) {          // debug 6: round-robin items (the A/B for the XCD grouping)
+    grid &= ~7;
+    wl.xcd_chunk = cdiv(w.items, 8);
+  }
   conv_wgrad_h3d_kernel<BM, BN, NS><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh, (const _Float16*)dyl,
-                                                         sx, sdy, (const int4v*)table, wsf, w, x_bytes, dy_bytes, tbl_bytes);
+                                                         sx, sdy, (const int4v*)table, wsf, wl, x_bytes, dy_bytes, tbl_bytes);
 }
 
 // wsf: split workspace [splits][ntap][K][R] (or dwp itself when splits == 1). Returns WDNO_EUNSUPPORTED for geometries the

@@ -50,11 +50,15 @@ def _lib_():
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()      # ctypes takes a plain int for a c_void_p argument
+
+
+_raw_stream = torch._C._cuda_getCurrentRawStream     # torch.cuda.current_stream() costs ~3 us of host time per launch
+_cur_device = torch._C._cuda_getDevice
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _raw_stream(_cur_device())
 
 
 def _chk(t, name='tensor'):
@@ -373,7 +377,7 @@ def split_f16(x2d, amax=None):
         amax = tensor_amax(x2d)
     hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
-    scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
+    scale = amax[1:2]            # a float of the record's first line that no slot uses: saves an allocation per split
     _lib.check(lib.wdno_split_f16(_p(x2d), _p(amax), _p(hi), _p(lo), _p(scale), rows, c, c8, _stream()), 'split_f16')
     return hi, lo, scale
 
@@ -391,7 +395,7 @@ def split_f16_colsum(x2d, amax=None):
         amax = tensor_amax(x2d)
     hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
     lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
-    scale = torch.empty(1, device=x2d.device, dtype=torch.float32)
+    scale = amax[1:2]
     cs = torch.empty(c8, device=x2d.device, dtype=torch.float32)
     nb = lib.wdno_split_colsum_ws_bytes(rows, c8)
     ws = _ws(nb, x2d.device)
