@@ -312,3 +312,18 @@ def test_smoke_dataset_matches_reference_golden(trees, tmp_path):
     # the packer itself is device-agnostic: same result when called directly
     st = pack_smoke_state(T(G['time_coef0']), T(G['time_init0']), T(G['time_smokeout0']), torch.from_numpy(G['out_base_rescaler']))
     assert np.array_equal(st.numpy(), G['out_base_state'])
+
+
+def test_no_kernel_spills_registers():
+    """hipcc's resource report from the last build (wdno_amd/build/kernel_resources.json): a kernel that falls into scratch
+    memory still computes the right thing, only several times slower (the linear-attention backward once went from 0.26 to
+    1.5 ms that way), so it is treated as a build failure here."""
+    import json
+    from wdno_amd import build
+    build.build_library(verbose=False)
+    if not os.path.exists(build.RESOURCES):
+        pytest.skip('library was built without the resource report')
+    res = json.load(open(build.RESOURCES))
+    assert len(res) > 50
+    bad = {k: v for k, v in res.items() if v.get('vgpr_spill', 0) or v.get('scratch_bytes', 0)}
+    assert not bad, bad

@@ -855,10 +855,11 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
     kl[e] = 1.0f / kstats[((int64_t)unit * HD + e) * 2 + 1];
     tv[e] = tvec[(int64_t)unit * HD + e];
   }
+  __shared__ unsigned blk_amax;
+  if (threadIdx.x == 0) blk_amax = 0u;
   __syncthreads();
-  const int jt = blockIdx.y * 64 + (threadIdx.x & 63);
-  const bool ok = jt < n;
-  const int j = ok ? jt : n - 1;           // as in linattn_out_kernel
+  const int j = blockIdx.y * 64 + (threadIdx.x & 63);
+  if (j >= n) return;                       // (a finished wave no longer counts at the barrier below)
   float am = 0.f;
   const int64_t row = (int64_t)unit * n + j;
   const float4* cp = reinterpret_cast<const float4*>(cs + h * DH * DH);
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
     for (int e = 0; e < 8; ++e) {
       const float4 v = make_float4(scale * q[4 * e] * (dqs[4 * e] - dot), scale * q[4 * e + 1] * (dqs[4 * e + 1] - dot),
                                    scale * q[4 * e + 2] * (dqs[4 * e + 2] - dot), scale * q[4 * e + 3] * (dqs[4 * e + 3] - dot));
-      if (ok) reinterpret_cast<float4*>(wq)[e] = v;
+      reinterpret_cast<float4*>(wq)[e] = v;
       am = amax4(am, v);
     }
   }
@@ -929,14 +930,17 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
     for (int e = 0; e < 8; ++e) {
       const float4 gk = make_float4(dk[4 * e], dk[4 * e + 1], dk[4 * e + 2], dk[4 * e + 3]);
       const float4 gv = make_float4(dv[4 * e], dv[4 * e + 1], dv[4 * e + 2], dv[4 * e + 3]);
-      if (ok) {
-        reinterpret_cast<float4*>(wq + HD)[e] = gk;
-        reinterpret_cast<float4*>(wq + 2 * HD)[e] = gv;
-      }
+      reinterpret_cast<float4*>(wq + HD)[e] = gk;
+      reinterpret_cast<float4*>(wq + 2 * HD)[e] = gv;
       am = amax4(amax4(am, gk), gv);
     }
   }
-  if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * heads + h));
+  if (amax_rec) {     // lanes past the last token have left: an LDS atomic per lane instead of a wave shuffle, one global atomic per block
+    atomicMax(&blk_amax, __float_as_uint(am));
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicMax(reinterpret_cast<unsigned*>(amax_rec) + ((blockIdx.y * gridDim.x + blockIdx.x) & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE, blk_amax);
+  }
 }
 
 static int la_check(int64_t units, int n, int heads) {
