@@ -220,6 +220,15 @@ int wdno_linattn_fwd_amax(const float* qkv, float* out, float* kstats, float* ct
 int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv, float* amax_rec,
                           void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 
+/* ------------------------------------------------------------------------------------------------ nn.Linear on a few rows
+ * (time-embedding MLPs; conv3d.py:118-133, 286-296; unet.py:151-165). P <= 16 rows, C % 4 == 0, strides in floats. The weight
+ * is the reference's own [K][C] tensor (row stride w_stride), no packing. y [P][Kp] is zero in columns K..Kp-1. The data
+ * gradient is the same call on the transposed weight. dw [K][C] contiguous; db [K] or NULL. */
+int wdno_linear_rows_fwd(const float* x, int x_stride, const float* w, int w_stride, const float* bias, float* y, int P, int C, int K,
+                         int Kp, wdno_stream_t s);
+int wdno_linear_rows_wgrad(const float* x, int x_stride, const float* dy, int dy_stride, float* dw, float* db, int P, int C, int K,
+                           wdno_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------ pointwise
  * act: 0 = SiLU, 1 = GELU(erf). */
 int wdno_act_fwd(const float* x, float* y, int64_t n, int act, wdno_stream_t s);

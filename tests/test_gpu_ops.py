@@ -255,6 +255,24 @@ def test_linear(ops):
     conv_case(ops, (2, 5, 3, 128), (64, 128), 1, 0, seed=13, bias=False, residual=True)
 
 
+@pytest.mark.parametrize('rows,cin,cout,bias', [(8, 256, 512, True), (8, 64, 256, True), (16, 256, 128, False), (1, 32, 12, True),
+                                               (3, 128, 256, True)])
+def test_linear_on_a_few_rows(ops, rows, cin, cout, bias):
+    """The time-embedding MLPs (8 samples): the one-wave-per-feature kernels on the unpacked weight, forward, data gradient
+    (same kernel on the transposed weight), weight and bias gradient."""
+    seen = {}
+    orig = ops._linear_rows_backward
+    def spy(ctx, gy):
+        seen['bwd'] = True
+        return orig(ctx, gy)
+    ops._linear_rows_backward = spy
+    try:
+        conv_case(ops, (rows, cin), (cout, cin), 1, 0, seed=300 + rows + cout, bias=bias)
+    finally:
+        ops._linear_rows_backward = orig
+    assert seen.get('bwd'), 'the few-rows path was not taken'
+
+
 @pytest.mark.parametrize('c', [16, 64])
 def test_conv_transpose(ops, c):
     conv_case(ops, (2, c, 3, 5, 6), (c, c, 1, 4, 4), (1, 2, 2), (0, 1, 1), seed=14 + c, transposed=True)

@@ -98,6 +98,8 @@ PROTOTYPES = {
     'wdno_linattn_bwd_amax': (I, [P, P, P, P, P, P, P, Z, L, I, I, F, P]),
     'wdno_act_fwd': (I, [P, P, L, I, P]),
     'wdno_act_bwd': (I, [P, P, P, L, I, P]),
+    'wdno_linear_rows_fwd': (I, [P, I, P, I, P, P, I, I, I, I, P]),
+    'wdno_linear_rows_wgrad': (I, [P, I, P, I, P, P, I, I, I, P]),
     'wdno_add': (I, [P, P, P, L, P]),
     'wdno_add_amax': (I, [P, P, P, P, L, P]),
     'wdno_sinusoidal_emb': (I, [P, P, P, I, I, P]),

@@ -279,20 +279,28 @@ __device__ __forceinline__ void am_stage_rows(float* __restrict__ tile, const fl
                                               const float* __restrict__ rc, const float* __restrict__ rs, float scale, int n, int lane) {
   // ubase: wave-uniform pointer to row 0 of the operand (am_uniform); the per-lane part of every address is a 32-bit offset,
   // so nothing 64-bit per lane has to stay live across the item loop
-#pragma unroll 1
-  for (int k = 0; k < 4; ++k) {          // not unrolled: the four passes would otherwise keep 48 registers of loads in flight per call
+  // the four 1-KiB row groups are requested together (4 KB in flight per wave; one at a time, sixteen waves per CU keep only
+  // ~4 MB in flight chip-wide and the kernel sits at a latency-bound 2.9 TB/s); the rotation tables are fetched pass by pass
+  float4 xs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
     const int idx = lane + 64 * k;
     const int r = idx >> 3, c4 = (idx & 7) * 4;
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < n) {
-      x = *reinterpret_cast<const float4*>(ubase + ((unsigned)r * row_stride + (unsigned)c4));
-      x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
-      if (rc) {
-        const float4 c = *reinterpret_cast<const float4*>(rc + r * DH + c4), sn = *reinterpret_cast<const float4*>(rs + r * DH + c4);
-        x = make_float4(x.x * c.x - x.y * sn.x, x.y * c.y + x.x * sn.y, x.z * c.z - x.w * sn.z, x.w * c.w + x.z * sn.w);
-      }
+    xs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n) xs[k] = *reinterpret_cast<const float4*>(ubase + ((unsigned)r * row_stride + (unsigned)c4));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = lane + 64 * k;
+    const int r = idx >> 3, c4 = (idx & 7) * 4;
+    float4 x = xs[k];
+    x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+    if (rc && r < n) {
+      const float4 c = *reinterpret_cast<const float4*>(rc + r * DH + c4), sn = *reinterpret_cast<const float4*>(rs + r * DH + c4);
+      x = make_float4(x.x * c.x - x.y * sn.x, x.y * c.y + x.x * sn.y, x.z * c.z - x.w * sn.z, x.w * c.w + x.z * sn.w);
     }
     *reinterpret_cast<float4*>(tile + r * AM_TS + c4) = x;
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // the 16 values of row `li` this lane feeds to the MFMA: channels d = 2m + hh

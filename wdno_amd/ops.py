@@ -652,6 +652,32 @@ def _pad_vec(v, n):
     return out
 
 
+LINEAR_ROWS_MAX = int(os.environ.get('WDNO_LINEAR_ROWS', '16'))      # at most LR_MAXP of csrc/linear_rows.hip; 0 = off
+
+
+def _linear_rows_backward(ctx, gy):
+    x, weight = ctx.saved_tensors
+    _, _, _, k, c, cp, kp, has_bias, _, _, _ = ctx.meta
+    gy = _chk(gy, 'grad')
+    rows = x.shape[0]
+    lib = _lib_()
+    gx = gw = gb = None
+    if ctx.needs_input_grad[0]:
+        wt = _cached(weight, 'lin_t', 0, 0, lambda: weight.detach().t())          # [C, K]: the data gradient is the forward on it
+        gx = torch.empty((rows, cp), device=x.device, dtype=torch.float32)
+        _lib.check(lib.wdno_linear_rows_fwd(_p(gy), kp, _p(wt), k, None, _p(gx), rows, k, c, cp, _stream()), 'linear_rows_dgrad')
+    if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        gw = torch.empty((k, c), device=x.device, dtype=torch.float32)
+        gb = torch.empty((k,), device=x.device, dtype=torch.float32) if has_bias else None
+        _lib.check(lib.wdno_linear_rows_wgrad(_p(x), cp, _p(gy), kp, _p(gw), _p(gb), rows, c, k, _stream()), 'linear_rows_wgrad')
+        gw = gw.reshape(weight.shape)
+        if not ctx.needs_input_grad[1]:
+            gw = None
+        if not (has_bias and ctx.needs_input_grad[2]):
+            gb = None
+    return gx, gw, gb, None, None, None
+
+
 class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (+ residual). weight in the reference layout [K, C, (kd,) (kh, kw)] or [K, C]."""
 
@@ -670,7 +696,20 @@ class _Conv(torch.autograd.Function):
         cp, kp = x5.shape[-1], pad4(k)
         assert cp == pad4(c), f'channel mismatch: tensor has {cp}, weight expects {c}'
         ks = tuple(w5.shape[2:])
-        wp = pack_fwd(weight, cp, kp)
+        if x.dim() == 2 and x.shape[0] <= LINEAR_ROWS_MAX and weight.dim() == 2 and residual is None and c % 4 == 0 and k % 4 == 0:
+            # nn.Linear on a handful of rows (time-embedding MLPs): one wave per output feature on the unpacked weight
+            wc = weight.detach()
+            wc = wc if wc.is_contiguous() else wc.contiguous()
+            rows = x.shape[0]
+            y = torch.empty((rows, kp), device=x.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_linear_rows_fwd(_p(x), cp, _p(wc), c, _p(None if bias is None else bias.detach()), _p(y), rows, c, k, kp,
+                                                    _stream()), 'linear_rows_fwd')
+            ctx.save_for_backward(x, weight)
+            ctx.h3 = False
+            ctx.rows = True
+            ctx.meta = (ks, stride, padding, k, c, cp, kp, bias is not None, False, lead, 2)
+            return y
+        ctx.rows = False
         with torch.no_grad():
             bias_p = _pad_vec(bias.detach() if bias is not None else None, kp)
         res5 = None
@@ -686,7 +725,7 @@ class _Conv(torch.autograd.Function):
                                         amax_rec=yrec), yrec)
             ctx.save_for_backward(planes[0], planes[1], planes[2], weight)     # the split planes replace x for wgrad
         else:
-            y = conv_fwd_raw(x5, wp, bias_p, res5, ks, stride, padding, kp)
+            y = conv_fwd_raw(x5, pack_fwd(weight, cp, kp), bias_p, res5, ks, stride, padding, kp)
             ctx.save_for_backward(x5, weight)
         ctx.h3 = h3
         ctx.xshape = tuple(x5.shape)
@@ -697,6 +736,8 @@ class _Conv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if ctx.rows:
+            return _linear_rows_backward(ctx, gy)
         if ctx.h3:
             xh, xl, sx, weight = ctx.saved_tensors
             x5 = None
