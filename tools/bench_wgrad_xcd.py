@@ -28,9 +28,9 @@ for name, xs, ws in CASES:
     ypl = ops.split_f16(y.reshape(-1, k))
     flops = 2.0 * y.numel() * c * 27
     out = []
-    for mode in (6, 0, 6, 0):
+    for mode in (int(os.environ.get('MODE_A', '6')), 0, int(os.environ.get('MODE_A', '6')), 0):
         lib.wdno_set_debug(mode)
         t = timeit(lambda: ops.conv_wgrad_h3(xpl, tuple(xs[:4]), ypl, tuple(xs[1:4]), (3, 3, 3), (1, 1, 1), (1, 1, 1)))
-        out.append(f'{"rr " if mode == 6 else "xcd"} {t:6.3f} ms {flops / t / 1e9:6.1f} TF/s')
+        out.append(f'm{mode} {t:6.3f} ms {flops / t / 1e9:6.1f} TF/s')
     lib.wdno_set_debug(0)
     print(f'{name:20s} ' + ' | '.join(out), flush=True)

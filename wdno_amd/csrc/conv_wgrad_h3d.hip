@@ -361,7 +361,7 @@ void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits,
   // column tile of the kw*C run: the width that pads the run least; 192 on a tie (more MFMAs per step and barrier)
   *bn = cdiv(c.R, 192) * 192 <= cdiv(c.R, 128) * 128 ? 192 : 128;
   const int tiles = cdiv(g->K, *bm) * cdiv(c.R, *bn) * g->kd * g->kh;
-  int64_t want = 512 / tiles;                              // two items per persistent block
+  int64_t want = 512 / tiles;                              // two items per persistent block (one item of twice the length measures the same)
   int64_t max_splits = cdiv64(c.P, 16 * 32);               // at least 16 steps per item
   if (want > max_splits) want = max_splits;
   if (want < 1) want = 1;
@@ -386,8 +386,9 @@ static void launch_wd(const void* xh, const void* xl, const void* dyh, const voi
   WgradDP wl = w;
   wl.xcd_chunk = 0;
   if (grid >= 64 && wdno_debug_mode != 6) {          // debug 6: round-robin items (the A/B for the XCD grouping)
-    grid &= ~7;
     wl.xcd_chunk = cdiv(w.items, 8);
+    grid = wd_num_cus() & ~7;
+    if (8 * wl.xcd_chunk < grid) grid = 8 * wl.xcd_chunk;      // every XCD's blocks walk its chunk in whole rounds; spare blocks idle
   }
   conv_wgrad_h3d_kernel<BM, BN, NS><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh, (const _Float16*)dyl,
                                                          sx, sdy, (const int4v*)table, wsf, wl, x_bytes, dy_bytes, tbl_bytes);
