@@ -951,6 +951,148 @@ __global__ __launch_bounds__(256) void linattn_bwd_tok_kernel(const float* __res
   }
 }
 
+// The same backward pass on MFMA tiles: one wave per (unit, head, 32-token chunk), the four waves of a block take four
+// consecutive chunks of one (unit, head) and share its ctx / dctx tiles. The thread-per-token kernel above needs 256 + 182
+// registers (one wave per SIMD) and every lane walks its own 1.5-KB-strided rows; here the rows are staged through LDS by
+// coalesced 128-byte reads (am_stage_rows) and the three 32 x 32 x 32 products run on v_mfma_f32_32x32x2_f32, computed
+// TRANSPOSED so that lane (token, half) ends up with 16 of the token's 32 channels (runs of four: 16-byte stores):
+//   dqs^T[d][t] = sum_e ctx[d][e]  dout[t][e]       a^T[d][t] = sum_e dctx[d][e] v[t][e]       dv^T[e][t] = sum_d dctx[d][e] ks[t][d]
+// The channel softmax of q and the <qsm, dqs> dot product need the other half of the row: one lane ^ 32 exchange each.
+#define LAM_TILE (32 * AM_TS)
+__global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                       const float* __restrict__ kstats, const float* __restrict__ ctx,
+                                                                       const float* __restrict__ dctx, const float* __restrict__ tvec,
+                                                                       float* __restrict__ dqkv, int n, int heads, float scale,
+                                                                       float* __restrict__ amax_rec) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  float* Tc = lsm;                       // ctx  [d][e]
+  float* Td = Tc + LAM_TILE;             // dctx [d][e]
+  float* km = Td + LAM_TILE;             // per d: max, 1 / sum of the token softmax of k; T[d]
+  float* kl = km + DH;
+  float* tv = kl + DH;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+  float* T1 = tv + DH + wave * 3 * LAM_TILE;      // q, then dout
+  float* T2 = T1 + LAM_TILE;                      // k
+  float* T3 = T2 + LAM_TILE;                      // v
+  const int HD = heads * DH, RW = 3 * HD;
+  const int unit = blockIdx.x / heads, h = blockIdx.x - unit * heads;
+  {
+    const float* cs = ctx + ((int64_t)unit * heads + h) * DH * DH;
+    const float* ds = dctx + ((int64_t)unit * heads + h) * DH * DH;
+    for (int e = threadIdx.x; e < DH * DH / 4; e += 256) {
+      const int r = e >> 3, c4 = (e & 7) * 4;
+      *reinterpret_cast<float4*>(Tc + r * AM_TS + c4) = reinterpret_cast<const float4*>(cs)[e];
+      *reinterpret_cast<float4*>(Td + r * AM_TS + c4) = reinterpret_cast<const float4*>(ds)[e];
+    }
+    if (threadIdx.x < DH) {
+      const int64_t col = (int64_t)unit * HD + h * DH + threadIdx.x;
+      km[threadIdx.x] = kstats[col * 2];
+      kl[threadIdx.x] = 1.0f / kstats[col * 2 + 1];
+      tv[threadIdx.x] = tvec[col];
+    }
+  }
+  __syncthreads();
+  float am = 0.f;
+  const int t0 = (blockIdx.y * 4 + wave) * 32;
+  if (t0 < n) {                                     // (no block-wide barrier below)
+    const int nv = min(32, n - t0);
+    const bool tok = li < nv;
+    const int64_t row0 = (int64_t)unit * n + t0;
+    const float* qb = am_uniform(qkv + row0 * RW + h * DH);
+    const float* gb = am_uniform(dout + row0 * HD + h * DH);
+    float* db = const_cast<float*>(am_uniform(dqkv + row0 * RW + h * DH)) + (unsigned)(tok ? li : 0) * (unsigned)RW;
+    am_stage_rows(T1, qb, (unsigned)RW, nullptr, nullptr, 1.0f, nv, lane);
+    am_stage_rows(T2, qb + HD, (unsigned)RW, nullptr, nullptr, 1.0f, nv, lane);
+    am_stage_rows(T3, qb + 2 * HD, (unsigned)RW, nullptr, nullptr, 1.0f, nv, lane);
+    __builtin_amdgcn_wave_barrier();
+    // channel softmax of this lane's token: channels d = 8*e4 + 4*hh + c here, the other sixteen in lane ^ 32
+    float qsm[16];
+    {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const float4 t = *reinterpret_cast<const float4*>(T1 + li * AM_TS + 8 * e4 + 4 * hh);
+        qsm[4 * e4] = t.x; qsm[4 * e4 + 1] = t.y; qsm[4 * e4 + 2] = t.z; qsm[4 * e4 + 3] = t.w;
+        mx = fmaxf(fmaxf(mx, fmaxf(t.x, t.y)), fmaxf(t.z, t.w));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { qsm[e] = expf(qsm[e] - mx); sm += qsm[e]; }
+      sm += __shfl_xor(sm, 32);
+      const float inv = 1.0f / sm;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) qsm[e] *= inv;
+    }
+    __builtin_amdgcn_wave_barrier();                // every lane has read its q row: the tile takes dout now
+    am_stage_rows(T1, gb, (unsigned)HD, nullptr, nullptr, 1.0f, nv, lane);
+    __builtin_amdgcn_wave_barrier();
+    {   // ---- dq = scale * qsm * (dqs - <qsm, dqs>)
+      float ca[16], ga[16];
+      am_sel(Tc, li, hh, ca);
+      am_sel(T1, li, hh, ga);
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], ga[m], acc, 0, 0, 0);
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dot = fmaf(qsm[e], acc[e], dot);
+      dot += __shfl_xor(dot, 32);
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const float4 v = make_float4(scale * qsm[4 * e4] * (acc[4 * e4] - dot), scale * qsm[4 * e4 + 1] * (acc[4 * e4 + 1] - dot),
+                                     scale * qsm[4 * e4 + 2] * (acc[4 * e4 + 2] - dot), scale * qsm[4 * e4 + 3] * (acc[4 * e4 + 3] - dot));
+        if (tok) *reinterpret_cast<float4*>(db + 8 * e4 + 4 * hh) = v;
+        am = amax4(am, v);
+      }
+    }
+    {   // ---- dk[d] = ks[d] * (sum_e v[e] dctx[d][e] - T[d]),  ks = exp(k - max) / sum
+      float da[16], va[16];
+      am_sel(Td, li, hh, da);
+      am_sel(T3, li, hh, va);
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[m], va[m], acc, 0, 0, 0);
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int d0 = 8 * e4 + 4 * hh;
+        const float4 kk = *reinterpret_cast<const float4*>(T2 + li * AM_TS + d0);
+        const float4 m4 = *reinterpret_cast<const float4*>(km + d0), l4 = *reinterpret_cast<const float4*>(kl + d0);
+        const float4 t4 = *reinterpret_cast<const float4*>(tv + d0);
+        const float4 v = make_float4(expf(kk.x - m4.x) * l4.x * (acc[4 * e4] - t4.x), expf(kk.y - m4.y) * l4.y * (acc[4 * e4 + 1] - t4.y),
+                                     expf(kk.z - m4.z) * l4.z * (acc[4 * e4 + 2] - t4.z), expf(kk.w - m4.w) * l4.w * (acc[4 * e4 + 3] - t4.w));
+        if (tok) *reinterpret_cast<float4*>(db + HD + d0) = v;
+        am = amax4(am, v);
+      }
+    }
+    {   // ---- dv[e] = sum_d ks[d] dctx[d][e]: row operand = dctx read by columns (lane = e), column operand = ks[t][2m + hh]
+      float da[16], ka[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int d = 2 * m + hh;
+        da[m] = Td[d * AM_TS + li];
+        ka[m] = expf(T2[li * AM_TS + d] - km[d]) * kl[d];
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[m], ka[m], acc, 0, 0, 0);
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const float4 v = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
+        if (tok) *reinterpret_cast<float4*>(db + 2 * HD + 8 * e4 + 4 * hh) = v;
+        am = amax4(am, v);
+      }
+    }
+  }
+  if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave));
+}
+
 static int la_check(int64_t units, int n, int heads) {
   if (units <= 0 || n <= 0 || heads <= 0 || units > 0x7fffffff / 8) return WDNO_EINVAL;
   if (heads != 1 && heads != 2 && heads != 4) return WDNO_EUNSUPPORTED;   // 64*heads threads per block
@@ -998,6 +1140,14 @@ extern "C" int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const 
   float* dctx = (float*)ws;
   float* tvec = dctx + (size_t)units * heads * DH * DH;
   linattn_ctx_kernel<1><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, dout, nullptr, ctx, dctx, tvec, n_tok, heads, scale);
+  if (wdno_debug_mode != 5) {            // debug 5: the thread-per-token kernel
+    const size_t lds2 = ((size_t)(2 + 4 * 3) * LAM_TILE + 3 * DH) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)linattn_bwd_tok_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done = true; }
+    linattn_bwd_tok_mfma_kernel<<<dim3((unsigned)(units * heads), (unsigned)cdiv(n_tok, 128)), 256, lds2, st>>>(qkv, dout, kstats, ctx, dctx, tvec,
+                                                                                                          dqkv, n_tok, heads, scale, amax_rec);
+    return wdno_check_launch();
+  }
   size_t lds = ((size_t)2 * heads * DH * DH + 3 * heads * DH) * sizeof(float);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)linattn_bwd_tok_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   linattn_bwd_tok_kernel<<<dim3((unsigned)units, (unsigned)cdiv(n_tok, 64)), 64 * heads, lds, st>>>(qkv, dout, kstats, ctx, dctx, tvec, dqkv,
