@@ -701,10 +701,19 @@ __global__ __launch_bounds__(256) void linattn_kstats_kernel(const float* __rest
   const int col = threadIdx.x % HD, rg = threadIdx.x / HD, nrg = 256 / HD;
   const float* kp = qkv + ((int64_t)unit * n) * (3 * HD) + HD + col;
   float m = -INFINITY, l = 0.f;
-  for (int j = jb + rg; j < je; j += nrg) {
-    float v = kp[(int64_t)j * 3 * HD];
-    float mn = fmaxf(m, v);
-    l = l * expf(m - mn) + expf(v - mn);
+  // eight rows per round: the loads are requested together and the running sum is rescaled once per round (row by row the
+  // online softmax is a chain of load -> exp -> exp with one 512-byte request in flight per wave)
+  for (int j = jb + rg; j < je; j += 8 * nrg) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = j + u * nrg < je ? kp[(int64_t)(j + u * nrg) * 3 * HD] : -INFINITY;
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mn = fmaxf(mn, v[u]);
+    float add = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) add += expf(v[u] - mn);        // exp(-inf) = 0 for the rows past the end
+    l = (m == -INFINITY ? 0.f : l * expf(m - mn)) + add;
     m = mn;
   }
   rm[threadIdx.x] = m; rl[threadIdx.x] = l;
@@ -751,23 +760,37 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const float* base = qkv + ((int64_t)unit * n) * RW + h * DH + dd;
   const float* ob = MODE == 1 ? other + ((int64_t)unit * n) * HD + h * DH + dd : nullptr;
-  for (int j0 = wave * 2; j0 < n; j0 += 8) {
-    int j = j0 + hh;
-    bool ok = j < n;
-    float a, b;
-    if (MODE == 0) {
-      float kv = ok ? base[(int64_t)j * RW + HD] : 0.f;
-      a = ok ? expf(kv - km) * kinvl : 0.f;
-      b = ok ? base[(int64_t)j * RW + 2 * HD] : 0.f;
-    } else {
-      float qv = ok ? base[(int64_t)j * RW] : 0.f;
-      float mx = group_max<32>(qv);
-      float ex = expf(qv - mx);
-      float sm = group_sum<32>(ex);
-      a = ok ? scale * ex / sm : 0.f;
-      b = ok ? ob[(int64_t)j * HD] : 0.f;
+  // eight token pairs per round: all sixteen row loads of a round are requested before the first is used (one pair per
+  // iteration leaves a single 256-byte request in flight per wave and the kernel at ~1.5 TB/s)
+  constexpr int UN = 8;
+  for (int j0 = wave * 2; j0 < n; j0 += 8 * UN) {
+    float ra[UN], rb[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int j = j0 + 8 * u + hh;
+      const bool ok = j < n;
+      if (MODE == 0) {
+        ra[u] = ok ? base[(int64_t)j * RW + HD] : 0.f;
+        rb[u] = ok ? base[(int64_t)j * RW + 2 * HD] : 0.f;
+      } else {
+        ra[u] = ok ? base[(int64_t)j * RW] : 0.f;
+        rb[u] = ok ? ob[(int64_t)j * HD] : 0.f;
+      }
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool ok = j0 + 8 * u + hh < n;
+      float a;
+      if (MODE == 0) {
+        a = ok ? expf(ra[u] - km) * kinvl : 0.f;
+      } else {
+        float mx = group_max<32>(ra[u]);
+        float ex = expf(ra[u] - mx);
+        float sm = group_sum<32>(ex);
+        a = ok ? scale * ex / sm : 0.f;
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rb[u], acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * hh][dd] = acc[e];
@@ -1093,6 +1116,63 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
   if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave));
 }
 
+// pass 3 on MFMA tiles (same layout as linattn_bwd_tok_mfma_kernel): out^T[e][t] = sum_d ctx[d][e] qs[t][d], qs = scale * softmax_d(q).
+// Row operand = ctx read by columns (lane = e), column operand = qs[t][2m + hh]; the two halves of a token's softmax sit in
+// lanes t and t + 32.
+__global__ __launch_bounds__(256, 2) void linattn_out_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+                                                                   float* __restrict__ out, int n, int heads, float scale,
+                                                                   float* __restrict__ amax_rec) {
+  __shared__ __attribute__((aligned(16))) float Tc[LAM_TILE];
+  __shared__ __attribute__((aligned(16))) float Tq[4][LAM_TILE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+  const int HD = heads * DH, RW = 3 * HD;
+  const int unit = blockIdx.x / heads, h = blockIdx.x - unit * heads;
+  {
+    const float* cs = ctx + ((int64_t)unit * heads + h) * DH * DH;
+    for (int e = threadIdx.x; e < DH * DH / 4; e += 256) {
+      const int r = e >> 3, c4 = (e & 7) * 4;
+      *reinterpret_cast<float4*>(Tc + r * AM_TS + c4) = reinterpret_cast<const float4*>(cs)[e];
+    }
+  }
+  __syncthreads();
+  float am = 0.f;
+  const int t0 = (blockIdx.y * 4 + wave) * 32;
+  if (t0 < n) {
+    const int nv = min(32, n - t0);
+    const bool tok = li < nv;
+    const int64_t row0 = (int64_t)unit * n + t0;
+    float* T1 = Tq[wave];
+    am_stage_rows(T1, am_uniform(qkv + row0 * RW + h * DH), (unsigned)RW, nullptr, nullptr, 1.0f, nv, lane);
+    __builtin_amdgcn_wave_barrier();
+    float qs[16], ca[16];
+    am_sel(T1, li, hh, qs);
+    float mx = qs[0];
+#pragma unroll
+    for (int m = 1; m < 16; ++m) mx = fmaxf(mx, qs[m]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sm = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { qs[m] = expf(qs[m] - mx); sm += qs[m]; }
+    sm += __shfl_xor(sm, 32);
+    const float f = scale / sm;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { qs[m] *= f; ca[m] = Tc[(2 * m + hh) * AM_TS + li]; }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], qs[m], acc, 0, 0, 0);
+    float* orow = out + (row0 + (tok ? li : 0)) * HD + h * DH;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const float4 v = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
+      if (tok) *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;
+      am = amax4(am, v);
+    }
+  }
+  if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave));
+}
+
 static int la_check(int64_t units, int n, int heads) {
   if (units <= 0 || n <= 0 || heads <= 0 || units > 0x7fffffff / 8) return WDNO_EINVAL;
   if (heads != 1 && heads != 2 && heads != 4) return WDNO_EUNSUPPORTED;   // 64*heads threads per block
@@ -1122,6 +1202,10 @@ extern "C" int wdno_linattn_fwd_amax(const float* qkv, float* out, float* kstats
     linattn_kstats_merge_kernel<<<(unsigned)cdiv64(cols, 256), 256, 0, st>>>(ctx, kstats, cols, heads * DH, chunks);
   }
   linattn_ctx_kernel<0><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, nullptr, kstats, nullptr, ctx, nullptr, n_tok, heads, scale);
+  if (wdno_debug_mode != 5) {            // debug 5: the thread-per-token kernel
+    linattn_out_mfma_kernel<<<dim3((unsigned)(units * heads), (unsigned)cdiv(n_tok, 128)), 256, 0, st>>>(qkv, ctx, out, n_tok, heads, scale, amax_rec);
+    return wdno_check_launch();
+  }
   size_t lds = (size_t)heads * DH * DH * sizeof(float);
   linattn_out_kernel<<<dim3((unsigned)units, (unsigned)cdiv(n_tok, 64)), 64 * heads, lds, st>>>(qkv, ctx, out, n_tok, heads, scale, amax_rec);
   return wdno_check_launch();
