@@ -48,22 +48,35 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     }
     const float* xp = x + ((int64_t)n * S) * C + tx * 4;
     const float* dp = MODE == 1 ? dy + ((int64_t)n * S) * C + tx * 4 : nullptr;
-    for (int64_t r = r0 + ty; r < r1; r += nty) {
-      float4 v = *reinterpret_cast<const float4*>(xp + r * C);
-      float xv[4] = {v.x, v.y, v.z, v.w};
-      if (MODE == 0) {
+    // four rows per round, all loads requested before the first is used (one row at a time leaves ~4 MB in flight chip-wide)
+    for (int64_t rb = r0 + ty; rb < r1; rb += 4 * nty) {
+      float4 vv[4], dd[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s0[j] += (double)xv[j]; s1[j] += (double)xv[j] * (double)xv[j]; }
-      } else {
-        float4 d = *reinterpret_cast<const float4*>(dp + r * C);
-        float dv[4] = {d.x, d.y, d.z, d.w};
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = rb + u * nty;
+        const bool ok = r < r1;
+        vv[u] = ok ? *reinterpret_cast<const float4*>(xp + r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1) dd[u] = ok ? *reinterpret_cast<const float4*>(dp + r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float dz = dv[j];
-          if (silu) dz *= silu_grad_f(ca[j] * xv[j] + cbb[j]);
-          float xh = (xv[j] - mean[j]) * rstd[j];
-          s0[j] += (double)dz;
-          s1[j] += (double)dz * (double)xh;
+      for (int u = 0; u < 4; ++u) {
+        if (rb + u * nty >= r1) break;
+        const float4 v = vv[u];
+        float xv[4] = {v.x, v.y, v.z, v.w};
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s0[j] += (double)xv[j]; s1[j] += (double)xv[j] * (double)xv[j]; }
+        } else {
+          const float4 d = dd[u];
+          float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float dz = dv[j];
+            if (silu) dz *= silu_grad_f(ca[j] * xv[j] + cbb[j]);
+            float xh = (xv[j] - mean[j]) * rstd[j];
+            s0[j] += (double)dz;
+            s1[j] += (double)dz * (double)xh;
+          }
         }
       }
     }
