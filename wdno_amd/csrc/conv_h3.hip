@@ -833,11 +833,8 @@ static int wgrad_h3_partials(const void* xh, const void* xl, const float* sx, co
     return WDNO_EUNSUPPORTED;        // 32-bit buffer offsets
   WgradHP w;
   wgrad_h3_plan(w, g);
-  // persistent LDS-DMA kernel, except for 64 output channels with a long 128-multiple run (kw*C >= 384), where its 32-row
-  // wave tiles carry too few MFMAs per barrier and the register-staged 64 x 128 kernel below measures ~8 % faster.
-  // debug 5 = never, 7 = always
-  const bool dma_ok = !(g->K <= 64 && w.c.R >= 384 && w.c.R % 128 == 0) || wdno_debug_mode == 7;
-  if (wdno_debug_mode != 5 && dma_ok) {
+  // persistent LDS-DMA kernel for everything it takes (debug 5 = never); the register-staged kernels below are the fallback
+  if (wdno_debug_mode != 5) {
     int bm, bn, splits, pps;
     wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps);
     size_t need_d = (size_t)splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);

@@ -8,10 +8,14 @@
 //     steps (pixels past the end contribute zeros), so producers and consumers count steps without talking.
 // What is specific to the weight gradient:
 //   * both operands are pixel-major in memory while the MFMA wants 8 consecutive pixels per lane -> fragments are read
-//     with ds_read_b64_tr_b16 (see conv_h3.hip). The LDS plane layout is [4-pixel group][16-byte channel chunk][pixel
-//     in group][16 B]: a DMA piece (64 lanes x 16 B, lane-linear) covers 16 chunks x 4 pixels, and the 32 lanes that one
-//     transpose read serves together touch 4 consecutive chunks x 4 pixels = 256 contiguous bytes: conflict-free without
-//     padding (which lane-linear DMA could not produce).
+//     with ds_read_b64_tr_b16 (see conv_h3.hip). The LDS plane layout is [4-pixel group][64-byte unit = 32 channels]
+//     [pixel in group][64 B]. A DMA piece is lane-linear (lane L lands at +16 L), so the LDS layout IS the lane -> address
+//     map of the fetch: here four consecutive lanes fetch 64 contiguous bytes of one pixel row and a piece is 4 pixels x
+//     256 contiguous bytes. (The first layout, [group][16-byte chunk][pixel][16 B], put four different pixels into every
+//     lane quad: 64 separate 16-byte requests per instruction, producers alone 0.353 of the kernel's 0.395 ms on the
+//     64 -> 64 level-0 layer at ~19 B/clk per CU; now 0.269 ms for the kernel, 253 TFLOP/s.) On the read side the 32 lanes
+//     that one transpose read serves together (two 16-lane groups = the two 16-channel halves of the units of 4 pixels)
+//     still touch 256 contiguous bytes: conflict-free without padding (which lane-linear DMA could not produce).
 //   * the per-pixel geometry comes from the host-cached pixel table (wdno_conv_pixel_table). Producer lanes fetch the
 //     records of the pixels they serve two steps before they need them, with loads that are part of the same counted
 //     queue as the pieces.
@@ -55,7 +59,7 @@ template <int NCH>
 __device__ __forceinline__ half8 wd_frag(const char* plane, int lane_off, int pix0, int ch0) {
   typedef short short4v __attribute__((ext_vector_type(4)));
   typedef short4v __attribute__((address_space(3))) * lds_s4;
-  const char* p0 = plane + lane_off + (pix0 / 4) * (NCH * 64) + (ch0 / 8) * 64;
+  const char* p0 = plane + lane_off + (pix0 / 4) * (NCH * 64) + (ch0 / 32) * 256;
   short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0));
   short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(p0 + NCH * 64));
   typedef short short8v __attribute__((ext_vector_type(8)));
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
     asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rdh), "+s"(rdl), "+s"(rtb));
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
     // pair j of this producer = global pair pq + 4*j: pairs [0, APC) are dy pieces, [APC, NPAIR) are x pieces.
-    // lane L of piece q covers flat position f = 64*q + L of the plane: pixel = 4*(f / (4*NCH)) + f % 4, chunk = (f / 4) % NCH
+    // lane L of piece q covers the 16-byte slot f = 64*q + L of the plane: pixel = 4*(f / (16*NU)) + (f / 4) % 4, unit = (f / 16) % NU, chunk f % 4 of the unit
     int row[R], chk[R];            // pixel inside the step, channel offset (elements)
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -126,8 +130,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
       const bool isA = gp < APC;
       const int f = 64 * (isA ? gp : gp - APC) + lane;
       const int nch = isA ? ACH : BCH;
-      row[j] = 4 * (f / (4 * nch)) + (f & 3);
-      chk[j] = ((f >> 2) % nch) * 8;
+      const int nu = nch / 4;                         // 64-byte units (32 channels) per pixel
+      row[j] = 4 * (f / (16 * nu)) + ((f >> 2) & 3);
+      chk[j] = (((f >> 4) % nu) * 4 + (f & 3)) * 8;
     }
     // cursors over the global step stream of this block: (item slot, step)
     struct Cur { int t, s; };
@@ -258,9 +263,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
   const int li = lane & 31;
   const int gq = lane >> 4, xq = lane & 15;
   const int m_base = wm * (TM * 32), n_base = wn * (TN * 32);
-  // per-lane part of the transpose-read address (see wd_frag): pixel group 2*(gq>>1), chunk 2*(gq&1) + ((xq&3)>>1), pixel xq>>2 (xq = lane & 15)
-  const int offA = (2 * (gq >> 1)) * (ACH * 64) + (2 * (gq & 1) + ((xq & 3) >> 1)) * 64 + (xq >> 2) * 16 + 8 * (xq & 1);
-  const int offB = (2 * (gq >> 1)) * (BCH * 64) + (2 * (gq & 1) + ((xq & 3) >> 1)) * 64 + (xq >> 2) * 16 + 8 * (xq & 1);
+  // per-lane part of the transpose-read address (see wd_frag): pixel group 2*(gq>>1), pixel xq>>2, 16-channel half gq&1 of the unit, 8-byte piece xq&3 (xq = lane & 15)
+  const int offA = (2 * (gq >> 1)) * (ACH * 64) + (xq >> 2) * 64 + (gq & 1) * 32 + (xq & 3) * 8;
+  const int offB = (2 * (gq >> 1)) * (BCH * 64) + (xq >> 2) * 64 + (gq & 1) * 32 + (xq & 3) * 8;
   half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
   auto read_frags = [&](auto SET, int stage, int ks) {
     constexpr int B = decltype(SET)::value;

@@ -546,8 +546,6 @@ def _fwd_h3_kernel_name(pixels, k, ks):
 def _wgrad_h3_kernel_name(k, run):
     """Same for wdno_conv_wgrad_f16x3 (run = kw * C8)."""
     cdiv = lambda a, b: -(-a // b)
-    if k <= 64 and run >= 384 and run % 128 == 0:
-        return 'conv_wgrad_h3_kernel<64,128>'
     bn = 192 if cdiv(run, 192) * 192 <= cdiv(run, 128) * 128 else 128
     return f'conv_wgrad_h3d_kernel<{128 if k > 64 else 64},{bn}>'
 
