@@ -367,6 +367,20 @@ def tensor_amax(x):
     return amax
 
 
+def split_f16_of(t, x2d, amax=None):
+    """split_f16(x2d) for the rows of tensor t, remembered on t (with its version): a tensor that feeds two convolutions -- the
+    input of a ResnetBlock with a projection skip -- is split once, and both keep the same planes for their backward."""
+    h = getattr(t, '_wdno_planes', None)
+    if h is not None and h[1] == t._version and h[0][0].shape[0] == x2d.shape[0]:
+        return h[0]
+    planes = split_f16(x2d, amax)
+    try:
+        t._wdno_planes = (planes, t._version)
+    except Exception:
+        pass
+    return planes
+
+
 def split_f16(x2d, amax=None):
     """[rows, C] fp32 -> (hi, lo) fp16 [rows, C8] and the device scalar scale: one amax sweep (unless the producer of the
     tensor left its amax record, `amax`) + one split pass."""
@@ -682,6 +696,7 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, padding):
         xrec = _known_amax(x)
+        x_in = x
         x = _chk(x, 'x')
         lead = None
         if x.dim() != 5:       # [P, C] rows (nn.Linear) or [N, H, W, C]
@@ -717,7 +732,7 @@ class _Conv(torch.autograd.Function):
         osp_ = tuple(_out_size(a, kk, s_, p_) for a, kk, s_, p_ in zip(x5.shape[1:4], ks, stride, padding))
         h3 = _use_h3(x5.shape[0] * osp_[0] * osp_[1] * osp_[2], cp * ks[0] * ks[1] * ks[2])
         if h3:
-            planes = split_f16(x5.reshape(-1, cp), xrec)
+            planes = split_f16_of(x_in, x5.reshape(-1, cp), xrec)
             yrec = _new_amax_record(x5.device)
             y = _leave_amax(conv_fwd_h3(planes, tuple(x5.shape[:4]), weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp,
                                         amax_rec=yrec), yrec)
