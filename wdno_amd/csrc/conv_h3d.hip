@@ -321,6 +321,13 @@ int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const v
   const wdno_conv_geom& g = p.g;
   (void)stages;
   if (g.kd > 8 || g.kh > 8 || g.kw > 8 || g.C < 8) return WDNO_EUNSUPPORTED;
-  if (g.K > 64) return launch_h3d<128, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (g.K > 64) {
+    // 128 or 192 output pixels per tile: whichever needs less (rounds of the grid) x (tile height). At the 10 x 10 level a
+    // 256-channel layer is 300 tiles of 128 x 128 -- two rounds on 256 CUs, the second with 44 tiles -- but 200 tiles of 192 x 128.
+    const int cus = num_cus() & ~7;
+    auto cost = [&](int bm) { return cdiv64(cdiv64(p.P, bm) * cdiv(g.K, 128), cus) * bm; };
+    if (cost(192) < cost(128) && wdno_debug_mode != 9) return launch_h3d<192, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+    return launch_h3d<128, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  }
   return launch_h3d<256, 64, 4, 1, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }
