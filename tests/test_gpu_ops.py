@@ -184,7 +184,8 @@ CONV_CASES_H3 = [
 # more tiles / work items than CUs: every persistent block of the LDS-DMA kernels walks over several tiles (forward, dgrad)
 # and several (tap, split) items (wgrad), with the producers prefetching across the tile boundary
 CONV_CASES_PERSISTENT = [
-    ('persist_k32', (2, 16, 24, 40, 40), (32, 16, 3, 3, 3), 1, 1),        # 300 tiles of 256 x 64
+    ('persist_k32', (2, 16, 24, 40, 40), (32, 16, 3, 3, 3), 1, 1),        # 300 tiles of 256 x 64 -> run as 400 tiles of 192 x 64
+    ('persist_k32b', (4, 16, 24, 40, 40), (32, 16, 3, 3, 3), 1, 1),       # 600 tiles of 256 x 64 (three rounds; 192-row tiles would need four)
     ('persist_k96', (1, 16, 24, 40, 40), (96, 16, 3, 3, 3), 1, 1),        # 300 tiles of 128 x 128 -> run as 200 tiles of 192 x 128
     ('persist_k96b', (2, 16, 24, 40, 40), (96, 16, 3, 3, 3), 1, 1),       # 600 tiles of 128 x 128 (three rounds either way)
     ('persist_1x1', (2, 64, 24, 40, 40), (24, 64, 1, 1, 1), 1, 0),        # one step per tile

@@ -329,5 +329,12 @@ int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const v
     if (cost(192) < cost(128) && wdno_debug_mode != 9) return launch_h3d<192, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
     return launch_h3d<128, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   }
+  {
+    // up to 64 output channels: 256 x 64 tiles (64 x 64 per wave), or 192 x 64 (96 x 32 per wave) where that saves a round --
+    // 300 tiles of 256 rows are two rounds on 256 CUs, 400 tiles of 192 rows are two shorter ones
+    const int cus = num_cus() & ~7;
+    auto cost = [&](int bm) { return cdiv64(cdiv64(p.P, bm), cus) * bm; };
+    if (cost(192) < cost(256) && wdno_debug_mode != 9) return launch_h3d<192, 64, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  }
   return launch_h3d<256, 64, 4, 1, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }

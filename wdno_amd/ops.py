@@ -553,9 +553,10 @@ def _fwd_h3_kernel_name(pixels, k, ks):
     cdiv = lambda a, b: -(-a // b)
     tiles = cdiv(pixels, 128) * cdiv(k, 128) if k > 64 else cdiv(pixels, 256)
     if tiles >= 100 and max(ks) <= 8:
+        cus = 256                                    # the choice between tile heights is made for the device's CU count
         if k <= 64:
-            return 'conv_fwd_h3d_kernel<256,64>'
-        cus = 256                                    # the choice between 128- and 192-row tiles is made for the device's CU count
+            cost64 = lambda bm: cdiv(cdiv(pixels, bm), cus) * bm
+            return 'conv_fwd_h3d_kernel<192,64>' if cost64(192) < cost64(256) else 'conv_fwd_h3d_kernel<256,64>'
         cost = lambda bm: cdiv(cdiv(pixels, bm) * cdiv(k, 128), cus) * bm
         return 'conv_fwd_h3d_kernel<192,128>' if cost(192) < cost(128) else 'conv_fwd_h3d_kernel<128,128>'
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
