@@ -321,20 +321,22 @@ int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const v
   const wdno_conv_geom& g = p.g;
   (void)stages;
   if (g.kd > 8 || g.kh > 8 || g.kw > 8 || g.C < 8) return WDNO_EUNSUPPORTED;
-  if (g.K > 64) {
-    // 128 or 192 output pixels per tile: whichever needs less (rounds of the grid) x (tile height). At the 10 x 10 level a
-    // 256-channel layer is 300 tiles of 128 x 128 -- two rounds on 256 CUs, the second with 44 tiles -- but 200 tiles of 192 x 128.
-    const int cus = num_cus() & ~7;
-    auto cost = [&](int bm) { return cdiv64(cdiv64(p.P, bm) * cdiv(g.K, 128), cus) * bm; };
-    if (cost(192) < cost(128) && wdno_debug_mode != 9) return launch_h3d<192, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-    return launch_h3d<128, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  }
-  {
-    // up to 64 output channels: 256 x 64 tiles (64 x 64 per wave), or 192 x 64 (96 x 32 per wave) where that saves a round --
-    // 300 tiles of 256 rows are two rounds on 256 CUs, 400 tiles of 192 rows are two shorter ones
-    const int cus = num_cus() & ~7;
-    auto cost = [&](int bm) { return cdiv64(cdiv64(p.P, bm), cus) * bm; };
-    if (cost(192) < cost(256) && wdno_debug_mode != 9) return launch_h3d<192, 64, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  }
+  // Tile shape: the one with the least (rounds of the persistent grid) x (tile area), lightly weighted by how much operand
+  // traffic a shape needs per MFMA. Examples on 256 CUs: a 256-channel layer at the 10 x 10 level is 300 tiles of 128 x 128 --
+  // two rounds, the second with 44 tiles -- but 200 tiles of 192 x 128 (0.258 -> 0.196 ms); a 64-channel layer at the 20 x 20
+  // level is 300 tiles of 256 x 64 but 400 shorter ones of 192 x 64 (0.329 -> 0.267 ms). debug 9: the two original shapes only.
+  const int cus = num_cus() & ~7;
+  auto cost = [&](int bm, int bn, double weight) {
+    return (double)(cdiv64(cdiv64(p.P, bm) * cdiv(g.K, bn), cus) * bm * bn) * weight;
+  };
+  const bool narrow_only = g.K <= 64, all = wdno_debug_mode != 9;
+  int best = narrow_only ? 2 : 0;
+  double c = narrow_only ? cost(256, 64, 1.04) : cost(128, 128, 1.0);
+  if (!narrow_only && all && cost(192, 128, 1.0) < c) { best = 1; c = cost(192, 128, 1.0); }
+  if (!narrow_only && all && cost(256, 64, 1.04) < c) { best = 2; c = cost(256, 64, 1.04); }
+  if (all && cost(192, 64, 1.08) < c) { best = 3; c = cost(192, 64, 1.08); }
+  if (best == 0) return launch_h3d<128, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (best == 1) return launch_h3d<192, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (best == 3) return launch_h3d<192, 64, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   return launch_h3d<256, 64, 4, 1, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }

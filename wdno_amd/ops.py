@@ -553,12 +553,14 @@ def _fwd_h3_kernel_name(pixels, k, ks):
     cdiv = lambda a, b: -(-a // b)
     tiles = cdiv(pixels, 128) * cdiv(k, 128) if k > 64 else cdiv(pixels, 256)
     if tiles >= 100 and max(ks) <= 8:
-        cus = 256                                    # the choice between tile heights is made for the device's CU count
-        if k <= 64:
-            cost64 = lambda bm: cdiv(cdiv(pixels, bm), cus) * bm
-            return 'conv_fwd_h3d_kernel<192,64>' if cost64(192) < cost64(256) else 'conv_fwd_h3d_kernel<256,64>'
-        cost = lambda bm: cdiv(cdiv(pixels, bm) * cdiv(k, 128), cus) * bm
-        return 'conv_fwd_h3d_kernel<192,128>' if cost(192) < cost(128) else 'conv_fwd_h3d_kernel<128,128>'
+        cus = 256                                    # the tile shape is chosen for the device's CU count (csrc/conv_h3d.hip)
+        cost = lambda bm, bn, wgt: cdiv(cdiv(pixels, bm) * cdiv(k, bn), cus) * bm * bn * wgt
+        shapes = [(256, 64, 1.04), (192, 64, 1.08)] if k <= 64 else [(128, 128, 1.0), (192, 128, 1.0), (256, 64, 1.04), (192, 64, 1.08)]
+        best = shapes[0]
+        for sh in shapes[1:]:
+            if cost(*sh) < cost(*best):
+                best = sh
+        return f'conv_fwd_h3d_kernel<{best[0]},{best[1]}>'
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
 
 
