@@ -221,7 +221,7 @@ int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const float* ksta
                           void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ nn.Linear on a few rows
- * (time-embedding MLPs; conv3d.py:118-133, 286-296; unet.py:151-165). P <= 16 rows, C % 4 == 0, strides in floats. The weight
+ * (time-embedding MLPs; conv3d.py:118-133, 286-296; unet.py:151-165). P <= 1024 rows, C % 4 == 0, strides in floats. The weight
  * is the reference's own [K][C] tensor (row stride w_stride), no packing. y [P][Kp] is zero in columns K..Kp-1. The data
  * gradient is the same call on the transposed weight. dw [K][C] contiguous; db [K] or NULL. */
 int wdno_linear_rows_fwd(const float* x, int x_stride, const float* w, int w_stride, const float* bias, float* y, int P, int C, int K,

@@ -258,7 +258,7 @@ def test_linear(ops):
 
 
 @pytest.mark.parametrize('rows,cin,cout,bias', [(8, 256, 512, True), (8, 64, 256, True), (16, 256, 128, False), (1, 32, 12, True),
-                                               (3, 128, 256, True)])
+                                               (3, 128, 256, True), (64, 512, 1024, True), (100, 128, 256, True)])
 def test_linear_on_a_few_rows(ops, rows, cin, cout, bias):
     """The time-embedding MLPs (8 samples): the one-wave-per-feature kernels on the unpacked weight, forward, data gradient
     (same kernel on the transposed weight), weight and bias gradient."""

@@ -1,5 +1,6 @@
 // linear_rows.hip -- nn.Linear on a handful of rows (the time-embedding MLPs: 8 samples x 64..512 features).
 //
+// (any row count up to LR_MAXROWS works -- rows go in groups of 16 -- but the point is the small batches.)
 // A train step of the smoke U-Net runs ~50 of these forward and as many backward (time_mlp and the scale/shift projection
 // of every ResnetBlock, video_diffusion_pytorch_conv3d.py:118-133, 286-296; burgers unet.py:151-165). As 128 x 128 implicit-GEMM
 // tiles each is ONE block walking the whole reduction: ~34 us for 1 MFLOP. Here the weight stays in the reference layout
@@ -10,7 +11,8 @@
 //   wgrad     dw[k][c] = sum_p dy[p][k] x[p][c], db[k] = sum_p dy[p][k]
 #include "common.h"
 
-#define LR_MAXP 16
+#define LR_MAXP 16          // rows handled per pass (registers)
+#define LR_MAXROWS 1024     // beyond this the implicit-GEMM kernels take over anyway
 
 __global__ __launch_bounds__(256) void linear_rows_fwd_kernel(const float* __restrict__ x, int xs, const float* __restrict__ w, int ws,
                                                                const float* __restrict__ bias, float* __restrict__ y, int P, int C, int K,
@@ -18,6 +20,9 @@ __global__ __launch_bounds__(256) void linear_rows_fwd_kernel(const float* __res
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + wave;
   if (k >= Kp) return;
+  x += (int64_t)blockIdx.y * LR_MAXP * xs;        // rows in groups of LR_MAXP over blockIdx.y
+  y += (int64_t)blockIdx.y * LR_MAXP * Kp;
+  P = min(LR_MAXP, P - (int)blockIdx.y * LR_MAXP);
   float acc[LR_MAXP];
 #pragma unroll
   for (int p = 0; p < LR_MAXP; ++p) acc[p] = 0.f;
@@ -48,38 +53,44 @@ __global__ __launch_bounds__(256) void linear_rows_wgrad_kernel(const float* __r
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + wave;
   if (k >= K) return;
-  float g[LR_MAXP];
   float gs = 0.f;
+  float4* orow = reinterpret_cast<float4*>(dw + (int64_t)k * C);
+  for (int c4 = lane; c4 < (C >> 2) || c4 == lane; c4 += 64) {       // (every lane makes at least one pass: db)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gsum = 0.f;
+    for (int p0 = 0; p0 < P; p0 += LR_MAXP) {                         // rows in groups of LR_MAXP
+      float g[LR_MAXP];
 #pragma unroll
-  for (int p = 0; p < LR_MAXP; ++p) {
-    g[p] = p < P ? dy[(int64_t)p * dys + k] : 0.f;
-    gs += g[p];
+      for (int p = 0; p < LR_MAXP; ++p) {
+        g[p] = p0 + p < P ? dy[(int64_t)(p0 + p) * dys + k] : 0.f;
+        gsum += g[p];
+      }
+      if (c4 < (C >> 2)) {
+#pragma unroll
+        for (int p = 0; p < LR_MAXP; ++p)
+          if (p0 + p < P) {
+            const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)(p0 + p) * xs)[c4];
+            a.x += g[p] * xv.x; a.y += g[p] * xv.y; a.z += g[p] * xv.z; a.w += g[p] * xv.w;
+          }
+      }
+    }
+    if (c4 < (C >> 2)) orow[c4] = a;
+    gs = gsum;
   }
   if (db && lane == 0) db[k] = gs;
-  float4* orow = reinterpret_cast<float4*>(dw + (int64_t)k * C);
-  for (int c4 = lane; c4 < (C >> 2); c4 += 64) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int p = 0; p < LR_MAXP; ++p)
-      if (p < P) {
-        const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)p * xs)[c4];
-        a.x += g[p] * xv.x; a.y += g[p] * xv.y; a.z += g[p] * xv.z; a.w += g[p] * xv.w;
-      }
-    orow[c4] = a;
-  }
 }
 
 extern "C" int wdno_linear_rows_fwd(const float* x, int x_stride, const float* w, int w_stride, const float* bias, float* y, int P, int C,
                                     int K, int Kp, wdno_stream_t s) {
   WDNO_REQUIRE(P > 0 && C > 0 && K > 0 && Kp >= K && x_stride >= C && w_stride >= C);
-  if (P > LR_MAXP || (C & 3) || (x_stride & 3) || (w_stride & 3)) return WDNO_EUNSUPPORTED;
-  linear_rows_fwd_kernel<<<cdiv(Kp, 4), 256, 0, as_stream(s)>>>(x, x_stride, w, w_stride, bias, y, P, C, K, Kp);
+  if (P > LR_MAXROWS || (C & 3) || (x_stride & 3) || (w_stride & 3)) return WDNO_EUNSUPPORTED;
+  linear_rows_fwd_kernel<<<dim3(cdiv(Kp, 4), cdiv(P, LR_MAXP)), 256, 0, as_stream(s)>>>(x, x_stride, w, w_stride, bias, y, P, C, K, Kp);
   return wdno_check_launch();
 }
 extern "C" int wdno_linear_rows_wgrad(const float* x, int x_stride, const float* dy, int dy_stride, float* dw, float* db, int P, int C, int K,
                                       wdno_stream_t s) {
   WDNO_REQUIRE(P > 0 && C > 0 && K > 0 && x_stride >= C && dy_stride >= K);
-  if (P > LR_MAXP || (C & 3) || (x_stride & 3)) return WDNO_EUNSUPPORTED;
+  if (P > LR_MAXROWS || (C & 3) || (x_stride & 3)) return WDNO_EUNSUPPORTED;
   linear_rows_wgrad_kernel<<<cdiv(K, 4), 256, 0, as_stream(s)>>>(x, x_stride, dy, dy_stride, dw, db, P, C, K);
   return wdno_check_launch();
 }

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   int64_t r1 = r0 + rows_per_block;
   if (r1 > P) r1 = P;
-  for (int c0 = 0; c0 < C; c0 += 64) {
-    int c = c0 + tx;
+  for (int c0 = blockIdx.y * 64; c0 < C; c0 += 64 * gridDim.y) {      // column tiles over blockIdx.y: few rows x many columns
+    int c = c0 + tx;                                                    // (a [64, 2048] matrix was ONE block walking 32 tiles: 51 us)
     double acc = 0.0;
     if (c < C)
       for (int64_t r = r0 + ty; r < r1; r += 4) acc += (double)in[r * C + c];
@@ -314,7 +314,9 @@ extern "C" int wdno_colsum(const float* in, float* out, int64_t P, int C, void* 
   if (ws_bytes < wdno_colsum_ws_bytes(P, C)) return WDNO_EWORKSPACE;
   int nb = colsum_blocks(P);
   int64_t rpb = cdiv64(P, nb);
-  colsum_partial_kernel<<<nb, 256, 0, as_stream(s)>>>(in, (double*)ws, P, C, rpb);
+  int gy = cdiv(C, 64);
+  if ((int64_t)gy * nb > 2048) gy = 2048 / nb > 1 ? 2048 / nb : 1;
+  colsum_partial_kernel<<<dim3(nb, gy), 256, 0, as_stream(s)>>>(in, (double*)ws, P, C, rpb);
   partial_rows_sum_kernel<double><<<cdiv(C, 32), PRS_THREADS, 0, as_stream(s)>>>((const double*)ws, out, nb, C);
   return wdno_check_launch();
 }

@@ -671,7 +671,7 @@ def _pad_vec(v, n):
     return out
 
 
-LINEAR_ROWS_MAX = int(os.environ.get('WDNO_LINEAR_ROWS', '16'))      # at most LR_MAXP of csrc/linear_rows.hip; 0 = off
+LINEAR_ROWS_MAX = int(os.environ.get('WDNO_LINEAR_ROWS', '512'))      # at most LR_MAXROWS of csrc/linear_rows.hip; 0 = off
 
 
 def _linear_rows_backward(ctx, gy):
