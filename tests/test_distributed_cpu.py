@@ -56,3 +56,50 @@ def test_flat_gradient_allreduce_world2():
     tot.backward()
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     assert torch.allclose(out[0], ref, rtol=1e-6, atol=1e-7)
+
+
+def _worker_overlap(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from wdno_amd.trainer import FlatBuffers, OverlappedAllReduce, allreduce_mean_
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3),
+                                torch.nn.Linear(3, 3))
+    model[5].weight.requires_grad_(True)
+    unused = torch.nn.Parameter(torch.ones(7))                  # never reached by backward: its bucket is launched by finish()
+    buf = FlatBuffers(list(model.parameters()) + [unused])
+    ar = OverlappedAllReduce(buf, n_buckets=3)
+    assert len(ar.bounds) >= 2 and ar.bounds[0][0] == 0 and ar.bounds[-1][1] == buf.numel
+    assert all(a[1] == b[0] for a, b in zip(ar.bounds, ar.bounds[1:]))          # contiguous, parameter-aligned spans
+    g = torch.Generator().manual_seed(200 + rank)
+    res = []
+    for it in range(2):                                         # two steps: the hooks must re-arm
+        x = torch.randn(4, 6, generator=g)
+        y = torch.randn(4, 3, generator=g)
+        buf.zero_grad()
+        ar.begin()
+        ((model(x) - y) ** 2).mean().backward()
+        ar.finish()
+        over = buf.flat_grad.clone()
+        buf.zero_grad()                                         # the same step with one all-reduce after backward
+        ((model(x) - y) ** 2).mean().backward()
+        buf.gather_grads()
+        allreduce_mean_(buf.flat_grad, world)
+        res.append((over, buf.flat_grad.clone()))
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce_world2():
+    """OverlappedAllReduce (buckets launched from gradient hooks during backward) gives the same flat gradient as the single
+    all-reduce after backward, including a bucket holding a parameter that receives no gradient."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_overlap, args=(world, port, out), nprocs=world, join=True)
+    for rank in range(world):
+        for over, plain in out[rank]:
+            assert torch.equal(over, plain)
+    assert torch.equal(out[0][0][0], out[1][0][0])

@@ -6,13 +6,16 @@ smoke/ddpm/diffusion_2d.py:1268-1305), whose per-step work is
 MI355X-first design:
   * all parameters live in ONE flat fp32 buffer and all gradients in another (nn.Parameters are views), so the
     gradient exchange is a single RCCL all-reduce over xGMI (95 MB smoke / 563 MB Burgers) instead of DDP's 25 MB
-    buckets, and clip + Adam are two launches over the whole model (wdno_sumsq, wdno_adam_clip_step) with the clip
+    buckets (optionally four contiguous spans, each started as soon as backward has filled it: OverlappedAllReduce,
+    WDNO_DP_OVERLAP=1), and clip + Adam are two launches over the whole model (wdno_sumsq, wdno_adam_clip_step) with the clip
     coefficient computed on the device (no host sync);
   * one process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm; gloo is used by the CPU tests, which
     exercise exactly this exchange on host buffers.
 """
 import ctypes as C
 import math
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -74,6 +77,73 @@ def allreduce_mean_(flat, world_size=None, group=None):
         return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+class OverlappedAllReduce:
+    """The gradient all-reduce of a data-parallel step, started bucket by bucket while backward is still running.
+
+    The flat gradient buffer is cut at parameter boundaries into `n_buckets` contiguous spans of about equal size. Every
+    parameter carries a post-accumulate hook; when the last parameter of a bucket has received its gradient the bucket's
+    sum all-reduce is launched asynchronously (RCCL runs it on its own stream, ordered after the kernels that wrote the
+    span), so only the bucket that finishes last -- the first layers of the network -- is exposed after backward. All ranks
+    run the same graph, hence launch the buckets in the same order. Buckets whose parameters got no gradient in this
+    backward are launched by finish()."""
+
+    def __init__(self, buf, group=None, n_buckets=4):
+        self.buf, self.group = buf, group
+        spans = list(buf._spans())
+        target = max(1, buf.numel // max(1, n_buckets))
+        self.bounds, self.bucket_of, self.members = [], [], []
+        start, members = 0, []
+        for i, (o, n) in enumerate(spans):
+            members.append(i)
+            self.bucket_of.append(len(self.bounds))
+            if o + n - start >= target and len(self.bounds) < n_buckets - 1:
+                self.bounds.append((start, o + n)); self.members.append(members)
+                start, members = o + n, []
+        if members or not self.bounds:
+            self.bounds.append((start, buf.numel)); self.members.append(members)
+        self.spans = spans
+        self.active = False
+        self.pending, self.launched, self.handles = [], [], []
+        for i, p in enumerate(buf.params):
+            p.register_post_accumulate_grad_hook(lambda t, i=i: self._ready(i))
+
+    def begin(self):
+        self.pending = [len(m) for m in self.members]
+        self.launched = [False] * len(self.bounds)
+        self.handles = []
+        self.active = True
+
+    def _ready(self, i):
+        if not self.active:
+            return
+        b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0 and not self.launched[b]:
+            self._launch(b)
+
+    def _launch(self, b):
+        flat = self.buf.flat_grad
+        for i in self.members[b]:                     # autograd adds in place into the flat views; anything else is copied in first
+            p, (o, n) = self.buf.params[i], self.spans[i]
+            if p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + 4 * o:
+                flat[o:o + n].view(p.shape).copy_(p.grad)
+                p.grad = flat[o:o + n].view(p.shape)
+        s, e = self.bounds[b]
+        self.launched[b] = True
+        if e > s:
+            self.handles.append(dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Launch what backward did not complete, then make the current stream wait for every bucket."""
+        self.active = False
+        for b in range(len(self.bounds)):
+            if not self.launched[b]:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
 
 
 class FlatAdam:
@@ -165,14 +235,28 @@ class TrainStep:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.ema = FlatEMA(self.opt.buf.flat_param, ema_decay, ema_update_every) if (use_ema and self.rank == 0) else None
         self.step_idx = 0
+        # WDNO_DP_OVERLAP=1: the gradient exchange starts bucket by bucket during backward. Opt-in: it is verified on gloo
+        # (tests/test_distributed_cpu.py) but has not run over RCCL on a multi-GPU node yet; the default is one all-reduce of the
+        # whole buffer after backward (~1-2 ms of a 45 ms step at 8 GPUs).
+        self.overlap = (OverlappedAllReduce(self.opt.buf, group, int(os.environ.get('WDNO_DP_BUCKETS', '4')))
+                        if self.world > 1 and os.environ.get('WDNO_DP_OVERLAP', '0') == '1' else None)
 
-    def step(self, batch, **loss_kwargs):
-        self.opt.zero_grad()
-        loss = self.model(batch, **loss_kwargs)
+    def _backward_and_exchange(self, loss):
+        if self.overlap is not None:
+            self.overlap.begin()
+            loss.backward()
+            self.overlap.finish()
+            self.opt.buf.gather_grads()
+            return
         loss.backward()
         self.opt.buf.gather_grads()
         if self.world > 1:
             allreduce_mean_(self.opt.buf.flat_grad, self.world, self.group)
+
+    def step(self, batch, **loss_kwargs):
+        self.opt.zero_grad()
+        loss = self.model(batch, **loss_kwargs)
+        self._backward_and_exchange(loss)
         lr = self.lr_schedule(self.base_lr, self.step_idx)
         gnorm = self.opt.step(lr=lr, grad_scale=1.0 / self.world)
         self.step_idx += 1
@@ -184,10 +268,7 @@ class TrainStep:
         """Same as step() with injected timestep / noise (parity tests)."""
         self.opt.zero_grad()
         loss = self.model.p_losses(x0, t, noise=noise)
-        loss.backward()
-        self.opt.buf.gather_grads()
-        if self.world > 1:
-            allreduce_mean_(self.opt.buf.flat_grad, self.world, self.group)
+        self._backward_and_exchange(loss)
         lr = self.lr_schedule(self.base_lr, self.step_idx)
         gnorm = self.opt.step(lr=lr, grad_scale=1.0 / self.world)
         self.step_idx += 1
