@@ -28,8 +28,9 @@ def sinusoidal_embedding(t, dim, theta=10000.0):
 
 def time_mlp(sd, pfx, t, dim):
     """[SinusoidalPosEmb, Linear, GELU(erf), Linear]   unet.py:301-306 / conv3d.py:405-410."""
-    e = sinusoidal_embedding(t, dim)
-    e = F.linear(e, sd[pfx + '1.weight'], sd[pfx + '1.bias'])
+    w1 = sd[pfx + '1.weight']
+    e = sinusoidal_embedding(t, dim).to(w1.dtype)      # always built in fp32 like the reference; upcast only for an fp64 evaluation
+    e = F.linear(e, w1, sd[pfx + '1.bias'])
     e = F.gelu(e)
     return F.linear(e, sd[pfx + '3.weight'], sd[pfx + '3.bias'])
 

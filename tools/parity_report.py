@@ -1,0 +1,305 @@
+"""Parity report (GPU box): how far is the HIP product path from the reference, measured honestly.
+
+Three evaluations of the SAME function on the SAME inputs are compared:
+  hip  : the product path (wdno_amd modules on the MI355X), default arithmetic and WDNO_CONV_MATH=fp32
+  cpu32: the CPU oracle in fp32 (on the golden chains this is bit-identical to the reference's own outputs: same torch CPU kernels)
+  cpu64: the CPU oracle evaluated in fp64 on the same fp32 weights / inputs = the exact value of the function
+so that `hip vs cpu64` is the true error of the product path and `cpu32 vs cpu64` is the round-off the reference's own
+fp32 evaluation carries. Prints one JSON document (also written to gpurun_out/parity_report.json).
+
+    python tools/parity_report.py [--quick]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wdno_amd import tree_path  # noqa: E402
+for _t in ('third_party', 'smoke', 'burgers'):
+    sys.path.insert(0, tree_path(_t))
+from oracle import diffusion_ref as D, unet_ref as U  # noqa: E402  (checker only)
+from tests.helpers import load_npz, manifest, noise_seq, rel_l2, weights  # noqa: E402
+from wdno_amd import ops  # noqa: E402
+
+DEV = 'cuda'
+M = manifest()
+f64 = torch.float64
+
+
+def cast_sd(sd, dt):
+    return {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def cast_buf(buf, dt):
+    return {k: v.to(dt) for k, v in buf.items()}
+
+
+def set_math(mode):
+    ops.CONV_MATH = mode
+
+
+# ------------------------------------------------------------------------------------------------ golden chains (tiny models)
+def smoke_chains():
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion
+    g = load_npz('ref_smoke_diffusion.npz')
+    c = M['smoke_diffusion']
+    u, d = c['unet'], dict(c['diffusion'])
+    d['padded_shape'] = tuple(d['padded_shape']); d['ori_shape'] = tuple(d['ori_shape'])
+    out = {}
+
+    def cpu(dt):
+        sd = cast_sd(weights(g, 'w::model.'), dt)
+        model = lambda x, t: U.unet3d_forward(sd, x, t, dim=u['dim'], dim_mults=tuple(u['dim_mults']), groups=u['resnet_groups'])
+        kw = dict(padded_shape=d['padded_shape'], init=torch.from_numpy(g['ddim_init']).to(dt), control=torch.from_numpy(g['ddim_control']).to(dt))
+        with torch.no_grad():
+            a = D.smoke_ddim_sample(model, cast_buf(D.make_buffers('sigmoid', 1000), dt), [n.to(dt) for n in noise_seq(g, 'ddim')], 1000, 4, 1.0, **kw)
+            b = D.smoke_p_sample_loop(model, cast_buf(D.make_buffers('sigmoid', 5), dt), [n.to(dt) for n in noise_seq(g, 'ddpm5')], 5, **kw)
+        return a, b
+
+    def hip():
+        net = Unet3D_with_Conv3D(dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_groups=u['resnet_groups'])
+        dif = GaussianDiffusion(net, loss_layer_weight=torch.from_numpy(g['lw']), **d)
+        dif.load_state_dict(weights(g, 'w::'), strict=True)
+        dif = dif.to(DEV)
+        init, control = torch.from_numpy(g['ddim_init']).to(DEV), torch.from_numpy(g['ddim_control']).to(DEV)
+        seq = iter([n.to(DEV) for n in noise_seq(g, 'ddim')])
+        dif.sample_noise = lambda shape, device: next(seq)
+        a = dif.sample(batch_size=2, init=init, control=control)
+        dif5 = GaussianDiffusion(dif.model, loss_layer_weight=torch.from_numpy(g['lw']), **{**d, 'timesteps': 5, 'sampling_timesteps': None}).to(DEV)
+        seq5 = iter([n.to(DEV) for n in noise_seq(g, 'ddpm5')])
+        dif5.sample_noise = lambda shape, device: next(seq5)
+        b = dif5.sample(batch_size=2, init=init, control=control)
+        return a.cpu(), b.cpu()
+
+    a64, b64 = cpu(f64)
+    ah, bh = hip()
+    for tag, h, e, ref in (('ddim4', ah, a64, g['ddim_out']), ('ddpm5', bh, b64, g['ddpm5_out'])):
+        out[tag] = {'hip_vs_reference': rel_l2(h, ref), 'hip_vs_exact': rel_l2(h, e), 'reference_vs_exact': rel_l2(torch.from_numpy(ref), e)}
+    return out
+
+
+def burgers_chains():
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion
+    g = load_npz('ref_burgers_diffusion.npz')
+    c = M['burgers_diffusion']
+    u, d = c['unet'], dict(c['diffusion'])
+    d['seq_length'] = tuple(d['seq_length'])
+    flags = dict(pad=True, u0=True, uT=False, f=True)
+    out = {}
+
+    def cpu(dt):
+        sd = cast_sd(weights(g, 'w::model.'), dt)
+        model = lambda x, t: U.unet2d_forward(sd, x, t, dim=u['dim'], dim_mults=tuple(u['dim_mults']), groups=u['resnet_block_groups'])
+        kw = dict(padded_shape=d['padded_shape'], flags=flags, u0=torch.from_numpy(g['ddim_u_init']).to(dt), f=torch.from_numpy(g['ddim_f']).to(dt))
+        with torch.no_grad():
+            a = D.burgers_ddim_sample(model, cast_buf(D.make_buffers('cosine', 1000), dt), [n.to(dt) for n in noise_seq(g, 'ddim')], 1000, 4, 1.0, **kw)
+            b = D.burgers_p_sample_loop(model, cast_buf(D.make_buffers('cosine', 5), dt), [n.to(dt) for n in noise_seq(g, 'ddpm5')], 5, **kw)
+        return a, b
+
+    def make(**over):
+        dd = dict(d); dd.update(over)
+        net = Unet2D(dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_block_groups=u['resnet_block_groups'])
+        dif = GaussianDiffusion(net, loss_layer_weight=torch.from_numpy(g['lw']), **dd)
+        sd = weights(g, 'w::')
+        if over.get('timesteps'):
+            dif.load_state_dict({k: v for k, v in sd.items() if k.startswith('model.')}, strict=False)
+        else:
+            dif.load_state_dict(sd, strict=True)
+        return dif.to(DEV)
+
+    u_init, f = torch.from_numpy(g['ddim_u_init']).to(DEV), torch.from_numpy(g['ddim_f']).to(DEV)
+    dif = make()
+    seq = iter([n.to(DEV) for n in noise_seq(g, 'ddim')])
+    dif.sample_noise = lambda shape, device: next(seq)
+    ah = dif.sample(batch_size=2, u_init=u_init, f=f).cpu()
+    dif5 = make(timesteps=5, sampling_timesteps=None)
+    seq5 = iter([n.to(DEV) for n in noise_seq(g, 'ddpm5')])
+    dif5.sample_noise = lambda shape, device: next(seq5)
+    bh = dif5.sample(batch_size=2, u_init=u_init, f=f).cpu()
+    a64, b64 = cpu(f64)
+    for tag, h, e, ref in (('ddim4', ah, a64, g['ddim_out']), ('ddpm5', bh, b64, g['ddpm5_out'])):
+        out[tag] = {'hip_vs_reference': rel_l2(h, ref), 'hip_vs_exact': rel_l2(h, e), 'reference_vs_exact': rel_l2(torch.from_numpy(ref), e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ full-size training step
+def _grad_table(named_hip, ref32, ref64):
+    """worst / median rel-L2 over parameters of: hip vs cpu32, hip vs cpu64, cpu32 vs cpu64."""
+    rows = []
+    for k, gh in named_hip.items():
+        if k not in ref64 or ref64[k] is None:
+            continue
+        rows.append((k, rel_l2(gh, ref32[k]), rel_l2(gh, ref64[k]), rel_l2(ref32[k], ref64[k])))
+    def stat(i):
+        v = sorted(r[i] for r in rows)
+        return {'worst': v[-1], 'median': v[len(v) // 2], 'worst_param': max(rows, key=lambda r: r[i])[0]}
+    return {'n_params': len(rows), 'hip_vs_cpu32': stat(1), 'hip_vs_exact': stat(2), 'cpu32_vs_exact': stat(3)}
+
+
+def smoke_full(batch=2, frames=24, size=40, modes=('f16x3', 'f32')):
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion
+    torch.manual_seed(0)
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    lw = torch.linspace(1.0, 22.0, 42).reshape(1, 1, 42, 1, 1)
+    ps = (18, 34, 34) if size == 40 else (frames * 3 // 4, size * 3 // 4, size * 3 // 4)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(batch, frames, 42, size, size, generator=g) * 0.5
+    noise = torch.randn(batch, frames, 42, size, size, generator=g)
+    t = torch.tensor([37, 911][:batch] if batch <= 2 else list(range(17, 17 + 97 * batch, 97)))
+    res = {'shape': list(x0.shape)}
+
+    def cpu(dt):
+        sd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() and not k.endswith('freqs') else (v.to(dt) if v.is_floating_point() else v))
+              for k, v in sd0.items()}
+        model = lambda x, tt: U.unet3d_forward(sd, x, tt, dim=64, dim_mults=(1, 2, 4), groups=8)
+        t0 = time.perf_counter()
+        loss = D.smoke_p_losses(model, cast_buf(D.make_buffers('sigmoid', 1000), dt), x0.to(dt), t, noise.to(dt), padded_shape=ps, loss_layer_weight=lw.to(dt))
+        loss.backward()
+        return loss.item(), {k: v.grad for k, v in sd.items() if v.requires_grad}, time.perf_counter() - t0
+
+    l32, g32, s32 = cpu(torch.float32)
+    l64, g64, s64 = cpu(f64)
+    res['cpu_seconds'] = {'fp32': round(s32, 2), 'fp64': round(s64, 2)}
+    res['loss'] = {'cpu32': l32, 'exact': l64, 'cpu32_vs_exact': abs(l32 - l64) / abs(l64)}
+    for mode in modes:
+        set_math(mode)
+        ops.bump_weight_epoch()
+        net_h = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+        net_h.load_state_dict(sd0)
+        dif = GaussianDiffusion(net_h, lw, True, True, True, False, 'bior1.3', 'zero', ps, (32, 64, 64), image_size=size, frames=frames).to(DEV)
+        ops.PROFILE = {}
+        loss = dif.p_losses(x0.to(DEV), t.to(DEV), noise=noise.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        kernels, ops.PROFILE = sorted(ops.PROFILE), None
+        gh = {k: p.grad.cpu() for k, p in net_h.named_parameters() if p.grad is not None}
+        res[mode] = {'loss': loss.item(), 'loss_vs_cpu32': abs(loss.item() - l32) / abs(l32), 'loss_vs_exact': abs(loss.item() - l64) / abs(l64),
+                     'conv_kernels_used': kernels, 'grads': _grad_table(gh, g32, g64)}
+    set_math('f16x3')
+    return res
+
+
+def burgers_full(batch=2, modes=('f16x3', 'f32')):
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion
+    torch.manual_seed(1)
+    net = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    x0 = torch.randn(batch, 9, 64, 64, generator=g) * 0.5
+    noise = torch.randn(batch, 9, 64, 64, generator=g)
+    t = torch.tensor([77, 805][:batch])
+    lw = torch.ones(1, 9, 1, 1)
+    flags = dict(pad=True, u0=True, uT=False, f=True)
+    res = {'shape': list(x0.shape)}
+
+    def cpu(dt):
+        sd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd0.items()}
+        model = lambda x, tt: U.unet2d_forward(sd, x, tt, dim=128, dim_mults=(1, 2, 4, 8), groups=1)
+        t0 = time.perf_counter()
+        loss = D.burgers_p_losses(model, cast_buf(D.make_buffers('cosine', 1000), dt), x0.to(dt), t, noise.to(dt), padded_shape=[41, 60],
+                                  loss_layer_weight=lw.to(dt), flags=flags)
+        loss.backward()
+        return loss.item(), {k: v.grad for k, v in sd.items() if v.requires_grad}, time.perf_counter() - t0
+
+    l32, g32, s32 = cpu(torch.float32)
+    l64, g64, s64 = cpu(f64)
+    res['cpu_seconds'] = {'fp32': round(s32, 2), 'fp64': round(s64, 2)}
+    res['loss'] = {'cpu32': l32, 'exact': l64, 'cpu32_vs_exact': abs(l32 - l64) / abs(l64)}
+    for mode in modes:
+        set_math(mode)
+        ops.bump_weight_epoch()
+        net_h = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+        net_h.load_state_dict(sd0)
+        dif = GaussianDiffusion(net_h, seq_length=(64, 64), padded_shape=[41, 60], ori_shape=[81, 120], loss_layer_weight=lw,
+                                is_condition_pad=True, is_condition_u0=True, is_condition_f=True).to(DEV)
+        ops.PROFILE = {}
+        loss = dif.p_losses(x0.to(DEV), t.to(DEV), noise=noise.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        kernels, ops.PROFILE = sorted(ops.PROFILE), None
+        gh = {k: p.grad.cpu() for k, p in net_h.named_parameters() if p.grad is not None}
+        res[mode] = {'loss': loss.item(), 'loss_vs_cpu32': abs(loss.item() - l32) / abs(l32), 'loss_vs_exact': abs(loss.item() - l64) / abs(l64),
+                     'conv_kernels_used': kernels, 'grads': _grad_table(gh, g32, g64)}
+    set_math('f16x3')
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ full-size DDIM chain A/B
+def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32')):
+    """A `steps`-step DDIM chain (eta = 1, injected noise) of the full-width smoke model at the bench shape."""
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion
+    torch.manual_seed(0)
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    lw = torch.ones(1, 1, 42, 1, 1)
+    g = torch.Generator().manual_seed(7)
+    shape = (batch, 24, 42, 40, 40)
+    ns = [torch.randn(shape, generator=g) for _ in range(steps + 1)]
+    init = torch.randn(batch, 24, 40, 40, generator=g) * 0.3
+    control = torch.randn(batch, 24, 16, 40, 40, generator=g) * 0.3
+    res = {'shape': list(shape), 'ddim_steps': steps}
+
+    def cpu(dt):
+        sd = cast_sd(sd0, dt)
+        model = lambda x, tt: U.unet3d_forward(sd, x, tt, dim=64, dim_mults=(1, 2, 4), groups=8)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            o = D.smoke_ddim_sample(model, cast_buf(D.make_buffers('sigmoid', 1000), dt), [n.to(dt) for n in ns], 1000, steps, 1.0,
+                                    padded_shape=(18, 34, 34), init=init.to(dt), control=control.to(dt))
+        return o, time.perf_counter() - t0
+
+    o32, s32 = cpu(torch.float32)
+    o64, s64 = cpu(f64)
+    res['cpu_seconds'] = {'fp32': round(s32, 2), 'fp64': round(s64, 2)}
+    res['cpu32_vs_exact'] = rel_l2(o32, o64)
+    for mode in modes:
+        set_math(mode)
+        ops.bump_weight_epoch()
+        net_h = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+        net_h.load_state_dict(sd0)
+        dif = GaussianDiffusion(net_h, lw, True, True, True, False, 'bior1.3', 'zero', (18, 34, 34), (32, 64, 64), image_size=40, frames=24,
+                                sampling_timesteps=steps, ddim_sampling_eta=1.0).to(DEV)
+        seq = iter([n.to(DEV) for n in ns])
+        dif.sample_noise = lambda shape, device: next(seq)
+        o = dif.sample(batch_size=batch, init=init.to(DEV), control=control.to(DEV)).cpu()
+        res[mode] = {'hip_vs_cpu32': rel_l2(o, o32), 'hip_vs_exact': rel_l2(o, o64)}
+    set_math('f16x3')
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'parity_report.json'))
+    args = ap.parse_args()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    rep = {}
+    for name, fn in (('smoke_golden_chains', smoke_chains), ('burgers_golden_chains', burgers_chains),
+                     ('smoke_full_train_step', smoke_full), ('burgers_full_train_step', burgers_full),
+                     ('smoke_full_ddim_chain', (lambda: smoke_chain_full(4)) if args.quick else smoke_chain_full)):
+        t0 = time.perf_counter()
+        try:
+            rep[name] = fn()
+        except Exception as e:      # keep going: the report is diagnostic
+            import traceback
+            rep[name] = {'error': repr(e), 'trace': traceback.format_exc()[-1500:]}
+        rep[name]['seconds'] = round(time.perf_counter() - t0, 1)
+        print(name, json.dumps(rep[name], indent=1), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, 'w') as f:
+        json.dump(rep, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
