@@ -278,6 +278,11 @@ int wdno_p_sample_update(const float* x, const float* eps, const float* noise, c
 int wdno_ddim_update(const float* x, const float* eps, const float* noise, const int64_t* t,
                      const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, float sqrt_an, float c, float sigma,
                      float* x_next, float* x_start, int64_t B, int64_t per_sample, wdno_stream_t s);
+/* the same update with (sqrt_an, c, sigma) read from three device floats: every step of a sampling loop is then the SAME launch,
+ * which is what lets one captured HIP graph be replayed for the whole loop (diffusion_1d.py:376-460, diffusion_2d.py:851-933) */
+int wdno_ddim_update_dev(const float* x, const float* eps, const float* noise, const int64_t* t,
+                         const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* coef_dev,
+                         float* x_next, float* x_start, int64_t B, int64_t per_sample, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ trainer step
  * Flat-buffer optimiser (train_diffusion.py:117,211-216 ; diffusion_2d.py:1159,1283-1291).

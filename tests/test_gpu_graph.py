@@ -1,0 +1,99 @@
+"""HIP-graph replay of the unguided sampling step (diffusion_core.sampling_loop / _StepGraph): a loop whose steps are replays of
+ONE captured graph must give bit-identical results to the same loop issued launch by launch, for both trees, ancestral and DDIM
+sampling, and for the full-width split-fp16 convolution path (whose amax records are re-zeroed inside the graph). GPU box only.
+
+Reference loops: burgers/ddpm_burgers/diffusion_1d.py:310-460, smoke/ddpm/diffusion_2d.py:788-933."""
+import sys
+
+import pytest
+import torch
+
+from tests.helpers import load_npz, manifest, weights
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+M = manifest()
+
+
+@pytest.fixture(scope='module')
+def trees():
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion as GD1
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion as GD2
+    return dict(Unet2D=Unet2D, GD1=GD1, Unet3D=Unet3D_with_Conv3D, GD2=GD2)
+
+
+def _run(dif, use_graph, seed, **kw):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    dif.sample_noise = lambda shape, device: torch.randn(tuple(shape), device=device, generator=g)
+    dif.use_graph = use_graph
+    out = dif.sample(**kw)
+    torch.cuda.synchronize()
+    return out
+
+
+def _smoke(trees, **over):
+    gz = load_npz('ref_smoke_diffusion.npz')
+    c = M['smoke_diffusion']
+    u, d = c['unet'], dict(c['diffusion'])
+    d['padded_shape'] = tuple(d['padded_shape']); d['ori_shape'] = tuple(d['ori_shape'])
+    d.update(over)
+    net = trees['Unet3D'](dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_groups=u['resnet_groups'])
+    dif = trees['GD2'](net, loss_layer_weight=torch.from_numpy(gz['lw']), **d)
+    dif.load_state_dict({k: v for k, v in weights(gz, 'w::').items() if k.startswith('model.')}, strict=False)
+    return gz, dif.to(DEV)
+
+
+@pytest.mark.parametrize('over', [dict(timesteps=20, sampling_timesteps=None), dict(timesteps=1000, sampling_timesteps=12, ddim_sampling_eta=1.0),
+                                  dict(timesteps=1000, sampling_timesteps=9, ddim_sampling_eta=0.0)])
+def test_smoke_graph_replay_equals_eager(trees, over):
+    gz, dif = _smoke(trees, **over)
+    init, control = torch.from_numpy(gz['ddim_init']).to(DEV), torch.from_numpy(gz['ddim_control']).to(DEV)
+    a = _run(dif, False, 11, batch_size=2, init=init, control=control)
+    b = _run(dif, True, 11, batch_size=2, init=init, control=control)
+    assert torch.equal(a, b)
+    # second call re-uses the cached graph with new conditions and new noise
+    a2 = _run(dif, False, 12, batch_size=2, init=init * 0.5, control=control * 2.0)
+    b2 = _run(dif, True, 12, batch_size=2, init=init * 0.5, control=control * 2.0)
+    assert torch.equal(a2, b2) and not torch.equal(a, a2)
+
+
+@pytest.mark.parametrize('over', [dict(timesteps=16, sampling_timesteps=None), dict(timesteps=1000, sampling_timesteps=10, ddim_sampling_eta=1.0)])
+def test_burgers_graph_replay_equals_eager(trees, over):
+    gz = load_npz('ref_burgers_diffusion.npz')
+    c = M['burgers_diffusion']
+    u, d = c['unet'], dict(c['diffusion'])
+    d.update(over)
+    d['seq_length'] = tuple(d['seq_length'])
+    net = trees['Unet2D'](dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_block_groups=u['resnet_block_groups'])
+    dif = trees['GD1'](net, loss_layer_weight=torch.from_numpy(gz['lw']), **d)
+    dif.load_state_dict({k: v for k, v in weights(gz, 'w::').items() if k.startswith('model.')}, strict=False)
+    dif = dif.to(DEV)
+    u_init, f = torch.from_numpy(gz['ddim_u_init']).to(DEV), torch.from_numpy(gz['ddim_f']).to(DEV)
+    a = _run(dif, False, 21, batch_size=2, u_init=u_init, f=f)
+    b = _run(dif, True, 21, batch_size=2, u_init=u_init, f=f)
+    assert torch.equal(a, b)
+
+
+def test_full_width_split_path_graph_replay_equals_eager(trees):
+    """dim = 64 on a grid large enough for the split-fp16 convolutions (amax records + split planes inside the graph)."""
+    from wdno_amd import ops
+    torch.manual_seed(0)
+    net = trees['Unet3D'](dim=64, dim_mults=(1, 2, 4), channels=42)
+    dif = trees['GD2'](net, torch.ones(1, 1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero', (5, 12, 12), (8, 20, 20),
+                       image_size=16, frames=6, timesteps=1000, sampling_timesteps=10, ddim_sampling_eta=1.0).to(DEV)
+    init = torch.randn(1, 6, 16, 16, device=DEV) * 0.3
+    control = torch.randn(1, 6, 16, 16, 16, device=DEV) * 0.3
+    ops.PROFILE = {}
+    a = _run(dif, False, 31, batch_size=1, init=init, control=control)
+    used, ops.PROFILE = set(ops.PROFILE), None
+    assert any('h3' in k for k in used), used          # the split-fp16 kernels really ran
+    b = _run(dif, True, 31, batch_size=1, init=init, control=control)
+    assert torch.equal(a, b)
+    assert torch.isfinite(a).all()

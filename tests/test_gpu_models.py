@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 M = manifest()
 TOL = 1e-5
-# sampled chains start at t = T-1 where x_start = c1 x - c2 eps_hat has c2 ~ 1e2..1e3: fp32 round-off of the U-Net is
-# amplified before the clamp, so chain outputs are compared at 2e-4 (single evaluations stay at 1e-5)
-CHAIN_TOL = 2e-4
+# Sampled chains against the reference's fp32 outputs: 1e-5 where the chain is well conditioned (ancestral chains, Burgers DDIM).
+# The 4-step smoke DDIM chain starts at t = 999 where x_start = c1 x - c2 eps has c1 ~ c2 ~ 1.8e3 in fp32: the reference's own
+# output is 1.2e-5 away from the exact value of the chain (fp64 evaluation) and one fp32 step from a common state already differs
+# by 3e-5 between ANY two fp32 implementations -- measured in tests/test_gpu_fullsize.py, which gates that chain against the exact
+# evaluation instead. Here it only has to stay within what that amplification explains.
+CHAIN_TOL = 1e-5
+SMOKE_DDIM4_TOL = 1e-4
 
 
 @pytest.fixture(scope='module')
@@ -117,11 +121,13 @@ def test_smoke_sampling(trees):
     seq = iter([n.to(DEV) for n in noise_seq(gz, 'ddim')])
     dif.sample_noise = lambda shape, device: next(seq)
     out = dif.sample(batch_size=2, init=init, control=control)
-    assert rel_l2(out, gz['ddim_out']) < CHAIN_TOL
+    print('smoke ddim4 chain vs reference rel-L2', rel_l2(out, gz['ddim_out']))
+    assert rel_l2(out, gz['ddim_out']) < SMOKE_DDIM4_TOL
     dif5 = trees['GD2'](dif.model, loss_layer_weight=torch.from_numpy(gz['lw']), **{**d, 'timesteps': 5, 'sampling_timesteps': None}).to(DEV)
     seq5 = iter([n.to(DEV) for n in noise_seq(gz, 'ddpm5')])
     dif5.sample_noise = lambda shape, device: next(seq5)
     out = dif5.sample(batch_size=2, init=init, control=control)
+    print('smoke ddpm5 chain vs reference rel-L2', rel_l2(out, gz['ddpm5_out']))
     assert rel_l2(out, gz['ddpm5_out']) < CHAIN_TOL
 
 
@@ -165,11 +171,13 @@ def test_burgers_sampling(trees):
     seq = iter([n.to(DEV) for n in noise_seq(gz, 'ddim')])
     dif.sample_noise = lambda shape, device: next(seq)
     out = dif.sample(batch_size=2, u_init=u_init, f=f)
+    print('burgers ddim4 chain vs reference rel-L2', rel_l2(out, gz['ddim_out']))
     assert rel_l2(out, gz['ddim_out']) < CHAIN_TOL
     gz5, dif5 = _burgers(trees, timesteps=5, sampling_timesteps=None)
     seq5 = iter([n.to(DEV) for n in noise_seq(gz, 'ddpm5')])
     dif5.sample_noise = lambda shape, device: next(seq5)
     out = dif5.sample(batch_size=2, u_init=u_init, f=f)
+    print('burgers ddpm5 chain vs reference rel-L2', rel_l2(out, gz['ddpm5_out']))
     assert rel_l2(out, gz['ddpm5_out']) < CHAIN_TOL
 
 

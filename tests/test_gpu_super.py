@@ -11,7 +11,8 @@ from tests.helpers import GOLDEN, load_npz, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
-TOL, CHAIN_TOL = 1e-5, 2e-4
+TOL, CHAIN_TOL = 1e-5, 1e-5
+DDIM3_TOL = 1e-4      # 3-step DDIM from t = 999: c1 ~ c2 ~ 1.8e3 in fp32, see tests/test_gpu_fullsize.py
 
 
 @pytest.fixture(scope='module')
@@ -70,12 +71,14 @@ def test_smoke_super_model(trees, tag):
     seq = iter([torch.from_numpy(gz[f'ddim_noise_{i}']).to(DEV) for i in range(int(gz['ddim_n_noise']))])
     dif.sample_noise = lambda shp, device: next(seq)
     out = dif.sample(batch_size=shape[0], N_upsample=m['n_up'], init=init, control=control, low=low)
-    assert rel_l2(out, gz['ddim_out']) < CHAIN_TOL
+    print(tag, 'ddim3 chain vs reference rel-L2', rel_l2(out, gz['ddim_out']))
+    assert rel_l2(out, gz['ddim_out']) < DDIM3_TOL
     if 'ddpm3_out' in gz:
         dif3 = trees['GD2'](dif.model, **{**kw, 'timesteps': 3, 'sampling_timesteps': None}).to(DEV)
         seq3 = iter([torch.from_numpy(gz[f'ddpm3_noise_{i}']).to(DEV) for i in range(int(gz['ddpm3_n_noise']))])
         dif3.sample_noise = lambda shp, device: next(seq3)
         out = dif3.sample(batch_size=shape[0], N_upsample=m['n_up'], init=init, control=control, low=low)
+        print(tag, 'ddpm3 chain vs reference rel-L2', rel_l2(out, gz['ddpm3_out']))
         assert rel_l2(out, gz['ddpm3_out']) < CHAIN_TOL
         assert torch.equal(out[:, :, 40:80].cpu(), torch.from_numpy(gz['ddim_low']))     # p_sample_loop re-imposes the low-resolution channels
 

@@ -278,16 +278,86 @@ def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32')):
     return res
 
 
+# ------------------------------------------------------------------------------------------------ per-step errors from a common state
+def smoke_chain_steps(steps=4):
+    """Every DDIM step of the golden smoke configuration, started from the SAME state (the fp64 chain's state rounded to fp32) and
+    evaluated by the HIP path, the fp32 CPU oracle and the fp64 oracle. Separates what a step adds (U-Net round-off, and at
+    t = T-1 the fp32 arithmetic of x_start = c1 x - c2 eps with c1 ~ c2 ~ 1.8e3) from what the chain amplifies."""
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion
+    from wdno_amd import diffusion_core as K
+    g = load_npz('ref_smoke_diffusion.npz')
+    c = M['smoke_diffusion']
+    u, d = c['unet'], dict(c['diffusion'])
+    d['padded_shape'] = tuple(d['padded_shape']); d['ori_shape'] = tuple(d['ori_shape'])
+    d['sampling_timesteps'] = steps
+    net = Unet3D_with_Conv3D(dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_groups=u['resnet_groups'])
+    dif = GaussianDiffusion(net, loss_layer_weight=torch.from_numpy(g['lw']), **d)
+    dif.load_state_dict(weights(g, 'w::'), strict=True)
+    dif = dif.to(DEV)
+    sd32 = weights(g, 'w::model.')
+    sd64 = cast_sd(sd32, f64)
+    cfg = dict(dim=u['dim'], dim_mults=tuple(u['dim_mults']), groups=u['resnet_groups'])
+    b32 = D.make_buffers('sigmoid', 1000)
+    b64 = cast_buf(b32, f64)
+    gen = torch.Generator().manual_seed(7)
+    shape = (2, 4, 42, 8, 8)
+    ns = [torch.randn(shape, generator=gen) for _ in range(steps + 1)]
+    init, control = torch.from_numpy(g['ddim_init']), torch.from_numpy(g['ddim_control'])
+    x = ns[0].double().clone()
+    D.smoke_apply_conditions(x, d['padded_shape'], init=init.double(), control=control.double())
+    desc = dif._desc(shape, dif.padded_shape)
+    src = dif._condition_source(shape, DEV, init.to(DEV), control.to(DEV), None)
+    rows = []
+    with torch.no_grad():
+        for i, (time, time_next) in enumerate(D.ddim_times(1000, steps)):
+            t = torch.full((2,), time, dtype=torch.long)
+            x32 = x.float()
+            m64 = lambda a, b: U.unet3d_forward(sd64, a, b, **cfg)
+            m32 = lambda a, b: U.unet3d_forward(sd32, a, b, **cfg)
+            raw64, raw32 = m64(x32.double(), t), m32(x32, t)
+            e64, s64 = D.smoke_model_predictions(m64, b64, x32.double(), t, clip_x_start=True, rederive=True)
+            e32, s32 = D.smoke_model_predictions(m32, b32, x32, t, clip_x_start=True, rederive=True)
+            rawh = dif.model(x32.to(DEV), t.to(DEV), None)
+            if time_next < 0:
+                n64, n32 = s64, s32
+                nh, sh = K.ddim_update(dif, x32.to(DEV), rawh, None, t.to(DEV), 0., 0., 0.)
+            else:
+                n64 = D.ddim_update(b64, s64, e64, time, time_next, 1.0, ns[i + 1].double())
+                n32 = D.ddim_update(b32, s32, e32, time, time_next, 1.0, ns[i + 1])
+                sigma, cc, sqrt_an = K.ddim_coefficients(dif._ac_host, time, time_next, 1.0)
+                nh, sh = K.ddim_update(dif, x32.to(DEV), rawh, ns[i + 1].to(DEV), t.to(DEV), sqrt_an, cc, sigma)
+                D.smoke_apply_conditions(n64, d['padded_shape'], init=init.double(), control=control.double())
+                D.smoke_apply_conditions(n32, d['padded_shape'], init=init, control=control)
+                nh = K.apply_cond(nh, src, desc)
+            rows.append({'t': time, 't_next': time_next, 'c2': float(b32['sqrt_recipm1_alphas_cumprod'][time]),
+                         'eps': {'hip': rel_l2(rawh, raw64), 'cpu32': rel_l2(raw32, raw64)},
+                         'x_start': {'hip': rel_l2(sh, s64), 'cpu32': rel_l2(s32, s64)},
+                         'x_next': {'hip': rel_l2(nh, n64), 'cpu32': rel_l2(n32, n64)}})
+            x = n64
+    return {'steps': rows}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--h3-min-pixels', type=int, default=None, help='experiment: override ops.H3_MIN_PIXELS')
+    ap.add_argument('--h3-min-reduction', type=int, default=None)
+    ap.add_argument('--only', default=None, help='comma-separated section names')
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'parity_report.json'))
     args = ap.parse_args()
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    rep = {}
+    if args.h3_min_pixels is not None:
+        ops.H3_MIN_PIXELS = args.h3_min_pixels
+    if args.h3_min_reduction is not None:
+        ops.H3_MIN_REDUCTION = args.h3_min_reduction
+    rep = {'settings': {'H3_MIN_PIXELS': ops.H3_MIN_PIXELS, 'H3_MIN_REDUCTION': ops.H3_MIN_REDUCTION}}
     for name, fn in (('smoke_golden_chains', smoke_chains), ('burgers_golden_chains', burgers_chains),
                      ('smoke_full_train_step', smoke_full), ('burgers_full_train_step', burgers_full),
-                     ('smoke_full_ddim_chain', (lambda: smoke_chain_full(4)) if args.quick else smoke_chain_full)):
+                     ('smoke_full_ddim_chain', (lambda: smoke_chain_full(4)) if args.quick else smoke_chain_full),
+                     ('smoke_golden_chain_steps', smoke_chain_steps)):
+        if args.only and name not in args.only.split(','):
+            continue
         t0 = time.perf_counter()
         try:
             rep[name] = fn()

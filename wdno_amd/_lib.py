@@ -110,6 +110,7 @@ PROTOTYPES = {
     'wdno_weighted_mse_bwd': (I, [P, P, P, P, F, P, P, L, L, I, L, P]),
     'wdno_p_sample_update': (I, [P, P, P, P, P, P, P, P, P, P, P, L, L, I, P]),
     'wdno_ddim_update': (I, [P, P, P, P, P, P, F, F, F, P, P, L, L, P]),
+    'wdno_ddim_update_dev': (I, [P, P, P, P, P, P, P, P, P, L, L, P]),
     'wdno_sumsq_ws_bytes': (Z, [L]),
     'wdno_sumsq': (I, [P, L, P, P, Z, P]),
     'wdno_adam_clip_step': (I, [P, P, P, P, L, P, F, F, F, F, F, F, I, P]),

@@ -95,6 +95,7 @@ class GaussianDiffusion(nn.Module):
         self.padded_shape = padded_shape
         self.ori_shape = torch.tensor([81, 128]) if ori_shape is None else ori_shape
         self._wc_cache = None
+        self.use_graph = None       # None: HIP-graph replay of the unguided sampling step when the loop is long enough (WDNO_SAMPLE_GRAPH)
 
     # ------------------------------------------------------------------ helpers
     def sample_noise(self, shape, device):
@@ -219,12 +220,15 @@ class GaussianDiffusion(nn.Module):
         device = self.betas.device
         src, desc = self._sampling_setup(shape, kwargs)
         img = self.sample_noise(shape, device).contiguous()
-        x_start = None
-        for t in reversed(range(0, self.num_timesteps)):
-            K.apply_cond(img, src, desc)
-            self_cond = x_start if self.self_condition else None
-            img, x_start, _ = self.p_sample(img, t, self_cond, **kwargs)
-            img = img.detach().contiguous()
+        if not self._guided(kwargs) and not self.self_condition:   # unguided: fused launches, the step replayed from one HIP graph
+            img = K.sampling_loop(self, img, src, desc, cond_first=True, use_graph=self.use_graph)
+        else:
+            x_start = None
+            for t in reversed(range(0, self.num_timesteps)):
+                K.apply_cond(img, src, desc)
+                self_cond = x_start if self.self_condition else None
+                img, x_start, _ = self.p_sample(img, t, self_cond, **kwargs)
+                img = img.detach().contiguous()
         K.apply_cond(img, src, desc)
         return self.unnormalize(img)
 
@@ -234,23 +238,17 @@ class GaussianDiffusion(nn.Module):
         batch = shape[0]
         src, desc = self._sampling_setup(shape, kwargs)
         img = self.sample_noise(shape, device).contiguous()
-        x_start = None
-        guided = self._guided(kwargs)
-        for time, time_next in K.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps):
-            K.apply_cond(img, src, desc)
-            tc = torch.full((batch,), time, device=device, dtype=torch.long)
-            self_cond = x_start if self.self_condition else None
-            last = time_next < 0
-            if not guided:
-                eps = self.model(img, tc, self_cond)
-                if last:
-                    img, x_start = K.ddim_update(self, img, eps, None, tc, 0., 0., 0.)
-                    continue
-                sigma, c, sqrt_an = K.ddim_coefficients(self._ac_host, time, time_next, eta)
-                img, x_start = K.ddim_update(self, img, eps, self.sample_noise(shape, device), tc, sqrt_an, c, sigma)
-            else:
+        pairs = K.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)
+        if not self._guided(kwargs) and not self.self_condition:
+            img = K.sampling_loop(self, img, src, desc, ddim_pairs=pairs, eta=eta, cond_first=True, use_graph=self.use_graph)
+        else:
+            x_start = None
+            for time, time_next in pairs:
+                K.apply_cond(img, src, desc)
+                tc = torch.full((batch,), time, device=device, dtype=torch.long)
+                self_cond = x_start if self.self_condition else None
                 pred_noise, x_start, *_ = self.model_predictions(img, tc, self_cond, clip_x_start=True, rederive_pred_noise=True, **kwargs)
-                if last:
+                if time_next < 0:
                     img = x_start.contiguous()
                     continue
                 sigma, c, sqrt_an = K.ddim_coefficients(self._ac_host, time, time_next, eta)

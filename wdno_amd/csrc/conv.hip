@@ -19,7 +19,7 @@
 // and land while the 32..64 MFMAs (64 cycles each) of step s+1 run. Address arithmetic is incremental: no divisions in
 // the steady state (tap row state is refreshed once per (dz,dy), the (dx, c) position of this thread's float4 column
 // advances by BK per step).
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TWO_LEVEL = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, const float* __restrict__ res,
                                                        float* __restrict__ y, ConvP p) {
@@ -130,6 +130,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+  // Two-level summation: `acc` collects FLUSH_STEPS steps (16 sequential MFMA accumulations each), then is added into `tot`.
+  // A 7x7x7 stem is 490 steps = 7840 sequential roundings on one chain otherwise, and its error grows like the square root of
+  // the chain length: with the flush the longest chains are 64 and ~120 long (measured: tools/error_trace.py).
+  // Instantiated for long reductions only (TWO_LEVEL; dispatch in wdno_conv_fwd): the second accumulator set costs registers.
+  constexpr int FLUSH_STEPS = 4;
+  f32x16 tot[TWO_LEVEL ? TM : 1][TWO_LEVEL ? TN : 1];
+  if (TWO_LEVEL) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[TWO_LEVEL ? a : 0][TWO_LEVEL ? b : 0][e] = 0.f;
+  }
+
   load_tile();
   store_tile(0);
   __syncthreads();
@@ -154,9 +169,28 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
         }
     }
+    if (TWO_LEVEL && (step & (FLUSH_STEPS - 1)) == FLUSH_STEPS - 1) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            tot[TWO_LEVEL ? a : 0][TWO_LEVEL ? b : 0][e] += acc[a][b][e];
+            acc[a][b][e] = 0.f;
+          }
+    }
     if (step + 1 < p.nsteps) store_tile((step + 1) & 1);
     __syncthreads();
     if (step + 2 < p.nsteps) load_tile();
+  }
+  if (TWO_LEVEL) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] += tot[TWO_LEVEL ? a : 0][TWO_LEVEL ? b : 0][e];
   }
 
   // ---- epilogue: acc[reg] <-> (row = (reg&3) + 8*(reg>>2) + 4*hh, col = li)
@@ -182,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const float* __restrict__
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TWO_LEVEL = false>
 static int launch_fwd(const float* x, const float* wp, const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
   const wdno_conv_geom& g = p.g;
   int64_t tiles_m = cdiv64(p.P, BM);
@@ -193,10 +227,10 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, const 
   size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<BM, BN, WM, WN, TWO_LEVEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  conv_fwd_kernel<BM, BN, WM, WN><<<p.ntiles, 256, lds, st>>>(x, wp, bias, residual, y, p);
+  conv_fwd_kernel<BM, BN, WM, WN, TWO_LEVEL><<<p.ntiles, 256, lds, st>>>(x, wp, bias, residual, y, p);
   return WDNO_OK;
 }
 
@@ -211,7 +245,10 @@ extern "C" int wdno_conv_fwd(const float* x, const float* wp, const float* bias,
   const int64_t P = p.P;
   const int K = g->K;
   auto blocks = [&](int bm, int bn) { return cdiv64(P, bm) * cdiv(K, bn); };
-  if (K > 64) {
+  if (p.nsteps >= 64) {       // reductions of >= 2048 terms (the 7x7x7 stem: 15 092): two-level summation, see conv_fwd_kernel
+    if (K > 64 && blocks(64, 128) >= 256) rc = launch_fwd<64, 128, 1, 4, true>(x, wp, bias, residual, y, p, st);
+    else rc = launch_fwd<64, 64, 2, 2, true>(x, wp, bias, residual, y, p, st);
+  } else if (K > 64) {
     if (blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) rc = launch_fwd<128, 128, 2, 2>(x, wp, bias, residual, y, p, st);
     else rc = launch_fwd<64, 128, 1, 4>(x, wp, bias, residual, y, p, st);
   } else {

@@ -181,9 +181,14 @@ extern "C" int wdno_p_sample_update(const float* x, const float* eps, const floa
 __global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ x, const float* __restrict__ eps,
                                                     const float* __restrict__ noise, const int64_t* __restrict__ t,
                                                     const float* __restrict__ c1, const float* __restrict__ c2, float sqrt_an, float cc,
-                                                    float sigma, float* __restrict__ xn, float* __restrict__ xs, int64_t total,
-                                                    int64_t per_sample) {
+                                                    float sigma, const float* __restrict__ coef_dev, float* __restrict__ xn,
+                                                    float* __restrict__ xs, int64_t total, int64_t per_sample) {
   int64_t stride = (int64_t)gridDim.x * 256;
+  if (coef_dev) {       // step coefficients in device memory: the launch is identical for every step (HIP-graph replay)
+    sqrt_an = coef_dev[0];
+    cc = coef_dev[1];
+    sigma = coef_dev[2];
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     int64_t tb = t[i / per_sample];
     float a = c1[tb] * x[i];
@@ -201,6 +206,15 @@ extern "C" int wdno_ddim_update(const float* x, const float* eps, const float* n
   WDNO_REQUIRE(B > 0 && per_sample > 0);
   int64_t total = B * per_sample;
   ddim_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, eps, noise, t, sqrt_recip_ac, sqrt_recipm1_ac, sqrt_an, c, sigma,
-                                                               x_next, x_start, total, per_sample);
+                                                               nullptr, x_next, x_start, total, per_sample);
+  return wdno_check_launch();
+}
+extern "C" int wdno_ddim_update_dev(const float* x, const float* eps, const float* noise, const int64_t* t,
+                                    const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* coef_dev,
+                                    float* x_next, float* x_start, int64_t B, int64_t per_sample, wdno_stream_t s) {
+  WDNO_REQUIRE(B > 0 && per_sample > 0 && coef_dev != nullptr && noise != nullptr);
+  int64_t total = B * per_sample;
+  ddim_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, eps, noise, t, sqrt_recip_ac, sqrt_recipm1_ac, 0.f, 0.f, 0.f,
+                                                               coef_dev, x_next, x_start, total, per_sample);
   return wdno_check_launch();
 }

@@ -11,6 +11,7 @@
 // folded into the store/load addressing of the pass that touches the coefficient tensor, so no separate
 // packing kernel exists. Taps travel as kernel arguments (<= 16 per filter).
 #include "common.h"
+#include <algorithm>
 
 #define WDNO_MAXL 16
 #define WDNO_MAXCOMP 5
@@ -126,6 +127,427 @@ __global__ __launch_bounds__(256) void synthesis_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused single-launch transforms
+// One launch per 2-D / 3-D transform, no workspace round trip ("fuse all axes in LDS").
+// A block owns a tile of coefficients (analysis) / signal samples (synthesis) of one image and runs the per-axis passes back to
+// back: the pass along the SLOWEST transformed axis lives in registers (it needs no neighbours across lanes: a thread owns one
+// column, its loads / stores are coalesced over the contiguous axis and touch global memory), the other passes go through LDS.
+//     analysis : global --T (regs)--> S1 --H--> S2 --W--> packed coefficients          (2-D: global --H (regs)--> S2 --W--> coef)
+//     synthesis: packed coefficients --W--> S1 --H--> S2 --T (regs)--> global          (2-D: coef --W--> S1 --H (regs)--> global)
+// Boundary rules (zero extension / periodization / repeated last sample of an odd length) are applied where a pass reads its
+// operand from global memory, so the LDS passes are unconditional. Pass order and the order of every fmaf chain are those of the
+// per-axis kernels above, hence the results are BIT-IDENTICAL to them (tests compare with torch.equal).
+// Halo rows/frames of neighbouring tiles are re-read through L2: logical tile ids are laid out so that one XCD (= one L2) owns a
+// contiguous range of tiles, i.e. whole images.
+extern int wdno_debug_mode;      // 11: force the per-axis passes (A/B and bit-equality tests)
+
+struct FusedGeom {
+  int n_img, T, H, W, To, Ho, Wo;
+  int64_t cs_img, cs_band, cs0, cs1;
+  int off, odd_t, odd_h, odd_w;
+  int NH;                 // analysis: coefficient rows per tile; synthesis: q rows per tile (q = (n + off) >> 1)
+  int tiles_t, tiles_h, n_blocks;
+  int FW;                 // analysis: columns incl. boundary extension (2 Wo + L - 2); synthesis: 2 * QW
+  int qt0, qh0, qw0;      // synthesis: first q along each axis (off >> 1)
+  int QH, QT;             // synthesis: number of q rows / frames in total
+};
+
+__device__ __forceinline__ int xcd_tile(int bid, int nb) {
+  return (nb & 7) ? bid : (bid & 7) * (nb >> 3) + (bid >> 3);
+}
+template <int MODE>
+__device__ __forceinline__ int amap(int j, int N, int odd) {      // signal index read by an analysis pass: [0, N) or -1 (= zero)
+  if (MODE == 1) return (j >= 0 && j < N) ? j : -1;
+  const int Next = N + odd;
+  j %= Next;
+  if (j < 0) j += Next;
+  return j > N - 1 ? N - 1 : j;
+}
+template <int MODE>
+__device__ __forceinline__ int smap(int K, int M) {               // coefficient index read by a synthesis pass
+  if (MODE == 1) return (K >= 0 && K < M) ? K : -1;
+  K %= M;
+  return K < 0 ? K + M : K;
+}
+
+// ND = 3: register pass along T, NK coefficient frames per block.  ND = 2: register pass along H, NK coefficient rows per item.
+template <int ND, int L, int MODE, int NK>
+__global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __restrict__ x, float* __restrict__ coef, FusedGeom g, Taps t) {
+  extern __shared__ float lds[];
+  int b = xcd_tile(blockIdx.x, g.n_blocks);
+  const int th = b % g.tiles_h;
+  b /= g.tiles_h;
+  const int tt = (ND == 3) ? b % g.tiles_t : 0;
+  const int img = (ND == 3) ? b / g.tiles_t : b;
+  const int FW = g.FW, NH = g.NH, off = g.off;
+  const int kh0 = th * NH;
+  const int nh = min(NH, g.Ho - kh0);
+  const float* __restrict__ xi = x + (int64_t)img * g.T * g.H * g.W;
+  constexpr int NP = (ND == 3) ? 2 * NK : 1;
+  float* S2;                                     // [NP][2][NH][FW]
+  int kt0 = 0;
+  if (ND == 3) {
+    const int FH = 2 * NH + L - 2;               // signal rows under the tile: row r <-> h = 2 kh0 - off + r
+    const int rows = 2 * nh + L - 2;
+    float* S1 = lds;                             // [2 NK][FH][FW]
+    S2 = lds + 2 * NK * FH * FW;
+    kt0 = tt * NK;
+    const int64_t fs = (int64_t)g.H * g.W;
+    for (int it = threadIdx.x; it < rows * FW; it += 256) {
+      const int r = it / FW, c = it - r * FW;
+      const int h = amap<MODE>(2 * kh0 - off + r, g.H, g.odd_h);
+      const int w = amap<MODE>(c - off, g.W, g.odd_w);
+      float lo[NK], hi[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { lo[k] = 0.f; hi[k] = 0.f; }
+      if (h >= 0 && w >= 0) {
+        const float* col = xi + (int64_t)h * g.W + w;
+#pragma unroll
+        for (int jj = 0; jj < 2 * NK + L - 2; ++jj) {
+          const int tj = amap<MODE>(2 * kt0 - off + jj, g.T, g.odd_t);
+          const float v = tj >= 0 ? col[tj * fs] : 0.f;
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const int m = jj - 2 * k;
+            if (m >= 0 && m < L) {
+              lo[k] = fmaf(t.lo[L - 1 - m], v, lo[k]);
+              hi[k] = fmaf(t.hi[L - 1 - m], v, hi[k]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        S1[(k * FH + r) * FW + c] = lo[k];
+        S1[((NK + k) * FH + r) * FW + c] = hi[k];
+      }
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < NP * nh * FW; it += 256) {
+      const int c = it % FW;
+      int q = it / FW;
+      const int kh = q % nh, p = q / nh;
+      const float* col = S1 + (p * FH + 2 * kh) * FW + c;
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int m = 0; m < L; ++m) {
+        const float v = col[m * FW];
+        lo = fmaf(t.lo[L - 1 - m], v, lo);
+        hi = fmaf(t.hi[L - 1 - m], v, hi);
+      }
+      S2[((p * 2 + 0) * NH + kh) * FW + c] = lo;
+      S2[((p * 2 + 1) * NH + kh) * FW + c] = hi;
+    }
+  } else {
+    S2 = lds;
+    const int ngroups = (nh + NK - 1) / NK;
+    for (int it = threadIdx.x; it < ngroups * FW; it += 256) {
+      const int c = it % FW, k0 = (it / FW) * NK;
+      const int w = amap<MODE>(c - off, g.W, g.odd_w);
+      float lo[NK], hi[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { lo[k] = 0.f; hi[k] = 0.f; }
+      if (w >= 0) {
+#pragma unroll
+        for (int jj = 0; jj < 2 * NK + L - 2; ++jj) {
+          const int hj = amap<MODE>(2 * (kh0 + k0) - off + jj, g.H, g.odd_h);
+          const float v = hj >= 0 ? xi[(int64_t)hj * g.W + w] : 0.f;
+#pragma unroll
+          for (int k = 0; k < NK; ++k) {
+            const int m = jj - 2 * k;
+            if (m >= 0 && m < L) {
+              lo[k] = fmaf(t.lo[L - 1 - m], v, lo[k]);
+              hi[k] = fmaf(t.hi[L - 1 - m], v, hi[k]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        if (k0 + k < nh) {
+          S2[(k0 + k) * FW + c] = lo[k];
+          S2[(NH + k0 + k) * FW + c] = hi[k];
+        }
+    }
+  }
+  __syncthreads();
+  // pass W: LDS -> packed coefficients. float2 reads (index 2 kw + m): conflict-free, and m ascends inside each pair
+  float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
+  const int Wo = g.Wo;
+  for (int it = threadIdx.x; it < NP * 2 * nh * Wo; it += 256) {
+    const int kw = it % Wo;
+    int q = it / Wo;
+    const int kh = q % nh;
+    q /= nh;
+    const int bh = q & 1, p = q >> 1;
+    const int bt = (ND == 3) ? p / NK : 0;
+    const int kt = (ND == 3) ? kt0 + p % NK : 0;
+    if (ND == 3 && kt >= g.To) continue;
+    const float2* row = reinterpret_cast<const float2*>(S2 + ((p * 2 + bh) * NH + kh) * FW) + kw;
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int i = 0; i < L / 2; ++i) {
+      const float2 v = row[i];
+      lo = fmaf(t.lo[L - 1 - 2 * i], v.x, lo);
+      hi = fmaf(t.hi[L - 1 - 2 * i], v.x, hi);
+      lo = fmaf(t.lo[L - 2 - 2 * i], v.y, lo);
+      hi = fmaf(t.hi[L - 2 - 2 * i], v.y, hi);
+    }
+    const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
+    const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
+    float* o = ci + (int64_t)kt * g.cs0 + (int64_t)(kh0 + kh) * g.cs1 + kw;
+    o[band_lo * g.cs_band] = lo;
+    o[band_hi * g.cs_band] = hi;
+  }
+}
+
+// q = (n + off) >> 1, r = (n + off) & 1: x[n] = sum_i lo[q - i] g_lo[r + 2 i] + hi[q - i] g_hi[r + 2 i], i < L/2.
+// ND = 3: register pass along T with NQ q-frames (2 NQ signal frames) per block. ND = 2: register pass along H, NQ q-rows per item.
+template <int ND, int L, int MODE, int NQ>
+__global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* __restrict__ coef, float* __restrict__ x, FusedGeom g, Taps t) {
+  extern __shared__ float lds[];
+  constexpr int E = L / 2 - 1;
+  constexpr int ET = NQ + E;
+  int b = xcd_tile(blockIdx.x, g.n_blocks);
+  const int th = b % g.tiles_h;
+  b /= g.tiles_h;
+  const int tt = (ND == 3) ? b % g.tiles_t : 0;
+  const int img = (ND == 3) ? b / g.tiles_t : b;
+  const int NW = g.FW, QW = NW >> 1, NQH = g.NH, off = g.off;
+  const int EH = NQH + E;
+  const int qh_start = g.qh0 + th * NQH;
+  const int nqh = min(NQH, g.qh0 + g.QH - qh_start);       // valid q rows of this tile
+  const int qt_start = (ND == 3) ? g.qt0 + tt * NQ : 0;
+  const float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
+  float* __restrict__ xi = x + (int64_t)img * g.T * g.H * g.W;
+  constexpr int NP = (ND == 3) ? 2 * ET : 1;
+  float* S1 = lds;                                           // [NP][2][EH][NW]
+  // pass W: packed coefficients -> S1
+  const int eh_used = nqh + E;
+  for (int it = threadIdx.x; it < NP * 2 * eh_used * QW; it += 256) {
+    const int ql = it % QW;
+    int q = it / QW;
+    const int eh = q % eh_used;
+    q /= eh_used;
+    const int bh = q & 1, p = q >> 1;
+    const int bt = (ND == 3) ? p / ET : 0;
+    const int Kt = (ND == 3) ? smap<MODE>(qt_start - E + p % ET, g.To) : 0;
+    const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
+    float a0 = 0.f, a1 = 0.f;
+    if (Kt >= 0 && Kh >= 0) {
+      const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
+      const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
+      const float* base = ci + (int64_t)Kt * g.cs0 + (int64_t)Kh * g.cs1;
+      const float* rl = base + band_lo * g.cs_band;
+      const float* rh = base + band_hi * g.cs_band;
+#pragma unroll
+      for (int i = 0; i < L / 2; ++i) {
+        const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
+        if (Kw >= 0) {
+          const float cl = rl[Kw], ch = rh[Kw];
+          a0 = fmaf(cl, t.lo[2 * i], a0);
+          a0 = fmaf(ch, t.hi[2 * i], a0);
+          a1 = fmaf(cl, t.lo[2 * i + 1], a1);
+          a1 = fmaf(ch, t.hi[2 * i + 1], a1);
+        }
+      }
+    }
+    reinterpret_cast<float2*>(S1 + ((p * 2 + bh) * EH + eh) * NW)[ql] = make_float2(a0, a1);
+  }
+  __syncthreads();
+  const int wshift = off & 1;                                // position pw <-> n_w = pw - (off & 1)
+  if (ND == 3) {
+    float* S2 = lds + NP * 2 * EH * NW;                      // [2 ET][2 NQH][NW]
+    for (int it = threadIdx.x; it < NP * 2 * nqh * NW; it += 256) {
+      const int pw = it % NW;
+      int q = it / NW;
+      const int ph = q % (2 * nqh), p = q / (2 * nqh);
+      const int ql = ph >> 1, r = ph & 1;
+      const float* cl = S1 + ((p * 2 + 0) * EH + ql + E) * NW + pw;
+      const float* ch = S1 + ((p * 2 + 1) * EH + ql + E) * NW + pw;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < L / 2; ++i) {
+        acc = fmaf(cl[-i * NW], r ? t.lo[2 * i + 1] : t.lo[2 * i], acc);
+        acc = fmaf(ch[-i * NW], r ? t.hi[2 * i + 1] : t.hi[2 * i], acc);
+      }
+      S2[(p * 2 * NQH + ph) * NW + pw] = acc;
+    }
+    __syncthreads();
+    const int64_t fs = (int64_t)g.H * g.W;
+    for (int it = threadIdx.x; it < 2 * nqh * NW; it += 256) {
+      const int pw = it % NW, ph = it / NW;
+      const int nw = pw - wshift;
+      const int nhh = 2 * (qh_start + (ph >> 1)) + (ph & 1) - off;
+      if (nw < 0 || nw >= g.W || nhh < 0 || nhh >= g.H) continue;
+      float cl[ET], ch[ET];
+#pragma unroll
+      for (int e = 0; e < ET; ++e) {
+        cl[e] = S2[(e * 2 * NQH + ph) * NW + pw];
+        ch[e] = S2[((ET + e) * 2 * NQH + ph) * NW + pw];
+      }
+      float* o = xi + (int64_t)nhh * g.W + nw;
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i < L / 2; ++i) {
+            acc = fmaf(cl[qq - i + E], t.lo[r + 2 * i], acc);
+            acc = fmaf(ch[qq - i + E], t.hi[r + 2 * i], acc);
+          }
+          const int nt = 2 * (qt_start + qq) + r - off;
+          if (nt >= 0 && nt < g.T) o[nt * fs] = acc;
+        }
+      }
+    }
+  } else {
+    // register pass along H: items (group of NQ q-rows, pw); EH rows of S1 hold the tile's coefficient rows (after the W pass)
+    const int ngroups = (nqh + NQ - 1) / NQ;
+    for (int it = threadIdx.x; it < ngroups * NW; it += 256) {
+      const int pw = it % NW, q0 = (it / NW) * NQ;
+      const int nw = pw - wshift;
+      if (nw < 0 || nw >= g.W) continue;
+      float cl[ET], ch[ET];
+#pragma unroll
+      for (int e = 0; e < ET; ++e) {
+        const bool ok = q0 + e < eh_used;
+        cl[e] = ok ? S1[(q0 + e) * NW + pw] : 0.f;
+        ch[e] = ok ? S1[(EH + q0 + e) * NW + pw] : 0.f;
+      }
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i < L / 2; ++i) {
+            acc = fmaf(cl[qq - i + E], t.lo[r + 2 * i], acc);
+            acc = fmaf(ch[qq - i + E], t.hi[r + 2 * i], acc);
+          }
+          const int nhh = 2 * (qh_start + q0 + qq) + r - off;
+          if (q0 + qq < nqh && nhh >= 0 && nhh < g.H) xi[(int64_t)nhh * g.W + nw] = acc;
+        }
+      }
+    }
+  }
+}
+
+static const size_t FUSED_LDS_BYTES = 64 * 1024;      // default dynamic-LDS limit: no function attribute needed (graph-capture safe)
+
+template <int ND, int L, int MODE>
+static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
+  FusedGeom g = {};
+  g.n_img = d->n_img;
+  g.T = d->in_dims[0]; g.H = d->in_dims[1]; g.W = d->in_dims[2];
+  g.To = d->out_dims[0]; g.Ho = d->out_dims[1]; g.Wo = d->out_dims[2];
+  g.cs_img = d->cs_img; g.cs_band = d->cs_band; g.cs0 = d->cs0; g.cs1 = d->cs1;
+  g.off = MODE == 1 ? L - 2 : L / 2 - 1;
+  const bool odd = MODE == 0 && odd_rule;
+  g.odd_t = odd && (g.T & 1); g.odd_h = odd && (g.H & 1); g.odd_w = odd && (g.W & 1);
+  g.FW = 2 * g.Wo + L - 2;
+  constexpr int NK = (ND == 3) ? 3 : 4;
+  size_t lds;
+  if (ND == 3) {
+    // floats: 2 NK FW (FH + 2 NH) with FH = 2 NH + L - 2
+    const size_t per_row = (size_t)2 * NK * g.FW * sizeof(float);
+    const long nh_max = ((long)(FUSED_LDS_BYTES / per_row) - (L - 2)) / 4;
+    if (nh_max < 1) return false;
+    const int tiles = cdiv(g.Ho, (int)std::min<long>(nh_max, g.Ho));
+    g.NH = cdiv(g.Ho, tiles);
+    g.tiles_h = tiles;
+    g.tiles_t = cdiv(g.To, NK);
+    lds = per_row * (size_t)(4 * g.NH + L - 2);
+  } else {
+    const size_t per_row = (size_t)2 * g.FW * sizeof(float);
+    long nh_max = (long)(FUSED_LDS_BYTES / per_row);
+    nh_max = std::min<long>(nh_max / NK * NK, 2 * NK);        // two register groups per block: plenty of blocks for small images
+    if (nh_max < NK) return false;
+    g.NH = (int)nh_max;
+    g.tiles_h = cdiv(g.Ho, g.NH);
+    g.tiles_t = 1;
+    lds = per_row * (size_t)g.NH;
+  }
+  const int64_t nb = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
+  if (nb > 0x7fffffff) return false;
+  g.n_blocks = (int)nb;
+  dwt_analysis_fused_kernel<ND, L, MODE, NK><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
+  return true;
+}
+
+template <int ND, int L, int MODE>
+static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, hipStream_t st) {
+  FusedGeom g = {};
+  g.n_img = d->n_img;
+  g.T = d->in_dims[0]; g.H = d->in_dims[1]; g.W = d->in_dims[2];
+  g.To = d->out_dims[0]; g.Ho = d->out_dims[1]; g.Wo = d->out_dims[2];
+  g.cs_img = d->cs_img; g.cs_band = d->cs_band; g.cs0 = d->cs0; g.cs1 = d->cs1;
+  g.off = MODE == 1 ? L - 2 : L / 2 - 1;
+  constexpr int E = L / 2 - 1;
+  auto qcount = [&](int N) { return ((N - 1 + g.off) >> 1) - (g.off >> 1) + 1; };
+  g.qt0 = g.qh0 = g.qw0 = g.off >> 1;
+  g.QH = qcount(g.H);
+  g.QT = qcount(g.T);
+  g.FW = 2 * qcount(g.W);
+  constexpr int NQ = (ND == 3) ? 4 : 4;
+  size_t lds;
+  if (ND == 3) {
+    // floats: 2 ET NW (2 EH + 2 NQH), EH = NQH + E
+    const size_t per_row = (size_t)2 * (NQ + E) * g.FW * sizeof(float);
+    const long nq_max = ((long)(FUSED_LDS_BYTES / per_row) - 2 * E) / 4;
+    if (nq_max < 1) return false;
+    const int tiles = cdiv(g.QH, (int)std::min<long>(nq_max, g.QH));
+    g.NH = cdiv(g.QH, tiles);
+    g.tiles_h = tiles;
+    g.tiles_t = cdiv(g.QT, NQ);
+    lds = per_row * (size_t)(4 * g.NH + 2 * E);
+  } else {
+    const size_t per_row = (size_t)2 * g.FW * sizeof(float);
+    long nq_max = (long)(FUSED_LDS_BYTES / per_row) - E;
+    nq_max = std::min<long>(nq_max / NQ * NQ, 2 * NQ);
+    if (nq_max < NQ) return false;
+    g.NH = (int)nq_max;
+    g.tiles_h = cdiv(g.QH, g.NH);
+    g.tiles_t = 1;
+    lds = per_row * (size_t)(g.NH + E);
+  }
+  const int64_t nb = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
+  if (nb > 0x7fffffff) return false;
+  g.n_blocks = (int)nb;
+  dwt_synthesis_fused_kernel<ND, L, MODE, NQ><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
+  return true;
+}
+
+template <int ND, int L>
+static bool fused_dispatch2(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
+  if (d->mode == 1) return analysis_dir ? fused_analysis<ND, L, 1>(src, dst, d, taps, odd_rule, st) : fused_synthesis<ND, L, 1>(src, dst, d, taps, st);
+  return analysis_dir ? fused_analysis<ND, L, 0>(src, dst, d, taps, odd_rule, st) : fused_synthesis<ND, L, 0>(src, dst, d, taps, st);
+}
+template <int ND>
+static bool fused_dispatch(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
+  switch (d->L) {
+    case 2: return fused_dispatch2<ND, 2>(analysis_dir, src, dst, d, taps, odd_rule, st);
+    case 4: return fused_dispatch2<ND, 4>(analysis_dir, src, dst, d, taps, odd_rule, st);
+    case 6: return fused_dispatch2<ND, 6>(analysis_dir, src, dst, d, taps, odd_rule, st);
+    case 8: return fused_dispatch2<ND, 8>(analysis_dir, src, dst, d, taps, odd_rule, st);
+    case 10: return fused_dispatch2<ND, 10>(analysis_dir, src, dst, d, taps, odd_rule, st);
+    default: return false;
+  }
+}
+// true = the transform was launched as ONE fused kernel; false = not covered (1-D, long filters, rows that do not fit LDS, the
+// odd-length synthesis-shaped adjoint), the caller falls back to the per-axis passes.
+static bool fused_try(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
+  if (wdno_debug_mode == 11 || d->nd < 2) return false;
+  if (!analysis_dir && d->mode == 0 && odd_rule)
+    for (int a = 3 - d->nd; a < 3; ++a)
+      if (d->in_dims[a] & 1) return false;
+  if (!analysis_dir && d->mode == 0)
+    for (int a = 3 - d->nd; a < 3; ++a)
+      if (d->in_dims[a] != 2 * d->out_dims[a]) return false;
+  return d->nd == 3 ? fused_dispatch<3>(analysis_dir, src, dst, d, taps, odd_rule, st) : fused_dispatch<2>(analysis_dir, src, dst, d, taps, odd_rule, st);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int validate(const wdno_dwt_desc* d) {
   if (!d || d->nd < 1 || d->nd > 3 || (d->mode != 0 && d->mode != 1)) return WDNO_EINVAL;
@@ -189,9 +611,10 @@ static void set_outer(OuterMap& om, int ncomp, const int* n, const int64_t* sa, 
 // sig = the signal-side tensor of the whole transform, coef = the packed coefficient tensor.
 static int run(const float* src, float* dst, const wdno_dwt_desc* d, const float* fl, const float* fh, bool reverse_taps,
                bool analysis_dir, bool odd_rule, void* ws, size_t ws_bytes, hipStream_t st) {
-  if (ws_elems(d) * sizeof(float) > ws_bytes) return WDNO_EWORKSPACE;
   Taps taps;
   fill_taps(taps, fl, fh, d->L, reverse_taps);
+  if (fused_try(analysis_dir, src, dst, d, taps, odd_rule, st)) return wdno_check_launch();
+  if (ws_elems(d) * sizeof(float) > ws_bytes) return WDNO_EWORKSPACE;
   const int T = d->in_dims[0], H = d->in_dims[1], W = d->in_dims[2];
   const int To = d->out_dims[0], Ho = d->out_dims[1], Wo = d->out_dims[2];
   const int img = d->n_img;

@@ -5,6 +5,8 @@ smoke/ddpm/diffusion_2d.py:513-547,627-685 (schedule tables are built in fp64 on
 """
 import ctypes as C
 import math
+import os
+import weakref
 
 import torch
 
@@ -155,9 +157,129 @@ def ddim_update(mod, x, eps, noise, t, sqrt_an, c, sigma):
     return x_next, x_start
 
 
+def ddim_update_dev(mod, x, eps, noise, t, coef_dev):
+    """ddim_update with (sqrt_alpha_next, c, sigma) read from the three device floats `coef_dev` (graph-replayable launch)."""
+    x, eps, nz = _chk(x, 'x'), _chk(eps, 'eps'), _chk(noise, 'noise')
+    x_next, x_start = torch.empty_like(x), torch.empty_like(x)
+    b = x.shape[0]
+    _lib.check(_lib_().wdno_ddim_update_dev(_p(x), _p(eps), _p(nz), _p(t), _p(mod.sqrt_recip_alphas_cumprod), _p(mod.sqrt_recipm1_alphas_cumprod),
+                                            _p(coef_dev), _p(x_next), _p(x_start), b, x.numel() // b, _stream()), 'ddim_update_dev')
+    return x_next, x_start
+
+
 def ddim_coefficients(alphas_cumprod_host, time, time_next, eta):
     """sigma, c, sqrt(alpha_next) as python floats from a host copy of alphas_cumprod (fp32, reference arithmetic)."""
     a, an = alphas_cumprod_host[time], alphas_cumprod_host[time_next]
     sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
     c = (1 - an - sigma ** 2).sqrt()
     return float(sigma), float(c), float(an.sqrt())
+
+
+# ----------------------------------------------------------------------------------------------------- sampling loops
+SAMPLE_GRAPH = os.environ.get('WDNO_SAMPLE_GRAPH', '1') != '0'      # capture the unguided sampling step in a HIP graph
+SAMPLE_GRAPH_MIN_STEPS = int(os.environ.get('WDNO_SAMPLE_GRAPH_MIN_STEPS', '8'))
+
+
+_graph_cache = weakref.WeakKeyDictionary()      # diffusion module -> {key: _StepGraph}; outside the module so deepcopy / state_dict never see it
+
+
+class _StepGraph:
+    """One unguided sampling step -- [conditions] -> U-Net -> posterior / DDIM update -> [conditions] -- captured once in a HIP
+    graph (ops.graph_capture) on static buffers and replayed for every step of a loop: the timestep, the DDIM coefficients and
+    the noise draw live in device memory that is refreshed between replays, so all steps are the same ~10^3-launch graph."""
+
+    def __init__(self, mod, shape, desc, ddim, cond_first, device):
+        from . import ops
+        self.mod, self.ddim, self.cond_first, self.desc = mod, ddim, cond_first, desc
+        b = shape[0]
+        self.x = torch.zeros(shape, device=device, dtype=torch.float32)
+        self.src = torch.zeros(shape, device=device, dtype=torch.float32)
+        self.noise = torch.zeros(shape, device=device, dtype=torch.float32)
+        self.t = torch.zeros((b,), device=device, dtype=torch.long)
+        self.coef = torch.zeros(3, device=device, dtype=torch.float32)
+        self.x_start = None
+        self._body()                              # eager warm-up: weight operands, pixel tables, function attributes
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with ops.graph_capture(self.graph):
+            self._body()
+
+    def _body(self):
+        mod, x = self.mod, self.x
+        if self.cond_first:
+            apply_cond(x, self.src, self.desc)
+        eps = mod.model(x, self.t, None)
+        if self.ddim:
+            xn, xs = ddim_update_dev(mod, x, eps, self.noise, self.t, self.coef)
+        else:
+            xn, xs = p_sample_update(mod, x, eps, self.noise, self.t, clamp=True)
+        if not self.cond_first:
+            apply_cond(xn, self.src, self.desc)
+        x.copy_(xn)
+        self.x_start = xs
+
+
+def _step_graph(mod, shape, desc, ddim, cond_first, device):
+    from . import ops
+    cache = _graph_cache.setdefault(mod, {})
+    key = (tuple(shape), bytes(desc), bool(ddim), bool(cond_first), str(device), ops.WEIGHT_EPOCH)
+    sg = cache.get(key)
+    if sg is None:
+        if len(cache) >= 2:                       # a graph pins one step's worth of activations
+            cache.clear()
+        sg = cache[key] = _StepGraph(mod, tuple(shape), desc, ddim, cond_first, device)
+    return sg
+
+
+def sampling_loop(mod, x, src, desc, *, ddim_pairs=None, eta=0.0, cond_first, use_graph=None):
+    """The unguided sampling loop of both GaussianDiffusion classes (diffusion_1d.py:310-460, diffusion_2d.py:788-933).
+
+    x: the initial draw [B, ...]; src / desc: clean values and predicate of the conditioned positions. cond_first = True is the
+    Burgers order (conditions imposed before every U-Net call; the caller imposes them once more on the result), False the
+    smoke order (imposed after every update except the last DDIM one; the caller imposes them on the initial draw).
+    ddim_pairs = None: ancestral sampling over all mod.num_timesteps; else the (time, time_next) pairs of ddim_time_pairs.
+    Noise comes from mod.sample_noise, one draw per step that uses noise, in step order. Steps with noise run as replays of one
+    captured HIP graph when there are enough of them (bit-identical to the eager launches); the final noise-free step is eager."""
+    dev, shape, b = x.device, tuple(x.shape), x.shape[0]
+    assert not mod.self_condition, 'self-conditioning is never enabled on the WDNO path'
+    ddim = ddim_pairs is not None
+    if ddim:
+        steps = [(time, None if time_next < 0 else ddim_coefficients(mod._ac_host, time, time_next, eta)) for time, time_next in ddim_pairs]
+        noisy = [co is not None for _, co in steps]
+    else:
+        steps = [(t, None) for t in reversed(range(mod.num_timesteps))]
+        noisy = [t > 0 for t, _ in steps]
+    if use_graph is None:
+        use_graph = SAMPLE_GRAPH and sum(noisy) >= SAMPLE_GRAPH_MIN_STEPS
+    sg = None
+    if use_graph and any(noisy):
+        sg = _step_graph(mod, shape, desc, ddim, cond_first, dev)
+        sg.src.copy_(src)
+        sg.x.copy_(x)
+        if ddim:
+            table = torch.tensor([[co[2], co[1], co[0]] if co is not None else [0., 0., 0.] for _, co in steps], dtype=torch.float32).to(dev)
+        x = sg.x
+    for i, (t, co) in enumerate(steps):
+        noise = mod.sample_noise(shape, dev) if noisy[i] else None
+        if sg is not None and noisy[i]:
+            sg.t.fill_(t)
+            if ddim:
+                sg.coef.copy_(table[i])
+            sg.noise.copy_(noise)
+            sg.graph.replay()
+            continue
+        if cond_first:
+            apply_cond(x, src, desc)
+        bt = torch.full((b,), t, device=dev, dtype=torch.long)
+        eps = mod.model(x, bt, None)
+        if ddim:
+            if noise is None:
+                x, _ = ddim_update(mod, x, eps, None, bt, 0., 0., 0.)
+                continue                          # diffusion_2d.py:897-899: the last DDIM step returns x_start as it is
+            sigma, c, sqrt_an = co
+            x, _ = ddim_update(mod, x, eps, noise, bt, sqrt_an, c, sigma)
+        else:
+            x, _ = p_sample_update(mod, x, eps, noise, bt, clamp=True)
+        if not cond_first:
+            x = apply_cond(x, src, desc)
+    return x.clone() if sg is not None and x is sg.x else x

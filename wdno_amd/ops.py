@@ -4,6 +4,7 @@ PyTorch is used for device memory, streams and the autograd tape only; every for
 or more launches of libwdno_hip.so. Activations are channels-last ("CL"): [N, (D,) H, W, C] with C padded to a
 multiple of 4. There is no CPU path: non-CUDA tensors raise.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -331,9 +332,36 @@ AMAX_FLOATS = 64 * 16    # WDNO_AMAX_FLOATS
 AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 
+_CAPTURE = None          # [pool, next index] while a HIP graph is being captured through graph_capture()
+
+
+@contextlib.contextmanager
+def graph_capture(graph):
+    """`torch.cuda.graph(graph)` for launches of this library. Everything the library needs per launch is either a kernel
+    argument or device memory, so a captured step replays unchanged; the one piece of state that eager execution renews per
+    launch -- the zeroed amax records -- comes, during a capture, from a pool that is allocated AND zero-filled inside the
+    graph: every replay starts from zeroed records exactly like an eager step, and replays are bit-identical to eager runs.
+    Run the step once eagerly first (packed / split weight operands and pixel tables are built on first use)."""
+    global _CAPTURE
+    assert _CAPTURE is None, 'nested graph captures are not supported'
+    with torch.cuda.graph(graph):
+        _CAPTURE = [None, 0]
+        try:
+            yield graph
+        finally:
+            _CAPTURE = None
+
+
 def _amax_slot(device):
     """A zeroed amax record (AMAX_FLOATS floats whose maximum will be max|x|, include/wdno_hip.h) from a pool. An exhausted
     pool is replaced, never re-zeroed: records left on tensors by their producers (_leave_amax) may still be read."""
+    if _CAPTURE is not None:
+        st = _CAPTURE
+        if st[0] is None or st[1] >= st[0].shape[0]:
+            st[0], st[1] = torch.zeros((1024, AMAX_FLOATS), device=device, dtype=torch.float32), 0      # a captured fill: redone by every replay
+        rec = st[0][st[1]]
+        st[1] += 1
+        return rec
     key = str(device)
     st = _amax_pool.get(key)
     if st is None or st[1] >= st[0].shape[0]:

@@ -125,6 +125,7 @@ class GaussianDiffusion(nn.Module):
         K.register_schedule(self, betas, loss_weight)
         self._ac_host = self.alphas_cumprod.clone()      # host copy for the scalar DDIM coefficients
         self._lw_cache = None
+        self.use_graph = None       # None: HIP-graph replay of the unguided sampling step when the loop is long enough (WDNO_SAMPLE_GRAPH)
 
     # ------------------------------------------------------------------ helpers
     def _coef_shape(self, shape, N_upsample=None):
@@ -228,6 +229,8 @@ class GaussianDiffusion(nn.Module):
         desc = self._desc(shape, self._coef_shape(shape, N_upsample))
         src = self._condition_source(shape, device, init, control, low)
         x = K.apply_cond(self.sample_noise(list(shape), device).contiguous(), src, desc)
+        if design_fn is None and not self.self_condition:          # unguided: fused launches, the step replayed from one HIP graph
+            return K.sampling_loop(self, x, src, desc, cond_first=False, use_graph=self.use_graph)
         x_start = None
         for t in reversed(range(0, self.num_timesteps)):
             self_cond = x_start if self.self_condition else None
@@ -244,26 +247,20 @@ class GaussianDiffusion(nn.Module):
         desc = self._desc(shape, self._coef_shape(shape, N_upsample))
         src = self._condition_source(shape, device, init, control, low)
         img = K.apply_cond(self.sample_noise(shape, device).contiguous(), src, desc)
+        pairs = K.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)
+        if design_fn is None and not self.self_condition:
+            return K.sampling_loop(self, img, src, desc, ddim_pairs=pairs, eta=eta, cond_first=False, use_graph=self.use_graph)
         x_start = None
-        for time, time_next in K.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps):
+        for time, time_next in pairs:
             tc = torch.full((batch,), time, device=device, dtype=torch.long)
             self_cond = x_start if self.self_condition else None
-            last = time_next < 0
-            if design_fn is None:
-                eps = self.model(img, tc, self_cond)
-                if last:
-                    img, x_start = K.ddim_update(self, img, eps, None, tc, 0., 0., 0.)
-                    continue
-                sigma, c, sqrt_an = K.ddim_coefficients(self._ac_host, time, time_next, eta)
-                img, x_start = K.ddim_update(self, img, eps, self.sample_noise(shape, device), tc, sqrt_an, c, sigma)
-            else:
-                pred_noise, x_start = self.model_predictions(shape, img, tc, self_cond, clip_x_start=True, rederive_pred_noise=True,
-                                                             design_fn=design_fn, design_guidance=design_guidance, init=init, init_u=init_u, low=low)
-                if last:
-                    img = x_start
-                    continue
-                sigma, c, sqrt_an = K.ddim_coefficients(self._ac_host, time, time_next, eta)
-                img = x_start * sqrt_an + c * pred_noise + sigma * self.sample_noise(shape, device)
+            pred_noise, x_start = self.model_predictions(shape, img, tc, self_cond, clip_x_start=True, rederive_pred_noise=True,
+                                                         design_fn=design_fn, design_guidance=design_guidance, init=init, init_u=init_u, low=low)
+            if time_next < 0:
+                img = x_start
+                continue
+            sigma, c, sqrt_an = K.ddim_coefficients(self._ac_host, time, time_next, eta)
+            img = x_start * sqrt_an + c * pred_noise + sigma * self.sample_noise(shape, device)
             img = K.apply_cond(img.contiguous(), src, desc)
         return img
 
