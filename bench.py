@@ -1,14 +1,21 @@
 """bench.py -- WDNO hot-path benchmark on MI355X.
 
-Workload (BASELINE.json configs[2]/[3], the configuration the metric is quoted on): 2-D smoke base-resolution DDPM,
+Default workload (BASELINE.json configs[2]/[3], the configuration the metric is quoted on): 2-D smoke base-resolution DDPM,
 Unet3D_with_Conv3D(dim=64, dim_mults=(1,2,4), channels=42) + GaussianDiffusion(image_size=40, frames=24, T=1000) exactly as
 smoke/train_2d.py:94-121 builds it, fp32, synthetic wavelet-coefficient tensors [8, 24, 42, 40, 40] per GPU resident in
 HBM. One "step" = one full training step of the hot path on one batch: q_sample + conditioning, U-Net forward,
 loss, U-Net backward, gradient all-reduce (N > 1), global-norm clip, Adam, EMA.  value = rank-steps / s over all GPUs
-(weak scaling: 8 samples per GPU per step). The DDPM sampling step rate (U-Net forward + posterior update + condition
-re-imposition) is measured after the timed region and reported alongside.
+(weak scaling: 8 samples per GPU per step).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+Reported next to it in the same JSON line (never part of `value`):
+  sampling : DDPM sampling steps/s of the same model (U-Net forward + posterior update + condition re-imposition), issued launch by
+             launch and as replays of one captured HIP graph, at the bench batch and at batch 1;
+  dwt      : the four wavelet transforms of the path at BASELINE.json's synthetic shapes, HIP-event timed, GB/s of algorithmic
+             bytes (in + out) and the fraction of the 8 TB/s HBM peak;
+  burgers  : (--workload burgers / burgers-bf16 make it the main line instead) the Burgers base model's train / sample step;
+  roofline : the dominant convolution kernel of the main workload; cpu_baseline: the oracle on the host cores.
+
+    python bench.py --gpus 1 --steps 100 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -23,14 +30,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_F16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16, dense (the 3 x fp16-split kernels spend 3 MFMA flop per algorithmic flop)
+PEAK_F16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16 / _bf16, dense (the 3 x fp16-split kernels spend 3 MFMA flop per algorithmic flop)
 PEAK_HBM_TBS = 8.0
+PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
 
 
-def build_model(device, batch):
+def _trees():
     from wdno_amd import tree_path
     for t in ('third_party', 'smoke', 'burgers'):
-        sys.path.insert(0, tree_path(t))
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def build_model(device, batch=8):
+    """The smoke base model exactly as smoke/train_2d.py:94-121 builds it."""
+    _trees()
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     from ddpm.diffusion_2d import GaussianDiffusion
     torch.manual_seed(0)                      # identical replicas on every rank
@@ -41,13 +56,61 @@ def build_model(device, batch):
     return dif.to(device)
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU restatement, torch fp32 on the host cores) doing the same training step on a bounded sample."""
-    from oracle import diffusion_ref as D, unet_ref as U
+def build_burgers(device):
+    """The Burgers base model exactly as burgers/train_ddpm_burgers.py:128-182 builds it (scripts/burgers/train_base_sim.sh)."""
+    _trees()
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion
+    torch.manual_seed(0)
+    net = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+    dif = GaussianDiffusion(net, seq_length=(64, 64), padded_shape=[41, 60], ori_shape=[81, 120], loss_layer_weight=torch.ones(1, 9, 1, 1),
+                            is_condition_pad=True, is_condition_u0=True, is_condition_f=True, beta_schedule='cosine', timesteps=1000)
+    return dif.to(device)
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def cpu_baseline(budget_s=30.0):
+    """The oracle (CPU restatement of the reference's path, torch fp32 / numpy on the host cores) on bounded samples of the same
+    workloads: train step and p_sample step of both models, and the four wavelet transforms. One warm-up,
+    then >= 3 timed iterations (median) where the budget allows."""
+    from oracle import diffusion_ref as D, unet_ref as U, dwt_ref as R
+    import numpy as np
+    _trees()
     torch.manual_seed(0)
     cores = min(os.cpu_count() or 1, 32)       # torch CPU convolutions stop scaling (and regress) beyond a few dozen threads
     torch.set_num_threads(cores)
-    from wdno_amd import tree_path
+    t_begin = time.perf_counter()
+    out = {'cores': cores, 'cpu_model': _cpu_model(), 'kind': 'port'}
+
+    def timed(fn, n=3, warm=1):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > budget_s:
+                break
+        return _median(ts), len(ts)
+
+    # ---- smoke
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and not k.endswith('freqs') else v) for k, v in net.state_dict().items()}
@@ -57,156 +120,352 @@ def cpu_baseline(seconds_budget=25.0):
     lw = torch.linspace(1.0, 22.0, 42).reshape(1, 1, 42, 1, 1)
     model = lambda x, t: U.unet3d_forward(sd, x, t, dim=64, dim_mults=(1, 2, 4), groups=8)
     g = torch.Generator().manual_seed(1)
-    times = []
-    b = 1
-    for it in range(3):
-        x0 = torch.randn(b, 24, 42, 40, 40, generator=g) * 0.5
-        noise = torch.randn(b, 24, 42, 40, 40, generator=g)
-        t = torch.randint(0, 1000, (b,), generator=g)
-        t0 = time.perf_counter()
+    x0 = torch.randn(1, 24, 42, 40, 40, generator=g) * 0.5
+    noise = torch.randn(1, 24, 42, 40, 40, generator=g)
+    t = torch.randint(0, 1000, (1,), generator=g)
+
+    def smoke_train():
         loss = D.smoke_p_losses(model, buf, x0, t, noise, padded_shape=(18, 34, 34), loss_layer_weight=lw)
         opt.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
-        times.append(time.perf_counter() - t0)
-        if sum(times) > seconds_budget:
-            break
-    per_sample = min(times[1:]) if len(times) > 1 else times[0]
-    return {'value': 1.0 / (per_sample * 8), 'unit': 'steps/s (8-sample steps)', 'cores': cores, 'kind': 'port',
-            'sample': f'{len(times)} training steps at batch 1 of the same [24,42,40,40] workload on the host CPU (oracle/), best {per_sample:.2f} s per sample; '
-                      'value = 1 / (8 x that)'}
+
+    def smoke_sample():
+        with torch.no_grad():
+            D.smoke_p_sample(model, buf, x0, 500, noise)
+    s, n = timed(smoke_train)
+    out['smoke_train_step'] = {'seconds_per_sample': round(s, 3), 'iters': n, 'steps_per_sec_at_batch8': round(1.0 / (8 * s), 4), 'batch': 1}
+    s2, n = timed(smoke_sample)
+    out['smoke_p_sample_step'] = {'seconds_per_sample': round(s2, 3), 'iters': n, 'steps_per_sec_at_batch8': round(1.0 / (8 * s2), 4), 'batch': 1}
+    del sd, params, opt, net
+
+    # ---- Burgers
+    from ddpm_burgers.unet import Unet2D
+    netb = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+    sdb = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in netb.state_dict().items()}
+    pb = [v for v in sdb.values() if v.requires_grad]
+    optb = torch.optim.Adam(pb, lr=1e-4, betas=(0.9, 0.99))
+    bufb = D.make_buffers('cosine', 1000)
+    modelb = lambda x, t: U.unet2d_forward(sdb, x, t, dim=128, dim_mults=(1, 2, 4, 8), groups=1)
+    xb = torch.randn(4, 9, 64, 64, generator=g) * 0.5
+    nb = torch.randn(4, 9, 64, 64, generator=g)
+    tb = torch.randint(0, 1000, (4,), generator=g)
+    flags = dict(pad=True, u0=True, uT=False, f=True)
+
+    def burgers_train():
+        loss = D.burgers_p_losses(modelb, bufb, xb, tb, nb, padded_shape=[41, 60], loss_layer_weight=torch.ones(1, 9, 1, 1), flags=flags)
+        optb.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        optb.step()
+
+    def burgers_sample():
+        with torch.no_grad():
+            tt = torch.full((4,), 500, dtype=torch.long)
+            _, xs = D.burgers_model_predictions(modelb, bufb, xb, tt)
+            D.posterior_step(bufb, xb, 500, xs.clamp(-1., 1.), nb)
+    s, n = timed(burgers_train)
+    out['burgers_train_step'] = {'seconds_per_batch4': round(s, 3), 'iters': n, 'steps_per_sec_at_batch16': round(1.0 / (4 * s), 4), 'batch': 4}
+    s, n = timed(burgers_sample)
+    out['burgers_p_sample_step'] = {'seconds_per_batch4': round(s, 3), 'iters': n, 'steps_per_sec_at_batch16': round(1.0 / (4 * s), 4), 'batch': 4}
+    del sdb, pb, optb, netb
+
+    # ---- wavelet transforms (numpy restatement), 1/8 of the synthetic batch, scaled
+    x2 = np.random.default_rng(0).standard_normal((8, 2, 160, 128)).astype(np.float32)
+    x3 = np.random.default_rng(1).standard_normal((4, 32, 64, 64)).astype(np.float32)
+    yl, yh = R.dwt2(x2, 'bior2.4', 'periodization')
+    lll, det = R.dwt3(x3, 'bior1.3')
+    for key, fn, scale, nbytes in (('dwt2_fwd', lambda: R.dwt2(x2, 'bior2.4', 'periodization'), 8, 20.97e6),
+                                   ('dwt2_inv', lambda: R.idwt2(yl, yh, 'bior2.4', 'periodization'), 8, 20.97e6),
+                                   ('dwt3_fwd', lambda: R.dwt3(x3, 'bior1.3'), 8, 38.08e6),
+                                   ('dwt3_inv', lambda: R.idwt3(lll, det, 'bior1.3'), 8, 38.08e6)):
+        s, n = timed(fn, n=3, warm=1)
+        out[key] = {'ms_full_shape': round(s * scale * 1e3, 2), 'GB/s': round(nbytes / (s * scale) / 1e9, 3), 'iters': n, 'threads': 1}
+    out['seconds_total'] = round(time.perf_counter() - t_begin, 1)
+    # the JSON contract's required keys: the baseline of the main metric
+    s = out['smoke_train_step']['seconds_per_sample']
+    out.update(value=round(1.0 / (8 * s), 4), unit='steps/s (8-sample steps)',
+               sample=f'oracle/ (CPU restatement, torch fp32) on {cores} threads of {out["cpu_model"]}: median of '
+                      f'{out["smoke_train_step"]["iters"]} training steps at batch 1 of the same [24,42,40,40] workload after one warm-up, '
+                      f'{s:.2f} s per sample; value = 1 / (8 x that). Other entries: p_sample step, the Burgers model at batch 4, and the numpy DWT oracle on 1/8 of the synthetic batch (1 thread).')
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- side legs
+def _ev_time(fn, iters, warm=3):
+    """Average duration in ms of fn() measured with HIP events on the launch stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def dwt_leg(device):
+    """W1/W2/W4/W5 at BASELINE.json's synthetic shapes: one fused launch each (csrc/dwt.hip), algorithmic bytes = input + output."""
+    from wdno_amd import wavelets
+    out = {}
+    x2 = torch.randn(64, 2, 160, 128, device=device)
+    c2 = wavelets.dwt_packed(x2, 'bior2.4', 'periodization', 2)
+    x3 = torch.randn(32, 32, 64, 64, device=device)
+    c3 = wavelets.dwt_packed(x3, 'bior1.3', 'zero', 3)
+    cases = (('dwt2_per_bior2.4_fwd [64,2,160,128]', lambda: wavelets.dwt_packed(x2, 'bior2.4', 'periodization', 2), (x2.numel() + c2.numel()) * 4),
+             ('dwt2_per_bior2.4_inv', lambda: wavelets.idwt_packed(c2, 'bior2.4', 'periodization', 2), (x2.numel() + c2.numel()) * 4),
+             ('dwt3_zero_bior1.3_fwd [32,32,64,64]', lambda: wavelets.dwt_packed(x3, 'bior1.3', 'zero', 3), (x3.numel() + c3.numel()) * 4),
+             ('dwt3_zero_bior1.3_inv', lambda: wavelets.idwt_packed(c3, 'bior1.3', 'zero', 3), (x3.numel() + c3.numel()) * 4))
+    g = torch.cuda.CUDAGraph()
+    for name, fn, nbytes in cases:
+        ms_call = _ev_time(fn, 50)              # includes the host side of one Python call per transform
+        # kernel alone: 20 launches captured in one graph (no host gaps between them)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                fn()
+        ms_k = _ev_time(g.replay, 10) / 20
+        out[name] = {'us_per_launch': round(ms_k * 1e3, 2), 'us_per_python_call': round(ms_call * 1e3, 2), 'MB_algorithmic': round(nbytes / 1e6, 2),
+                     'GB/s': round(nbytes / (ms_k * 1e-3) / 1e9, 1), 'frac_of_hbm_peak': round(nbytes / (ms_k * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
+    return out
+
+
+def sampling_leg(dif, device, batch, steps):
+    """DDPM sampling steps/s: the step issued launch by launch vs replays of one captured HIP graph (same arithmetic, bit-equal)."""
+    from wdno_amd import diffusion_core as K
+    out = {}
+    for b in sorted({batch, 1}):
+        shape = (b, 24, 42, 40, 40)
+        x = torch.randn(shape, device=device)
+        init = torch.randn(b, 24, 40, 40, device=device)
+        control = torch.randn(b, 24, 16, 40, 40, device=device)
+        desc = dif._desc(shape, dif.padded_shape)
+        src = dif._condition_source(shape, device, init, control, None)
+        with torch.no_grad():
+            for _ in range(2):
+                x, _ = dif.p_sample(shape, x, 500)
+                x = K.apply_cond(x, src, desc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                x, _ = dif.p_sample(shape, x, 500 - i)
+                x = K.apply_cond(x, src, desc)
+            torch.cuda.synchronize()
+            eager = steps / (time.perf_counter() - t0)
+            sg = K._step_graph(dif, shape, desc, False, False, device)
+            sg.src.copy_(src)
+            sg.x.copy_(x)
+            for _ in range(2):
+                sg.graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                sg.t.fill_(500 - i)
+                sg.noise.normal_()
+                sg.graph.replay()
+            torch.cuda.synchronize()
+            graph = steps / (time.perf_counter() - t0)
+        out[f'batch{b}'] = {'eager_steps_per_sec': round(eager, 2), 'graph_steps_per_sec': round(graph, 2)}
+        K._graph_cache.pop(dif, None)
+    return out
+
+
+def burgers_leg(device, batch, steps, lowp=None):
+    """Burgers base model: train step and p_sample step (BASELINE.json configs[0] shape at batch 16, configs[1] at batch 256)."""
+    from wdno_amd import ops
+    from wdno_amd.trainer import TrainStep, cosine_annealing_lr
+    prev = ops.CONV_MATH
+    if lowp:
+        ops.CONV_MATH = lowp
+    try:
+        dif = build_burgers(device)
+        ts = TrainStep(dif, lr=1e-4, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=lambda b, s: cosine_annealing_lr(b, s, 10000))
+        x = (torch.randn(batch, 9, 64, 64) * 0.5).to(device)
+        for _ in range(3):
+            ts.step(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _ = ts.step(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        with torch.no_grad():
+            xs = torch.randn(batch, 9, 64, 64, device=device)
+            for t in (500, 499):
+                xs = dif.p_sample(xs, t)[0]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                xs = dif.p_sample(xs, 400 - i)[0]
+            torch.cuda.synchronize()
+            ds = (time.perf_counter() - t0) / steps
+        return {'batch': batch, 'conv_math': ops.CONV_MATH, 'train_ms_per_step': round(dt * 1e3, 2), 'train_steps_per_sec': round(1 / dt, 2),
+                'train_samples_per_sec': round(batch / dt, 1), 'p_sample_ms_per_step': round(ds * 1e3, 2), 'final_loss': float(loss)}
+    finally:
+        ops.CONV_MATH = prev
+
+
+def conv_roofline(ts_step, ops):
+    """Per-launch HIP-event timing of the convolution kernels over one extra step -> roofline of the dominant kernel."""
+    ops.PROFILE = {}
+    ts_step()
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for key, evs in prof.items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+        fl = sum(f for _, _, f in evs)
+        agg[key] = (ms, fl, len(evs))
+    if not agg:
+        return None
+    dom = max(agg, key=lambda k: agg[k][0])
+    ms, fl, n = agg[dom]
+    achieved = fl / (ms * 1e-3) / 1e12
+    split = 'h3' in dom and ops.CONV_MATH == 'f16x3'
+    peak = PEAK_F32_MFMA_TFLOPS if 'h3' not in dom else PEAK_F16_MFMA_TFLOPS
+    traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json)
+    try:
+        fam, dims = dom.split('<')
+        dims = dims.rstrip('>').split(',')
+        sym = fam + 'I' + ''.join(f'Li{d}E' for d in dims) if all(d.isdigit() for d in dims) else None
+        path = PROFILE_JSON if os.path.exists(PROFILE_JSON) else os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        with open(path) as f:
+            for kname, rec in json.load(f)['kernels'].items():
+                if sym and sym in kname:          # entries are ordered by total time: the first match is the main instantiation
+                    traffic = round(rec['hbm_bytes_per_launch'])
+                    break
+    except Exception:
+        traffic = None
+    return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'traffic': traffic, 'launches_per_step': n,
+            'frac_of_fp32_equivalent_ceiling': round(achieved / (peak / 3), 4) if split else None,
+            'note': ('fp32-equivalent 3 x fp16-split MFMA: 3 matrix flop per algorithmic flop, so frac <= 0.333; the exact-fp32 MFMA peak is 157.3 TFLOP/s'
+                     if split else ('single-product 16-bit MFMA' if 'h3' in dom else 'exact-fp32 MFMA')),
+            'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
+            'conv_ms_per_step': {k: round(v[0], 3) for k, v in agg.items()}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=8, help='samples per GPU per step')
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=None, help='samples per GPU per step (default 8 smoke, 16 burgers, 256 burgers-bf16)')
+    ap.add_argument('--workload', default='smoke', choices=['smoke', 'burgers', 'burgers-bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--sample-steps', type=int, default=5)
+    ap.add_argument('--no-extras', action='store_true', help='skip the sampling / DWT / Burgers side legs')
+    ap.add_argument('--sample-steps', type=int, default=20)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback on the product path)'
-    torch.cuda.set_device(local)
+    from wdno_amd.trainer import init_distributed
+    rank, world, local = init_distributed()                # torchrun: set_device(LOCAL_RANK) + RCCL ("nccl") process group
+    import torch.distributed as dist
     device = torch.device('cuda', local)
 
     from wdno_amd import _lib, ops
-    from wdno_amd.trainer import TrainStep, multistep_lr
+    from wdno_amd.trainer import TrainStep, cosine_annealing_lr, multistep_lr
     _lib.load()
-    dif = build_model(device, args.batch)
-    ts = TrainStep(dif, lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=multistep_lr, use_ema=True)
+    smoke = args.workload == 'smoke'
+    if args.workload == 'burgers-bf16':
+        ops.CONV_MATH = 'bf16'
+    batch = args.batch or (8 if smoke else (256 if args.workload == 'burgers-bf16' else 16))
+    if smoke:
+        dif = build_model(device, batch)
+        ts = TrainStep(dif, lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=multistep_lr, use_ema=True)
+        shape = (batch, 24, 42, 40, 40)
+        grad_mb = 95.3
+    else:
+        dif = build_burgers(device)
+        ts = TrainStep(dif, lr=1e-4, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=lambda b, s: cosine_annealing_lr(b, s, 10000), use_ema=True)
+        shape = (batch, 9, 64, 64)
+        grad_mb = 563.0
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
-    batch = (torch.randn(args.batch, 24, 42, 40, 40, generator=g) * 0.5).to(device)      # resident in HBM before timing
+    x = (torch.randn(shape, generator=g) * 0.5).to(device)      # resident in HBM before timing
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    ts.time_comm = world > 1
     losses = []
     for _ in range(args.warmup):
-        loss, _ = ts.step(batch)
+        loss, _ = ts.step(x)
     barrier()
+    ts.comm_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, gn = ts.step(batch)
+        loss, gn = ts.step(x)
         losses.append(loss)
+    torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+        comm_ms = sum(a.elapsed_time(b) for a, b in ts.comm_events) / max(1, len(ts.comm_events))
+        tt = torch.tensor([elapsed, local_elapsed / args.steps * 1e3, comm_ms], device=device, dtype=torch.float64)
+        allv = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allv, tt)
+        elapsed = max(float(v[0]) for v in allv)
+        per_rank = {'ms_per_step': [round(float(v[1]), 3) for v in allv], 'exposed_allreduce_ms': [round(float(v[2]), 3) for v in allv]}
     final_loss = float(losses[-1]) if losses else float('nan')
 
-    # ---- DDPM sampling step rate (not part of `value`)
-    x = torch.randn(args.batch, 24, 42, 40, 40, device=device)
-    init = torch.randn(args.batch, 24, 40, 40, device=device)
-    control = torch.randn(args.batch, 24, 16, 40, 40, device=device)
-    from wdno_amd import diffusion_core as K
-    desc = dif._desc(tuple(x.shape), dif.padded_shape)
-    src = dif._condition_source(tuple(x.shape), device, init, control, None)
-    with torch.no_grad():
-        for _ in range(2):
-            x, _ = dif.p_sample(tuple(x.shape), x, 500)
-            x = K.apply_cond(x, src, desc)
-        torch.cuda.synchronize()
-        s0 = time.perf_counter()
-        for i in range(args.sample_steps):
-            x, _ = dif.p_sample(tuple(x.shape), x, 500 - i)
-            x = K.apply_cond(x, src, desc)
-        torch.cuda.synchronize()
-        sample_elapsed = time.perf_counter() - s0
-
-    # ---- per-launch HIP-event timing of the convolution kernels over one extra step -> roofline of the dominant kernel
-    roofline = None
+    extras = {}
+    roofline = cpu = None
     if rank == 0:
-        ops.PROFILE = {}
-        ts.step(batch)
-        torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
-        agg = {}
-        for key, evs in prof.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-            fl = sum(f for _, _, f in evs)
-            agg[key] = (ms, fl, len(evs))
-        if agg:
-            dom = max(agg, key=lambda k: agg[k][0])
-            ms, fl, n = agg[dom]
-            achieved = fl / (ms * 1e-3) / 1e12
-            peak = PEAK_F16_MFMA_TFLOPS if 'h3' in dom else PEAK_F32_MFMA_TFLOPS
-            traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json)
+        roofline = conv_roofline(lambda: ts.step(x), ops)
+        if world == 1 and not args.no_extras:
             try:
-                # profiling key 'conv_fwd_h3d_kernel<256,64>' -> mangled symbol prefix 'conv_fwd_h3d_kernelILi256ELi64E'
-                fam, dims = dom.split('<')
-                dims = dims.rstrip('>').split(',')
-                sym = fam + 'I' + ''.join(f'Li{d}E' for d in dims) if all(d.isdigit() for d in dims) else None
-                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-                    for kname, rec in json.load(f)['kernels'].items():
-                        if sym and sym in kname:          # entries are ordered by total time: the first match is the main instantiation
-                            traffic = round(rec['hbm_bytes_per_launch'])
-                            break
-            except Exception:
-                traffic = None
-            roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / peak, 4), 'traffic': traffic, 'launches_per_step': n,
-                        'frac_of_fp32_equivalent_ceiling': round(achieved / (peak / 3), 4) if 'h3' in dom else None,
-                        'note': ('fp32-equivalent 3 x fp16-split MFMA: 3 matrix flop per algorithmic flop, so frac <= 0.333; '
-                                 'the exact-fp32 MFMA peak is 157.3 TFLOP/s') if 'h3' in dom else 'exact-fp32 MFMA',
-                        'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
-                        'conv_ms_per_step': {k: round(v[0], 3) for k, v in agg.items()}}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            cpu = cpu_baseline()
-        except Exception as e:      # the baseline is informative only
-            cpu = {'error': repr(e)}
+                if smoke:
+                    extras['sampling'] = sampling_leg(dif, device, batch, args.sample_steps)
+                extras['dwt'] = dwt_leg(device)
+                if smoke:
+                    del ts, dif
+                    torch.cuda.empty_cache()
+                    extras['burgers'] = {'fp32_equivalent_batch16': burgers_leg(device, 16, 20),
+                                         'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16') if ops.LOWP_AVAILABLE else 'bf16 path not built'}
+            except Exception as e:      # side legs never invalidate the main line
+                import traceback
+                extras['error'] = repr(e) + ' | ' + traceback.format_exc()[-600:]
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline()
+            except Exception as e:      # the baseline is informative only
+                cpu = {'error': repr(e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        if smoke:
+            metric = 'diffusion train steps/sec, 2D smoke U-Net (8 samples per GPU per step)'
+            wl = (f'smoke base-resolution DDPM train step: Unet3D_with_Conv3D(dim=64,(1,2,4),ch=42) on wavelet tensor [{batch},24,42,40,40] per GPU, '
+                  'fp32 in/out, convolutions on the fp32-equivalent 3 x fp16-split MFMA path (small ones exact-fp32 MFMA), Adam+clip+EMA')
+            dtype = 'f32'
+        else:
+            metric = f'diffusion train steps/sec, 1D Burgers U-Net ({batch} samples per GPU per step)'
+            math = 'bf16 single-product MFMA with fp32 master weights and accumulators' if args.workload == 'burgers-bf16' else 'fp32-equivalent 3 x fp16-split MFMA'
+            wl = f'Burgers base-resolution DDPM train step: Unet2D(dim=128,(1,2,4,8),ch=9,groups=1) on [{batch},9,64,64] per GPU, convolutions: {math}, Adam+clip+EMA'
+            dtype = 'bf16' if args.workload == 'burgers-bf16' else 'f32'
         out = {
-            'metric': 'diffusion train steps/sec, 2D smoke U-Net (8 samples per GPU per step)',
-            'value': round(world * args.steps / elapsed, 4), 'unit': 'steps/s',
+            'metric': metric, 'value': round(world * args.steps / elapsed, 4), 'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'smoke base-resolution DDPM train step: Unet3D_with_Conv3D(dim=64,(1,2,4),ch=42) on wavelet tensor '
-                                   f'[{args.batch},24,42,40,40] per GPU, fp32 in/out, convolutions on the fp32-equivalent 3 x fp16-split MFMA path (small ones exact-fp32 MFMA), Adam+clip+EMA',
-                       'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': 95.3 if world > 1 else 0},
-            'samples_per_sec': round(world * args.steps * args.batch / elapsed, 3),
-            'ddpm_sample_steps_per_sec': round(args.sample_steps / sample_elapsed, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
+            'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0},
+            'samples_per_sec': round(world * args.steps * batch / elapsed, 3),
             'final_loss': final_loss,
             'roofline': roofline, 'cpu_baseline': cpu,
         }
+        if 'sampling' in extras:
+            out['ddpm_sample_steps_per_sec'] = extras['sampling'][f'batch{batch}']['graph_steps_per_sec']
+        if per_rank:
+            out['per_rank'] = per_rank
+        out.update(extras)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

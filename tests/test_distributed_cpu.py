@@ -19,7 +19,7 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from wdno_amd.trainer import FlatBuffers, allreduce_mean_
+    from wdno_amd.trainer import FlatBuffers, allreduce_sum_
     torch.manual_seed(0)                                       # identical replicas
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
     buf = FlatBuffers(model.parameters())
@@ -30,7 +30,7 @@ def _worker(rank, world, port, out):
     ((model(x) - y) ** 2).mean().backward()
     buf.gather_grads()
     assert all(p.grad.data_ptr() == buf.flat_grad[o:o + 1].data_ptr() for p, (o, n) in zip(buf.params, buf._spans()))
-    allreduce_mean_(buf.flat_grad, world)
+    allreduce_sum_(buf.flat_grad, world)
     mean_grad = buf.flat_grad / world
     out[rank] = mean_grad.clone()
     dist.barrier()
@@ -61,7 +61,7 @@ def test_flat_gradient_allreduce_world2():
 def _worker_overlap(rank, world, port, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from wdno_amd.trainer import FlatBuffers, OverlappedAllReduce, allreduce_mean_
+    from wdno_amd.trainer import FlatBuffers, OverlappedAllReduce, allreduce_sum_
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3),
                                 torch.nn.Linear(3, 3))
@@ -84,7 +84,7 @@ def _worker_overlap(rank, world, port, out):
         buf.zero_grad()                                         # the same step with one all-reduce after backward
         ((model(x) - y) ** 2).mean().backward()
         buf.gather_grads()
-        allreduce_mean_(buf.flat_grad, world)
+        allreduce_sum_(buf.flat_grad, world)
         res.append((over, buf.flat_grad.clone()))
     out[rank] = res
     dist.barrier()

@@ -70,8 +70,9 @@ class Trainer(TrainerCore):
             dl = self.make_loader(dataset, self.local_batch_size, workers)
         else:                                      # a list of datasets, one group drawn at random per batch (data_burgers_1d.py SuperDataLoader)
             from ddpm_burgers.data_burgers_1d import SuperDataLoader
-            dl = SuperDataLoader(dataset, batch_size=self.local_batch_size, shuffle=True, pin_memory=True, num_workers=workers)
-        self.dl = cycle(dl)
+            dl = SuperDataLoader(dataset, batch_size=self.local_batch_size, shuffle=True, pin_memory=True, num_workers=workers,
+                                 seed=self.data_seed if self.world > 1 else None)
+        self.dl = self.cycle(dl)          # advances DistributedSampler epochs
 
     def _path(self, milestone):
         if type(milestone) is int:

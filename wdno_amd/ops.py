@@ -46,6 +46,14 @@ def bump_weight_epoch():
     WEIGHT_EPOCH += 1
 
 
+def drop_weight_caches():
+    """Forget every packed / split weight operand (they hold references to the parameter storages they were built from)."""
+    _pack_cache.clear()
+    _wplans.clear()
+    _wtables.clear()
+    bump_weight_epoch()
+
+
 def _lib_():
     return _lib.load()
 
@@ -319,6 +327,7 @@ def pack_transposed(w_io, cin_p, cout_p):
 # 'f16x3' = fp32-equivalent 3 x fp16-split MFMA for the large convolutions (forward and data gradient); 'f32' = exact-fp32
 # MFMA everywhere. Small problems always take the exact kernel.
 CONV_MATH = os.environ.get('WDNO_CONV_MATH', 'f16x3')
+LOWP_AVAILABLE = False     # single-product bf16 / fp16 convolution path (CONV_MATH = 'bf16' | 'f16')
 H3_MIN_PIXELS = 1024
 H3_MIN_REDUCTION = 64
 

@@ -111,13 +111,18 @@ class Smoke_wave(Dataset):
 class SuperDataLoader:
     """One batch per iteration, drawn from a randomly chosen dataset of the list (super-resolution levels)."""
 
-    def __init__(self, dataset, batch_size=1, shuffle=True, pin_memory=True, num_workers=1):
+    def __init__(self, dataset, batch_size=1, shuffle=True, pin_memory=True, num_workers=1, seed=None):
+        """seed (an extension): private shuffle / level-choice streams, e.g. base + 1000 * rank under data parallelism -- the
+        reference's loader is not sharded by accelerate, and identically seeded ranks would draw identical batches."""
         self.dataset = dataset
-        self.dl = [cycle(DataLoader(ds, batch_size=batch_size, shuffle=shuffle, pin_memory=pin_memory, num_workers=num_workers)) for ds in dataset]
+        gens = [None if seed is None else torch.Generator().manual_seed(seed + i) for i in range(len(dataset))]
+        self.dl = [cycle(DataLoader(ds, batch_size=batch_size, shuffle=shuffle, pin_memory=pin_memory, num_workers=num_workers, generator=g))
+                   for ds, g in zip(dataset, gens)]
         self.num_batches = len(dataset) * ((len(dataset[0]) + batch_size - 1) // batch_size)
+        self._rng = random if seed is None else random.Random(seed)
 
     def __iter__(self):
-        yield next(self.dl[random.randint(0, len(self.dl) - 1)])
+        yield next(self.dl[self._rng.randint(0, len(self.dl) - 1)])
 
     def __len__(self):
         return self.num_batches

@@ -380,11 +380,12 @@ class Trainer(_TrainerCore):
         if isinstance(self.ds, (list, tuple)):
             from ddpm.data_2d import SuperDataLoader
             workers = 4 if num_workers is None else num_workers
-            dl = SuperDataLoader(self.ds, batch_size=self.local_batch_size, shuffle=True, pin_memory=True, num_workers=workers)
+            dl = SuperDataLoader(self.ds, batch_size=self.local_batch_size, shuffle=True, pin_memory=True, num_workers=workers,
+                                 seed=self.data_seed if self.world > 1 else None)
         else:
             workers = 16 if num_workers is None else num_workers
             dl = self.make_loader(self.ds, self.local_batch_size, workers)
-        self.dl = cycle(dl)
+        self.dl = self.cycle(dl)          # advances DistributedSampler epochs
 
     def save(self, milestone):
         if not self.is_main_process:
@@ -405,8 +406,9 @@ class Trainer(_TrainerCore):
     def train(self):
         import logging
         import os
-        logging.basicConfig(filename=os.path.join(self.results_path, 'info.log'), level=logging.INFO,
-                            format='%(asctime)s - %(levelname)s - %(message)s')
+        if self.is_main_process:          # one writer: under torchrun every rank runs this method
+            logging.basicConfig(filename=os.path.join(self.results_path, 'info.log'), level=logging.INFO,
+                                format='%(asctime)s - %(levelname)s - %(message)s')
         while self.step < self.train_num_steps:
             lr = self.lr_schedule(self.train_lr, self.step)
             total_loss = self.optimisation_step(self._next_state)

@@ -42,6 +42,43 @@ class FlatBuffers:
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
                 off += n
+        ops.drop_weight_caches()          # operands packed from the old storages would pin them (and can never hit again)
+        self._untouched = None
+
+    def params_changed(self):
+        """Call after ANY write to flat_param (optimiser step, broadcast, checkpoint load, EMA copy): the packed / split weight
+        operands the convolutions cache are keyed on this epoch, parameter version counters do not see writes through the flat
+        buffer. Every writer in this module goes through here."""
+        ops.bump_weight_epoch()
+
+    def watch_gradient_coverage(self):
+        """Arms a one-step check that every parameter receives a gradient. The flat optimiser keeps zero-filled gradients
+        (never None), so a parameter that backward does not reach still has its moments decayed and takes a momentum-driven
+        update, whereas torch.optim.Adam after zero_grad(set_to_none=True) -- the reference -- skips it. Every trainable
+        parameter of the WDNO models is reached in every step; anything else is refused rather than silently diverging."""
+        self._untouched = set(range(len(self.params)))
+        handles = []
+
+        def make(i):
+            def hook(_):
+                if self._untouched is not None:
+                    self._untouched.discard(i)
+            return hook
+        for i, p in enumerate(self.params):
+            handles.append(p.register_post_accumulate_grad_hook(make(i)))
+        self._watch_handles = handles
+
+    def check_gradient_coverage(self):
+        if self._untouched is None:
+            return
+        missing, self._untouched = sorted(self._untouched), None
+        for h in self._watch_handles:
+            h.remove()
+        if missing:
+            shapes = [tuple(self.params[i].shape) for i in missing[:8]]
+            raise RuntimeError(f'wdno_amd FlatAdam: {len(missing)} trainable parameter(s) received no gradient in the first step '
+                               f'(indices {missing[:8]}, shapes {shapes}); the flat optimiser would still update them, unlike '
+                               'torch.optim.Adam with set_to_none gradients. Freeze them (requires_grad_(False)) before building the trainer.')
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -67,9 +104,10 @@ class FlatBuffers:
                 p.grad = view
 
 
-def allreduce_mean_(flat, world_size=None, group=None):
-    """DDP semantics on one flat buffer: sum over ranks, then divide by the world size (in place). Works for CUDA
-    tensors over RCCL and for CPU tensors over gloo."""
+def allreduce_sum_(flat, world_size=None, group=None):
+    """SUM over ranks, in place (no-op without a process group). The 1/world factor of DDP's mean is NOT applied here: the
+    callers fold it into the clip + Adam launch (FlatAdam.step(grad_scale=1/world)). Works for CUDA tensors over RCCL and, in
+    the tests, for CPU / CUDA tensors over gloo."""
     if not (dist.is_available() and dist.is_initialized()):
         return flat
     ws = world_size or dist.get_world_size(group)
@@ -146,6 +184,53 @@ class OverlappedAllReduce:
         self.handles = []
 
 
+def init_distributed(backend=None):
+    """One process per GPU: what `accelerate` did implicitly for the reference Trainers (train_diffusion.py:71-74,
+    diffusion_2d.py:1093-1098). Under torchrun (RANK / WORLD_SIZE / LOCAL_RANK in the environment) this selects the rank's GPU
+    BEFORE anything is allocated or launched on it (ops._stream() takes the current device's stream) and creates the process
+    group -- backend "nccl" is RCCL on ROCm. Returns (rank, world, local_rank); (0, 1, LOCAL_RANK or 0) without torchrun."""
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if dist.is_available() and not dist.is_initialized() and world_env > 1 and 'RANK' in os.environ:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend or os.environ.get('WDNO_DIST_BACKEND', 'nccl'), rank=int(os.environ['RANK']), world_size=world_env)
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), local
+    return 0, 1, local
+
+
+def broadcast_parameters(buf, model=None, group=None):
+    """Rank 0's parameters (and buffers) to every rank, as DistributedDataParallel does at construction: replicas that were built
+    from different seeds would otherwise only share gradients, never weights."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    dist.broadcast(buf.flat_param, 0, group=group)
+    if model is not None:
+        for b in model.buffers():
+            if b.is_floating_point() or b.dtype in (torch.int64, torch.int32):
+                dist.broadcast(b, 0, group=group)
+        for p in model.parameters():
+            if not p.requires_grad:           # frozen parameters are not part of the flat buffer
+                dist.broadcast(p.data, 0, group=group)
+    buf.params_changed()
+
+
+def cycle_loader(dl):
+    """`cycle(dl)` of the reference (model_utils.py / diffusion_2d.py) that also advances the epoch of a DistributedSampler, so
+    every pass reshuffles like accelerate's prepared loader does (without set_epoch each epoch replays the same permutation)."""
+    epoch = 0
+    while True:
+        sampler = getattr(dl, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)
+        for data in dl:
+            yield data
+        epoch += 1
+
+
 class FlatAdam:
     """clip_grad_norm_(max_grad_norm) + torch.optim.Adam(lr, betas, eps) over flat buffers; two HIP launches per step."""
 
@@ -173,6 +258,7 @@ class FlatAdam:
     def step(self, lr=None, grad_scale=1.0):
         """Returns the (pre-clip) global gradient norm as a 0-d device tensor (no host sync)."""
         self.buf.gather_grads()
+        self.buf.check_gradient_coverage()
         lib = _lib_()
         n = self.buf.numel
         self.step_count += 1
@@ -181,7 +267,7 @@ class FlatAdam:
                                            _p(self.sumsq), float(self.max_grad_norm or 0.0), float(grad_scale),
                                            float(self.lr if lr is None else lr), float(self.betas[0]), float(self.betas[1]),
                                            float(self.eps), int(self.step_count), _stream()), 'adam_clip_step')
-        ops.bump_weight_epoch()
+        self.buf.params_changed()
         return self.sumsq.sqrt()[0] * grad_scale
 
     def state_dict(self):
@@ -233,8 +319,11 @@ class TrainStep:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        broadcast_parameters(self.opt.buf, diffusion, group)          # identical replicas, whatever the ranks' seeds were
+        self.opt.buf.watch_gradient_coverage()
         self.ema = FlatEMA(self.opt.buf.flat_param, ema_decay, ema_update_every) if (use_ema and self.rank == 0) else None
         self.step_idx = 0
+        self.time_comm, self.comm_events = False, []
         # WDNO_DP_OVERLAP=1: the gradient exchange starts bucket by bucket during backward. Opt-in: it is verified on gloo
         # (tests/test_distributed_cpu.py) but has not run over RCCL on a multi-GPU node yet; the default is one all-reduce of the
         # whole buffer after backward (~1-2 ms of a 45 ms step at 8 GPUs).
@@ -251,7 +340,13 @@ class TrainStep:
         loss.backward()
         self.opt.buf.gather_grads()
         if self.world > 1:
-            allreduce_mean_(self.opt.buf.flat_grad, self.world, self.group)
+            if self.time_comm:                    # bench.py: the exposed part of the exchange (backward has finished), HIP events
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            allreduce_sum_(self.opt.buf.flat_grad, self.world, self.group)
+            if self.time_comm:
+                e1.record()
+                self.comm_events.append((e0, e1))
 
     def step(self, batch, **loss_kwargs):
         self.opt.zero_grad()
@@ -415,12 +510,10 @@ class TrainerCore:
     def __init__(self, diffusion_model, *, train_batch_size, gradient_accumulate_every, train_lr, train_num_steps, ema_update_every,
                  ema_decay, adam_betas, save_and_sample_every, split_batches, max_grad_norm, lr_schedule, results_dir):
         from pathlib import Path
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
-        import os
-        self._device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
         if not torch.cuda.is_available():
             raise RuntimeError('wdno_amd Trainer needs an MI355X (no CPU fallback on the hot path)')
+        self.rank, self.world, local = init_distributed()          # torchrun: set_device(LOCAL_RANK) + RCCL process group
+        self._device = torch.device('cuda', local)
         self.model = diffusion_model.to(self._device)
         self.channels = diffusion_model.channels
         self.batch_size = train_batch_size
@@ -433,6 +526,9 @@ class TrainerCore:
         self.train_lr = train_lr
         self.lr_schedule = lr_schedule
         self.opt = FlatAdam(self.model.parameters(), lr=train_lr, betas=adam_betas, max_grad_norm=max_grad_norm)
+        broadcast_parameters(self.opt.buf, self.model)             # DDP semantics: every replica starts from rank 0's weights
+        self.opt.buf.watch_gradient_coverage()
+        self.data_seed = 1234 + 1000 * self.rank                   # loaders that are not sharded by a sampler draw per-rank streams
         if self.is_main_process:
             self.ema = ModelEMA(self.model, self.opt.buf.flat_param, beta=ema_decay, update_every=ema_update_every)
         self.results_dir = Path(results_dir)
@@ -448,6 +544,8 @@ class TrainerCore:
     @property
     def is_main_process(self):
         return self.rank == 0
+
+    cycle = staticmethod(cycle_loader)
 
     def make_loader(self, dataset, batch_size, num_workers, shuffle=True):
         from torch.utils.data import DataLoader
@@ -467,7 +565,7 @@ class TrainerCore:
             total += float(loss.detach())
         self.opt.buf.gather_grads()
         if self.world > 1:
-            allreduce_mean_(self.opt.buf.flat_grad, self.world)
+            allreduce_sum_(self.opt.buf.flat_grad, self.world)
         self.last_grad_norm = self.opt.step(lr=self.lr_schedule(self.train_lr, self.step), grad_scale=1.0 / self.world)
         self.total_loss = total
         return total
