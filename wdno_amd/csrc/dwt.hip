@@ -12,6 +12,7 @@
 // packing kernel exists. Taps travel as kernel arguments (<= 16 per filter).
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 #define WDNO_MAXL 16
 #define WDNO_MAXCOMP 5
@@ -141,7 +142,20 @@ __global__ __launch_bounds__(256) void synthesis_kernel(const float* __restrict_
 // contiguous range of tiles, i.e. whole images.
 extern int wdno_debug_mode;      // 11: force the per-axis passes (A/B and bit-equality tests)
 
+// n / d for 0 <= n, n * d < 2^32 as one multiply-high (m = floor(2^32 / d) + 1): the item loops below decode (row, column)
+// from a linear index several times per item, and a hardware integer division is ~30 VALU instructions on gfx950 -- with them
+// the 3-D synthesis kernel was ALU-bound at 50 us for 38 MB.
+struct FastDiv { unsigned d, m; };
+static inline FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  f.d = (unsigned)d;
+  f.m = d > 1 ? (unsigned)((1ull << 32) / (unsigned)d + 1ull) : 0u;
+  return f;
+}
+__device__ __forceinline__ int fd_div(int n, FastDiv f) { return f.d == 1 ? n : (int)__umulhi((unsigned)n, f.m); }
+
 struct FusedGeom {
+  FastDiv dFW, dNH, dWo, dQW, dEH, dNQH2;
   int n_img, T, H, W, To, Ho, Wo;
   int64_t cs_img, cs_band, cs0, cs1;
   int off, odd_t, odd_h, odd_w;
@@ -155,19 +169,25 @@ struct FusedGeom {
 __device__ __forceinline__ int xcd_tile(int bid, int nb) {
   return (nb & 7) ? bid : (bid & 7) * (nb >> 3) + (bid >> 3);
 }
+// Periodic wrap without an integer division: every index a valid item asks for lies within one period of [0, P) (|j| < 2 P is
+// guaranteed by L <= P, checked on the host); items of a ragged last tile may ask for more and are clamped (their results are
+// never stored), so that no read leaves the tensor.
+__device__ __forceinline__ int wrap_period(int j, int P) {
+  j = j < 0 ? j + P : j;
+  j = j >= P ? j - P : j;
+  j = j >= P ? j - P : j;
+  return min(max(j, 0), P - 1);
+}
 template <int MODE>
 __device__ __forceinline__ int amap(int j, int N, int odd) {      // signal index read by an analysis pass: [0, N) or -1 (= zero)
   if (MODE == 1) return (j >= 0 && j < N) ? j : -1;
-  const int Next = N + odd;
-  j %= Next;
-  if (j < 0) j += Next;
+  j = wrap_period(j, N + odd);
   return j > N - 1 ? N - 1 : j;
 }
 template <int MODE>
 __device__ __forceinline__ int smap(int K, int M) {               // coefficient index read by a synthesis pass
   if (MODE == 1) return (K >= 0 && K < M) ? K : -1;
-  K %= M;
-  return K < 0 ? K + M : K;
+  return wrap_period(K, M);
 }
 
 // ND = 3: register pass along T, NK coefficient frames per block.  ND = 2: register pass along H, NK coefficient rows per item.
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
     kt0 = tt * NK;
     const int64_t fs = (int64_t)g.H * g.W;
     for (int it = threadIdx.x; it < rows * FW; it += 256) {
-      const int r = it / FW, c = it - r * FW;
+      const int r = fd_div(it, g.dFW), c = it - r * FW;
       const int h = amap<MODE>(2 * kh0 - off + r, g.H, g.odd_h);
       const int w = amap<MODE>(c - off, g.W, g.odd_w);
       float lo[NK], hi[NK];
@@ -223,10 +243,11 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
       }
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < NP * nh * FW; it += 256) {
-      const int c = it % FW;
-      int q = it / FW;
-      const int kh = q % nh, p = q / nh;
+    for (int it = threadIdx.x; it < NP * NH * FW; it += 256) {
+      int q = fd_div(it, g.dFW);
+      const int c = it - q * FW;
+      const int p = fd_div(q, g.dNH), kh = q - p * NH;
+      if (kh >= nh) continue;
       const float* col = S1 + (p * FH + 2 * kh) * FW + c;
       float lo = 0.f, hi = 0.f;
 #pragma unroll
@@ -242,7 +263,8 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
     S2 = lds;
     const int ngroups = (nh + NK - 1) / NK;
     for (int it = threadIdx.x; it < ngroups * FW; it += 256) {
-      const int c = it % FW, k0 = (it / FW) * NK;
+      const int gq = fd_div(it, g.dFW);
+      const int c = it - gq * FW, k0 = gq * NK;
       const int w = amap<MODE>(c - off, g.W, g.odd_w);
       float lo[NK], hi[NK];
 #pragma unroll
@@ -274,12 +296,12 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
   // pass W: LDS -> packed coefficients. float2 reads (index 2 kw + m): conflict-free, and m ascends inside each pair
   float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
   const int Wo = g.Wo;
-  for (int it = threadIdx.x; it < NP * 2 * nh * Wo; it += 256) {
-    const int kw = it % Wo;
-    int q = it / Wo;
-    const int kh = q % nh;
-    q /= nh;
-    const int bh = q & 1, p = q >> 1;
+  for (int it = threadIdx.x; it < NP * 2 * NH * Wo; it += 256) {
+    int q = fd_div(it, g.dWo);
+    const int kw = it - q * Wo;
+    const int q2 = fd_div(q, g.dNH), kh = q - q2 * NH;
+    if (kh >= nh) continue;
+    const int bh = q2 & 1, p = q2 >> 1;
     const int bt = (ND == 3) ? p / NK : 0;
     const int kt = (ND == 3) ? kt0 + p % NK : 0;
     if (ND == 3 && kt >= g.To) continue;
@@ -324,12 +346,12 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
   float* S1 = lds;                                           // [NP][2][EH][NW]
   // pass W: packed coefficients -> S1
   const int eh_used = nqh + E;
-  for (int it = threadIdx.x; it < NP * 2 * eh_used * QW; it += 256) {
-    const int ql = it % QW;
-    int q = it / QW;
-    const int eh = q % eh_used;
-    q /= eh_used;
-    const int bh = q & 1, p = q >> 1;
+  for (int it = threadIdx.x; it < NP * 2 * EH * QW; it += 256) {
+    int q = fd_div(it, g.dQW);
+    const int ql = it - q * QW;
+    const int q2 = fd_div(q, g.dEH), eh = q - q2 * EH;
+    if (eh >= eh_used) continue;
+    const int bh = q2 & 1, p = q2 >> 1;
     const int bt = (ND == 3) ? p / ET : 0;
     const int Kt = (ND == 3) ? smap<MODE>(qt_start - E + p % ET, g.To) : 0;
     const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
@@ -358,10 +380,11 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
   const int wshift = off & 1;                                // position pw <-> n_w = pw - (off & 1)
   if (ND == 3) {
     float* S2 = lds + NP * 2 * EH * NW;                      // [2 ET][2 NQH][NW]
-    for (int it = threadIdx.x; it < NP * 2 * nqh * NW; it += 256) {
-      const int pw = it % NW;
-      int q = it / NW;
-      const int ph = q % (2 * nqh), p = q / (2 * nqh);
+    for (int it = threadIdx.x; it < NP * 2 * NQH * NW; it += 256) {
+      int q = fd_div(it, g.dFW);
+      const int pw = it - q * NW;
+      const int p = fd_div(q, g.dNQH2), ph = q - p * 2 * NQH;
+      if (ph >= 2 * nqh) continue;
       const int ql = ph >> 1, r = ph & 1;
       const float* cl = S1 + ((p * 2 + 0) * EH + ql + E) * NW + pw;
       const float* ch = S1 + ((p * 2 + 1) * EH + ql + E) * NW + pw;
@@ -376,7 +399,7 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
     __syncthreads();
     const int64_t fs = (int64_t)g.H * g.W;
     for (int it = threadIdx.x; it < 2 * nqh * NW; it += 256) {
-      const int pw = it % NW, ph = it / NW;
+      const int ph = fd_div(it, g.dFW), pw = it - ph * NW;
       const int nw = pw - wshift;
       const int nhh = 2 * (qh_start + (ph >> 1)) + (ph & 1) - off;
       if (nw < 0 || nw >= g.W || nhh < 0 || nhh >= g.H) continue;
@@ -406,7 +429,8 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
     // register pass along H: items (group of NQ q-rows, pw); EH rows of S1 hold the tile's coefficient rows (after the W pass)
     const int ngroups = (nqh + NQ - 1) / NQ;
     for (int it = threadIdx.x; it < ngroups * NW; it += 256) {
-      const int pw = it % NW, q0 = (it / NW) * NQ;
+      const int gq = fd_div(it, g.dFW);
+      const int pw = it - gq * NW, q0 = gq * NQ;
       const int nw = pw - wshift;
       if (nw < 0 || nw >= g.W) continue;
       float cl[ET], ch[ET];
@@ -434,7 +458,19 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
   }
 }
 
-static const size_t FUSED_LDS_BYTES = 64 * 1024;      // default dynamic-LDS limit: no function attribute needed (graph-capture safe)
+// LDS budget per block (<= 64 KB: the default dynamic-LDS limit, no function attribute needed -> graph-capture safe). Smaller
+// tiles = more blocks per CU to hide the latency of the global reads, at the price of more halo re-reads through L2.
+static size_t fused_lds_budget(long default_kb) {
+  static long env_kb = -1;
+  if (env_kb < 0) {
+    const char* e = getenv("WDNO_DWT_LDS_KB");        // A/B switch (tools/bench_dwt.py)
+    env_kb = e ? atol(e) : 0;
+  }
+  long kb = env_kb > 0 ? env_kb : default_kb;
+  if (kb < 8) kb = 8;
+  if (kb > 64) kb = 64;
+  return (size_t)kb * 1024;
+}
 
 template <int ND, int L, int MODE>
 static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
@@ -452,7 +488,7 @@ static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d,
   if (ND == 3) {
     // floats: 2 NK FW (FH + 2 NH) with FH = 2 NH + L - 2
     const size_t per_row = (size_t)2 * NK * g.FW * sizeof(float);
-    const long nh_max = ((long)(FUSED_LDS_BYTES / per_row) - (L - 2)) / 4;
+    const long nh_max = ((long)(fused_lds_budget(32) / per_row) - (L - 2)) / 4;
     if (nh_max < 1) return false;
     const int tiles = cdiv(g.Ho, (int)std::min<long>(nh_max, g.Ho));
     g.NH = cdiv(g.Ho, tiles);
@@ -461,7 +497,7 @@ static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d,
     lds = per_row * (size_t)(4 * g.NH + L - 2);
   } else {
     const size_t per_row = (size_t)2 * g.FW * sizeof(float);
-    long nh_max = (long)(FUSED_LDS_BYTES / per_row);
+    long nh_max = (long)(fused_lds_budget(32) / per_row);
     nh_max = std::min<long>(nh_max / NK * NK, 2 * NK);        // two register groups per block: plenty of blocks for small images
     if (nh_max < NK) return false;
     g.NH = (int)nh_max;
@@ -472,6 +508,8 @@ static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d,
   const int64_t nb = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
   if (nb > 0x7fffffff) return false;
   g.n_blocks = (int)nb;
+  g.dFW = make_fastdiv(g.FW); g.dNH = make_fastdiv(g.NH); g.dWo = make_fastdiv(g.Wo);
+  if ((int64_t)2 * NK * 2 * g.NH * std::max(g.FW, g.Wo) * (int64_t)std::max(g.FW, g.NH) >= (1ll << 32)) return false;   // fd_div range
   dwt_analysis_fused_kernel<ND, L, MODE, NK><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
   return true;
 }
@@ -495,7 +533,7 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
   if (ND == 3) {
     // floats: 2 ET NW (2 EH + 2 NQH), EH = NQH + E
     const size_t per_row = (size_t)2 * (NQ + E) * g.FW * sizeof(float);
-    const long nq_max = ((long)(FUSED_LDS_BYTES / per_row) - 2 * E) / 4;
+    const long nq_max = ((long)(fused_lds_budget(64) / per_row) - 2 * E) / 4;
     if (nq_max < 1) return false;
     const int tiles = cdiv(g.QH, (int)std::min<long>(nq_max, g.QH));
     g.NH = cdiv(g.QH, tiles);
@@ -504,7 +542,7 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
     lds = per_row * (size_t)(4 * g.NH + 2 * E);
   } else {
     const size_t per_row = (size_t)2 * g.FW * sizeof(float);
-    long nq_max = (long)(FUSED_LDS_BYTES / per_row) - E;
+    long nq_max = (long)(fused_lds_budget(64) / per_row) - E;
     nq_max = std::min<long>(nq_max / NQ * NQ, 2 * NQ);
     if (nq_max < NQ) return false;
     g.NH = (int)nq_max;
@@ -515,6 +553,8 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
   const int64_t nb = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
   if (nb > 0x7fffffff) return false;
   g.n_blocks = (int)nb;
+  g.dFW = make_fastdiv(g.FW); g.dQW = make_fastdiv(g.FW / 2); g.dEH = make_fastdiv(g.NH + E); g.dNQH2 = make_fastdiv(2 * g.NH);
+  if ((int64_t)2 * (NQ + E) * 2 * (g.NH + E) * g.FW * (int64_t)std::max(g.FW, 2 * (g.NH + E)) >= (1ll << 32)) return false;   // fd_div range
   dwt_synthesis_fused_kernel<ND, L, MODE, NQ><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
   return true;
 }
