@@ -158,6 +158,21 @@ int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_
 size_t wdno_colsum_ws_bytes(int64_t P, int C);
 int wdno_colsum(const float* in, float* out, int64_t P, int C, void* ws, size_t ws_bytes, wdno_stream_t s);
 
+/* ---- single-product bf16 convolutions (BASELINE.json configs[1]: "bf16 on 1 x MI355X, batch 256"; the reference's knob is
+ * Trainer(amp=True, mixed_precision_type=...) burgers/ddpm_burgers/train_diffusion.py:62,71-74). Activations, weights and output
+ * gradients are rounded to ONE bf16 plane [rows][C8] (round-to-nearest-even, no scale) and multiplied on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulators; master weights, bias, residual, outputs and all reductions stay fp32.
+ * Same geometry contract and packed-weight layout as the f16x3 entry points (pack with wdno_pack_split_weight and lo == NULL,
+ * amax == NULL, scale_out == NULL: one bf16 plane in `hi`; wdno_wsplit_item likewise). Accuracy is bf16-class (2^-8 per
+ * operand): tests/test_gpu_bf16.py documents the tolerance against the oracle; it cannot meet the fp32 path's 1e-5. */
+int wdno_cast_bf16(const float* x, void* out16, int64_t rows, int C, int C8, wdno_stream_t s);
+int wdno_cast_bf16_colsum(const float* x, void* out16, float* colsum_out, void* ws, size_t ws_bytes, int64_t rows, int C, int C8, wdno_stream_t s);
+int wdno_conv_fwd_bf16(const void* x16, const void* wp16, const float* bias, const float* residual, float* y, float* amax_rec,
+                       const wdno_conv_geom* g, wdno_stream_t s);
+/* dw[Kn][Cn][kd][kh][kw] (the parameter's layout); workspace size = wdno_conv_wgrad_f16x3_ws_bytes(g) */
+int wdno_conv_wgrad_bf16_param(const void* x16, const void* dy16, const void* pixel_table, float* dw, int Kn, int Cn, void* ws,
+                               size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------ normalisation
  * GroupNorm (+ optional (scale+1, shift) modulation) + optional SiLU on CL [N, S, C]:
  *   y = act( (GN(x)*gamma + beta) * (ss[n, c] + 1) + ss[n, C + c] ),  ss = [N, 2C] or NULL.

@@ -74,6 +74,10 @@ PROTOTYPES = {
     'wdno_conv_pixel_table': (I, [P, PG, P]),
     'wdno_conv_wgrad_f16x3': (I, [P, P, P, P, P, P, P, P, P, Z, PG, P]),
     'wdno_conv_wgrad_f16x3_param': (I, [P, P, P, P, P, P, P, P, I, I, P, Z, PG, P]),
+    'wdno_cast_bf16': (I, [P, P, L, I, I, P]),
+    'wdno_cast_bf16_colsum': (I, [P, P, P, P, Z, L, I, I, P]),
+    'wdno_conv_fwd_bf16': (I, [P, P, P, P, P, P, PG, P]),
+    'wdno_conv_wgrad_bf16_param': (I, [P, P, P, P, I, I, P, Z, PG, P]),
     'wdno_conv_wgrad_ws_bytes': (Z, [PG]),
     'wdno_conv_wgrad': (I, [P, P, P, P, Z, PG, P]),
     'wdno_colsum_ws_bytes': (Z, [L, I]),

@@ -15,6 +15,18 @@
 #include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// LP = single bf16 plane per operand, one product (see conv_h3d.hip); !LP = (hi, lo) fp16 planes, three products
+template <bool LP>
+__device__ __forceinline__ f32x16 mfma_16(half8 a, half8 b, f32x16 c) {
+  if constexpr (LP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned short bf16_rne(float v) {      // round-to-nearest-even, NaN kept quiet
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 
 #define HBK 32   // reduction elements per step
 #define HST 40   // LDS row stride in halves
@@ -74,8 +86,9 @@ __device__ __forceinline__ float scale_from_amax(float amax) {
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, const float* __restrict__ amax,
                                                      _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ scale_out,
                                                      int64_t rows, int C, int C8) {
-  const float s = scale_from_amax(amax_record_read(amax));
-  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const bool lp = lo == nullptr;                             // single bf16 plane, no scale
+  const float s = lp ? 1.0f : scale_from_amax(amax_record_read(amax));
+  if (!lp && blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
   const int g8 = C8 >> 3;
   const int64_t total = rows * g8;
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -91,6 +104,14 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? xp[e] : 0.f;
     }
+    if (lp) {
+      typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+      us8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = bf16_rne(v[e]);
+      *reinterpret_cast<us8*>(hi + r * C8 + c0) = b;
+      continue;
+    }
     half8 h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -102,6 +123,12 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     *reinterpret_cast<half8*>(hi + r * C8 + c0) = h;
     *reinterpret_cast<half8*>(lo + r * C8 + c0) = l;
   }
+}
+extern "C" int wdno_cast_bf16(const float* x, void* out, int64_t rows, int C, int C8, wdno_stream_t s) {
+  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 8);
+  int64_t total = rows * (C8 / 8);
+  split_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, nullptr, (_Float16*)out, nullptr, nullptr, rows, C, C8);
+  return wdno_check_launch();
 }
 extern "C" int wdno_split_f16(const float* x, const float* amax, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8,
                               wdno_stream_t s) {
@@ -119,8 +146,9 @@ __global__ __launch_bounds__(256) void split_colsum_kernel(const float* __restri
                                                             _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ scale_out,
                                                             double* __restrict__ part, int64_t rows, int C, int C8) {
   __shared__ float red[256][9];
-  const float s = scale_from_amax(amax_record_read(amax));
-  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const bool lp = lo == nullptr;
+  const float s = lp ? 1.0f : scale_from_amax(amax_record_read(amax));
+  if (!lp && blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
   const int g8 = C8 >> 3;
   const int64_t total = rows * g8;
   const int64_t stride = (int64_t)gridDim.x * 256;            // a multiple of g8: the channel group of a thread never changes
@@ -138,6 +166,14 @@ __global__ __launch_bounds__(256) void split_colsum_kernel(const float* __restri
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? xp[e] : 0.f;
+    }
+    if (lp) {
+      typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+      us8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs[e] += v[e]; b[e] = bf16_rne(v[e]); }
+      *reinterpret_cast<us8*>(hi + r * C8 + c0) = b;
+      continue;
     }
     half8 h, l;
 #pragma unroll
@@ -178,6 +214,18 @@ extern "C" int wdno_split_f16_colsum(const float* x, const float* amax, void* hi
   return wdno_check_launch();
 }
 
+extern "C" int wdno_cast_bf16_colsum(const float* x, void* out, float* colsum_out, void* ws, size_t ws_bytes, int64_t rows, int C, int C8,
+                                     wdno_stream_t s) {
+  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 8);
+  const int g8 = C8 / 8;
+  if (g8 > 256 || (g8 & (g8 - 1))) return WDNO_EUNSUPPORTED;
+  if (ws_bytes < wdno_split_colsum_ws_bytes(rows, C8)) return WDNO_EWORKSPACE;
+  const int grid = stream_grid(rows * g8, 256);
+  split_colsum_kernel<<<grid, 256, 0, as_stream(s)>>>(x, nullptr, (_Float16*)out, nullptr, nullptr, (double*)ws, rows, C, C8);
+  partial_rows_sum_kernel<double><<<cdiv(C8, 32), PRS_THREADS, 0, as_stream(s)>>>((const double*)ws, colsum_out, grid, C8);
+  return wdno_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------- convolution
 // The fp16 MFMAs of one 32-deep step take only ~400 cycles per wave, so the per-step integer work matters as much as the
 // math. All operand fetches are raw buffer loads with 32-bit byte offsets: out-of-range pieces (zero padding, tile tails)
@@ -208,7 +256,7 @@ __device__ __forceinline__ int4v asm_buffer_load_b128(int4v rsrc, int byte_off) 
   return v;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool LP>
 __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                            const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
                                                            const float* __restrict__ sx, const float* __restrict__ sw,
@@ -219,7 +267,8 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
   constexpr int AROWS = BM / 64;   // row passes of the 256 loader threads (64 rows x 4 column groups per pass)
   constexpr int BROWS = BN / 64;
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
-  constexpr int STAGE = 2 * (BM + BN) * HST;     // [Ah | Al | Bh | Bl]
+  constexpr int NPL = LP ? 1 : 2;                // planes per operand
+  constexpr int STAGE = NPL * (BM + BN) * HST;   // [Ah | Al | Bh | Bl]  (LP: [A | B])
   const wdno_conv_geom& g = p.g;
   const int tid = threadIdx.x;
   const int tile = xcd_swizzle(blockIdx.x, p.ntiles);
@@ -285,14 +334,14 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
       const bool ok = row_ok[i] && r_ok && (unsigned)(a_w0[i] + l_dx) < (unsigned)g.W;
       const int off = ok ? (a_base[i] + tap_off + chunk_off) * 2 : OOB_OFFSET;
       ah[S][i] = asm_buffer_load_b128(rxh, off);
-      al[S][i] = asm_buffer_load_b128(rxl, off);
+      if (!LP) al[S][i] = asm_buffer_load_b128(rxl, off);
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
       const bool ok = b_ok[i] && r_ok;
       const int off = ok ? (b_base[i] + wtap_off + chunk_off) * 2 : OOB_OFFSET;
       bh[S][i] = asm_buffer_load_b128(rwh, off);
-      bl[S][i] = asm_buffer_load_b128(rwl, off);
+      if (!LP) bl[S][i] = asm_buffer_load_b128(rwl, off);
     }
     ++l_chunk;
     l_r += HBK;
@@ -309,37 +358,39 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
   };
   // wait until at most `newer` younger loads are outstanding; names every register of the set so that no consumer of
   // them can be scheduled above the wait
-  constexpr int NLOADS = 2 * (AROWS + BROWS);
+  constexpr int NLOADS = NPL * (AROWS + BROWS);
   auto wait_set = [&](auto SET, bool newer_in_flight) {
     constexpr int S = decltype(SET)::value;
     if (newer_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NLOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      int4v &r0 = ah[S][i], &r1 = al[S][i];
-      asm volatile("" : "+v"(r0), "+v"(r1));
+      int4v &r0 = ah[S][i], &r1 = al[S][LP ? 0 : i];
+      if (LP) asm volatile("" : "+v"(r0));
+      else asm volatile("" : "+v"(r0), "+v"(r1));
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
-      int4v &r0 = bh[S][i], &r1 = bl[S][i];
-      asm volatile("" : "+v"(r0), "+v"(r1));
+      int4v &r0 = bh[S][i], &r1 = bl[S][LP ? 0 : i];
+      if (LP) asm volatile("" : "+v"(r0));
+      else asm volatile("" : "+v"(r0), "+v"(r1));
     }
   };
   auto store_tile = [&](auto SET, int buf) {
     constexpr int S = decltype(SET)::value;
     _Float16* Ah = hsm + buf * STAGE;
     _Float16* Al = Ah + BM * HST;
-    _Float16* Bh = Al + BM * HST;
+    _Float16* Bh = Ah + NPL * BM * HST;
     _Float16* Bl = Bh + BN * HST;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       *reinterpret_cast<int4v*>(&Ah[(lrow + 64 * i) * HST + c8]) = ah[S][i];
-      *reinterpret_cast<int4v*>(&Al[(lrow + 64 * i) * HST + c8]) = al[S][i];
+      if (!LP) *reinterpret_cast<int4v*>(&Al[(lrow + 64 * i) * HST + c8]) = al[S][i];
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
       *reinterpret_cast<int4v*>(&Bh[(lrow + 64 * i) * HST + c8]) = bh[S][i];
-      *reinterpret_cast<int4v*>(&Bl[(lrow + 64 * i) * HST + c8]) = bl[S][i];
+      if (!LP) *reinterpret_cast<int4v*>(&Bl[(lrow + 64 * i) * HST + c8]) = bl[S][i];
     }
   };
 
@@ -363,7 +414,7 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
     constexpr int B = decltype(PAR)::value;
     const _Float16* Ah = hsm + B * STAGE;
     const _Float16* Al = Ah + BM * HST;
-    const _Float16* Bh = Al + BM * HST;
+    const _Float16* Bh = Ah + NPL * BM * HST;
     const _Float16* Bl = Bh + BN * HST;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -372,27 +423,29 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
 #pragma unroll
       for (int a = 0; a < TM; ++a) {
         fah[a] = *reinterpret_cast<const half8*>(&Ah[(m_base + a * 32 + li) * HST + col]);
-        fal[a] = *reinterpret_cast<const half8*>(&Al[(m_base + a * 32 + li) * HST + col]);
+        if (!LP) fal[a] = *reinterpret_cast<const half8*>(&Al[(m_base + a * 32 + li) * HST + col]);
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         fbh[b] = *reinterpret_cast<const half8*>(&Bh[(n_base + b * 32 + li) * HST + col]);
-        fbl[b] = *reinterpret_cast<const half8*>(&Bl[(n_base + b * 32 + li) * HST + col]);
+        if (!LP) fbl[b] = *reinterpret_cast<const half8*>(&Bl[(n_base + b * 32 + li) * HST + col]);
       }
       // the three partial products go to the same accumulator: issue them tile-interleaved so that consecutive MFMAs
       // never depend on each other
+      if constexpr (!LP) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fal[a], fbh[b], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fah[a], fbl[b], acc[a][b]);
+      }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<LP>(fah[a], fbh[b], acc[a][b]);
     }
     using NXT = std::integral_constant<int, 1 - B>;
     if (step + 1 < p.nsteps) {
@@ -413,7 +466,7 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
     if (step + 1 < p.nsteps) iter(S1{}, step + 1);
   }
 
-  const float inv = 1.0f / (sx[0] * sw[0]);
+  const float inv = LP ? 1.0f : 1.0f / (sx[0] * sw[0]);
   float am = 0.f;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
@@ -439,7 +492,7 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
   if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * 4 + wave);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool LP>
 static int launch_h3(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                      const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
   const wdno_conv_geom& g = p.g;
@@ -448,16 +501,16 @@ static int launch_h3(const void* xh, const void* xl, const void* wh, const void*
   int64_t nt = tiles_m * p.tiles_n;
   if (nt > 0x7fffffff) return WDNO_EUNSUPPORTED;
   p.ntiles = (int)nt;
-  size_t lds = (size_t)2 * 2 * (BM + BN) * HST * sizeof(_Float16);
+  size_t lds = (size_t)2 * (LP ? 1 : 2) * (BM + BN) * HST * sizeof(_Float16);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_fwd_h3_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_fwd_h3_kernel<BM, BN, WM, WN, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const int64_t x_elems = (int64_t)g.N * g.D * g.H * g.W * g.C;
   const int64_t w_elems = (int64_t)g.kd * g.kh * g.K * p.R;
   if (x_elems * 2 >= OOB_OFFSET || w_elems * 2 >= OOB_OFFSET || p.P >= 0x7fffffff) return WDNO_EUNSUPPORTED;   // 32-bit buffer offsets
-  conv_fwd_h3_kernel<BM, BN, WM, WN><<<p.ntiles, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh,
+  conv_fwd_h3_kernel<BM, BN, WM, WN, LP><<<p.ntiles, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh,
                                                               (const _Float16*)wl, sx, sw, bias, residual, y, p,
                                                               (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
   return WDNO_OK;
@@ -467,12 +520,12 @@ extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* 
                                    const float* bias, const float* residual, float* y, const wdno_conv_geom* g, wdno_stream_t s) {
   return wdno_conv_fwd_f16x3_amax(xh, xl, sx, wph, wpl, sw, bias, residual, y, nullptr, g, s);
 }
-extern "C" int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
-                                        const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
-                                        wdno_stream_t s) {
+template <bool LP>
+static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                       const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g, wdno_stream_t s) {
   int rc = check_geom(g);
   if (rc) return rc;
-  if (g->C & 7) return WDNO_EUNSUPPORTED;       // fp16 rows must be 16-byte multiples
+  if (g->C & 7) return WDNO_EUNSUPPORTED;       // 16-bit rows must be 16-byte multiples
   ConvP p;
   fill_params(p, g);
   p.amax_rec = amax_rec;
@@ -486,19 +539,28 @@ extern "C" int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const fl
   // fewer tiles than CUs they beat the register-staged kernels (l2 512->128: 0.36 -> 0.24 ms). debug: 5 = never, 7 = always
   const int dbg = wdno_debug_mode;
   if (dbg != 5 && dbg != 3 && dbg != 1 && (dbg == 7 || (K > 64 ? blocks(128, 128) : blocks(256, 64)) >= 100)) {
-    rc = wdno_conv_fwd_h3_dma(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st, 3);
+    rc = wdno_conv_fwd_h3_dma(xh, LP ? nullptr : xl, wph, LP ? nullptr : wpl, sx, sw, bias, residual, y, p, st, 3);
     if (rc == WDNO_OK) return wdno_check_launch();
     if (rc != WDNO_EUNSUPPORTED) return rc;
   }
   if (K > 64) {
-    if ((blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) && wdno_debug_mode != 3) rc = launch_h3<128, 128, 2, 2>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
-    else rc = launch_h3<64, 128, 1, 4>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    if ((blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) && wdno_debug_mode != 3) rc = launch_h3<128, 128, 2, 2, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    else rc = launch_h3<64, 128, 1, 4, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
   } else {
-    if ((blocks(128, 64) >= 512 || P <= 128) && wdno_debug_mode != 3) rc = launch_h3<128, 64, 4, 1>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
-    else rc = launch_h3<64, 64, 2, 2>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    if ((blocks(128, 64) >= 512 || P <= 128) && wdno_debug_mode != 3) rc = launch_h3<128, 64, 4, 1, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    else rc = launch_h3<64, 64, 2, 2, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
   }
   if (rc) return rc;
   return wdno_check_launch();
+}
+extern "C" int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                                        const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
+                                        wdno_stream_t s) {
+  return conv_fwd_16<false>(xh, xl, sx, wph, wpl, sw, bias, residual, y, amax_rec, g, s);
+}
+extern "C" int wdno_conv_fwd_bf16(const void* x16, const void* wp16, const float* bias, const float* residual, float* y, float* amax_rec,
+                                  const wdno_conv_geom* g, wdno_stream_t s) {
+  return conv_fwd_16<true>(x16, x16, nullptr, wp16, wp16, nullptr, bias, residual, y, amax_rec, g, s);
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradient (3 x fp16 split)
@@ -562,7 +624,7 @@ __device__ __forceinline__ half8 tr_frag(const _Float16* tile, int stride, int p
 }
 
 #define WH_RING 4
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool LP>
 __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                              const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
                                                              const float* __restrict__ sx, const float* __restrict__ sdy,
@@ -575,7 +637,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
   constexpr int A_RPP = 256 / A_C8;                           // pixel rows per pass
   constexpr int A_PASSES = WH_BKP / A_RPP, B_PASSES = WH_BKP * B_C8 / 256;
   static_assert(256 % A_C8 == 0 && (WH_BKP * B_C8) % 256 == 0, "loader mapping");
-  constexpr int STAGE = 2 * WH_BKP * (SA + SB);               // halves per stage: Ah, Al, Bh, Bl
+  constexpr int NPL = LP ? 1 : 2;
+  constexpr int STAGE = NPL * WH_BKP * (SA + SB);             // halves per stage: Ah, Al, Bh, Bl (LP: A, B)
   extern __shared__ __attribute__((aligned(16))) _Float16 hsm[];
   int4v* pinfo = reinterpret_cast<int4v*>(hsm + 2 * STAGE);   // [WH_RING][WH_BKP]
 
@@ -640,7 +703,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
       const int4v e = ps[a_row + i * A_RPP];
       const int off = (e.x >= 0 && ka_ok) ? (e.x * g.K + ka) * 2 : OOB_OFFSET;
       ah[i] = __builtin_amdgcn_raw_buffer_load_b128(rdh, off, 0, 0);
-      al[i] = __builtin_amdgcn_raw_buffer_load_b128(rdl, off, 0, 0);
+      if (!LP) al[i] = __builtin_amdgcn_raw_buffer_load_b128(rdl, off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
@@ -649,23 +712,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
       const bool ok = e.x >= 0 && r_ok[i] && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
       const int off = ok ? (e.y + tap_off + r[i]) * 2 : OOB_OFFSET;
       bh[i] = __builtin_amdgcn_raw_buffer_load_b128(rxh, off, 0, 0);
-      bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
+      if (!LP) bl[i] = __builtin_amdgcn_raw_buffer_load_b128(rxl, off, 0, 0);
     }
   };
   auto store_tile = [&](int buf) {
     _Float16* Ah = hsm + buf * STAGE;
     _Float16* Al = Ah + WH_BKP * SA;
-    _Float16* Bh = Al + WH_BKP * SA;
+    _Float16* Bh = Ah + NPL * WH_BKP * SA;
     _Float16* Bl = Bh + WH_BKP * SB;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       *reinterpret_cast<int4v*>(&Ah[(a_row + i * A_RPP) * SA + a_c8]) = ah[i];
-      *reinterpret_cast<int4v*>(&Al[(a_row + i * A_RPP) * SA + a_c8]) = al[i];
+      if (!LP) *reinterpret_cast<int4v*>(&Al[(a_row + i * A_RPP) * SA + a_c8]) = al[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
       *reinterpret_cast<int4v*>(&Bh[b_row[i] * SB + b_c8[i]]) = bh[i];
-      *reinterpret_cast<int4v*>(&Bl[b_row[i] * SB + b_c8[i]]) = bl[i];
+      if (!LP) *reinterpret_cast<int4v*>(&Bl[b_row[i] * SB + b_c8[i]]) = bl[i];
     }
   };
 
@@ -694,7 +757,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
     for (int step = 0; step < nsteps; ++step) {
       const _Float16* Ah = hsm + (step & 1) * STAGE;
       const _Float16* Al = Ah + WH_BKP * SA;
-      const _Float16* Bh = Al + WH_BKP * SA;
+      const _Float16* Bh = Ah + NPL * WH_BKP * SA;
       const _Float16* Bl = Bh + WH_BKP * SB;
       put_rec(step + 3, rec);            // slot (step+3)&3 was last read by load_tile(step-1): two barriers ago
       rec = fetch_rec(step + 4);
@@ -704,25 +767,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
           fah[a] = tr_frag(Ah, SA, ks * 16, m_base + a * 32, lane);
-          fal[a] = tr_frag(Al, SA, ks * 16, m_base + a * 32, lane);
+          if (!LP) fal[a] = tr_frag(Al, SA, ks * 16, m_base + a * 32, lane);
         }
 #pragma unroll
         for (int bb = 0; bb < TN; ++bb) {
           fbh[bb] = tr_frag(Bh, SB, ks * 16, n_base + bb * 32, lane);
-          fbl[bb] = tr_frag(Bl, SB, ks * 16, n_base + bb * 32, lane);
+          if (!LP) fbl[bb] = tr_frag(Bl, SB, ks * 16, n_base + bb * 32, lane);
+        }
+        if constexpr (!LP) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int bb = 0; bb < TN; ++bb) acc[a][bb] = mfma_16<false>(fal[a], fbh[bb], acc[a][bb]);
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int bb = 0; bb < TN; ++bb) acc[a][bb] = mfma_16<false>(fah[a], fbl[bb], acc[a][bb]);
         }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int bb = 0; bb < TN; ++bb) acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[a], fbh[bb], acc[a][bb], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int bb = 0; bb < TN; ++bb) acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbl[bb], acc[a][bb], 0, 0, 0);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int bb = 0; bb < TN; ++bb) acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[a], fbh[bb], acc[a][bb], 0, 0, 0);
+          for (int bb = 0; bb < TN; ++bb) acc[a][bb] = mfma_16<LP>(fah[a], fbh[bb], acc[a][bb]);
       }
       if (step + 1 < nsteps) store_tile((step + 1) & 1);
       __syncthreads();
@@ -730,7 +795,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_h3_kernel(const _Float16* __re
     }
   }
 
-  const float inv = 1.0f / (sx[0] * sdy[0]);
+  const float inv = LP ? 1.0f : 1.0f / (sx[0] * sdy[0]);
   float* out = ws + ((int64_t)split * (g.kd * g.kh) + tap) * (int64_t)g.K * p.R;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -806,19 +871,19 @@ extern "C" size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g) {
   if (splits > w.splits) w.splits = splits;
   return (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
 }
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool LP>
 static void launch_wgrad_h3(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
                             const void* table, float* wsf, const WgradHP& w, dim3 grid, hipStream_t st) {
   const wdno_conv_geom& g = w.c.g;
   const unsigned x_bytes = (unsigned)((int64_t)g.N * g.D * g.H * g.W * g.C * 2);
   const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
-  size_t lds = (size_t)2 * 2 * WH_BKP * (BM + WH_PAD + BN + WH_PAD) * sizeof(_Float16) + WH_RING * WH_BKP * sizeof(int4v);
+  size_t lds = (size_t)2 * (LP ? 1 : 2) * WH_BKP * (BM + WH_PAD + BN + WH_PAD) * sizeof(_Float16) + WH_RING * WH_BKP * sizeof(int4v);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_h3_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_h3_kernel<BM, BN, WM, WN, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  conv_wgrad_h3_kernel<BM, BN, WM, WN><<<grid, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh,
+  conv_wgrad_h3_kernel<BM, BN, WM, WN, LP><<<grid, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh,
                                                             (const _Float16*)dyl, sx, sdy, (const int4v*)table, wsf, w, x_bytes, dy_bytes);
 }
 // Runs the weight-gradient kernels; the per-split partial results go to `ws` ([splits][ntap][K][R]; with one split `single`
@@ -849,9 +914,13 @@ static int wgrad_h3_partials(const void* xh, const void* xl, const float* sx, co
   if (wsf == (float*)ws && ws_bytes < need) return WDNO_EWORKSPACE;
   if (w.splits > 65535) return WDNO_EUNSUPPORTED;
   dim3 grid((unsigned)(w.tiles_k * g->kd * g->kh * w.tiles_r), (unsigned)w.splits);
-  if (g->K > 64) launch_wgrad_h3<128, 192, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
-  else if (w.bn == 192) launch_wgrad_h3<64, 192, 2, 2>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
-  else launch_wgrad_h3<64, 128, 1, 4>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
+  if (xl == nullptr) {          // single bf16 plane per operand
+    if (g->K > 64) launch_wgrad_h3<128, 192, 2, 2, true>(xh, xh, dyh, dyh, sx, sdy, pixel_table, wsf, w, grid, st);
+    else if (w.bn == 192) launch_wgrad_h3<64, 192, 2, 2, true>(xh, xh, dyh, dyh, sx, sdy, pixel_table, wsf, w, grid, st);
+    else launch_wgrad_h3<64, 128, 1, 4, true>(xh, xh, dyh, dyh, sx, sdy, pixel_table, wsf, w, grid, st);
+  } else if (g->K > 64) launch_wgrad_h3<128, 192, 2, 2, false>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
+  else if (w.bn == 192) launch_wgrad_h3<64, 192, 2, 2, false>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
+  else launch_wgrad_h3<64, 128, 1, 4, false>(xh, xl, dyh, dyl, sx, sdy, pixel_table, wsf, w, grid, st);
   *splits_out = w.splits;
   return WDNO_OK;
 }
@@ -927,6 +996,18 @@ extern "C" int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const
   return wdno_check_launch();
 }
 
+extern "C" int wdno_conv_wgrad_bf16_param(const void* x16, const void* dy16, const void* pixel_table, float* dw, int Kn, int Cn, void* ws,
+                                          size_t ws_bytes, const wdno_conv_geom* g, wdno_stream_t s) {
+  WDNO_REQUIRE(g && Kn > 0 && Cn > 0 && Kn <= g->K && Cn <= g->C);
+  hipStream_t st = as_stream(s);
+  int splits = 0;
+  int rc = wgrad_h3_partials(x16, nullptr, nullptr, dy16, nullptr, nullptr, pixel_table, nullptr, ws, ws_bytes, g, st, &splits);
+  if (rc) return rc;
+  const int64_t n = (int64_t)g->kd * g->kh * g->K * (int64_t)g->kw * g->C;
+  wgrad_h3_reduce_nat_kernel<<<stream_grid(n / 4, 32), 256, 0, st>>>((const float*)ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
+  return wdno_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------- weight pack + split
 // raw weight w[K][C][kd][kh][kw] fp32  ->  fp16 planes of the packed operand, in one launch:
 //   mode 0 (forward)  : out[dz][dy][a=k < A][dx][b=c < B]  = w[k][c][dz][dy][dx]
@@ -936,8 +1017,9 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
                                                 _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                 float* __restrict__ scale_out, int K, int C, int kd, int kh, int kw,
                                                 int A, int B, int mode, int block, int nblocks) {
-  const float s = scale_from_amax(amax[0]);
-  if (block == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const bool lp = lo == nullptr;                     // one bf16 plane, no scale (amax / scale_out may be NULL)
+  const float s = lp ? 1.0f : scale_from_amax(amax[0]);
+  if (!lp && block == 0 && threadIdx.x == 0) scale_out[0] = s;
   const int b8 = B >> 3;
   const int64_t total = (int64_t)kd * kh * A * kw * b8;
   const int64_t stride = (int64_t)nblocks * 256;
@@ -950,6 +1032,8 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
     int dz = (int)(t / kh);
     const int z = mode ? kd - 1 - dz : dz, yy = mode ? kh - 1 - dy : dy, x = mode ? kw - 1 - dx : dx;
     half8 h, l;
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    us8 bq;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       int b = g8 * 8 + e;
@@ -959,7 +1043,9 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
       _Float16 th = (_Float16)tv;
       h[e] = th;
       l[e] = (_Float16)(tv - (float)th);
+      bq[e] = bf16_rne(v);
     }
+    if (lp) { *reinterpret_cast<us8*>(hi + i * 8) = bq; continue; }
     *reinterpret_cast<half8*>(hi + i * 8) = h;
     *reinterpret_cast<half8*>(lo + i * 8) = l;
   }
@@ -1008,6 +1094,7 @@ extern "C" int wdno_pack_split_weight(const float* w, const float* amax, void* h
                                       int kw, int A, int B, int mode, wdno_stream_t s) {
   WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && (mode == 0 || mode == 1));
   WDNO_REQUIRE(mode == 0 ? (A >= K && B >= C) : (A >= C && B >= K));
+  WDNO_REQUIRE(lo == nullptr || (amax != nullptr && scale_out != nullptr));      // lo == NULL: one bf16 plane in `hi`
   int64_t total = (int64_t)kd * kh * A * kw * (B / 8);
   pack_split_weight_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(w, amax, (_Float16*)hi, (_Float16*)lo, scale_out, K, C, kd, kh, kw,
                                                                             A, B, mode);

@@ -25,8 +25,17 @@
 #include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int int4v __attribute__((ext_vector_type(4)));
 #define DMA_OOB 0x7ffffff0
+// LP ("low precision", BASELINE.json configs[1]): ONE bf16 plane per operand and one v_mfma_f32_32x32x16_bf16 per fragment pair
+// instead of the (hi, lo) fp16 planes and three products: a third of the matrix instructions, half of the DMA pieces and of
+// the LDS traffic; fp32 accumulators, bias / residual / output stay fp32; no scale (bf16 has the fp32 exponent range).
+template <bool LP>
+__device__ __forceinline__ f32x16 mfma_16(half8 a, half8 b, f32x16 c) {
+  if constexpr (LP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ int4v rsrc_words(const void* ptr, unsigned bytes) {
   uint64_t a = reinterpret_cast<uint64_t>(ptr);
@@ -42,7 +51,7 @@ __device__ __forceinline__ void dma_piece(int4v rsrc, int off, unsigned lds_dst)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(off), "s"(lds_dst), "s"(rsrc) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool UNIFORM_DX>
+template <int BM, int BN, int WM, int WN, int NS, bool UNIFORM_DX, bool LP>
 __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                             const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
                                                             const float* __restrict__ sx, const float* __restrict__ sw,
@@ -50,10 +59,11 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
                                                             float* __restrict__ y, ConvP p, unsigned x_bytes, unsigned w_bytes) {
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int AP = BM / 64, BP = BN / 64;              // pieces per producer wave and plane (a piece = 16 rows x 64 B)
-  constexpr int PW = 2 * (AP + BP);                      // pieces per producer wave and step
+  constexpr int NPL = LP ? 1 : 2;                        // planes per operand
+  constexpr int PW = NPL * (AP + BP);                    // pieces per producer wave and step
   static_assert((NS - 2) * PW <= 63, "vmcnt is a 6-bit counter");
-  constexpr int A_LO = BM * 64, B_HI = 2 * BM * 64;
-  constexpr int STAGE = 2 * (BM + BN) * 64;
+  constexpr int A_LO = BM * 64, B_HI = NPL * BM * 64;
+  constexpr int STAGE = NPL * (BM + BN) * 64;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const wdno_conv_geom& g = p.g;
   const int tid = threadIdx.x;
@@ -122,14 +132,14 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
       for (int i = 0; i < AP; ++i) {
         const int off = ((a_mask[i] & need) == need) ? a_off[i] + x_uni : DMA_OOB;
         dma_piece(rxh, off, pa_dst + i * 1024);
-        dma_piece(rxl, off, pa_dst + A_LO + i * 1024);
+        if (!LP) dma_piece(rxl, off, pa_dst + A_LO + i * 1024);
       }
       const bool r_ok = live && (s_chunk * 32 + c8 < p.R);
 #pragma unroll
       for (int i = 0; i < BP; ++i) {
         const int off = (b_ok[i] && r_ok) ? b_off[i] + w_uni : DMA_OOB;
         dma_piece(rwh, off, pb_dst + i * 1024);
-        dma_piece(rwl, off, pb_dst + BN * 64 + i * 1024);
+        if (!LP) dma_piece(rwl, off, pb_dst + BN * 64 + i * 1024);
       }
       if (!live) return;
       ++s_chunk;
@@ -188,33 +198,35 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       fah[B][a] = *reinterpret_cast<const half8*>(st + ((a_rd + a * 2048) ^ x));
-      fal[B][a] = *reinterpret_cast<const half8*>(st + A_LO + ((a_rd + a * 2048) ^ x));
+      if (!LP) fal[B][a] = *reinterpret_cast<const half8*>(st + A_LO + ((a_rd + a * 2048) ^ x));
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       fbh[B][b] = *reinterpret_cast<const half8*>(st + ((b_rd + b * 2048) ^ x));
-      fbl[B][b] = *reinterpret_cast<const half8*>(st + BN * 64 + ((b_rd + b * 2048) ^ x));
+      if (!LP) fbl[B][b] = *reinterpret_cast<const half8*>(st + BN * 64 + ((b_rd + b * 2048) ^ x));
     }
   };
   f32x16 acc[TM][TN];
   auto mfma_set = [&](auto SET) {
     constexpr int B = decltype(SET)::value;
+    if constexpr (!LP) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbh[B][b], fal[B][a], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbl[B][b], fah[B][a], acc[a][b]);
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[B][b], fal[B][a], acc[a][b], 0, 0, 0);
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[B][b], fah[B][a], acc[a][b], 0, 0, 0);
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[B][b], fah[B][a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<LP>(fbh[B][b], fah[B][a], acc[a][b]);
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  const float inv = 1.0f / (sx[0] * sw[0]);
+  const float inv = LP ? 1.0f : 1.0f / (sx[0] * sw[0]);
   int stage = 0;
   for (int t = 0; t < my_tiles; ++t) {
     const int tile = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, p.ntiles);
@@ -283,7 +295,7 @@ static int num_cus() {
   return n;
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool LP>
 static int launch_h3d(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                       const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
   const wdno_conv_geom& g = p.g;
@@ -292,7 +304,7 @@ static int launch_h3d(const void* xh, const void* xl, const void* wh, const void
   int64_t nt = tiles_m * p.tiles_n;
   if (nt > 0x7fffffff) return WDNO_EUNSUPPORTED;
   p.ntiles = (int)nt;
-  const size_t lds = (size_t)NS * 2 * (BM + BN) * 64;
+  const size_t lds = (size_t)NS * (LP ? 1 : 2) * (BM + BN) * 64;
   const int64_t x_elems = (int64_t)g.N * g.D * g.H * g.W * g.C;
   const int64_t w_elems = (int64_t)g.kd * g.kh * g.K * p.R;
   if (x_elems * 2 >= DMA_OOB || w_elems * 2 >= DMA_OOB || p.P >= 0x7fffffff) return WDNO_EUNSUPPORTED;
@@ -302,13 +314,13 @@ static int launch_h3d(const void* xh, const void* xl, const void* wh, const void
   const bool uni = (g.C % 32) == 0;
   if (uni) {
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-    conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, true><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
+    if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, true, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, true, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
                                                                         sx, sw, bias, residual, y, p, (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
   } else {
     static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-    conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, false><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
+    if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, false, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+    conv_fwd_h3d_kernel<BM, BN, WM, WN, NS, false, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
                                                                          sx, sw, bias, residual, y, p, (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
   }
   return WDNO_OK;
@@ -316,10 +328,10 @@ static int launch_h3d(const void* xh, const void* xl, const void* wh, const void
 
 // Returns WDNO_EUNSUPPORTED when the geometry is outside what the DMA kernels handle (the caller then uses the
 // register-staged kernels of conv_h3.hip).
-int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
-                         const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st, int stages) {
+template <bool LP>
+static int fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
+                      const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
   const wdno_conv_geom& g = p.g;
-  (void)stages;
   if (g.kd > 8 || g.kh > 8 || g.kw > 8 || g.C < 8) return WDNO_EUNSUPPORTED;
   // Tile shape: the one with the least (rounds of the persistent grid) x (tile area), lightly weighted by how much operand
   // traffic a shape needs per MFMA. Examples on 256 CUs: a 256-channel layer at the 10 x 10 level is 300 tiles of 128 x 128 --
@@ -335,8 +347,15 @@ int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const v
   if (!narrow_only && all && cost(192, 128, 1.0) < c) { best = 1; c = cost(192, 128, 1.0); }
   if (!narrow_only && all && cost(256, 64, 1.04) < c) { best = 2; c = cost(256, 64, 1.04); }
   if (all && cost(192, 64, 1.08) < c) { best = 3; c = cost(192, 64, 1.08); }
-  if (best == 0) return launch_h3d<128, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  if (best == 1) return launch_h3d<192, 128, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  if (best == 3) return launch_h3d<192, 64, 2, 2, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  return launch_h3d<256, 64, 4, 1, 3>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (best == 0) return launch_h3d<128, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (best == 1) return launch_h3d<192, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (best == 3) return launch_h3d<192, 64, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  return launch_h3d<256, 64, 4, 1, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+}
+// xl / wl / sx / sw == nullptr selects the single-plane bf16 kernels (LP)
+int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
+                         const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st, int stages) {
+  (void)stages;
+  if (xl == nullptr) return fwd_h3_dma<true>(xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
+  return fwd_h3_dma<false>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }

@@ -25,8 +25,15 @@
 #include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int int4v __attribute__((ext_vector_type(4)));
 #define WD_OOB 0x7ffffff0
+// LP = single bf16 plane per operand, one product (see conv_h3d.hip); !LP = (hi, lo) fp16 planes, three products
+template <bool LP>
+__device__ __forceinline__ f32x16 mfma_16(half8 a, half8 b, f32x16 c) {
+  if constexpr (LP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 struct WgradDP {
   ConvP c;
@@ -67,7 +74,7 @@ __device__ __forceinline__ half8 wd_frag(const char* plane, int lane_off, int pi
   return __builtin_bit_cast(half8, c);
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, bool LP>
 __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                               const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
                                                               const float* __restrict__ sx, const float* __restrict__ sdy,
@@ -76,13 +83,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
   constexpr int TM = BM / 64, TN = BN / 64;              // 32-wide MFMA tiles per compute wave (2 x 2 waves)
   constexpr int ACH = BM / 8, BCH = BN / 8;              // 16-byte chunks per pixel row
   constexpr int A_PLANE = 32 * ACH * 16, B_PLANE = 32 * BCH * 16;
-  constexpr int A_LO = A_PLANE, B_HI = 2 * A_PLANE, B_LO = B_HI + B_PLANE;
-  constexpr int STAGE = 2 * (A_PLANE + B_PLANE);
+  constexpr int NPL = LP ? 1 : 2;                        // planes per operand
+  constexpr int A_LO = A_PLANE, B_HI = NPL * A_PLANE, B_LO = B_HI + B_PLANE;
+  constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
   constexpr int APC = A_PLANE / 1024, BPC = B_PLANE / 1024;      // pieces per plane
   constexpr int NPAIR = APC + BPC;                                // (hi, lo) piece pairs per step
   static_assert(NPAIR % 4 == 0, "pieces are dealt to four producer waves");
   constexpr int R = NPAIR / 4;                                    // pairs (= pixel records) per producer lane and step
-  constexpr int PW = 2 * R;
+  constexpr int PW = NPL * R;
   constexpr int LA = 2;                                           // records are fetched LA steps ahead of their pieces
   static_assert(R + (NS - 2) * (R + PW) <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -194,13 +202,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
         if (gp < APC) {
           const int off = ok0 ? e.x * k2 + i_off[j] : WD_OOB;
           wd_piece(rdh, off, sb + gp * 1024);
-          wd_piece(rdl, off, sb + A_LO + gp * 1024);
+          if (!LP) wd_piece(rdl, off, sb + A_LO + gp * 1024);
         } else {
           const int d = (e.z >> 16) + c_dz, h = (int)(short)(e.z & 0xffff) + c_dy, w = e.w + i_dx[j];
           const bool ok = ok0 && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
           const int off = ok ? (e.y + c_tapoff + i_off[j]) * 2 : WD_OOB;
           wd_piece(rxh, off, sb + B_HI + (gp - APC) * 1024);
-          wd_piece(rxl, off, sb + B_LO + (gp - APC) * 1024);
+          if (!LP) wd_piece(rxl, off, sb + B_LO + (gp - APC) * 1024);
         }
       }
       if (live && ++pc.s == wp.nsteps) { pc.s = 0; if (++pc.t < my_items) load_item_p(); }
@@ -273,33 +281,35 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       fah[B][a] = wd_frag<ACH>(st, offA, ks * 16, m_base + a * 32);
-      fal[B][a] = wd_frag<ACH>(st + A_LO, offA, ks * 16, m_base + a * 32);
+      if (!LP) fal[B][a] = wd_frag<ACH>(st + A_LO, offA, ks * 16, m_base + a * 32);
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       fbh[B][b] = wd_frag<BCH>(st + B_HI, offB, ks * 16, n_base + b * 32);
-      fbl[B][b] = wd_frag<BCH>(st + B_LO, offB, ks * 16, n_base + b * 32);
+      if (!LP) fbl[B][b] = wd_frag<BCH>(st + B_LO, offB, ks * 16, n_base + b * 32);
     }
   };
   f32x16 acc[TM][TN];
   auto mfma_set = [&](auto SET) {          // row operand = x fragment (r), column operand = dy fragment (k): acc is [r][k]
     constexpr int B = decltype(SET)::value;
+    if constexpr (!LP) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbh[B][b], fal[B][a], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbl[B][b], fah[B][a], acc[a][b]);
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[B][b], fal[B][a], acc[a][b], 0, 0, 0);
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[B][b], fah[B][a], acc[a][b], 0, 0, 0);
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[B][b], fah[B][a], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<LP>(fbh[B][b], fah[B][a], acc[a][b]);
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  const float inv = 1.0f / (sx[0] * sdy[0]);
+  const float inv = LP ? 1.0f : 1.0f / (sx[0] * sdy[0]);
   const int hh = lane >> 5;
   int stage = 0;
   for (int t = 0; t < my_items; ++t) {
@@ -375,7 +385,7 @@ void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits,
   *splits = (int)cdiv64(c.P, pps);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool LP>
 static void launch_wd(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
                       const void* table, float* wsf, const WgradDP& w, hipStream_t st) {
   const wdno_conv_geom& g = w.c.g;
@@ -383,9 +393,9 @@ static void launch_wd(const void* xh, const void* xl, const void* dyh, const voi
   const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
   const unsigned tbl_bytes = (unsigned)(w.c.P * 16);
   constexpr int NS = 3;
-  const size_t lds = (size_t)NS * 2 * (32 * (BM / 8) * 16 + 32 * (BN / 8) * 16);
+  const size_t lds = (size_t)NS * (LP ? 1 : 2) * (32 * (BM / 8) * 16 + 32 * (BN / 8) * 16);
   static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_h3d_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  if (!done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_h3d_kernel<BM, BN, NS, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
   int grid = wd_num_cus();
   if (w.items < grid) grid = w.items;
   WgradDP wl = w;
@@ -395,7 +405,7 @@ static void launch_wd(const void* xh, const void* xl, const void* dyh, const voi
     grid = wd_num_cus() & ~7;
     if (8 * wl.xcd_chunk < grid) grid = 8 * wl.xcd_chunk;      // every XCD's blocks walk its chunk in whole rounds; spare blocks idle
   }
-  conv_wgrad_h3d_kernel<BM, BN, NS><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh, (const _Float16*)dyl,
+  conv_wgrad_h3d_kernel<BM, BN, NS, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh, (const _Float16*)dyl,
                                                          sx, sdy, (const int4v*)table, wsf, wl, x_bytes, dy_bytes, tbl_bytes);
 }
 
@@ -412,9 +422,16 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
   w.tiles_r = cdiv(w.c.R, bn);
   w.nsteps = w.pix_per_split / 32;
   w.items = w.tiles_k * w.tiles_r * g->kd * g->kh * w.splits;
-  if (bm == 128 && bn == 192) launch_wd<128, 192>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
-  else if (bm == 128) launch_wd<128, 128>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
-  else if (bn == 192) launch_wd<64, 192>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
-  else launch_wd<64, 128>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  if (xl == nullptr) {           // single bf16 plane per operand
+    if (bm == 128 && bn == 192) launch_wd<128, 192, true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);
+    else if (bm == 128) launch_wd<128, 128, true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);
+    else if (bn == 192) launch_wd<64, 192, true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);
+    else launch_wd<64, 128, true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);
+    return WDNO_OK;
+  }
+  if (bm == 128 && bn == 192) launch_wd<128, 192, false>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  else if (bm == 128) launch_wd<128, 128, false>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  else if (bn == 192) launch_wd<64, 192, false>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+  else launch_wd<64, 128, false>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
   return WDNO_OK;
 }

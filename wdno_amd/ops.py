@@ -326,8 +326,14 @@ def pack_transposed(w_io, cin_p, cout_p):
 
 # 'f16x3' = fp32-equivalent 3 x fp16-split MFMA for the large convolutions (forward and data gradient); 'f32' = exact-fp32
 # MFMA everywhere. Small problems always take the exact kernel.
+# 'bf16' = BASELINE.json configs[1]: one bf16 plane per operand and ONE product on v_mfma_f32_32x32x16_bf16, fp32 master weights and
+# accumulators (the reference's knob: Trainer(amp=True), train_diffusion.py:62,71-74). bf16-class accuracy, see tests/test_gpu_bf16.py.
 CONV_MATH = os.environ.get('WDNO_CONV_MATH', 'f16x3')
-LOWP_AVAILABLE = False     # single-product bf16 / fp16 convolution path (CONV_MATH = 'bf16' | 'f16')
+LOWP_AVAILABLE = True
+
+
+def _lp():
+    return CONV_MATH == 'bf16'
 H3_MIN_PIXELS = 1024
 H3_MIN_REDUCTION = 64
 
@@ -382,7 +388,7 @@ def _amax_slot(device):
 
 
 def _new_amax_record(device):
-    return _amax_slot(device) if AMAX_HINTS else None
+    return _amax_slot(device) if AMAX_HINTS and not _lp() else None          # bf16 planes carry no scale
 
 
 def _leave_amax(t, rec):
@@ -408,11 +414,11 @@ def split_f16_of(t, x2d, amax=None):
     """split_f16(x2d) for the rows of tensor t, remembered on t (with its version): a tensor that feeds two convolutions -- the
     input of a ResnetBlock with a projection skip -- is split once, and both keep the same planes for their backward."""
     h = getattr(t, '_wdno_planes', None)
-    if h is not None and h[1] == t._version and h[0][0].shape[0] == x2d.shape[0]:
+    if h is not None and h[1] == t._version and h[0][0].shape[0] == x2d.shape[0] and h[2] == CONV_MATH:
         return h[0]
     planes = split_f16(x2d, amax)
     try:
-        t._wdno_planes = (planes, t._version)
+        t._wdno_planes = (planes, t._version, CONV_MATH)
     except Exception:
         pass
     return planes
@@ -424,6 +430,10 @@ def split_f16(x2d, amax=None):
     rows, c = x2d.shape
     c8 = pad8(c)
     lib = _lib_()
+    if _lp():                    # one bf16 plane (carried in a float16-typed tensor: 16-bit storage, the kernels reinterpret it)
+        hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+        _lib.check(lib.wdno_cast_bf16(_p(x2d), _p(hi), rows, c, c8, _stream()), 'cast_bf16')
+        return hi, None, None
     if amax is None:
         amax = tensor_amax(x2d)
     hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
@@ -442,6 +452,13 @@ def split_f16_colsum(x2d, amax=None):
     if g8 > 256 or (g8 & (g8 - 1)):
         return split_f16(x2d, amax), colsum(x2d)
     lib = _lib_()
+    if _lp():
+        hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+        cs = torch.empty(c8, device=x2d.device, dtype=torch.float32)
+        nb = lib.wdno_split_colsum_ws_bytes(rows, c8)
+        ws = _ws(nb, x2d.device)
+        _lib.check(lib.wdno_cast_bf16_colsum(_p(x2d), _p(hi), _p(cs), _p(ws), nb, rows, c, c8, _stream()), 'cast_bf16_colsum')
+        return (hi, None, None), cs[:c]
     if amax is None:
         amax = tensor_amax(x2d)
     hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
@@ -457,7 +474,7 @@ def split_f16_colsum(x2d, amax=None):
 class _WPlan:
     """One packed split-fp16 weight operand that is refreshed every optimiser step: persistent output planes, so the refresh of
     all of them is two multi-tensor launches (wdno_amax_multi, wdno_pack_split_weight_multi) instead of two launches each."""
-    __slots__ = ('w', 'wd', 'kind', 'cp8', 'kp', 'hi', 'lo', 'sc', 'ver', 'used')
+    __slots__ = ('w', 'wd', 'kind', 'cp8', 'kp', 'hi', 'lo', 'sc', 'ver', 'used', 'lp')
 
 
 _wplans = {}            # key -> _WPlan
@@ -477,7 +494,8 @@ class _WsplitItem(C.Structure):
 def _refresh_weight_plans(epoch_used):
     """Refresh every registered plan that was used in one of the last few weight epochs (they will all be needed again; an
     EMA update also counts as an epoch)."""
-    keys = tuple(k for k, pl in _wplans.items() if pl.used >= epoch_used - 3 and pl.wd.is_contiguous())
+    lp = _lp()
+    keys = tuple(k for k, pl in _wplans.items() if pl.used >= epoch_used - 3 and pl.wd.is_contiguous() and pl.lp == lp)
     if len(keys) < 2:
         return
     dev = _wplans[keys[0]].wd.device
@@ -504,6 +522,9 @@ def _refresh_weight_plans(epoch_used):
             w5 = _as5(pl.wd)
             kk, cc, kd, kh, kw = w5.shape
             i = wptrs.index(pl.wd.data_ptr())
+            if lp:      # one bf16 plane: no amax, no lo plane, no scale
+                sitems[j] = _WsplitItem(pl.wd.data_ptr(), None, pl.hi.data_ptr(), None, None, kk, cc, kd, kh, kw, pl.kp, pl.cp8, 0 if pl.kind == 'f' else 1)
+                continue
             sitems[j] = _WsplitItem(pl.wd.data_ptr(), amax.data_ptr() + 4 * i, pl.hi.data_ptr(), pl.lo.data_ptr(), pl.sc.data_ptr(),
                                     kk, cc, kd, kh, kw, pl.kp, pl.cp8, 0 if pl.kind == 'f' else 1)
         at = torch.frombuffer(bytearray(bytes(aitems)), dtype=torch.uint8).to(dev)
@@ -513,8 +534,9 @@ def _refresh_weight_plans(epoch_used):
     amax, at, stt, nw = tabs
     lib = _lib_()
     with torch.no_grad():
-        amax.zero_()
-        _lib.check(lib.wdno_amax_multi(_p(at), nw, 256, _stream()), 'amax_multi')
+        if not lp:
+            amax.zero_()
+            _lib.check(lib.wdno_amax_multi(_p(at), nw, 256, _stream()), 'amax_multi')
         _lib.check(lib.wdno_pack_split_weight_multi(_p(stt), len(keys), 256, _stream()), 'pack_split_weight_multi')
     for k in keys:
         pl = _wplans[k]
@@ -525,7 +547,8 @@ def split_weight(w, kind, cp8, kp, pack=None):
     """Split planes of the packed weight operand (cached per weight version). kind 'f': forward operand
     [kd,kh,kp,kw,cp8]; kind 'd': data-gradient operand [kd,kh,kp(=Cp of x),kw,cp8(=K8 of dy)] with flipped taps.
     The first stale operand met after an optimiser step refreshes ALL operands of the previous step in two launches."""
-    key = (w.data_ptr(), kind, cp8, kp, tuple(w.shape), tuple(w.stride()))
+    lp = _lp()
+    key = (w.data_ptr(), kind, cp8, kp, tuple(w.shape), tuple(w.stride()), lp)
     ver = (w._version, WEIGHT_EPOCH)
     pl = _wplans.get(key)
     if pl is not None:
@@ -537,17 +560,19 @@ def split_weight(w, kind, cp8, kp, pack=None):
     with torch.no_grad():
         wd = w.detach()
         wc = wd if wd.is_contiguous() else wd.contiguous()
-        amax = torch.zeros(1, device=w.device, dtype=torch.float32)
-        _lib.check(_lib_().wdno_amax(_p(wc), wc.numel(), _p(amax), _stream()), 'amax')
+        amax = None
+        if not lp:
+            amax = torch.zeros(1, device=w.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_amax(_p(wc), wc.numel(), _p(amax), _stream()), 'amax')
         w5 = _as5(wc)
         k, c, kd, kh, kw = w5.shape
         rows = kd * kh * kp * kw
         if pl is None:
             pl = _WPlan()
-            pl.w, pl.wd, pl.kind, pl.cp8, pl.kp = w, wd, kind, cp8, kp
+            pl.w, pl.wd, pl.kind, pl.cp8, pl.kp, pl.lp = w, wd, kind, cp8, kp, lp
             pl.hi = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
-            pl.lo = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
-            pl.sc = torch.empty(1, device=w.device, dtype=torch.float32)
+            pl.lo = None if lp else torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
+            pl.sc = None if lp else torch.empty(1, device=w.device, dtype=torch.float32)
             if len(_wplans) > 4096:
                 _wplans.clear(); _wtables.clear()
             _wplans[key] = pl
@@ -577,6 +602,9 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
         g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp, y_sp=tuple(out.shape[1:4]), ostride=ostride, ooff=ooff)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
     with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks), flops):
+        if xl is None:       # single bf16 plane per operand
+            _lib.check(_lib_().wdno_conv_fwd_bf16(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_bf16')
+            return y
         _lib.check(_lib_().wdno_conv_fwd_f16x3_amax(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
                                                     _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_f16x3')
     return y
@@ -626,6 +654,13 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None):
         _lib.check(lib.wdno_conv_pixel_table(_p(table), C.byref(g), _stream()), 'conv_pixel_table')
         _pixel_tables[tkey] = table
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * k8 * ks[0] * ks[1] * ks[2] * c8
+    if xl is None:           # single bf16 plane per operand
+        assert param_kc is not None
+        kn, cn = param_kc
+        dw = torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
+        with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8), flops):
+            _lib.check(lib.wdno_conv_wgrad_bf16_param(_p(xh), _p(gh), _p(table), _p(dw), kn, cn, _p(ws), nb, C.byref(g), _stream()), 'conv_wgrad_bf16_param')
+        return dw
     if param_kc is not None:
         kn, cn = param_kc
         dw = torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
@@ -641,7 +676,7 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None):
 
 
 def _use_h3(pixels, reduction):
-    return CONV_MATH == 'f16x3' and pixels >= H3_MIN_PIXELS and reduction >= H3_MIN_REDUCTION
+    return CONV_MATH in ('f16x3', 'bf16') and pixels >= H3_MIN_PIXELS and reduction >= H3_MIN_REDUCTION
 
 
 def _out_size(n, k, s, p):
