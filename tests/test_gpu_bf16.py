@@ -100,7 +100,11 @@ def test_bf16_conv_equals_exact_product_of_rounded_operands(ops, name, xs, ws, s
         lib.wdno_set_debug(0)
     assert any('h3' in k for k in used), used
     assert rel_l2(from_cl(y.detach().cpu())[:, :ws[0]], yr) < 2e-6, 'forward'
-    assert rel_l2(from_cl(xd.grad.cpu())[:, :xs[1]], gxr) < 2e-6, 'dgrad'
+    if stride == 1:
+        assert rel_l2(from_cl(xd.grad.cpu())[:, :xs[1]], gxr) < 2e-6, 'dgrad'
+    else:       # the data gradient of the strided down-sampling convolution runs as four exact-fp32 parity-class convolutions
+        gx64 = grad.conv3d_input(x.shape, w.float().double(), go.float().double(), stride=stride, padding=padding)
+        assert rel_l2(from_cl(xd.grad.cpu())[:, :xs[1]], gx64) < 2e-6, 'dgrad (exact-fp32 path)'
     assert rel_l2(wd.grad.cpu(), gwr) < 2e-6, 'wgrad'
     assert rel_l2(bd.grad.cpu(), go.float().double().sum(dim=[0] + list(range(2, go.dim())))) < 2e-6, 'bias grad'
     # and the distance to the un-rounded fp64 convolution is bf16-sized, not fp32-sized
@@ -174,7 +178,7 @@ def test_bf16_training_reduces_the_loss(ops):
     for mode in ('bf16', 'f16x3'):
         ops.CONV_MATH = mode
         torch.manual_seed(3)
-        net = Unet2D(dim=32, dim_mults=(1, 2, 4), channels=9, resnet_block_groups=1)
+        net = Unet2D(dim=32, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)      # mid attention over 8 x 8 tokens
         dif = GaussianDiffusion(net, seq_length=(64, 64), padded_shape=[41, 60], ori_shape=[81, 120], loss_layer_weight=torch.ones(1, 9, 1, 1),
                                 is_condition_pad=True, is_condition_u0=True, is_condition_f=True).to(DEV)
         ts = TrainStep(dif, lr=2e-4, use_ema=False)

@@ -117,10 +117,12 @@ def _worker_trainer(rank, world, port, tmp, out):
     _trees()
     import torch.distributed as dist
     from ddpm.diffusion_2d import Trainer
+    from wdno_amd.trainer import TrainerCore
+    TrainerCore.num_workers = 0
     dif = _model(seed=5 + rank)
     data = torch.randn(8, 4, 42, 8, 8, generator=torch.Generator().manual_seed(3)) * 0.3
     tr = Trainer(dif, _Fixed(data), None, train_batch_size=4, train_lr=1e-3, train_num_steps=5, save_and_sample_every=5,
-                 results_path=os.path.join(tmp, 'res'), calculate_fid=False, num_workers=0)
+                 results_path=os.path.join(tmp, 'res'), calculate_fid=False)
     assert dist.is_initialized() and tr.world == 2 and tr.rank == rank and tr.local_batch_size == 2
     assert tr.is_main_process == (rank == 0) and hasattr(tr, 'ema') == (rank == 0)
     seen = []

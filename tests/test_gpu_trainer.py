@@ -27,6 +27,8 @@ def trees():
     from ddpm_burgers.train_diffusion import Trainer as TB
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     from ddpm.diffusion_2d import GaussianDiffusion as GD2, Trainer as TS
+    from wdno_amd.trainer import TrainerCore
+    TrainerCore.num_workers = 0            # in-process loading (the constructors keep the reference's parameter lists: no num_workers argument)
     return dict(Unet2D=Unet2D, GD1=GD1, TB=TB, Unet3D=Unet3D_with_Conv3D, GD2=GD2, TS=TS)
 
 
@@ -53,7 +55,7 @@ def test_burgers_trainer_loop_checkpoint_and_ema(trees, tmp_path):
     dif = _burgers(trees)
     data = torch.randn(4, 9, 8, 8) * 0.5
     tr = trees['TB'](dif, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=23, save_and_sample_every=10,
-                     test_every=1000, results_folder=str(tmp_path / 'res'), ema_update_every=2, num_workers=0)
+                     test_every=1000, results_folder=str(tmp_path / 'res'), ema_update_every=2)
     tr.ema.update_after_step = 6                      # exercise copy phase, init and the decayed phase within 23 steps
     ema_ref = {k: v.detach().cpu().clone() for k, v in dif.state_dict().items() if v.is_floating_point()}
     st = {'step': 0, 'initted': False}
@@ -85,7 +87,7 @@ def test_burgers_trainer_loop_checkpoint_and_ema(trees, tmp_path):
     # round trip into a fresh trainer, then both take the same next step
     dif2 = _burgers(trees, seed=5)
     tr2 = trees['TB'](dif2, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=30, results_folder=str(tmp_path / 'res'),
-                      ema_update_every=2, num_workers=0)
+                      ema_update_every=2)
     tr2.load(2)
     assert tr2.step == 23 and tr2.opt.step_count == tr.opt.step_count
     for (k, a), b in zip(dif.state_dict().items(), dif2.state_dict().values()):
@@ -107,7 +109,7 @@ def test_burgers_trainer_matches_torch_adam_trajectory(trees, tmp_path):
     CosineAnnealingLR on a second copy of the module: weights after 4 steps agree."""
     difa, difb = _burgers(trees, 3), _burgers(trees, 3)
     data = torch.randn(4, 9, 8, 8) * 0.5
-    tr = trees['TB'](difa, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=4, results_folder=str(tmp_path / 'a'), num_workers=0)
+    tr = trees['TB'](difa, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=4, results_folder=str(tmp_path / 'a'))
     difb = difb.to(DEV)
     w0 = {k: v.detach().clone() for k, v in difb.named_parameters()}
     opt = torch.optim.Adam(difb.parameters(), lr=1e-4, betas=(0.9, 0.99))
@@ -134,7 +136,7 @@ def test_smoke_trainer_runs_and_saves(trees, tmp_path):
                        timesteps=1000, sampling_timesteps=10, loss_type='l2')
     data = torch.randn(4, 4, 42, 8, 8) * 0.3
     tr = trees['TS'](dif, _Fixed(data, as_tuple=True), None, train_batch_size=2, train_lr=1e-3, train_num_steps=3, save_and_sample_every=3,
-                     results_path=str(tmp_path / 'smoke'), calculate_fid=False, num_workers=0)
+                     results_path=str(tmp_path / 'smoke'), calculate_fid=False)
     w0 = tr.opt.buf.flat_param.clone()
     tr.train()
     assert tr.step == 3 and (tr.opt.buf.flat_param - w0).abs().max() > 0 and torch.isfinite(tr.opt.buf.flat_param).all()
@@ -143,7 +145,7 @@ def test_smoke_trainer_runs_and_saves(trees, tmp_path):
     assert abs(tr.lr_schedule(1e-3, 49999) - 1e-3) < 1e-15 and abs(tr.lr_schedule(1e-3, 50000) - 1e-4) < 1e-15
     dif2 = trees['GD2'](trees['Unet3D'](dim=8, dim_mults=(1, 2), channels=42), torch.ones(1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero',
                         (3, 6, 6), (4, 8, 8), image_size=8, frames=4, timesteps=1000, sampling_timesteps=10, loss_type='l2')
-    tr2 = trees['TS'](dif2, _Fixed(data, as_tuple=True), None, train_batch_size=2, results_path=str(tmp_path / 'smoke'), num_workers=0)
+    tr2 = trees['TS'](dif2, _Fixed(data, as_tuple=True), None, train_batch_size=2, results_path=str(tmp_path / 'smoke'))
     tr2.load(1)
     assert tr2.step == 3 and torch.equal(tr2.opt.buf.flat_param, tr.opt.buf.flat_param)
     # the EMA copy is a usable module whose parameters live in the flat EMA buffer

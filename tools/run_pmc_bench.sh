@@ -2,7 +2,7 @@
 # --kernel-trace, one rocprofv3 run per counter group (see MI355X_MICROARCH.md, HBM / rocprofv3 section).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --sample-steps 0"
+CMD="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras"
 rm -rf /tmp/pmc_a /tmp/pmc_b /tmp/pmc_c
 t0=$(date +%s)
 rm -rf /tmp/pmc_a2

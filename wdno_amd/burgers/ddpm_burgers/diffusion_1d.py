@@ -31,7 +31,7 @@ class GaussianDiffusion(nn.Module):
         pad_mode=None,
         wave_type=None,
         padded_shape=None,
-        ori_shape=None,
+        ori_shape=torch.tensor([81, 128]),      # the reference default (diffusion_1d.py:51, there on 'cuda')
         is_super_model=False,
         upsample_t=1,
         upsample_x=1,
@@ -93,7 +93,7 @@ class GaussianDiffusion(nn.Module):
         self.is_condition_f = is_condition_f
         self.train_on_padded_locations = train_on_padded_locations
         self.padded_shape = padded_shape
-        self.ori_shape = torch.tensor([81, 128]) if ori_shape is None else ori_shape
+        self.ori_shape = ori_shape
         self._wc_cache = None
         self.use_graph = None       # None: HIP-graph replay of the unguided sampling step when the loop is long enough (WDNO_SAMPLE_GRAPH)
 
@@ -122,9 +122,30 @@ class GaussianDiffusion(nn.Module):
     def predict_noise_from_start(self, x_t, t, x0):
         return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
 
+    def predict_v(self, x_start, t, noise):
+        return extract(self.sqrt_alphas_cumprod, t, x_start.shape) * noise - extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * x_start
+
+    def predict_start_from_v(self, x_t, t, v):
+        return extract(self.sqrt_alphas_cumprod, t, x_t.shape) * x_t - extract(self.sqrt_one_minus_alphas_cumprod, t, x_t.shape) * v
+
     def q_posterior(self, x_start, x_t, t):
         mean = extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
         return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    @torch.no_grad()
+    def interpolate(self, x1, x2, t=None, lam=0.5):
+        """diffusion_1d.py:500-518: noise both ends to step t, blend, denoise back with p_sample (no conditioning, as in the reference)."""
+        b, device = x1.shape[0], x1.device
+        t = default(t, self.num_timesteps - 1)
+        assert x1.shape == x2.shape
+        t_batched = torch.full((b,), t, device=device, dtype=torch.long)
+        xt1, xt2 = (self.q_sample(v, t=t_batched) for v in (x1, x2))
+        img = (1 - lam) * xt1 + lam * xt2
+        x_start = None
+        for i in reversed(range(0, t)):
+            self_cond = x_start if self.self_condition else None
+            img, x_start, _ = self.p_sample(img.contiguous(), i, self_cond)
+        return img
 
     def get_guidance_options(self, **kwargs):
         nabla_J = kwargs.get('nablaJ')

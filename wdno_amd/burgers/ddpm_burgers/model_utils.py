@@ -102,19 +102,20 @@ def get_scheduler(scheduler):
 
 
 def get_proj_ep_orthogonal_func(norm='F'):
-    """eps + grad - <grad, eps> eps / ||eps|| with the inner product over the whole field ('F'), over x ('1D_x') or
-    over t ('1D_t') (model_utils.py:70-87)."""
-    if norm == 'F':
-        def proj_ep_orthogonal(ep, nabla_J):
-            return ep + nabla_J - (nabla_J * ep).sum() * ep / ep.square().sum((-2, -1)).sqrt().unsqueeze(-1).unsqueeze(-1)
-    elif norm == '1D_x':
-        def proj_ep_orthogonal(ep, nabla_J):
-            return ep + nabla_J - (nabla_J * ep).sum(-1).unsqueeze(-1) * ep / ep.square().sum(-1).sqrt().unsqueeze(-1)
-    elif norm == '1D_t':
-        def proj_ep_orthogonal(ep, nabla_J):
-            return ep + nabla_J - (nabla_J * ep).sum(-2) * ep / ep.square().sum(-2).sqrt()
-    else:
+    """Guidance combiner  eps + grad - <grad, eps> eps / ||eps||  (model_utils.py:70-87). The inner product runs over the whole
+    batch of fields for 'F' (with the per-field Frobenius norm of eps), over x for '1D_x', over t for '1D_t'."""
+    if norm not in ('F', '1D_x', '1D_t'):
         raise NotImplementedError
+
+    def proj_ep_orthogonal(ep, nabla_J):
+        prod, sq = nabla_J * ep, ep.square()
+        if norm == 'F':
+            inner, length = prod.sum(), sq.sum((-2, -1), keepdim=True).sqrt()
+        elif norm == '1D_x':
+            inner, length = prod.sum(-1, keepdim=True), sq.sum(-1, keepdim=True).sqrt()
+        else:                              # '1D_t': reduced over t, broadcast back along x
+            inner, length = prod.sum(-2), sq.sum(-2).sqrt()
+        return ep + nabla_J - inner * ep / length
     return proj_ep_orthogonal
 
 

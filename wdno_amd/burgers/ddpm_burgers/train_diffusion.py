@@ -47,7 +47,6 @@ class Trainer(TrainerCore):
         mixed_precision_type='fp16',
         split_batches=True,
         max_grad_norm=1.,
-        num_workers=None,
     ):
         if amp:
             raise ValueError('amp=True: mixed precision is not part of the fp32 WDNO path (train_ddpm_burgers.py never sets it)')
@@ -65,7 +64,7 @@ class Trainer(TrainerCore):
         self.num_samples = num_samples
         self.test_every = test_every
         self.results_folder = Path(results_folder)
-        workers = min(cpu_count(), 16) if num_workers is None else num_workers
+        workers = min(cpu_count(), 16) if self.num_workers is None else self.num_workers
         if not is_super_model:
             dl = self.make_loader(dataset, self.local_batch_size, workers)
         else:                                      # a list of datasets, one group drawn at random per batch (data_burgers_1d.py SuperDataLoader)

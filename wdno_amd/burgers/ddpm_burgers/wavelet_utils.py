@@ -2,7 +2,7 @@
 from wdno_amd import ops
 
 
-def upsample_coef(w_sub, shape=None):
+def upsample_coef(w_sub, shape):
     """Nearest x2 of wavelet coefficients along (t, x): [N, l, nt, nx] -> [N, l, 2 nt, 2 nx] (one HIP gather launch)."""
     n, l, nt, nx = w_sub.shape
     return ops.upsample_coef_raw(w_sub, n * l, nt, 1, 1, nx, 2, 1, 2).reshape(n, l, 2 * nt, 2 * nx)

@@ -159,9 +159,30 @@ class GaussianDiffusion(nn.Module):
     def predict_noise_from_start(self, x_t, t, x0):
         return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
 
+    def predict_v(self, x_start, t, noise):
+        return extract(self.sqrt_alphas_cumprod, t, x_start.shape) * noise - extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * x_start
+
+    def predict_start_from_v(self, x_t, t, v):
+        return extract(self.sqrt_alphas_cumprod, t, x_t.shape) * x_t - extract(self.sqrt_one_minus_alphas_cumprod, t, x_t.shape) * v
+
     def q_posterior(self, x_start, x_t, t):
         mean = extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
         return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    @torch.no_grad()
+    def interpolate(self, x1, x2, t=None, lam=0.5):
+        """diffusion_2d.py:950-968: noise both ends to step t, blend, denoise back (no conditioning is imposed, as in the reference)."""
+        b, device = x1.shape[0], x1.device
+        t = default(t, self.num_timesteps - 1)
+        assert x1.shape == x2.shape
+        t_batched = torch.full((b,), t, device=device, dtype=torch.long)
+        xt1, xt2 = (self.q_sample(v, t=t_batched) for v in (x1, x2))
+        img = (1 - lam) * xt1 + lam * xt2
+        x_start = None
+        for i in reversed(range(0, t)):
+            self_cond = x_start if self.self_condition else None
+            img, x_start = self.p_sample(tuple(img.shape), img.contiguous(), i, self_cond)
+        return img
 
     def sample_noise(self, shape, device):
         return torch.randn(shape, device=device)
@@ -188,8 +209,9 @@ class GaussianDiffusion(nn.Module):
             pred_noise = self.predict_noise_from_start(x, t, x_start)
         return ModelPrediction(pred_noise, x_start)
 
-    def p_mean_variance(self, shape, x, t, x_self_cond=None, clip_denoised=True, **kw):
-        preds = self.model_predictions(shape, x, t, x_self_cond, **kw)
+    def p_mean_variance(self, shape, x, t, x_self_cond=None, clip_denoised=True, design_fn=None, design_guidance='standard', low=None, init=None,
+                        init_u=None):
+        preds = self.model_predictions(shape, x, t, x_self_cond, design_fn=design_fn, design_guidance=design_guidance, low=low, init=init, init_u=init_u)
         x_start = preds.pred_x_start
         if clip_denoised:
             x_start = x_start.clamp(-1., 1.)
@@ -324,7 +346,7 @@ class Trainer(_TrainerCore):
         self,
         diffusion_model,
         dataset,
-        dataset_path=None,
+        dataset_path,
         *,
         N_downsample=0,
         train_batch_size=16,
@@ -347,7 +369,6 @@ class Trainer(_TrainerCore):
         is_schedule=True,
         resume=False,
         resume_step=0,
-        num_workers=None,
     ):
         if amp or fp16:
             raise ValueError('mixed precision is not part of the fp32 WDNO path (train_2d.py passes amp=False)')
@@ -379,11 +400,11 @@ class Trainer(_TrainerCore):
             self.ds = dataset
         if isinstance(self.ds, (list, tuple)):
             from ddpm.data_2d import SuperDataLoader
-            workers = 4 if num_workers is None else num_workers
+            workers = 4 if self.num_workers is None else self.num_workers
             dl = SuperDataLoader(self.ds, batch_size=self.local_batch_size, shuffle=True, pin_memory=True, num_workers=workers,
                                  seed=self.data_seed if self.world > 1 else None)
         else:
-            workers = 16 if num_workers is None else num_workers
+            workers = 16 if self.num_workers is None else self.num_workers
             dl = self.make_loader(self.ds, self.local_batch_size, workers)
         self.dl = self.cycle(dl)          # advances DistributedSampler epochs
 

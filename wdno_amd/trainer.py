@@ -546,6 +546,8 @@ class TrainerCore:
         return self.rank == 0
 
     cycle = staticmethod(cycle_loader)
+    num_workers = None          # DataLoader workers; None = the reference's choice (cpu_count() / 16). Class attribute, not a constructor
+                                # argument: the constructors keep exactly the reference's parameter lists (tests/test_host.py)
 
     def make_loader(self, dataset, batch_size, num_workers, shuffle=True):
         from torch.utils.data import DataLoader
