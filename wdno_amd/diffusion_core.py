@@ -188,9 +188,10 @@ class _StepGraph:
     graph (ops.graph_capture) on static buffers and replayed for every step of a loop: the timestep, the DDIM coefficients and
     the noise draw live in device memory that is refreshed between replays, so all steps are the same ~10^3-launch graph."""
 
-    def __init__(self, mod, shape, desc, ddim, cond_first, device):
+    def __init__(self, mod, shape, desc, ddim, cond_first, device, guided=None):
         from . import ops
         self.mod, self.ddim, self.cond_first, self.desc = mod, ddim, cond_first, desc
+        self.guided = guided              # None, or a callable (x, t, noise, coef) -> x_next for a guided step made of capturable launches
         b = shape[0]
         self.x = torch.zeros(shape, device=device, dtype=torch.float32)
         self.src = torch.zeros(shape, device=device, dtype=torch.float32)
@@ -208,6 +209,12 @@ class _StepGraph:
         mod, x = self.mod, self.x
         if self.cond_first:
             apply_cond(x, self.src, self.desc)
+        if self.guided is not None:
+            xn = self.guided(x, self.t, self.noise, self.coef).contiguous()
+            if not self.cond_first:
+                apply_cond(xn, self.src, self.desc)
+            x.copy_(xn)
+            return
         eps = mod.model(x, self.t, None)
         if self.ddim:
             xn, xs = ddim_update_dev(mod, x, eps, self.noise, self.t, self.coef)
@@ -219,15 +226,15 @@ class _StepGraph:
         self.x_start = xs
 
 
-def _step_graph(mod, shape, desc, ddim, cond_first, device):
+def _step_graph(mod, shape, desc, ddim, cond_first, device, guided=None, guided_key=None):
     from . import ops
     cache = _graph_cache.setdefault(mod, {})
-    key = (tuple(shape), bytes(desc), bool(ddim), bool(cond_first), str(device), ops.WEIGHT_EPOCH)
+    key = (tuple(shape), bytes(desc), bool(ddim), bool(cond_first), str(device), ops.WEIGHT_EPOCH, guided_key)
     sg = cache.get(key)
     if sg is None:
         if len(cache) >= 2:                       # a graph pins one step's worth of activations
             cache.clear()
-        sg = cache[key] = _StepGraph(mod, tuple(shape), desc, ddim, cond_first, device)
+        sg = cache[key] = _StepGraph(mod, tuple(shape), desc, ddim, cond_first, device, guided)
     return sg
 
 
@@ -282,4 +289,60 @@ def sampling_loop(mod, x, src, desc, *, ddim_pairs=None, eta=0.0, cond_first, us
             x, _ = p_sample_update(mod, x, eps, noise, bt, clamp=True)
         if not cond_first:
             x = apply_cond(x, src, desc)
+    return x.clone() if sg is not None and x is sg.x else x
+
+
+def guided_sampling_loop_smoke(mod, x, src, desc, design_fn, design_guidance, *, ddim_pairs=None, eta=0.0, low=None, init=None, init_u=None,
+                               use_graph=None):
+    """The guided smoke sampling loop (diffusion_2d.py:723-754 inside :788-933) for a `graph_safe` design_fn: every noisy step is a
+    replay of ONE captured graph (U-Net, predict-x0, the design gradient with its IDWT / adjoint-IDWT launches, the update and the
+    condition re-imposition); the timestep, the DDIM coefficients and the noise live in device memory. Same arithmetic as the eager
+    loop in GaussianDiffusion.ddim_sample / p_sample_loop (torch element-wise ops)."""
+    dev, shape, b = x.device, tuple(x.shape), x.shape[0]
+    ddim = ddim_pairs is not None
+    if ddim:
+        steps = [(time, None if time_next < 0 else ddim_coefficients(mod._ac_host, time, time_next, eta)) for time, time_next in ddim_pairs]
+        noisy = [co is not None for _, co in steps]
+    else:
+        steps = [(t, None) for t in reversed(range(mod.num_timesteps))]
+        noisy = [t > 0 for t, _ in steps]
+    kw = dict(design_fn=design_fn, design_guidance=design_guidance, low=low, init=init, init_u=init_u)
+
+    def guided(xx, t, noise, coef):
+        if ddim:
+            pred_noise, x_start = mod.model_predictions(shape, xx, t, None, clip_x_start=True, rederive_pred_noise=True, **kw)
+            return x_start * coef[0] + coef[1] * pred_noise + coef[2] * noise
+        mean, _, logvar, _ = mod.p_mean_variance(shape, x=xx, t=t, x_self_cond=None, clip_denoised=True, **kw)
+        return mean + (0.5 * logvar).exp() * noise
+    if use_graph is None:
+        use_graph = SAMPLE_GRAPH and sum(noisy) >= SAMPLE_GRAPH_MIN_STEPS
+    sg = None
+    if use_graph and any(noisy):
+        sg = _step_graph(mod, shape, desc, ddim, False, dev, guided, ('guided', id(design_fn), design_guidance))
+        sg.src.copy_(src)
+        sg.x.copy_(x)
+        if ddim:
+            table = torch.tensor([[co[2], co[1], co[0]] if co is not None else [0., 0., 0.] for _, co in steps], dtype=torch.float32).to(dev)
+        x = sg.x
+    for i, (t, co) in enumerate(steps):
+        noise = mod.sample_noise(shape, dev) if noisy[i] else None
+        if sg is not None and noisy[i]:
+            sg.t.fill_(t)
+            if ddim:
+                sg.coef.copy_(table[i])
+            sg.noise.copy_(noise)
+            sg.graph.replay()
+            continue
+        bt = torch.full((b,), t, device=dev, dtype=torch.long)
+        if ddim:
+            pred_noise, x_start = mod.model_predictions(shape, x, bt, None, clip_x_start=True, rederive_pred_noise=True, **kw)
+            if noise is None:
+                x = x_start
+                continue
+            sigma, c, sqrt_an = co
+            x = x_start * sqrt_an + c * pred_noise + sigma * noise
+        else:
+            mean, _, logvar, _ = mod.p_mean_variance(shape, x=x, t=bt, x_self_cond=None, clip_denoised=True, **kw)
+            x = mean if noise is None else mean + (0.5 * logvar).exp() * noise
+        x = apply_cond(x.contiguous(), src, desc)
     return x.clone() if sg is not None and x is sg.x else x

@@ -194,9 +194,12 @@ class GaussianDiffusion(nn.Module):
         maybe_clip = (lambda v: v.clamp(-1., 1.)) if clip_x_start else identity
         x_start = maybe_clip(self.predict_start_from_noise(x, t, pred_noise))
         if design_fn is not None:       # guidance hook (inference_2d.py:30-66): user callback under autograd
-            with torch.enable_grad():
-                x_clone = x_start.clone().detach().requires_grad_()
-                g = design_fn(x_clone, low=low, init=init, init_u=init_u)
+            if getattr(design_fn, 'graph_safe', False):       # closed-form gradient (smoke/guidance.py GuidanceFn): no tape needed
+                g = design_fn(x_start, low=low, init=init, init_u=init_u)
+            else:
+                with torch.enable_grad():
+                    x_clone = x_start.clone().detach().requires_grad_()
+                    g = design_fn(x_clone, low=low, init=init, init_u=init_u)
             if design_guidance == 'standard':
                 grad_final = self.standard_fixed_ratio * g
             elif design_guidance == 'standard-alpha':
@@ -253,6 +256,8 @@ class GaussianDiffusion(nn.Module):
         x = K.apply_cond(self.sample_noise(list(shape), device).contiguous(), src, desc)
         if design_fn is None and not self.self_condition:          # unguided: fused launches, the step replayed from one HIP graph
             return K.sampling_loop(self, x, src, desc, cond_first=False, use_graph=self.use_graph)
+        if getattr(design_fn, 'graph_safe', False) and not self.self_condition:
+            return K.guided_sampling_loop_smoke(self, x, src, desc, design_fn, design_guidance, low=low, init=init, init_u=init_u, use_graph=self.use_graph)
         x_start = None
         for t in reversed(range(0, self.num_timesteps)):
             self_cond = x_start if self.self_condition else None
@@ -272,6 +277,9 @@ class GaussianDiffusion(nn.Module):
         pairs = K.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)
         if design_fn is None and not self.self_condition:
             return K.sampling_loop(self, img, src, desc, ddim_pairs=pairs, eta=eta, cond_first=False, use_graph=self.use_graph)
+        if getattr(design_fn, 'graph_safe', False) and not self.self_condition:
+            return K.guided_sampling_loop_smoke(self, img, src, desc, design_fn, design_guidance, ddim_pairs=pairs, eta=eta, low=low, init=init,
+                                                init_u=init_u, use_graph=self.use_graph)
         x_start = None
         for time, time_next in pairs:
             tc = torch.full((batch,), time, device=device, dtype=torch.long)
