@@ -90,9 +90,9 @@ def guidance_fn_explicit(x, shape, ori_shape, rescaler, wave_type='bior1.3', pad
     g[:, :tc, :40, :hc, :wc] = dpacked.reshape(b, 5, 8, tc, hc, wc).permute(0, 3, 1, 2, 4, 5).reshape(b, tc, 40, hc, wc)
     if not is_condition_control:
         g_lo, g_hi = _success_gradient(tc, to, wave_type, pad_mode, xs.device)
-        half = ww // 2
-        g[:, :tc, -1, :, :half] -= (g_lo / (hh * half)).reshape(1, tc, 1, 1)
-        g[:, :tc, -1, :, half:] -= (g_hi / (hh * (ww - half))).reshape(1, tc, 1, 1)
+        half = ww // 2                         # the reference halves the ROW axis of the smoke-out channel (x[:, :T', -1, :20])
+        g[:, :tc, -1, :half, :] -= (g_lo / (half * ww)).reshape(1, tc, 1, 1)
+        g[:, :tc, -1, half:, :] -= (g_hi / ((hh - half) * ww)).reshape(1, tc, 1, 1)
     return g
 
 
