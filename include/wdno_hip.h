@@ -307,6 +307,11 @@ size_t wdno_sumsq_ws_bytes(int64_t n);
 int wdno_sumsq(const float* g, int64_t n, float* out, void* ws, size_t ws_bytes, wdno_stream_t s);
 int wdno_adam_clip_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
                         float grad_scale, float lr, float beta1, float beta2, float eps, int step, wdno_stream_t s);
+/* Gradient gather: one launch copies every per-parameter gradient tensor into its span of the flat gradient buffer (items with
+ * src == NULL are zero-filled): what DistributedDataParallel's bucket copies / AccumulateGrad's adds do one tensor at a time. The
+ * table of n_items wdno_copy_item lives in device memory. */
+typedef struct { const void* src; void* dst; int64_t n; } wdno_copy_item;
+int wdno_gather_items(const void* table, int n_items, int blocks_per_item, wdno_stream_t s);
 /* ema = ema*beta + p*(1-beta)  (ema_pytorch lerp) */
 int wdno_ema_update(float* ema, const float* p, int64_t n, float beta, wdno_stream_t s);
 

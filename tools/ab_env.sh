@@ -3,5 +3,5 @@ cd $GRAFT_REPO_ROOT
 A=${2:-0}; B=${3:-1}
 for v in $A $B $A $B; do
   echo -n "$1=$v  "
-  env $1=$v python bench.py --steps 30 --warmup 8 --no-cpu-baseline --sample-steps 0 2>&1 | tail -1 | cut -c83-130
+  env $1=$v python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-extras 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"ms_per_step\"])"
 done

@@ -119,6 +119,7 @@ PROTOTYPES = {
     'wdno_sumsq': (I, [P, L, P, P, Z, P]),
     'wdno_adam_clip_step': (I, [P, P, P, P, L, P, F, F, F, F, F, F, I, P]),
     'wdno_ema_update': (I, [P, P, L, F, P]),
+    'wdno_gather_items': (I, [P, I, I, P]),
 }
 
 _lib = None

@@ -24,6 +24,13 @@ from . import _lib, ops
 from .ops import _lib_, _p, _stream, _ws
 
 
+GRAD_GATHER = os.environ.get('WDNO_GRAD_GATHER', '1') != '0'
+
+
+class _CopyItem(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int64)]
+
+
 class FlatBuffers:
     """Re-homes every trainable parameter (and its .grad) of `params` as views into two flat fp32 tensors."""
 
@@ -44,6 +51,10 @@ class FlatBuffers:
                 off += n
         ops.drop_weight_caches()          # operands packed from the old storages would pin them (and can never hit again)
         self._untouched = None
+        self.span_list = list(self._spans())
+        self._gather_srcs, self._gather_table, self._gathered = None, None, False
+        self._views = [self.flat_grad[o:o + n].view(p.shape) for p, (o, n) in zip(self.params, self.span_list)]
+        self._view_ptrs = [v.data_ptr() for v in self._views]
 
     def params_changed(self):
         """Call after ANY write to flat_param (optimiser step, broadcast, checkpoint load, EMA copy): the packed / split weight
@@ -81,10 +92,17 @@ class FlatBuffers:
                                'torch.optim.Adam with set_to_none gradients. Freeze them (requires_grad_(False)) before building the trainer.')
 
     def zero_grad(self):
-        self.flat_grad.zero_()
-        for p, (o, n) in zip(self.params, self._spans()):      # autograd may have replaced .grad with a fresh tensor
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                p.grad = self.flat_grad[o:o + n].view(p.shape)
+        """Gradients are left as None: autograd then STORES each parameter's gradient instead of adding it into an existing
+        tensor (AccumulateGrad issues one `add` launch per parameter when .grad exists: ~230 launches, 3.9 % of the smoke step),
+        and gather_grads() moves all of them into the flat buffer with one launch."""
+        self._gathered = False
+        if not GRAD_GATHER:                  # A/B: the round-1 behaviour (zero-filled flat views, autograd adds into them)
+            self.flat_grad.zero_()
+            for p, v in zip(self.params, self._views):
+                p.grad = v
+            return
+        for p in self.params:
+            p.grad = None
 
     def _spans(self):
         off = 0
@@ -93,15 +111,50 @@ class FlatBuffers:
             off += p.numel()
 
     def gather_grads(self):
-        """Make sure every .grad is the flat view (autograd accumulates in place when .grad already exists)."""
-        for p, (o, n) in zip(self.params, self._spans()):
-            view = self.flat_grad[o:o + n].view(p.shape)
-            if p.grad is None:
-                view.zero_()
+        """After backward: every p.grad -> its span of flat_grad (zeros where backward produced none), then p.grad becomes the
+        flat view. One wdno_gather_items launch; the pointer table is re-uploaded only when an address changed (the caching
+        allocator hands out the same blocks step after step)."""
+        if not self.flat_grad.is_cuda:              # host buffers exist only in the gloo exchange tests (tests/test_distributed_cpu.py)
+            for p, (o, n) in zip(self.params, self.span_list):
+                view = self.flat_grad[o:o + n].view(p.shape)
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
                 p.grad = view
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-                p.grad = view
+            return
+        if self._gathered:
+            return
+        grads = [p.grad for p in self.params]
+        ptrs = [0 if g is None else g.data_ptr() for g in grads]
+        if ptrs == self._view_ptrs:                  # accumulated in place into the flat views (WDNO_GRAD_GATHER=0 / a second call)
+            self._gathered = True
+            return
+        for i, g in enumerate(grads):
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                grads[i] = g = g.to(torch.float32).contiguous()
+                ptrs[i] = g.data_ptr()
+        if ptrs != self._gather_srcs:
+            # (src, dst, n) rows = wdno_copy_item. The upload must not block the host (a pageable-memory copy waits for the stream and
+            # ends the host's run-ahead: +2 ms per step): pinned staging buffers, rotated so that a buffer is not rewritten while an
+            # earlier asynchronous copy of it may still be pending.
+            if self._gather_table is None:
+                n = len(ptrs)
+                self._gather_table = torch.empty((n, 3), dtype=torch.int64, device=self.flat_grad.device)
+                self._gather_hosts = [torch.empty((n, 3), dtype=torch.int64).pin_memory() for _ in range(8)]
+                for h in self._gather_hosts:
+                    h[:, 1] = torch.tensor(self._view_ptrs, dtype=torch.int64)
+                    h[:, 2] = torch.tensor([sp[1] for sp in self.span_list], dtype=torch.int64)
+                self._gather_turn = 0
+            h = self._gather_hosts[self._gather_turn % len(self._gather_hosts)]
+            self._gather_turn += 1
+            h[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
+            self._gather_table.copy_(h, non_blocking=True)
+            self._gather_srcs = ptrs
+        _lib.check(_lib_().wdno_gather_items(_p(self._gather_table), len(ptrs), 48, _stream()), 'gather_items')
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+        self._gathered = True
 
 
 def allreduce_sum_(flat, world_size=None, group=None):
