@@ -273,6 +273,48 @@ def sampling_leg(dif, device, batch, steps):
     return out
 
 
+def sr_leg(device, batch=2, steps=10):
+    """BASELINE.json configs[4] on one GPU (its batch shards over 8 GPUs with no communication): super-resolution DDIM sampling with
+    the step replayed from one HIP graph, then the IDWT reconstruction -- the cascade step of smoke/inference_2d.py:155-232 on a
+    tensor doubled in time AND space ([B, 48, 82, 80, 80]: the reference's 5-field channel layout, 82 = 2 * 40 + 2, rather than the
+    66 channels SURVEY 8d derives for 4 synthetic fields, because the conditioning predicates follow the reference's fixed channel
+    positions) -> coefficients [B*5, 8, 34, 66, 66] -> fields [B, 5, 64, 128, 128]."""
+    _trees()
+    import ptwt
+    import pywt
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion
+    from wave_trans_2d import tensor_to_coef
+    torch.manual_seed(0)
+    shapes = [[18, 34, 34], [34, 66, 66]]
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=82)
+    dif = GaussianDiffusion(net, torch.ones(1, 1, 82, 1, 1), True, True, True, True, 'bior1.3', 'zero', shapes, [[32, 64, 64], [64, 128, 128]],
+                            image_size=80, frames=48, timesteps=1000, sampling_timesteps=steps, loss_type='l2', ddim_sampling_eta=1.0).to(device)
+    low = torch.randn(batch, 48, 40, 80, 80, device=device) * 0.3
+    init = torch.randn(batch, 48, 80, 80, device=device)
+    control = torch.randn(batch, 48, 16, 80, 80, device=device)
+    out = {}
+    with torch.no_grad():
+        for tag, ug in (('eager', False), ('graph', True)):
+            dif.use_graph = ug
+            res = dif.sample(batch_size=batch, N_upsample=1, init=init, control=control, low=low)       # warm-up (and capture)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = dif.sample(batch_size=batch, N_upsample=1, init=init, control=control, low=low)
+            torch.cuda.synchronize()
+            out[f'{tag}_ddim_steps_per_sec'] = round(steps / (time.perf_counter() - t0), 2)
+
+        def reconstruct():
+            coef = tensor_to_coef(res[:, :, :40].permute(0, 2, 1, 3, 4), shapes[1], upsample_type='space')
+            rec = ptwt.waverec3([coef[0].contiguous(), {k: v.contiguous() for k, v in coef[1].items()}], pywt.Wavelet('bior1.3'))
+            return rec[:, :64, :128, :128].reshape(-1, 5, 64, 128, 128)
+        fields = reconstruct()
+        out['idwt_reconstruction_ms'] = round(_ev_time(reconstruct, 10), 3)
+        out['fields'] = list(fields.shape)
+    out.update(batch=batch, tensor=[batch, 48, 82, 80, 80], ddim_steps=steps)
+    return out
+
+
 def burgers_leg(device, batch, steps, lowp=None):
     """Burgers base model: train step and p_sample step (BASELINE.json configs[0] shape at batch 16, configs[1] at batch 256)."""
     from wdno_amd import ops
@@ -428,6 +470,8 @@ def main():
                 extras['dwt'] = dwt_leg(device)
                 if smoke:
                     del ts, dif
+                    torch.cuda.empty_cache()
+                    extras['sr_sampling'] = sr_leg(device)
                     torch.cuda.empty_cache()
                     extras['burgers'] = {'fp32_equivalent_batch16': burgers_leg(device, 16, 20),
                                          'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16') if ops.LOWP_AVAILABLE else 'bf16 path not built'}

@@ -5,7 +5,7 @@ src, dst = sys.argv[1], sys.argv[2]
 lines = [l for l in open(src) if l.startswith('|')]
 cols = [c.strip() for c in lines[0].strip().strip('|').split('|')]
 out = {'note': 'rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE and the SQ groups in separate runs; tools/run_pmc_bench.sh) of '
-               '`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --sample-steps 0`; per-dispatch averages. bytes = (2*FETCH_SIZE + '
+               '`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras`; per-dispatch averages. bytes = (2*FETCH_SIZE + '
                'WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); this is '
                'L2<->fabric traffic, i.e. HBM plus Infinity-Cache (MALL) hits. mfma_busy_frac = 32*SQ_INSTS_MFMA / (GRBM_GUI_ACTIVE/8 XCDs '
                '* 1024 SIMDs).',
