@@ -275,32 +275,37 @@ __device__ __forceinline__ int am_key(int m, int hh) { return 8 * (m >> 2) + 4 *
 // Rows of one operand ([n][32] floats: q, k, v or dO of one head) -> LDS tile [32][AM_TS], loaded cooperatively (8 lanes
 // per 128-byte row, three passes for 24 rows), optionally scaled and rotated on the way; rows >= n are zero-filled.
 #define AM_TS 36
+template <int NIF = 4>
 __device__ __forceinline__ void am_stage_rows(float* __restrict__ tile, const float* __restrict__ ubase, unsigned row_stride,
                                               const float* __restrict__ rc, const float* __restrict__ rs, float scale, int n, int lane) {
   // ubase: wave-uniform pointer to row 0 of the operand (am_uniform); the per-lane part of every address is a 32-bit offset,
   // so nothing 64-bit per lane has to stay live across the item loop
-  // the four 1-KiB row groups are requested together (4 KB in flight per wave; one at a time, sixteen waves per CU keep only
-  // ~4 MB in flight chip-wide and the kernel sits at a latency-bound 2.9 TB/s); the rotation tables are fetched pass by pass
-  float4 xs[4];
+  // NIF of the four 1-KiB row groups are requested together (4 KB in flight per wave; one at a time, sixteen waves per CU keep only
+  // ~4 MB in flight chip-wide and the kernel sits at a latency-bound 2.9 TB/s); the rotation tables are fetched pass by pass.
+  // NIF = 2 halves the staging registers where the caller is short of them.
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int idx = lane + 64 * k;
-    const int r = idx >> 3, c4 = (idx & 7) * 4;
-    xs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < n) xs[k] = *reinterpret_cast<const float4*>(ubase + ((unsigned)r * row_stride + (unsigned)c4));
-  }
+  for (int k0 = 0; k0 < 4; k0 += NIF) {
+    float4 xs[NIF];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int idx = lane + 64 * k;
-    const int r = idx >> 3, c4 = (idx & 7) * 4;
-    float4 x = xs[k];
-    x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
-    if (rc && r < n) {
-      const float4 c = *reinterpret_cast<const float4*>(rc + r * DH + c4), sn = *reinterpret_cast<const float4*>(rs + r * DH + c4);
-      x = make_float4(x.x * c.x - x.y * sn.x, x.y * c.y + x.x * sn.y, x.z * c.z - x.w * sn.z, x.w * c.w + x.z * sn.w);
+    for (int k = 0; k < NIF; ++k) {
+      const int idx = lane + 64 * (k0 + k);
+      const int r = idx >> 3, c4 = (idx & 7) * 4;
+      xs[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < n) xs[k] = *reinterpret_cast<const float4*>(ubase + ((unsigned)r * row_stride + (unsigned)c4));
     }
-    *reinterpret_cast<float4*>(tile + r * AM_TS + c4) = x;
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < NIF; ++k) {
+      const int idx = lane + 64 * (k0 + k);
+      const int r = idx >> 3, c4 = (idx & 7) * 4;
+      float4 x = xs[k];
+      x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+      if (rc && r < n) {
+        const float4 c = *reinterpret_cast<const float4*>(rc + r * DH + c4), sn = *reinterpret_cast<const float4*>(rs + r * DH + c4);
+        x = make_float4(x.x * c.x - x.y * sn.x, x.y * c.y + x.x * sn.y, x.z * c.z - x.w * sn.z, x.w * c.w + x.z * sn.w);
+      }
+      *reinterpret_cast<float4*>(tile + r * AM_TS + c4) = x;
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 // the 16 values of row `li` this lane feeds to the MFMA: channels d = 2m + hh
@@ -401,7 +406,7 @@ __device__ __forceinline__ float4 am_unrotate4(float4 g, const float* __restrict
   return make_float4(g.x * c.x + g.y * s.x, g.y * c.y - g.x * s.y, g.z * c.z + g.w * s.z, g.w * c.w - g.z * s.w);
 }
 
-__global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+__global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
                                                                        const float* __restrict__ rsin, const float* __restrict__ bias,
                                                                        const float* __restrict__ fout, const float* __restrict__ dout,
                                                                        float* __restrict__ dqkv, float* __restrict__ dbias, AttnP p) {
@@ -426,9 +431,6 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
     const int64_t unit = item / p.d.heads;
     const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
     const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
-    const int64_t rowl = row0 + (int64_t)(tok ? li : 0) * p.d.st;
-    const float* rcl = rcos ? rcos + li * DH : nullptr;
-    const float* rsl = rsin ? rsin + li * DH : nullptr;
     const float* qb = am_uniform(qkv + row0 * p.RW + h * DH);          // q of token 0 of this item; k at + HD, v at + 2 HD
     const float* gb = am_uniform(dout + row0 * p.HD + h * DH);
     const float* fb = am_uniform(fout + row0 * p.HD + h * DH);
@@ -440,22 +442,11 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
     asm volatile("" : "+v"(hz));
     const unsigned tstride = (unsigned)(p.d.st * p.RW), gstride = (unsigned)(p.d.st * p.HD);
     f32x16 pT, dsT;
-    {
-      am_stage_rows(Ta, qb, tstride, rcos, rsin, p.scale, n, lane);
-      am_stage_rows(Tb, qb + p.HD, tstride, rcos, rsin, 1.0f, n, lane);
-      __builtin_amdgcn_wave_barrier();
-      float qs[16], ks[16];
-      am_sel(Ta, li, hh, qs);
-      am_sel(Tb, li, hh, ks);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) pT[e] = 0.f;
-#pragma unroll
-      for (int m = 0; m < 16; ++m) pT = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[m], qs[m], pT, 0, 0, 0);
-      am_softmax(pT, bias ? bias + ((int64_t)h * n + (tok ? li : 0)) * n : nullptr, n, hh, tok);
-    }
+    // Phase order (round 2): V / dO first, Q / K second, so that the scaled + rotated Q and K tiles are still in LDS when the dQ and dK
+    // products need their columns. Round 1 staged Q / K first and re-read K, Q and dO column-wise from global memory for the three
+    // gradient products, re-applying the rotation per element (two table loads each); now only dO is re-read. Still two tiles per wave.
     {
       // dP^T[j][i] = sum_d V[j][d] dO[i][d]; delta_i = <dO_i, O_i> (8 lanes per row, reduced with three shuffles)
-      __builtin_amdgcn_wave_barrier();
       am_stage_rows(Ta, qb + 2 * p.HD, tstride, nullptr, nullptr, 1.0f, n, lane);
       am_stage_rows(Tb, gb, gstride, nullptr, nullptr, 1.0f, n, lane);
 #pragma unroll 1
@@ -472,42 +463,58 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
         if ((lane & 7) == 0) dl[r] = part;
       }
       __builtin_amdgcn_wave_barrier();
-      float vs[16], gs[16];
-      am_sel(Ta, li, hh, vs);
-      am_sel(Tb, li, hh, gs);
-      const float delta = dl[li];
 #pragma unroll
       for (int e = 0; e < 16; ++e) dsT[e] = 0.f;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[m], gs[m], dsT, 0, 0, 0);
+      for (int g4 = 0; g4 < 4; ++g4) {          // four steps at a time: bounded live registers (the kernel runs at 128 VGPRs)
+        float va[4], gg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          va[q] = Ta[li * AM_TS + 2 * (4 * g4 + q) + hh];
+          gg[q] = Tb[li * AM_TS + 2 * (4 * g4 + q) + hh];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(va[q], gg[q], dsT, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      __builtin_amdgcn_wave_barrier();                 // every lane has taken its V / dO values: the tiles may be overwritten
+      am_stage_rows<2>(Ta, qb, tstride, rcos, rsin, p.scale, n, lane);
+      am_stage_rows<2>(Tb, qb + p.HD, tstride, rcos, rsin, 1.0f, n, lane);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pT[e] = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float qa[4], kb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          qa[q] = Ta[li * AM_TS + 2 * (4 * g4 + q) + hh];
+          kb[q] = Tb[li * AM_TS + 2 * (4 * g4 + q) + hh];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pT = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[q], qa[q], pT, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      am_softmax(pT, bias ? bias + ((int64_t)h * n + (tok ? li : 0)) * n : nullptr, n, hh, tok);
+      const float delta = dl[li];                      // written in the first phase; the staging does not touch it
 #pragma unroll
       for (int e = 0; e < 16; ++e) dsT[e] = pT[e] * (dsT[e] - delta);
     }
-    // the two tiles with the lane roles swapped (lane = key) go through LDS (over the staged operands, which every lane has
-    // consumed by now); the relative-position-bias gradient is dS itself
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int j = am_key(e, hh);
-      Pt[j * AM_TS + li] = pT[e];
-      St[j * AM_TS + li] = dsT[e];
-      if (dbias && tok && j < n) atomicAdd(&dBs[(h * n + li) * n + j], dsT[e]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]  (K rotated, read as rows): lane i gets runs of four channels
+    // dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]: K columns from the staged (rotated) tile, dS^T straight from the accumulator
     {
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {          // four steps at a time: bounded live registers, the other waves hide the latency
+      for (int g4 = 0; g4 < 4; ++g4) {
         float ka[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = 4 * g4 + q;
           const unsigned j = (unsigned)(8 * (m >> 2) + (m & 3)) + hz;
-          const float x = j < (unsigned)n ? qb[j * tstride + (unsigned)(p.HD + li)] : 0.f;
-          ka[q] = am_rot_elem(x, rcos, rsin, (int)j, li, j < (unsigned)n);
+          ka[q] = Tb[j * AM_TS + (unsigned)li];        // rows >= n are zero-filled by the staging
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[q], dsT[4 * g4 + q], acc, 0, 0, 0);
@@ -518,16 +525,24 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
-          float4 gq = am_unrotate4(make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]), rcl, rsl, d0);
+          float4 gq = am_unrotate4(make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]), rcos ? rcos + li * DH : nullptr, rsin ? rsin + li * DH : nullptr, d0);
           gq = make_float4(gq.x * p.scale, gq.y * p.scale, gq.z * p.scale, gq.w * p.scale);
           *reinterpret_cast<float4*>(drow + d0) = gq;
           am = amax4(am, gq);
         }
       }
     }
+    // dS with the lane roles swapped (lane = key) goes through LDS, over the K tile every lane has finished with; the
+    // relative-position-bias gradient is dS itself
     __builtin_amdgcn_wave_barrier();
-    // dK^T[d][j] = sum_i Q[i][d] dS[i][j],  dV^T[d][j] = sum_i dO[i][d] P[i][j]: lane j, reduction over the queries
-    // (one after the other: 48 live registers each instead of 96)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int j = am_key(e, hh);
+      St[j * AM_TS + li] = dsT[e];
+      if (dbias && tok && j < n) atomicAdd(&dBs[(h * n + li) * n + j], dsT[e]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dK^T[d][j] = sum_i Q[i][d] dS[i][j]: Q columns from the staged (scaled, rotated) tile
     {
       f32x16 dk;
 #pragma unroll
@@ -539,9 +554,7 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
         for (int q = 0; q < 4; ++q) {
           const int m = 4 * g4 + q;
           const unsigned i = (unsigned)(8 * (m >> 2) + (m & 3)) + hz;
-          const bool ok = i < (unsigned)n;
-          const float x = ok ? qb[i * tstride + (unsigned)li] * p.scale : 0.f;
-          qa[q] = am_rot_elem(x, rcos, rsin, (int)i, li, ok);
+          qa[q] = Ta[i * AM_TS + (unsigned)li];
           sb[q] = St[li * AM_TS + i];
         }
 #pragma unroll
@@ -553,13 +566,17 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_bwd_mfma_kernel(const f
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
-          const float4 gk = am_unrotate4(make_float4(dk[4 * e4], dk[4 * e4 + 1], dk[4 * e4 + 2], dk[4 * e4 + 3]), rcl, rsl, d0);
+          const float4 gk = am_unrotate4(make_float4(dk[4 * e4], dk[4 * e4 + 1], dk[4 * e4 + 2], dk[4 * e4 + 3]), rcos ? rcos + li * DH : nullptr, rsin ? rsin + li * DH : nullptr, d0);
           *reinterpret_cast<float4*>(drow + d0) = gk;
           am = amax4(am, gk);
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    // P with the lane roles swapped, over the Q tile; dV^T[d][j] = sum_i dO[i][d] P[i][j] (dO columns are the one global re-read left)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Pt[am_key(e, hh) * AM_TS + li] = pT[e];
+    __builtin_amdgcn_wave_barrier();
     {
       f32x16 dv;
 #pragma unroll
