@@ -199,6 +199,10 @@ int wdno_layernorm_fwd_amax(const float* x, const float* g, float* y, float* ama
 size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C);
 int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
                        float eps, void* ws, size_t ws_bytes, wdno_stream_t s);
+/* the same with dx += add_to (the gradient that reaches x over the skip connection of Residual(PreNorm(fn)), unet.py:18-24,67-78,
+ * conv3d.py:131-137,176-184): saves the separate accumulation pass autograd would issue. add_to may be NULL. */
+int wdno_layernorm_bwd_add(const float* x, const float* g, const float* dy, const float* add_to, float* dx, float* dg, int64_t P, int C,
+                           float eps, void* ws, size_t ws_bytes, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ attention
  * qkv rows are [row][3*heads*32] = (q | k | v), each [heads][32]; outputs are [row][heads*32].

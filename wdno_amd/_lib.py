@@ -91,6 +91,7 @@ PROTOTYPES = {
     'wdno_layernorm_fwd_amax': (I, [P, P, P, P, L, I, F, P]),
     'wdno_layernorm_bwd_ws_bytes': (Z, [L, I]),
     'wdno_layernorm_bwd': (I, [P, P, P, P, P, L, I, F, P, Z, P]),
+    'wdno_layernorm_bwd_add': (I, [P, P, P, P, P, P, L, I, F, P, Z, P]),
     'wdno_attn_fwd': (I, [P, P, P, P, P, PA, F, P]),
     'wdno_attn_bwd': (I, [P, P, P, P, P, P, P, P, PA, F, P]),
     'wdno_attn_fwd_amax': (I, [P, P, P, P, P, P, PA, F, P]),

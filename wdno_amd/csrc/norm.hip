@@ -367,7 +367,8 @@ extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const flo
 template <int TPR, int VPL, bool BWD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ dy, float* __restrict__ out,
-                                                         float* __restrict__ dg_part, int64_t P, int C, float eps) {
+                                                         float* __restrict__ dg_part, int64_t P, int C, float eps,
+                                                         const float* __restrict__ add_to) {
   constexpr int RPB = 256 / TPR;
   __shared__ float red[BWD ? 256 * VPL * 4 : 1];
   const int C4 = C >> 2;
@@ -442,6 +443,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           float4 o;
           o.x = rstd * (dv[v].x - m1 - xv[v].x * m2); o.y = rstd * (dv[v].y - m1 - xv[v].y * m2);
           o.z = rstd * (dv[v].z - m1 - xv[v].z * m2); o.w = rstd * (dv[v].w - m1 - xv[v].w * m2);
+          if (add_to) {          // the gradient arriving at x over the skip connection of Residual(PreNorm(fn)): one add launch less
+            const float4 t = reinterpret_cast<const float4*>(add_to + r * C)[lane + v * TPR];
+            o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+          }
           reinterpret_cast<float4*>(out + r * C)[lane + v * TPR] = o;
         }
     }
@@ -479,11 +484,12 @@ static inline void ln_shape(int C, int& tpr, int& vpl) {
   else { tpr = 64; vpl = pow2ceil(cdiv(c4, 64)); }
 }
 template <bool BWD>
-static int ln_launch(const float* x, const float* g, const float* dy, float* out, float* dgp, int64_t P, int C, float eps, hipStream_t st) {
+static int ln_launch(const float* x, const float* g, const float* dy, float* out, float* dgp, int64_t P, int C, float eps, hipStream_t st,
+                     const float* add_to = nullptr) {
   int tpr, vpl;
   ln_shape(C, tpr, vpl);
   int nb = ln_blocks(P, 256 / tpr);
-#define LN_CASE(T, V) layernorm_kernel<T, V, BWD><<<nb, 256, 0, st>>>(x, g, dy, out, dgp, P, C, eps)
+#define LN_CASE(T, V) layernorm_kernel<T, V, BWD><<<nb, 256, 0, st>>>(x, g, dy, out, dgp, P, C, eps, add_to)
   if (vpl == 1) {
     switch (tpr) {
       case 2: LN_CASE(2, 1); break;
@@ -511,16 +517,20 @@ extern "C" int wdno_layernorm_fwd(const float* x, const float* g, float* y, int6
   return wdno_layernorm_fwd_amax(x, g, y, nullptr, P, C, eps, s);
 }
 extern "C" size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C) { return (size_t)1024 * C * sizeof(float); }
-extern "C" int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
-                                  float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {
+extern "C" int wdno_layernorm_bwd_add(const float* x, const float* g, const float* dy, const float* add_to, float* dx, float* dg, int64_t P,
+                                      int C, float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {
   WDNO_REQUIRE(P > 0 && C >= 4);
   if ((C & 3) || C > 1024) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_layernorm_bwd_ws_bytes(P, C)) return WDNO_EWORKSPACE;
   int tpr, vpl;
   ln_shape(C, tpr, vpl);
   int nb = ln_blocks(P, 256 / tpr);
-  int rc = ln_launch<true>(x, g, dy, dx, (float*)ws, P, C, eps, as_stream(s));
+  int rc = ln_launch<true>(x, g, dy, dx, (float*)ws, P, C, eps, as_stream(s), add_to);
   if (rc) return rc;
   partial_rows_sum_kernel<float><<<cdiv(C, 32), PRS_THREADS, 0, as_stream(s)>>>((const float*)ws, dg, nb, C);
   return wdno_check_launch();
+}
+extern "C" int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
+                                  float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_layernorm_bwd_add(x, g, dy, nullptr, dx, dg, P, C, eps, ws, ws_bytes, s);
 }

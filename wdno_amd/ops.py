@@ -347,6 +347,7 @@ AMAX_FLOATS = 64 * 16    # WDNO_AMAX_FLOATS
 AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 
+SKIP_FUSE = os.environ.get('WDNO_SKIP_FUSE', '1') != '0'      # skip connections handed through conv / LayerNorm (A/B switch)
 _CAPTURE = None          # [pool, next index] while a HIP graph is being captured through graph_capture()
 
 
@@ -773,7 +774,15 @@ class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (+ residual). weight in the reference layout [K, C, (kd,) (kh, kw)] or [K, C]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, padding):
+    def forward(ctx, x, weight, bias, residual, stride, padding, with_skip=False):
+        ctx.with_skip = with_skip
+        if with_skip:              # second output: x itself (see conv_cl_skip); its gradient is folded into the dgrad epilogue
+            y = _Conv._forward(ctx, x, weight, bias, residual, stride, padding)
+            return y, _alias_of(x)
+        return _Conv._forward(ctx, x, weight, bias, residual, stride, padding)
+
+    @staticmethod
+    def _forward(ctx, x, weight, bias, residual, stride, padding):
         xrec = _known_amax(x)
         x_in = x
         x = _chk(x, 'x')
@@ -827,9 +836,13 @@ class _Conv(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         if ctx.rows:
-            return _linear_rows_backward(ctx, gy)
+            return _linear_rows_backward(ctx, gy) + (None,)
+        return _Conv._backward(ctx, gy, gskip) + (None,)
+
+    @staticmethod
+    def _backward(ctx, gy, gskip):
         if ctx.h3:
             xh, xl, sx, weight = ctx.saved_tensors
             x5 = None
@@ -850,17 +863,19 @@ class _Conv(torch.autograd.Function):
             gyplanes, gbs = split_f16_colsum(gy5.reshape(-1, kp), grec)
             gb = gbs[:k].contiguous()
         if ctx.needs_input_grad[0]:
+            gs5 = None if gskip is None else _chk(gskip, 'skip gradient').reshape(n, d, h, w, cp)      # conv_cl_skip: + gradient over the skip
             if stride == (1, 1, 1):
                 pd = tuple(kk - 1 - p for kk, p in zip(ks, padding))
                 if _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]):
                     # dgrad = the same kernel on dy with flipped / transposed weights; "C" role = Kp, "K" role = Cp
                     if gyplanes is None:
                         gyplanes = split_f16(gy5.reshape(-1, kp), grec)
-                    gx5 = conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, None,
+                    gx5 = conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, gs5,
                                       ks, (1, 1, 1), pd, cp)
                 else:
                     wd = pack_dgrad(weight, cp, kp)
-                    gx5 = conv_fwd_raw(gy5, wd, None, None, ks, (1, 1, 1), pd, cp)
+                    gx5 = conv_fwd_raw(gy5, wd, None, gs5, ks, (1, 1, 1), pd, cp)
+                gs5 = None                                   # folded into the epilogue of the data-gradient convolution
             elif ks == (1, 4, 4) and stride == (1, 2, 2) and padding == (0, 1, 1):
                 wt = pack_transposed(_as5(weight), kp, cp)      # "in" = K (dy channels), "out" = C
                 gx5 = conv_transpose_raw(gy5, wt, None, cp)
@@ -869,6 +884,8 @@ class _Conv(torch.autograd.Function):
                 gx5 = _patch2_dgrad(gy5, weight, cp, kp)
             else:
                 raise RuntimeError(f'wdno_amd: unsupported convolution geometry for dgrad {ks} {stride} {padding}')
+            if gs5 is not None:
+                gx5 = gx5 + gs5
             gx = gx5
             if lead is not None:
                 gx = gx5.reshape(*lead, cp) if xdim != 4 else gx5.squeeze(1)
@@ -906,7 +923,7 @@ def _patch2_dgrad(gy5, weight, cp, kp):
     return gx
 
 
-def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None):
+def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None, with_skip=False):
     """Channels-last convolution / linear layer with the reference's weight layout.
 
     x: [N, D, H, W, Cp] or [N, H, W, Cp] with a conv weight [K, C, (kd,) kh, kw]; any [..., Cp] with a 2-D
@@ -918,7 +935,14 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None):
             return (fill,) * 3
         v = (v,) * nd if isinstance(v, int) else tuple(v)
         return (fill,) * (3 - nd) + v
-    return _Conv.apply(x, weight, bias, residual, trip(stride, 1), trip(padding, 0) if nd else (0, 0, 0))
+    return _Conv.apply(x, weight, bias, residual, trip(stride, 1), trip(padding, 0) if nd else (0, 0, 0), with_skip)
+
+
+def conv_cl_skip(x, weight, bias=None, stride=1, padding=0):
+    """-> (conv(x), x'): x' is x handed through the operator, for blocks whose input also feeds a skip connection
+    (ResnetBlock: h = block1(x) ...; out = h + x  or  res_conv(x) + h). The gradient that comes back over x' is added in the
+    epilogue of this convolution's data-gradient kernel instead of by a separate accumulation launch."""
+    return conv_cl(x, weight, bias, stride, padding, None, True)
 
 
 class _ConvT(torch.autograd.Function):
@@ -1047,9 +1071,24 @@ def groupnorm_act(x, gamma, beta, groups, scale_shift=None, act=True, eps=1e-5):
     return _GroupNormAct.apply(x, gamma, beta, scale_shift, groups, act, eps)
 
 
+def _alias_of(x):
+    """The same storage as a second autograd output (skip connections that pass THROUGH an operator so that its backward receives
+    the skip gradient and folds the sum into its own output pass). Producer-side hints follow the alias."""
+    xs = x.view_as(x)
+    for attr in ('_wdno_amax', '_wdno_planes'):
+        h = getattr(x, attr, None)
+        if h is not None:
+            try:
+                setattr(xs, attr, h)
+            except Exception:
+                pass
+    return xs
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, eps):
+    def forward(ctx, x, g, eps, with_skip):
+        x_in = x
         x = _chk(x, 'x')
         c = x.shape[-1]
         p = x.numel() // c
@@ -1059,10 +1098,12 @@ class _LayerNorm(torch.autograd.Function):
         _lib.check(_lib_().wdno_layernorm_fwd_amax(_p(x), _p(gf), _p(y), _p(rec), p, c, float(eps), _stream()), 'layernorm_fwd')
         ctx.save_for_backward(x, g)
         ctx.eps = eps
+        if with_skip:
+            return _leave_amax(y, rec), _alias_of(x_in)
         return _leave_amax(y, rec)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         x, g = ctx.saved_tensors
         gy = _chk(gy, 'grad')
         c = x.shape[-1]
@@ -1072,14 +1113,21 @@ class _LayerNorm(torch.autograd.Function):
         ws = _ws(nb, x.device)
         dx = torch.empty_like(x)
         dg = torch.empty((c,), device=x.device, dtype=torch.float32)
-        _lib.check(lib.wdno_layernorm_bwd(_p(x), _p(g.reshape(-1)), _p(gy), _p(dx), _p(dg), p, c, float(ctx.eps), _p(ws), nb, _stream()),
-                   'layernorm_bwd')
-        return dx, dg.reshape(g.shape), None
+        add_to = None if gskip is None else _chk(gskip, 'skip gradient')
+        _lib.check(lib.wdno_layernorm_bwd_add(_p(x), _p(g.reshape(-1)), _p(gy), _p(add_to), _p(dx), _p(dg), p, c, float(ctx.eps), _p(ws), nb,
+                                              _stream()), 'layernorm_bwd')
+        return dx, dg.reshape(g.shape), None, None
 
 
 def layernorm_cl(x, g, eps=1e-5):
     """Channel LayerNorm over the last (channel) axis of a CL tensor; g is the reference's [1, C, 1, 1(, 1)] gain."""
-    return _LayerNorm.apply(x, g, eps)
+    return _LayerNorm.apply(x, g, eps, False)
+
+
+def layernorm_cl_skip(x, g, eps=1e-5):
+    """-> (LayerNorm(x), x'): x' is x handed through the operator, for Residual(PreNorm(fn)): fn(norm(x), residual=x'). The gradient
+    that comes back over x' is added inside the LayerNorm backward kernel (dx += skip) instead of by a separate launch."""
+    return _LayerNorm.apply(x, g, eps, True)
 
 
 # ----------------------------------------------------------------------------------------------------- attention

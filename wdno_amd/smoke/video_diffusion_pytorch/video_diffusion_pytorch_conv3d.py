@@ -89,6 +89,8 @@ class Residual(nn.Module):
         self.fn = fn
 
     def forward(self, x, **kwargs):
+        if ops.SKIP_FUSE and isinstance(self.fn, PreNorm):          # x reaches the residual add THROUGH the norm (ops.layernorm_cl_skip)
+            return self.fn(x, residual=True, **kwargs)
         return self.fn(x, residual=x, **kwargs)
 
 
@@ -99,6 +101,9 @@ class PreNorm(nn.Module):
         self.norm = LayerNorm(dim)
 
     def forward(self, x, residual=None, **kwargs):
+        if residual is True:
+            y, xs = ops.layernorm_cl_skip(x, self.norm.gamma, self.norm.eps)
+            return self.fn(y, residual=xs, **kwargs)
         return self.fn(self.norm(x), residual=residual, **kwargs)
 
 
@@ -110,7 +115,10 @@ class Block(nn.Module):
         self.act = nn.SiLU()
         self.groups = groups
 
-    def forward(self, x, scale_shift=None):
+    def forward(self, x, scale_shift=None, with_skip=False):
+        if with_skip:              # block input that also feeds the skip connection: handed through the convolution (ops.conv_cl_skip)
+            x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1)
+            return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps), xs
         x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1)
         return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps)
 
@@ -129,11 +137,14 @@ class ResnetBlock(nn.Module):
             assert exists(time_emb), 'time emb must be passed in'
             # [B, 2*C]: first half = scale, second half = shift (chunk(2, dim=1) in the reference)
             scale_shift = ops.conv_cl(ops.silu(time_emb), self.mlp[1].weight, self.mlp[1].bias)
-        h = self.block1(x, scale_shift=scale_shift)
+        if ops.SKIP_FUSE:
+            h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True)
+        else:
+            h, xs = self.block1(x, scale_shift=scale_shift), x
         h = self.block2(h)
         if isinstance(self.res_conv, nn.Identity):
-            return ops.add(h, x)
-        return ops.conv_cl(x, self.res_conv.weight, self.res_conv.bias, residual=h)
+            return ops.add(h, xs)
+        return ops.conv_cl(xs, self.res_conv.weight, self.res_conv.bias, residual=h)
 
 
 class SpatialLinearAttention(nn.Module):
