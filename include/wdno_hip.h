@@ -239,6 +239,11 @@ int wdno_linattn_fwd_amax(const float* qkv, float* out, float* kstats, float* ct
 int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv, float* amax_rec,
                           void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 
+/* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]
+ * (nn.Embedding weight) and bucket [n, n] int64 (host-built integer table); and dW from d(bias). One launch each. */
+int wdno_relpos_bias_fwd(const float* w, const int64_t* bucket, float* out, int n, int heads, wdno_stream_t s);
+int wdno_relpos_bias_bwd(const float* dbias, const int64_t* bucket, float* dw, int n, int heads, int num_buckets, wdno_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------ nn.Linear on a few rows
  * (time-embedding MLPs; conv3d.py:118-133, 286-296; unet.py:151-165). P <= 1024 rows, C % 4 == 0, strides in floats. The weight
  * is the reference's own [K][C] tensor (row stride w_stride), no packing. y [P][Kp] is zero in columns K..Kp-1. The data

@@ -688,3 +688,20 @@ def test_flat_adam_matches_torch(ops):
         assert abs(float(gn) - float(gn_ref)) < 1e-5 * max(1.0, float(gn_ref))
     for r, m in zip(ref, mine):
         assert rel_l2(m.detach(), r.detach()) < 1e-6
+
+
+def test_relpos_bias_lookup_and_gradient(ops):
+    """Relative-position bias table lookup (conv3d.py:106-112) and its gradient against torch's embedding (bit-exact forward; the
+    backward sums at most 24 floats per table entry)."""
+    torch.manual_seed(5)
+    w = torch.randn(32, 4)
+    idx = torch.randint(0, 32, (24, 24))
+    wr = w.clone().requires_grad_(True)
+    ref = wr[idx].permute(2, 0, 1)
+    go = torch.randn(4, 24, 24)
+    ref.backward(go)
+    wd = w.to(DEV).requires_grad_(True)
+    out = ops.relpos_bias(wd, idx.to(DEV))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    out.backward(go.to(DEV))
+    assert rel_l2(wd.grad, wr.grad) < 1e-6

@@ -121,6 +121,8 @@ PROTOTYPES = {
     'wdno_adam_clip_step': (I, [P, P, P, P, L, P, F, F, F, F, F, F, I, P]),
     'wdno_ema_update': (I, [P, P, L, F, P]),
     'wdno_gather_items': (I, [P, I, I, P]),
+    'wdno_relpos_bias_fwd': (I, [P, P, P, I, I, P]),
+    'wdno_relpos_bias_bwd': (I, [P, P, P, I, I, I, P]),
 }
 
 _lib = None

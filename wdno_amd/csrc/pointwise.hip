@@ -430,3 +430,37 @@ extern "C" int wdno_gather_items(const void* table, int n_items, int blocks_per_
   gather_items_kernel<<<dim3((unsigned)blocks_per_item, (unsigned)n_items), 256, 0, as_stream(s)>>>((const wdno_copy_item*)table);
   return wdno_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------- relative-position bias
+// bias[h][i][j] = W[bucket[i][j]][h] (T5-style table lookup, conv3d.py:106-112) and its gradient dW[b][h] = sum_{bucket[i][j] = b}
+// dbias[h][i][j]. 32 x 4 table, 24 x 24 positions: one block each way. torch's embedding backward sorts the 576 indices with a
+// radix sort and launches four kernels for this.
+__global__ __launch_bounds__(256) void relpos_fwd_kernel(const float* __restrict__ w, const int64_t* __restrict__ bucket, float* __restrict__ out,
+                                                          int nn, int heads) {
+  for (int e = threadIdx.x; e < heads * nn; e += 256) {
+    const int h = e / nn, ij = e - h * nn;
+    out[e] = w[bucket[ij] * heads + h];
+  }
+}
+__global__ __launch_bounds__(256) void relpos_bwd_kernel(const float* __restrict__ dbias, const int64_t* __restrict__ bucket, float* __restrict__ dw,
+                                                          int nn, int heads, int nb) {
+  extern __shared__ float acc[];           // [nb * heads]
+  for (int e = threadIdx.x; e < nb * heads; e += 256) acc[e] = 0.f;
+  __syncthreads();
+  for (int e = threadIdx.x; e < heads * nn; e += 256) {
+    const int h = e / nn, ij = e - h * nn;
+    atomicAdd(&acc[(int)bucket[ij] * heads + h], dbias[e]);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nb * heads; e += 256) dw[e] = acc[e];
+}
+extern "C" int wdno_relpos_bias_fwd(const float* w, const int64_t* bucket, float* out, int n, int heads, wdno_stream_t s) {
+  WDNO_REQUIRE(n > 0 && heads > 0);
+  relpos_fwd_kernel<<<1, 256, 0, as_stream(s)>>>(w, bucket, out, n * n, heads);
+  return wdno_check_launch();
+}
+extern "C" int wdno_relpos_bias_bwd(const float* dbias, const int64_t* bucket, float* dw, int n, int heads, int num_buckets, wdno_stream_t s) {
+  WDNO_REQUIRE(n > 0 && heads > 0 && num_buckets > 0 && num_buckets * heads <= 8192);
+  relpos_bwd_kernel<<<1, 256, (size_t)num_buckets * heads * sizeof(float), as_stream(s)>>>(dbias, bucket, dw, n * n, heads, num_buckets);
+  return wdno_check_launch();
+}

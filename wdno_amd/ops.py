@@ -1205,6 +1205,32 @@ def linear_attention(qkv, units, n_tok, heads, scale):
     return _LinAttn.apply(qkv, units, n_tok, heads, scale)
 
 
+class _RelPosBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, bucket):
+        w = _chk(weight, 'relative_attention_bias.weight')
+        n, heads = bucket.shape[0], w.shape[1]
+        out = torch.empty((heads, n, n), device=w.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_relpos_bias_fwd(_p(w), _p(bucket), _p(out), n, heads, _stream()), 'relpos_bias_fwd')
+        ctx.save_for_backward(bucket)
+        ctx.meta = (n, heads, w.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (bucket,) = ctx.saved_tensors
+        n, heads, nb = ctx.meta
+        g = _chk(g, 'grad')
+        dw = torch.empty((nb, heads), device=g.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_relpos_bias_bwd(_p(g), _p(bucket), _p(dw), n, heads, nb, _stream()), 'relpos_bias_bwd')
+        return dw, None
+
+
+def relpos_bias(weight, bucket):
+    """[heads, n, n] bias from the bucket table (conv3d.py:106-112); one launch forward, one backward."""
+    return _RelPosBias.apply(weight, bucket.contiguous())
+
+
 _rot_cache = {}
 
 

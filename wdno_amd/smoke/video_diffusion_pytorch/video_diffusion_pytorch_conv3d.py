@@ -67,8 +67,7 @@ class RelativePositionBias(nn.Module):
         return self._buckets[key]
 
     def forward(self, n, device):
-        idx = self.bucket_table(n, device)
-        return self.relative_attention_bias.weight[idx].permute(2, 0, 1).contiguous()   # [heads, n, n]
+        return ops.relpos_bias(self.relative_attention_bias.weight, self.bucket_table(n, device))   # [heads, n, n]
 
 
 class LayerNorm(nn.Module):
