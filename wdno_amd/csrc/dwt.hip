@@ -164,6 +164,7 @@ struct FusedGeom {
   int FW;                 // analysis: columns incl. boundary extension (2 Wo + L - 2); synthesis: 2 * QW
   int qt0, qh0, qw0;      // synthesis: first q along each axis (off >> 1)
   int QH, QT;             // synthesis: number of q rows / frames in total
+  int debug;              // tools only: 12 / 13 / 14 skip the W / H / T pass of the synthesis kernel (timing breakdown, wrong results)
 };
 
 __device__ __forceinline__ int xcd_tile(int bid, int nb) {
@@ -346,40 +347,51 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
   float* S1 = lds;                                           // [NP][2][EH][NW]
   // pass W: packed coefficients -> S1
   const int eh_used = nqh + E;
+  // Branch-free body: every load is issued unconditionally from a clamped (always valid) address and masked by a select, so that
+  // the loads of several items are in flight together (with early-outs the loop was a chain of dependent L2 round trips: 22 of the
+  // kernel's 42 us at [32, 8, 18, 34, 34]). A masked term contributes fmaf(0, tap, a) = a, i.e. the skipped fmaf of the per-axis kernel.
+  if (g.debug != 12)
+#pragma unroll 2
   for (int it = threadIdx.x; it < NP * 2 * EH * QW; it += 256) {
     int q = fd_div(it, g.dQW);
     const int ql = it - q * QW;
     const int q2 = fd_div(q, g.dEH), eh = q - q2 * EH;
-    if (eh >= eh_used) continue;
     const int bh = q2 & 1, p = q2 >> 1;
     const int bt = (ND == 3) ? p / ET : 0;
     const int Kt = (ND == 3) ? smap<MODE>(qt_start - E + p % ET, g.To) : 0;
     const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
-    float a0 = 0.f, a1 = 0.f;
-    if (Kt >= 0 && Kh >= 0) {
-      const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
-      const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
-      const float* base = ci + (int64_t)Kt * g.cs0 + (int64_t)Kh * g.cs1;
-      const float* rl = base + band_lo * g.cs_band;
-      const float* rh = base + band_hi * g.cs_band;
+    const bool rowok = Kt >= 0 && Kh >= 0;
+    const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
+    const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
+    const float* base = ci + (rowok ? (int64_t)Kt * g.cs0 + (int64_t)Kh * g.cs1 : 0);
+    const float* rl = base + band_lo * g.cs_band;
+    const float* rh = base + band_hi * g.cs_band;
+    float cl[L / 2], ch[L / 2];
 #pragma unroll
-      for (int i = 0; i < L / 2; ++i) {
-        const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
-        if (Kw >= 0) {
-          const float cl = rl[Kw], ch = rh[Kw];
-          a0 = fmaf(cl, t.lo[2 * i], a0);
-          a0 = fmaf(ch, t.hi[2 * i], a0);
-          a1 = fmaf(cl, t.lo[2 * i + 1], a1);
-          a1 = fmaf(ch, t.hi[2 * i + 1], a1);
-        }
-      }
+    for (int i = 0; i < L / 2; ++i) {
+      const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
+      const bool ok = rowok && Kw >= 0;
+      const int kk = Kw >= 0 ? Kw : 0;
+      const float vl = rl[kk], vh = rh[kk];
+      cl[i] = ok ? vl : 0.f;
+      ch[i] = ok ? vh : 0.f;
     }
-    reinterpret_cast<float2*>(S1 + ((p * 2 + bh) * EH + eh) * NW)[ql] = make_float2(a0, a1);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < L / 2; ++i) {
+      a0 = fmaf(cl[i], t.lo[2 * i], a0);
+      a0 = fmaf(ch[i], t.hi[2 * i], a0);
+      a1 = fmaf(cl[i], t.lo[2 * i + 1], a1);
+      a1 = fmaf(ch[i], t.hi[2 * i + 1], a1);
+    }
+    if (eh < eh_used) reinterpret_cast<float2*>(S1 + ((p * 2 + bh) * EH + eh) * NW)[ql] = make_float2(a0, a1);
   }
   __syncthreads();
   const int wshift = off & 1;                                // position pw <-> n_w = pw - (off & 1)
   if (ND == 3) {
     float* S2 = lds + NP * 2 * EH * NW;                      // [2 ET][2 NQH][NW]
+    if (g.debug != 13)
+#pragma unroll 2
     for (int it = threadIdx.x; it < NP * 2 * NQH * NW; it += 256) {
       int q = fd_div(it, g.dFW);
       const int pw = it - q * NW;
@@ -398,6 +410,7 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
     }
     __syncthreads();
     const int64_t fs = (int64_t)g.H * g.W;
+    if (g.debug != 14)
     for (int it = threadIdx.x; it < 2 * nqh * NW; it += 256) {
       const int ph = fd_div(it, g.dFW), pw = it - ph * NW;
       const int nw = pw - wshift;
@@ -533,7 +546,7 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
   if (ND == 3) {
     // floats: 2 ET NW (2 EH + 2 NQH), EH = NQH + E
     const size_t per_row = (size_t)2 * (NQ + E) * g.FW * sizeof(float);
-    const long nq_max = ((long)(fused_lds_budget(64) / per_row) - 2 * E) / 4;
+    const long nq_max = ((long)(fused_lds_budget(40) / per_row) - 2 * E) / 4;
     if (nq_max < 1) return false;
     const int tiles = cdiv(g.QH, (int)std::min<long>(nq_max, g.QH));
     g.NH = cdiv(g.QH, tiles);
@@ -542,7 +555,7 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
     lds = per_row * (size_t)(4 * g.NH + 2 * E);
   } else {
     const size_t per_row = (size_t)2 * g.FW * sizeof(float);
-    long nq_max = (long)(fused_lds_budget(64) / per_row) - E;
+    long nq_max = (long)(fused_lds_budget(40) / per_row) - E;
     nq_max = std::min<long>(nq_max / NQ * NQ, 2 * NQ);
     if (nq_max < NQ) return false;
     g.NH = (int)nq_max;
@@ -554,6 +567,7 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
   if (nb > 0x7fffffff) return false;
   g.n_blocks = (int)nb;
   g.dFW = make_fastdiv(g.FW); g.dQW = make_fastdiv(g.FW / 2); g.dEH = make_fastdiv(g.NH + E); g.dNQH2 = make_fastdiv(2 * g.NH);
+  g.debug = wdno_debug_mode;
   if ((int64_t)2 * (NQ + E) * 2 * (g.NH + E) * g.FW * (int64_t)std::max(g.FW, 2 * (g.NH + E)) >= (1ll << 32)) return false;   // fd_div range
   dwt_synthesis_fused_kernel<ND, L, MODE, NQ><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
   return true;
