@@ -58,10 +58,25 @@ for name, xs, ws, st, pd in CASES:
     t_hf = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
     if '--ablate' in sys.argv:
         lib = ops._lib_()
-        lib.wdno_set_debug(1); t1 = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
-        lib.wdno_set_debug(3); t2 = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
+        f = lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp)
+        lib.wdno_set_debug(21); t1 = timeit(f)
         lib.wdno_set_debug(0)
-        print(f'   ablation fwd: full {t_hf:.3f} ms | no global loads (all-invalid) {t1:.3f} ms | small-tile variant {t2:.3f} ms')
+        print(f'   ablation fwd: full {t_hf:.3f} ms | compute waves alone (no DMA issue) {t1:.3f} ms')
+    if '--stamps' in sys.argv:
+        lib = ops._lib_()
+        for base, what in ((0, 'fwd'), (100, 'fwd, DMA issue off')):
+            vals = {}
+            for mode in (23, 24, 26):
+                lib.wdno_set_debug(base + mode)
+                rec = ops._amax_slot(x.device)
+                for _ in range(5):
+                    rec.zero_()
+                    ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp, amax_rec=rec)
+                torch.cuda.synchronize()
+                vals[mode] = float(rec.max())
+            lib.wdno_set_debug(0)
+            print(f'   stamps {what} (slowest compute wave): {vals[23]:.0f} shader cycles in the kernel, {vals[24]:.0f} of them in tile epilogues, '
+                  f'{vals[26] * 10:.0f} ns wall -> {vals[23] / (vals[26] * 10):.2f} GHz')
     t_hw = timeit(lambda: ops.conv_wgrad_h3(xpl, tuple(xs[:4]), ypl, osp, ks, st, pd))
     line += f' h3: fwd {t_hf:6.3f} ms {tf(t_hf):6.1f} TF/s | wgrad {t_hw:6.3f} ms {tf(t_hw):6.1f} TF/s'
     if st == (1, 1, 1):

@@ -54,6 +54,16 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
 // conv_h3d.hip: LDS-DMA variant of the split-fp16 forward / data-gradient kernel (WDNO_EUNSUPPORTED -> use conv_h3.hip's)
 int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st, int stages);
+#ifdef __HIPCC__
+// s_waitcnt lgkmcnt(0) + s_barrier. The wait is the BUILTIN so that the compiler's own s_waitcnt bookkeeping sees it: behind an
+// asm-only wait it still counts the scalar loads of the previous tile's epilogue as possibly outstanding at the head of the
+// step loop, and (scalar loads return out of order) protects the first MFMA of every step with lgkmcnt(0) -- a wait for the
+// LDS reads issued just before it.
+__device__ __forceinline__ void lgkm0_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  asm volatile("s_barrier" : : : "memory");
+}
+#endif
 static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.g = *g;
   p.amax_rec = nullptr;

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
     const int l_dx0 = l_dx, l_cc0 = l_cc;
     const int step_dx = 32 / g.C, step_cc = 32 % g.C;
     if (my_tiles > 0) setup_tile(0);
+    const bool no_dma = p.debug == 21 || p.debug >= 100;             // ablation (tools/bench_conv.py): compute waves alone, on stale LDS contents
     auto issue_step = [&](int stage) {
       const bool live = c_tile < my_tiles;
       const unsigned need_t = live ? ((1u << s_dz) | (1u << (8 + s_dy))) : 0x80000000u;      // bit 31 is never set in a mask
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const int off = ((a_mask[i] & need) == need) ? a_off[i] + x_uni : DMA_OOB;
+        if (no_dma) continue;
         dma_piece(rxh, off, pa_dst + i * 1024);
         if (!LP) dma_piece(rxl, off, pa_dst + A_LO + i * 1024);
       }
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
 #pragma unroll
       for (int i = 0; i < BP; ++i) {
         const int off = (b_ok[i] && r_ok) ? b_off[i] + w_uni : DMA_OOB;
+        if (no_dma) continue;
         dma_piece(rwh, off, pb_dst + i * 1024);
         if (!LP) dma_piece(rwl, off, pb_dst + BN * 64 + i * 1024);
       }
@@ -228,6 +231,12 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
   using B1 = std::integral_constant<int, 1>;
   const float inv = LP ? 1.0f : 1.0f / (sx[0] * sw[0]);
   int stage = 0;
+  // debug 23 / 24 / 26 (tools/bench_conv.py --stamps): the amax record carries this wave's shader cycles in the kernel / in
+  // the tile epilogues / its 100 MHz wall ticks instead of max|y|
+  const int sdbg = p.debug >= 100 ? p.debug - 100 : p.debug;      // 1xx = the same stamp with the DMA issue switched off (21)
+  const bool stamps = sdbg == 23 || sdbg == 24 || sdbg == 26;
+  const uint64_t c_begin = stamps ? __builtin_amdgcn_s_memtime() : 0, r_begin = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t c_epi = 0;
   for (int t = 0; t < my_tiles; ++t) {
     const int tile = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, p.ntiles);
     const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
@@ -239,22 +248,31 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
       for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+    lgkm0_barrier();
     read_frags(B0{}, stage, 0);
-    for (int step = 0; step < p.nsteps; ++step) {
+    // The last step is peeled: with the barrier + next-stage reads under a condition, the two paths into the second MFMA
+    // group carry different numbers of outstanding LDS reads and the compiler's s_waitcnt has to assume the smaller one --
+    // lgkmcnt(3..0), i.e. every step waited for the fragments it had just requested (1398 -> ~1000 shader cycles per step).
+    for (int step = 0; step + 1 < p.nsteps; ++step) {
       read_frags(B1{}, stage, 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma_set(B0{});
       __builtin_amdgcn_sched_barrier(0);
       stage = stage + 1 == NS ? 0 : stage + 1;
-      if (step + 1 < p.nsteps) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
-        read_frags(B0{}, stage, 0);
-      }
+      lgkm0_barrier();
+      read_frags(B0{}, stage, 0);
       __builtin_amdgcn_sched_barrier(0);
       mfma_set(B1{});
       __builtin_amdgcn_sched_barrier(0);
     }
+    read_frags(B1{}, stage, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_set(B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    mfma_set(B1{});
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t e_begin = stamps ? __builtin_amdgcn_s_memtime() : 0;
     // epilogue of this tile (the producers are already fetching the next one). The MFMAs are issued with the weight
     // fragment as the row operand, so the accumulator tile is [channel][pixel]: lane li owns ONE pixel and holds runs of
     // four consecutive channels -> 16-byte stores and one output-row computation per lane and tile row block.
@@ -280,7 +298,9 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
         }
       }
     }
+    if (stamps) c_epi += __builtin_amdgcn_s_memtime() - e_begin;
   }
+  if (stamps) am = sdbg == 23 ? (float)(__builtin_amdgcn_s_memtime() - c_begin) : sdbg == 24 ? (float)c_epi : (float)(__builtin_amdgcn_s_memrealtime() - r_begin);
   if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * (WM * WN) + wave);
 }
 

@@ -321,22 +321,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
       for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+    lgkm0_barrier();
     read_frags(B0{}, stage, 0);
-    for (int step = 0; step < wp.nsteps; ++step) {
+    for (int step = 0; step + 1 < wp.nsteps; ++step) {      // last step peeled, see conv_h3d.hip
       read_frags(B1{}, stage, 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma_set(B0{});
       __builtin_amdgcn_sched_barrier(0);
       stage = stage + 1 == NS ? 0 : stage + 1;
-      if (step + 1 < wp.nsteps) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
-        read_frags(B0{}, stage, 0);
-      }
+      lgkm0_barrier();
+      read_frags(B0{}, stage, 0);
       __builtin_amdgcn_sched_barrier(0);
       mfma_set(B1{});
       __builtin_amdgcn_sched_barrier(0);
     }
+    read_frags(B1{}, stage, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_set(B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    mfma_set(B1{});
+    __builtin_amdgcn_sched_barrier(0);
     // acc[a][b]: rows = r (n_base + b*32 + 8*(e>>2) + 4*hh + (e&3)), column = k (m_base + a*32 + li)
     float* out = ws + ((int64_t)split * ntap + tap) * (int64_t)g.K * p.R;
 #pragma unroll
