@@ -222,6 +222,32 @@ def test_conv_f16x3_dma_kernels(ops, name, xs, ws, stride, padding, mode):
         lib.wdno_set_debug(0)
 
 
+# stride-1 convolutions on equal grids with whole 32-channel blocks: the tap-resident kernels (csrc/conv_h3t.hip)
+CONV_CASES_TAP = [
+    ('tap_3d_64', (2, 64, 5, 9, 7), (64, 64, 3, 3, 3), 1, 1),              # rows of 7 pixels: every tile crosses rows, planes and the batch
+    ('tap_3d_c96_k40', (1, 96, 4, 10, 10), (40, 96, 3, 3, 3), 1, 1),       # three channel blocks, ragged output channels
+    ('tap_2d_c32', (3, 32, 17, 13), (72, 32, 3, 3), 1, 1),                 # one channel block, two N tiles (ragged)
+    ('tap_3d_133', (1, 64, 6, 12, 12), (128, 64, 1, 3, 3), 1, (0, 1, 1)),
+    ('tap_3d_313', (1, 64, 6, 12, 12), (64, 64, 3, 1, 3), 1, (1, 0, 1)),
+    ('tap_3d_w2', (1, 32, 3, 4, 2), (32, 32, 3, 3, 3), 1, 1),              # both W-neighbours missing somewhere in every row
+    ('tap_3d_multi', (8, 64, 6, 40, 40), (64, 64, 3, 3, 3), 1, 1),         # 300 tiles: persistent blocks prefetch across tile boundaries
+    ('tap_3d_multi_wide', (4, 128, 6, 20, 20), (192, 128, 3, 3, 3), 1, 1),
+]
+
+
+@pytest.mark.parametrize('mode', [7, 8], ids=['tap', 'chunked'])
+@pytest.mark.parametrize('name,xs,ws,stride,padding', CONV_CASES_TAP, ids=[c[0] for c in CONV_CASES_TAP])
+def test_conv_f16x3_tap_resident_kernels(ops, name, xs, ws, stride, padding, mode):
+    """debug 7 forces the LDS-DMA kernels (these geometries then take the tap-resident one); debug 8 keeps them on the chunked
+    kernel of conv_h3d.hip: both must meet the fp32 tolerance against the float64 reference."""
+    lib = ops._lib_()
+    lib.wdno_set_debug(mode)
+    try:
+        conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000)
+    finally:
+        lib.wdno_set_debug(0)
+
+
 def test_conv_f16x3_wide_dynamic_range(ops):
     """Gradient-like magnitudes (1e-7) and large activations (1e3) must survive the per-tensor scaling."""
     for scale in (1e-7, 1.0, 1e3):

@@ -56,6 +56,17 @@ for name, xs, ws, st, pd in CASES:
     xpl = ops.split_f16(x.reshape(-1, cp))
     ypl = ops.split_f16(y.reshape(-1, kp))
     t_hf = timeit(lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp))
+    if '--cold' in sys.argv:          # rotate over input copies larger than the 256 MB memory-side cache: every launch reads x from HBM
+        nrot = max(2, int(600e6 // (xpl[0].numel() * 4)) + 1)
+        rot = [(xpl[0].clone(), xpl[1].clone(), xpl[2]) for _ in range(nrot)]
+        outs = [torch.empty_like(y) for _ in range(nrot)]
+        it = [0]
+        def cold():
+            i = it[0] = (it[0] + 1) % nrot
+            ops.conv_fwd_h3(rot[i], tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp, out=outs[i])
+        t_c = timeit(cold, iters=2 * nrot)
+        print(f'   cold inputs ({nrot} rotating copies): fwd {t_c:.3f} ms vs {t_hf:.3f} ms warm')
+        del rot, outs
     if '--ablate' in sys.argv:
         lib = ops._lib_()
         f = lambda: ops.conv_fwd_h3(xpl, tuple(xs[:4]), w, ops.pack_fwd, 'f', None, None, ks, st, pd, kp)

@@ -54,6 +54,10 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
 // conv_h3d.hip: LDS-DMA variant of the split-fp16 forward / data-gradient kernel (WDNO_EUNSUPPORTED -> use conv_h3.hip's)
 int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st, int stages);
+// conv_h3t.hip: tap-resident variant for stride-1 convolutions on equal grids (called by conv_h3d.hip with the tile shape it chose)
+bool wdno_conv_h3t_takes(const wdno_conv_geom& g);
+int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
+                         const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st);
 #ifdef __HIPCC__
 // s_waitcnt lgkmcnt(0) + s_barrier. The wait is the BUILTIN so that the compiler's own s_waitcnt bookkeeping sees it: behind an
 // asm-only wait it still counts the scalar loads of the previous tile's epilogue as possibly outstanding at the head of the

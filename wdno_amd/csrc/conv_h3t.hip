@@ -1,0 +1,349 @@
+// conv_h3t.hip -- "tap-resident" variant of the LDS-DMA convolution (conv_h3d.hip) for stride-1 convolutions whose output
+// grid equals the input grid (every 3 x 3 x 3 ResnetBlock convolution of the U-Nets and its data gradient).
+//
+// conv_h3d.hip walks the reduction as (dz, dy, 32-wide chunk of the kw*C run): the run of a pixel overlaps the run of its
+// W-neighbour in all but C of its kw*C values, so every x value travels L2 -> LDS kw times per (dz, dy) -- and on gfx950 that
+// traffic is what the kernel pays for: with the DMA issue switched off the same MFMA stream needs 23 % fewer shader cycles AND
+// the chip clocks 1.54 -> 2.00 GHz (tools/bench_conv.py --stamps, level-0 64 -> 64 layer).
+// Here one LDS stage holds, for one (dz, dy) and one block of 32 input channels,
+//     A: the BM + kw - 1 consecutive source pixels the tile's BM output pixels touch  (rows of 64 B, fp16 hi / lo planes)
+//     B: the kw x BN weight rows of that (dz, dy, channel block)
+// and is used for kw reduction sub-steps: sub-step dx reads the A rows shifted by dx. x travels once per (dz, dy):
+// 1.04 MB instead of 2.16 MB of DMA per 256 x 64 tile of a 64 -> 64 layer, with 58 instead of 120 pieces.
+//   * Flat pixel indices: with equal grids the source pixel of output pixel p at tap (dz, dy, dx) is
+//     p + ((dz - pd) H + (dy - ph)) W + dx - pw, so LDS row r of the stage is flat pixel  tile_p0 + r - pw + (tap-row shift).
+//   * Validity: the (dz, dy) test is made by the producers on the output pixel a row is the centre tap of (rows shared
+//     by two output pixels of different image rows are w-invalid for one of them); an invalid row is fetched out of range =
+//     zeros. The dx test is made by the compute waves once per tile: a lane whose pixel has no W-neighbour on that side
+//     reads the stage's zero row instead (the row after the halo, which every DMA pass rewrites with zeros).
+//   * Two stages (58 .. 74 KB each), ONE barrier per stage, placed before the MFMAs of the stage's last sub-step: by then
+//     all fragments of the stage are in registers, so the same barrier hands the buffer back to the producers and takes
+//     the next stage from them; the first fragments of the next stage are in flight during those MFMAs.
+//     (Tried and dropped: warming L2 for the next tile's leading source plane with plain loads from the producer waves --
+//     no change on cold inputs, 0.212 vs 0.193 ms with x resident in the memory-side cache, and none in the training step.)
+// Arithmetic, operand formats, weight pack and epilogue are those of conv_h3d.hip; the fp32 accumulation order differs
+// (dz, dy, channel block, dx instead of dz, dy, dx, channel block), so the two agree to rounding, not bit for bit.
+#include "conv_common.h"
+#include <type_traits>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+#define T_OOB 0x7ffffff0
+
+template <bool LP>
+__device__ __forceinline__ f32x16 t_mfma(half8 a, half8 b, f32x16 c) {
+  if constexpr (LP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int4v t_rsrc(const void* ptr, unsigned bytes) {
+  uint64_t a = reinterpret_cast<uint64_t>(ptr);
+  int4v r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void t_piece(int4v rsrc, int off, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(off), "s"(lds_dst), "s"(rsrc) : "memory");
+}
+
+template <int BM, int BN, int KW>
+struct TapShape {
+  static constexpr int AROWS = BM + KW - 1;                       // source pixels of a stage; row AROWS is the zero row
+  static constexpr int APIECES = (AROWS + 1 + 15) / 16;           // 1-KiB pieces (16 rows) per A plane
+  static constexpr int A_PLANE = APIECES * 1024;
+  static constexpr int BPIECES = KW * BN / 16;
+  static constexpr int B_PLANE = BPIECES * 1024;
+};
+
+template <int BM, int BN, int WM, int WN, int KW, bool LP>
+__global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                            const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
+                                                            const float* __restrict__ sx, const float* __restrict__ sw,
+                                                            const float* __restrict__ bias, const float* __restrict__ res,
+                                                            float* __restrict__ y, ConvP p, unsigned x_bytes, unsigned w_bytes) {
+  using S = TapShape<BM, BN, KW>;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int NPL = LP ? 1 : 2;
+  constexpr int A_PLANE = S::A_PLANE, B_PLANE = S::B_PLANE;
+  constexpr int A_LO = A_PLANE, B_HI = NPL * A_PLANE, B_LO = B_HI + B_PLANE;
+  constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+  constexpr int PA = (S::APIECES + 3) / 4, PB = S::BPIECES / 4;      // pieces per producer wave and plane
+  static_assert(S::BPIECES % 4 == 0, "weight pieces are dealt evenly to the four producer waves");
+  constexpr int NSUB = 2 * KW;                                     // 16-deep sub-steps of a stage: (dx, ks)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const wdno_conv_geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int ncb = g.C >> 5;                                        // 32-channel blocks
+  const int nstages = g.kd * g.kh * ncb;                           // per tile
+
+  if (wave >= WM * WN) {
+    // ================================================================== producer waves
+    const int pq = wave - WM * WN;
+    int4v rxh = t_rsrc(xh, x_bytes), rxl = t_rsrc(xl, x_bytes), rwh = t_rsrc(wh, w_bytes), rwl = t_rsrc(wl, w_bytes);
+    asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rwh), "+s"(rwl));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    const int prow = lane >> 2;
+    const int c8 = (((lane & 3) ^ ((lane >> 4) & 3))) * 8;      // logical 8-half chunk this lane fetches (source-side swizzle)
+    int a_off[PA], b_off[PB];
+    unsigned a_mask[PA];
+    bool b_ok[PB];
+    auto tap_bits = [](int c0, int k, int n) -> unsigned {
+      int lo = c0 < 0 ? -c0 : 0, hi = n - c0 < k ? n - c0 : k;
+      return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    };
+    // piece i of this wave is piece pq + 4 i of the plane; its lane covers LDS row 16 (pq + 4 i) + prow
+    auto setup_tile = [&](int t) {
+      const int tile = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, p.ntiles);
+      const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+      const int64_t p0 = (int64_t)tile_m * BM;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int r = 16 * (pq + 4 * i) + prow;
+        const int64_t pr = p0 + r - g.pw;                          // output pixel this row is the centre tap of
+        const bool live = r < S::AROWS && pr >= 0 && pr < p.P;
+        int q = live ? (int)pr : 0;
+        q /= g.OW;
+        const int oh = q % g.OH; q /= g.OH;
+        const int od = q % g.OD;
+        a_mask[i] = live ? (tap_bits(od - g.pd, g.kd, g.D) | (tap_bits(oh - g.ph, g.kh, g.H) << 8)) : 0u;
+        a_off[i] = (((int)pr - (g.pd * g.H + g.ph) * g.W) * g.C + c8) * 2;      // tap row (0, 0), channel block 0; used only when valid
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int row = 16 * (pq + 4 * i) + prow;                  // (dx, k) = (row / BN, row % BN)
+        const int dx = row / BN, k = tile_n * BN + (row - dx * BN);
+        b_ok[i] = k < g.K;
+        b_off[i] = (k * p.R + dx * g.C + c8) * 2;
+      }
+    };
+    int c_tile = 0, s_dz = 0, s_dy = 0, s_cb = 0;                  // issue cursor
+    int x_uni = 0, w_uni = 0;
+    if (my_tiles > 0) setup_tile(0);
+    const bool no_dma = p.debug == 21 || p.debug >= 100;                             // ablation (tools/bench_conv.py): compute waves alone
+    auto issue_stage = [&](int buf) {
+      const unsigned need = (1u << s_dz) | (1u << (8 + s_dy));
+      const unsigned dst = lds0 + buf * STAGE + pq * 1024;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        if (pq + 4 * i >= S::APIECES) continue;                    // compile-time for all but the last i
+        const int off = ((a_mask[i] & need) == need) ? a_off[i] + x_uni : T_OOB;
+        if (no_dma) continue;
+        t_piece(rxh, off, dst + i * 4096);
+        if (!LP) t_piece(rxl, off, dst + A_LO + i * 4096);
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int off = b_ok[i] ? b_off[i] + w_uni : T_OOB;
+        if (no_dma) continue;
+        t_piece(rwh, off, dst + B_HI + i * 4096);
+        if (!LP) t_piece(rwl, off, dst + B_LO + i * 4096);
+      }
+      x_uni += 64; w_uni += 64;
+      if (++s_cb == ncb) {
+        s_cb = 0;
+        if (++s_dy == g.kh) { s_dy = 0; ++s_dz; }
+        if (s_dz == g.kd) {                                        // tile finished: move the cursor to the next one
+          s_dz = 0;
+          if (++c_tile < my_tiles) setup_tile(c_tile);
+        }
+        x_uni = (s_dz * g.H + s_dy) * g.W * g.C * 2;
+        w_uni = (s_dz * g.kh + s_dy) * g.K * p.R * 2;
+      }
+    };
+    const int total = my_tiles * nstages;
+    if (total > 0) issue_stage(0);
+    int buf = 0;
+    for (int gs = 0; gs < total; ++gs) {
+      // stage gs has landed -> meet the compute waves (which have all fragments of stage gs - 1 in registers by now), then refill
+      // the buffer of stage gs - 1 with stage gs + 1
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : : : "memory");
+      buf ^= 1;
+      if (gs + 1 < total) issue_stage(buf);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    return;
+  }
+
+  // ================================================================== compute waves
+  float am = 0.f;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int li = lane & 31, hh = lane >> 5;
+  const int m_base = wm * (TM * 32), n_base = wn * (TN * 32);
+  const int b_row = n_base + li;
+  const int b_rd = B_HI + b_row * 64 + ((hh ^ ((b_row >> 2) & 3)) * 16);       // dx = 0, b = 0, ks = 0 (ks = 1 is ^ 32)
+  int a_rd[TM][KW];                                                             // per tile: A row address of (a, dx), or the zero row
+  half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];                         // [set][tile]
+  auto read_frags = [&](int set, int boff, int dx, int ks) {
+    const char* st = smem + boff;
+    const int x = ks * 32;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      fah[set][a] = *reinterpret_cast<const half8*>(st + (a_rd[a][dx] ^ x));
+      if (!LP) fal[set][a] = *reinterpret_cast<const half8*>(st + A_LO + (a_rd[a][dx] ^ x));
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      fbh[set][b] = *reinterpret_cast<const half8*>(st + dx * (BN * 64) + b * 2048 + (b_rd ^ x));
+      if (!LP) fbl[set][b] = *reinterpret_cast<const half8*>(st + B_PLANE + dx * (BN * 64) + b * 2048 + (b_rd ^ x));
+    }
+  };
+  f32x16 acc[TM][TN];
+  auto mfma_set = [&](int set) {
+    if constexpr (!LP) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = t_mfma<false>(fbh[set][b], fal[set][a], acc[a][b]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = t_mfma<false>(fbl[set][b], fah[set][a], acc[a][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) acc[a][b] = t_mfma<LP>(fbh[set][b], fah[set][a], acc[a][b]);
+  };
+  const float inv = LP ? 1.0f : 1.0f / (sx[0] * sw[0]);
+  const int sdbg = p.debug >= 100 ? p.debug - 100 : p.debug;
+  const bool stamps = sdbg == 23 || sdbg == 24 || sdbg == 26;     // see conv_h3d.hip
+  const uint64_t c_begin = stamps ? __builtin_amdgcn_s_memtime() : 0, r_begin = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+  uint64_t c_epi = 0;
+  int boff = 0;                                                   // byte offset of the stage being read
+  for (int t = 0; t < my_tiles; ++t) {
+    const int tile = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, p.ntiles);
+    const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int ow = (int)((m0 + m_base + a * 32 + li) % g.OW);
+#pragma unroll
+      for (int dx = 0; dx < KW; ++dx) {
+        const int row = m_base + a * 32 + li + dx;
+        const bool ok = (unsigned)(ow - g.pw + dx) < (unsigned)g.W;
+        a_rd[a][dx] = ok ? row * 64 + ((hh ^ ((row >> 2) & 3)) * 16) : S::AROWS * 64 + hh * 16;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    lgkm0_barrier();
+    read_frags(0, boff, 0, 0);
+    for (int s = 0; s + 1 < nstages; ++s) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        if (sub + 1 < NSUB) {
+          read_frags((sub + 1) & 1, boff, (sub + 1) >> 1, (sub + 1) & 1);
+        } else {
+          boff = STAGE - boff;
+          lgkm0_barrier();
+          read_frags(0, boff, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(sub & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {                        // last stage of the tile: nothing to fetch behind it
+      if (sub + 1 < NSUB) read_frags((sub + 1) & 1, boff, (sub + 1) >> 1, (sub + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(sub & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    boff = STAGE - boff;
+    const uint64_t e_begin = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    // epilogue: as conv_h3d.hip (accumulator tile is [channel][pixel]: a lane owns one pixel and runs of four channels)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int64_t pm = m0 + m_base + a * 32 + li;
+      if (pm >= p.P) continue;
+      const int64_t yr = p.identity_out ? pm : out_row(g, pm);
+      float* yrow = y + yr * g.K;
+      const float* rrow = res ? res + yr * g.K : nullptr;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int kc = n0 + n_base + b * 32 + 8 * e4 + 4 * hh;
+          if (kc < g.K) {
+            float4 v = make_float4(acc[a][b][4 * e4] * inv, acc[a][b][4 * e4 + 1] * inv, acc[a][b][4 * e4 + 2] * inv, acc[a][b][4 * e4 + 3] * inv);
+            if (bias) { const float4 tb = *reinterpret_cast<const float4*>(bias + kc); v.x += tb.x; v.y += tb.y; v.z += tb.z; v.w += tb.w; }
+            if (rrow) { const float4 tr = *reinterpret_cast<const float4*>(rrow + kc); v.x += tr.x; v.y += tr.y; v.z += tr.z; v.w += tr.w; }
+            *reinterpret_cast<float4*>(yrow + kc) = v;
+            am = amax4(am, v);
+          }
+        }
+      }
+    }
+    if (stamps) c_epi += __builtin_amdgcn_s_memtime() - e_begin;
+  }
+  if (stamps) am = sdbg == 23 ? (float)(__builtin_amdgcn_s_memtime() - c_begin) : sdbg == 24 ? (float)c_epi : (float)(__builtin_amdgcn_s_memrealtime() - r_begin);
+  if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * (WM * WN) + wave);
+}
+
+static int t_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <int BM, int BN, int WM, int WN, int KW, bool LP>
+static int launch_h3t(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
+                      const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
+  using S = TapShape<BM, BN, KW>;
+  const wdno_conv_geom& g = p.g;
+  int64_t tiles_m = cdiv64(p.P, BM);
+  p.tiles_n = cdiv(g.K, BN);
+  int64_t nt = tiles_m * p.tiles_n;
+  if (nt > 0x7fffffff) return WDNO_EUNSUPPORTED;
+  p.ntiles = (int)nt;
+  constexpr size_t lds = (size_t)2 * (LP ? 1 : 2) * (S::A_PLANE + S::B_PLANE);
+  static_assert(lds <= 160 * 1024, "two stages must fit the LDS");
+  const int64_t x_elems = (int64_t)g.N * g.D * g.H * g.W * g.C;
+  const int64_t w_elems = (int64_t)g.kd * g.kh * g.K * p.R;
+  if (x_elems * 2 >= T_OOB || w_elems * 2 >= T_OOB || p.P >= 0x7fffffff - BM) return WDNO_EUNSUPPORTED;
+  int grid = t_num_cus() & ~7;
+  if (grid < 8) grid = 8;
+  if (p.ntiles < grid) grid = p.ntiles;
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
+                                                                    sx, sw, bias, residual, y, p, (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
+  return WDNO_OK;
+}
+
+// Geometries the tap-resident kernel takes: stride 1, output grid == input grid (so flat pixel indices shift by constants),
+// kw == 3, whole 32-channel blocks. `shape` = tile shape chosen by the caller (conv_h3d.hip: 0 = 128 x 128, 1 = 192 x 128,
+// 2 = 256 x 64, 3 = 192 x 64).
+bool wdno_conv_h3t_takes(const wdno_conv_geom& g) {
+  return g.sd == 1 && g.sh == 1 && g.sw == 1 && g.OD == g.D && g.OH == g.H && g.OW == g.W && g.kw == 3 && (g.C % 32) == 0 &&
+         g.kd <= 8 && g.kh <= 8 && wdno_debug_mode != 8;
+}
+template <bool LP>
+static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
+                   const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
+  if (shape == 0) return launch_h3t<128, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 1) return launch_h3t<192, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 3) return launch_h3t<192, 64, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  return launch_h3t<256, 64, 4, 1, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+}
+int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
+                         const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
+  if (xl == nullptr) return fwd_h3t<true>(shape, xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
+  return fwd_h3t<false>(shape, xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+}

@@ -602,7 +602,8 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
         y = out
         g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp, y_sp=tuple(out.shape[1:4]), ostride=ostride, ooff=ooff)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
-    with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks), flops):
+    tap = tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 3 and cp8 % 32 == 0      # csrc/conv_h3t.hip: wdno_conv_h3t_takes
+    with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks, tap), flops):
         if xl is None:       # single bf16 plane per operand
             _lib.check(_lib_().wdno_conv_fwd_bf16(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_bf16')
             return y
@@ -614,7 +615,7 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
 _pixel_tables = {}
 
 
-def _fwd_h3_kernel_name(pixels, k, ks):
+def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
     """Kernel family wdno_conv_fwd_f16x3 picks (mirrors the dispatch in csrc/conv_h3.hip; used as the profiling key)."""
     cdiv = lambda a, b: -(-a // b)
     tiles = cdiv(pixels, 128) * cdiv(k, 128) if k > 64 else cdiv(pixels, 256)
@@ -626,7 +627,7 @@ def _fwd_h3_kernel_name(pixels, k, ks):
         for sh in shapes[1:]:
             if cost(*sh) < cost(*best):
                 best = sh
-        return f'conv_fwd_h3d_kernel<{best[0]},{best[1]}>'
+        return f'conv_fwd_h3{"t" if tap else "d"}_kernel<{best[0]},{best[1]}>'
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
 
 
