@@ -227,6 +227,8 @@ CONV_CASES_TAP = [
     ('tap_3d_64', (2, 64, 5, 9, 7), (64, 64, 3, 3, 3), 1, 1),              # rows of 7 pixels: every tile crosses rows, planes and the batch
     ('tap_3d_c96_k40', (1, 96, 4, 10, 10), (40, 96, 3, 3, 3), 1, 1),       # three channel blocks, ragged output channels
     ('tap_2d_c32', (3, 32, 17, 13), (72, 32, 3, 3), 1, 1),                 # one channel block, two N tiles (ragged)
+    ('tap_3d_c128_k40', (1, 128, 4, 10, 10), (40, 128, 3, 3, 3), 1, 1),    # two 64-channel tiles in the weight gradient, ragged k
+    ('tap_2d_c64_w5', (5, 64, 9, 5), (64, 64, 3, 3), 1, 1),                # 5-pixel rows
     ('tap_3d_133', (1, 64, 6, 12, 12), (128, 64, 1, 3, 3), 1, (0, 1, 1)),
     ('tap_3d_313', (1, 64, 6, 12, 12), (64, 64, 3, 1, 3), 1, (1, 0, 1)),
     ('tap_3d_w2', (1, 32, 3, 4, 2), (32, 32, 3, 3, 3), 1, 1),              # both W-neighbours missing somewhere in every row

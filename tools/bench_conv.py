@@ -89,6 +89,13 @@ for name, xs, ws, st, pd in CASES:
             print(f'   stamps {what} (slowest compute wave): {vals[23]:.0f} shader cycles in the kernel, {vals[24]:.0f} of them in tile epilogues, '
                   f'{vals[26] * 10:.0f} ns wall -> {vals[23] / (vals[26] * 10):.2f} GHz')
     t_hw = timeit(lambda: ops.conv_wgrad_h3(xpl, tuple(xs[:4]), ypl, osp, ks, st, pd))
+    if '--ablate' in sys.argv:
+        lib = ops._lib_()
+        fw = lambda: ops.conv_wgrad_h3(xpl, tuple(xs[:4]), ypl, osp, ks, st, pd)
+        lib.wdno_set_debug(21); t1 = timeit(fw)
+        lib.wdno_set_debug(22); t2 = timeit(fw)
+        lib.wdno_set_debug(0)
+        print(f'   ablation wgrad: full {t_hw:.3f} ms | all pieces out of range (issued, nothing travels) {t1:.3f} ms | no piece instructions {t2:.3f} ms')
     line += f' h3: fwd {t_hf:6.3f} ms {tf(t_hf):6.1f} TF/s | wgrad {t_hw:6.3f} ms {tf(t_hw):6.1f} TF/s'
     if st == (1, 1, 1):
         pdd = tuple(kk - 1 - p for kk, p in zip(ks, pd))

@@ -238,6 +238,18 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     lgkm0_barrier();
     read_frags(0, boff, 0, 0);
+    // One scheduling region per sub-step: the fragment reads of the NEXT sub-step are dealt one per MFMA of this one (not all reads
+    // first, the order the kernel was first written in) -- a wave issues in order, so a block of 8 ds_read_b128 ahead
+    // of the MFMAs adds its issue time (the LDS is also serving the other three compute waves) to every sub-step.
+    constexpr int NRD = NPL * (TM + TN), NMF = (LP ? 1 : 3) * TM * TN;
+    constexpr int RPM = (NRD + NMF - 1) / NMF;                     // reads behind each MFMA until they are used up
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i * RPM < NRD) __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+      }
+    };
     for (int s = 0; s + 1 < nstages; ++s) {
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
@@ -248,16 +260,16 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
           lgkm0_barrier();
           read_frags(0, boff, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         mfma_set(sub & 1);
+        interleave();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {                        // last stage of the tile: nothing to fetch behind it
       if (sub + 1 < NSUB) read_frags((sub + 1) & 1, boff, (sub + 1) >> 1, (sub + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
       mfma_set(sub & 1);
+      if (sub + 1 < NSUB) interleave();
       __builtin_amdgcn_sched_barrier(0);
     }
     boff = STAGE - boff;

@@ -188,9 +188,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
       }
       if (live && ++rc.s == wp.nsteps) { rc.s = 0; if (++rc.t < my_items) load_item_r(); }
     };
+    // ablations (tools/bench_conv.py; records are still fetched): 21 = every piece out of range (the instructions issue, nothing
+    // travels), 22 = no piece instructions at all
+    const bool no_dma = p.debug == 21 || p.debug == 22, no_piece = p.debug == 22;
     auto issue = [&](auto SLOT, int stage) {
       constexpr int S = decltype(SLOT)::value;
-      const bool live = pc.t < my_items;
+      const bool live = pc.t < my_items && !no_dma;
       const unsigned sb = lds0 + stage * STAGE;
       const int k2 = g.K * 2;
 #pragma unroll
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
         asm volatile("" : "+v"(e));                                   // consumers of the record stay below the counted wait
         const int gp = pq + 4 * j;                                    // pq is wave-uniform: a scalar branch
         const bool ok0 = live && rok[S][j] && i_ok[j];
+        if (no_piece) continue;
         if (gp < APC) {
           const int off = ok0 ? e.x * k2 + i_off[j] : WD_OOB;
           wd_piece(rdh, off, sb + gp * 1024);
@@ -309,6 +313,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
+  // one scheduling region per half-step: the transpose reads of the next fragments are dealt out behind the MFMAs of the
+  // current ones (conv_h3t.hip has the measurement), RPM reads per MFMA until they are used up
+  constexpr int NRD = NPL * 2 * (TM + TN), NMF = (LP ? 1 : 3) * TM * TN, RPM = (NRD + NMF - 1) / NMF;
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i * RPM < NRD) __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+    }
+  };
   const float inv = LP ? 1.0f : 1.0f / (sx[0] * sdy[0]);
   const int hh = lane >> 5;
   int stage = 0;
@@ -325,19 +339,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
     read_frags(B0{}, stage, 0);
     for (int step = 0; step + 1 < wp.nsteps; ++step) {      // last step peeled, see conv_h3d.hip
       read_frags(B1{}, stage, 1);
-      __builtin_amdgcn_sched_barrier(0);
       mfma_set(B0{});
+      interleave();
       __builtin_amdgcn_sched_barrier(0);
       stage = stage + 1 == NS ? 0 : stage + 1;
       lgkm0_barrier();
       read_frags(B0{}, stage, 0);
-      __builtin_amdgcn_sched_barrier(0);
       mfma_set(B1{});
+      interleave();
       __builtin_amdgcn_sched_barrier(0);
     }
     read_frags(B1{}, stage, 1);
-    __builtin_amdgcn_sched_barrier(0);
     mfma_set(B0{});
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
     stage = stage + 1 == NS ? 0 : stage + 1;
     mfma_set(B1{});
