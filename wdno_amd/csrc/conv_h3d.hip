@@ -229,6 +229,15 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
+  // the fragment reads of the next half-step are dealt out behind the MFMAs of this one (conv_h3t.hip has the measurement)
+  constexpr int NRD = NPL * (TM + TN), NMF = (LP ? 1 : 3) * TM * TN, RPM = (NRD + NMF - 1) / NMF;
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i * RPM < NRD) __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+    }
+  };
   const float inv = LP ? 1.0f : 1.0f / (sx[0] * sw[0]);
   int stage = 0;
   // debug 23 / 24 / 26 (tools/bench_conv.py --stamps): the amax record carries this wave's shader cycles in the kernel / in
@@ -255,19 +264,19 @@ __global__ __launch_bounds__(512) void conv_fwd_h3d_kernel(const _Float16* __res
     // lgkmcnt(3..0), i.e. every step waited for the fragments it had just requested (1398 -> ~1000 shader cycles per step).
     for (int step = 0; step + 1 < p.nsteps; ++step) {
       read_frags(B1{}, stage, 1);
-      __builtin_amdgcn_sched_barrier(0);
       mfma_set(B0{});
+      interleave();
       __builtin_amdgcn_sched_barrier(0);
       stage = stage + 1 == NS ? 0 : stage + 1;
       lgkm0_barrier();
       read_frags(B0{}, stage, 0);
-      __builtin_amdgcn_sched_barrier(0);
       mfma_set(B1{});
+      interleave();
       __builtin_amdgcn_sched_barrier(0);
     }
     read_frags(B1{}, stage, 1);
-    __builtin_amdgcn_sched_barrier(0);
     mfma_set(B0{});
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
     stage = stage + 1 == NS ? 0 : stage + 1;
     mfma_set(B1{});
