@@ -376,6 +376,365 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
   }
 }
 
+// ====================================================================================================================
+// Window variant (stride 1, output grid == input grid, kw == 3, C a multiple of 64) -- the weight-gradient counterpart of
+// conv_h3t.hip. tools/bench_conv.py --ablate on the kernel above, level-0 64 -> 64 layer: 0.257 ms; with every piece out of
+// range (the DMA instructions issue, nothing travels) 0.182 ms; without piece instructions 0.123 ms: it is the operand
+// delivery -- 32 pieces and 32 KB of LDS writes per 72 MFMAs -- that costs half the time, not the MFMAs or the transpose reads.
+// Here an item is (k tile of 64) x (TWO tap rows) x (3 dx x 64 channels): per 32-pixel step the CU receives the 32 x 64 dy
+// tile and, per tap row, ONE window of 32 + 2 consecutive source pixels x 64 channels (the window of the centre tap; the
+// fragment of column tile (dx, channel half) is a transpose read of window rows shifted by dx) -- 28 pieces / 28 KB per 144
+// MFMAs; and a compute wave owns 64 k x 96 columns (TM = 2, TN = 3), 20 transpose reads per 18 MFMAs instead of 16 per 9.
+//   * dx validity (the W-neighbour of a pixel at the end of an image row): the compute waves track ow of the four pixels a
+//     lane addresses per step (two transpose reads x two 16-deep halves) and point an invalid (pixel, dx) at a window row that
+//     is always zero (rows 34 .. 39 are fetched out of range).
+//   * (dz, dy) validity: from the pixel-table record of the pixel the window row is the centre tap of.
+//   * 14 (hi, lo) piece pairs per step: producer waves 0 / 1 carry four, 2 / 3 three (the vmcnt immediates differ, so the
+//     producer body is instantiated for both counts).
+//   * an odd number of tap rows leaves the second window of the last pair empty (zeros; its result is not stored).
+template <int NS, bool LP>
+__global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                              const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
+                                                              const float* __restrict__ sx, const float* __restrict__ sdy,
+                                                              const int4v* __restrict__ table, float* __restrict__ ws, WgradDP wp,
+                                                              unsigned x_bytes, unsigned dy_bytes, unsigned tbl_bytes) {
+  constexpr int KW = 3, BM = 64, CT = 64;
+  constexpr int TM = 2, TN = 3;
+  constexpr int ACH = BM / 8, XCH = CT / 8;               // 16-byte chunks per pixel row
+  constexpr int XROWS = 32 + KW - 1;                      // window rows that carry data
+  constexpr int A_PLANE = 32 * ACH * 16, W_PLANE = 5 * 1024, B_PLANE = 2 * W_PLANE;      // a window: 40 rows x 128 B, rows >= XROWS stay zero
+  constexpr int ZADDR = 9 * (XCH * 64) + 3 * 64;          // window row 39
+  constexpr int NPL = LP ? 1 : 2;
+  constexpr int A_LO = A_PLANE, B_HI = NPL * A_PLANE, B_LO = B_HI + B_PLANE;
+  constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+  constexpr int APC = A_PLANE / 1024, WPC = W_PLANE / 1024;
+  constexpr int NPAIR = APC + 2 * WPC;
+  static_assert(NPAIR == 14, "pairs 0-3 dy, 4-8 window 0, 9-13 window 1");
+  constexpr int LA = 2;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const ConvP& p = wp.c;
+  const wdno_conv_geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int it_first, it_stride, my_items;                      // item order and XCD ownership: as conv_wgrad_h3d_kernel
+  if (wp.xcd_chunk > 0) {
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int beg = xcd * wp.xcd_chunk, end = min(beg + wp.xcd_chunk, wp.items);
+    it_stride = (int)gridDim.x >> 3;
+    it_first = beg + idx;
+    my_items = it_first < end ? (end - it_first + it_stride - 1) / it_stride : 0;
+  } else {
+    it_first = (int)blockIdx.x; it_stride = (int)gridDim.x;
+    my_items = (wp.items - it_first + it_stride - 1) / it_stride;
+  }
+  const int ntap = g.kd * g.kh, npair = (ntap + 1) >> 1;
+  auto decode_item = [&](int t, int& tile_k, int& tpair, int& tile_c, int& split) {
+    int id = it_first + t * it_stride;
+    tile_c = id % wp.tiles_r; id /= wp.tiles_r;
+    tpair = id % npair; id /= npair;
+    tile_k = id % wp.tiles_k;
+    split = id / wp.tiles_k;
+  };
+
+  if (wave >= 4) {
+    // ================================================================== producer waves
+    const int pq = wave - 4;
+    int4v rxh = wd_rsrc(xh, x_bytes), rxl = wd_rsrc(xl, x_bytes), rdh = wd_rsrc(dyh, dy_bytes), rdl = wd_rsrc(dyl, dy_bytes);
+    int4v rtb = wd_rsrc(table, tbl_bytes);
+    asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rdh), "+s"(rdl), "+s"(rtb));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    auto producer = [&](auto RC) {
+      constexpr int R = decltype(RC)::value;          // pairs of this wave: global pairs pq + 4 j
+      constexpr int PW = NPL * R;
+      static_assert(R + (NS - 2) * (R + PW) <= 63, "vmcnt is a 6-bit counter");
+      // Lane L of piece q of a plane covers its 16-byte slot f = 64 q + L: row 4 (f / 32) + (f / 4) % 4 (pixel of the step / window row),
+      // 64-byte unit (f / 16) % 2, chunk f % 4 of the unit.
+      int row[R], chk[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int gp = pq + 4 * j;
+        const int f = 64 * (gp < APC ? gp : (gp - APC) % WPC) + lane;
+        row[j] = 4 * (f >> 5) + ((f >> 2) & 3);
+        chk[j] = (((f >> 4) & 1) * 4 + (f & 3)) * 8;
+      }
+      struct Cur { int t, s; };
+      Cur rc{0, 0}, pc{0, 0};          // record cursor, piece cursor
+      int r_pbeg = 0;
+      int c_dz[2], c_dy[2], c_tapoff[2];
+      bool c_on[2];
+      int i_off[R];
+      bool i_ok[R];
+      auto load_item_r = [&]() {
+        int tk, tp, tc, sp;
+        decode_item(rc.t, tk, tp, tc, sp);
+        r_pbeg = sp * wp.pix_per_split;
+      };
+      auto load_item_p = [&]() {
+        int tk, tp, tc, sp;
+        decode_item(pc.t, tk, tp, tc, sp);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int tap = 2 * tp + s2;
+          c_on[s2] = tap < ntap;
+          c_dz[s2] = tap / g.kh; c_dy[s2] = tap - c_dz[s2] * g.kh;
+          c_tapoff[s2] = (c_dz[s2] * g.H + c_dy[s2]) * g.W * g.C;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (pq + 4 * j < APC) {
+            const int k = tk * BM + chk[j];
+            i_ok[j] = k < g.K;
+            i_off[j] = k * 2;
+          } else {
+            i_ok[j] = row[j] < XROWS;
+            i_off[j] = g.pw * g.C + tc * CT + chk[j];          // centre tap of the window row's pixel, channel tile
+          }
+        }
+      };
+      if (my_items > 0) { load_item_r(); load_item_p(); }
+      int4v rec[LA + 1][R];
+      bool rok[LA + 1][R];
+      auto fetch = [&](auto SLOT) {
+        constexpr int S = decltype(SLOT)::value;
+        const bool live = rc.t < my_items;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int pm = r_pbeg + rc.s * 32 + row[j] - (pq + 4 * j < APC ? 0 : g.pw);
+          rok[S][j] = live && pm >= 0 && pm < (int)p.P;
+          rec[S][j] = wd_load_rec(rtb, rok[S][j] ? pm * 16 : WD_OOB);
+        }
+        if (live && ++rc.s == wp.nsteps) { rc.s = 0; if (++rc.t < my_items) load_item_r(); }
+      };
+      auto issue = [&](auto SLOT, int stage) {
+        constexpr int S = decltype(SLOT)::value;
+        const bool live = pc.t < my_items;
+        const unsigned sb = lds0 + stage * STAGE;
+        const int k2 = g.K * 2;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          int4v e = rec[S][j];
+          asm volatile("" : "+v"(e));                                   // consumers of the record stay below the counted wait
+          const int gp = pq + 4 * j;                                    // pq is wave-uniform: scalar branches
+          const bool ok0 = live && rok[S][j] && i_ok[j];
+          if (gp < APC) {
+            const int off = ok0 ? e.x * k2 + i_off[j] : WD_OOB;
+            wd_piece(rdh, off, sb + gp * 1024);
+            if (!LP) wd_piece(rdl, off, sb + A_LO + gp * 1024);
+          } else {
+            const int s2 = gp - APC < WPC ? 0 : 1;
+            const int d = (e.z >> 16) + c_dz[s2], h = (int)(short)(e.z & 0xffff) + c_dy[s2];
+            const bool ok = ok0 && c_on[s2] && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H;
+            const int off = ok ? (e.y + c_tapoff[s2] + i_off[j]) * 2 : WD_OOB;
+            wd_piece(rxh, off, sb + B_HI + (gp - APC) * 1024);
+            if (!LP) wd_piece(rxl, off, sb + B_LO + (gp - APC) * 1024);
+          }
+        }
+        if (live && ++pc.s == wp.nsteps) { pc.s = 0; if (++pc.t < my_items) load_item_p(); }
+      };
+      using S0 = std::integral_constant<int, 0>;
+      using S1 = std::integral_constant<int, 1>;
+      using S2 = std::integral_constant<int, 2>;
+      auto wait_pin = [&](auto SLOT, auto COUNT, auto BAR) {
+        constexpr int S = decltype(SLOT)::value;
+        constexpr int N = decltype(COUNT)::value;
+        constexpr bool WITH_BARRIER = decltype(BAR)::value;
+        static_assert(R == 3 || R == 4, "record count");
+        int4v &r0 = rec[S][0], &r1 = rec[S][1], &r2 = rec[S][2], &r3 = rec[S][R > 3 ? 3 : 0];
+        if (WITH_BARRIER) {
+          if (R == 3) asm volatile("s_waitcnt vmcnt(%3)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+        } else {
+          if (R == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+        }
+      };
+      using YES = std::true_type;
+      using NO = std::false_type;
+      using ZERO = std::integral_constant<int, 0>;
+      using WSTEADY = std::integral_constant<int, R + (NS - 2) * (R + PW)>;
+      static_assert(NS == 3 && LA == 2, "slot schedule below is written for a 3-stage ring and 2 steps of record look-ahead");
+      fetch(S0{}); fetch(S1{}); fetch(S2{});
+      wait_pin(S0{}, ZERO{}, NO{});
+      wait_pin(S1{}, ZERO{}, NO{});
+      wait_pin(S2{}, ZERO{}, NO{});
+      issue(S0{}, 0);
+      fetch(S0{});
+      issue(S1{}, 1);
+      const int total = my_items * wp.nsteps;
+      int stage = 0;
+      auto iter = [&](auto FS, auto IS) {
+        fetch(FS);
+        wait_pin(IS, WSTEADY{}, YES{});
+        int nstage = stage + NS - 1;
+        if (nstage >= NS) nstage -= NS;
+        issue(IS, nstage);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+      };
+      for (int gs = 0; gs < total; gs += 3) {
+        iter(S1{}, S2{});
+        if (gs + 1 < total) iter(S2{}, S0{});
+        if (gs + 2 < total) iter(S0{}, S1{});
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    };
+    if (pq < 2) producer(std::integral_constant<int, 4>{});
+    else producer(std::integral_constant<int, 3>{});
+    return;
+  }
+
+  // ================================================================== compute waves: wave w owns columns [96 w, 96 w + 96) of the 384
+  const int wslot = wave >> 1, whalf = wave & 1;            // tap row of the pair, half of its six (dx, channel half) tiles
+  const int li = lane & 31;
+  const int gq = lane >> 4, xq = lane & 15;
+  const int offA = (2 * (gq >> 1)) * (ACH * 64) + (xq >> 2) * 64 + (gq & 1) * 32 + (xq & 3) * 8;
+  const int chan = (gq & 1) * 32 + (xq & 3) * 8;                // byte position of this lane's 8 bytes inside a 64-byte unit
+  const int pix_l = 8 * (gq >> 1) + (xq >> 2);                 // pixel (of 16) this lane addresses in the first transpose read; second: + 4
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  typedef short4v __attribute__((address_space(3))) * lds_s4;
+  auto x_addr = [&](int wrow, int unit) { return (wrow >> 2) * (XCH * 64) + unit * 256 + (wrow & 3) * 64 + chan; };
+  const float inv = LP ? 1.0f : 1.0f / (sx[0] * sdy[0]);
+  const int hh = lane >> 5;
+  const int step_ow = 32 % g.W;
+  const int wbase = B_HI + wslot * W_PLANE;
+
+  auto run = [&](auto HC) {
+    constexpr int HV = decltype(HC)::value;
+    // column tile b of this wave = tile 3 HV + b of the tap row's six (dx, channel half) tiles
+    constexpr int DX[3] = {(3 * HV) >> 1, (3 * HV + 1) >> 1, (3 * HV + 2) >> 1};
+    constexpr int UH[3] = {(3 * HV) & 1, (3 * HV + 1) & 1, (3 * HV + 2) & 1};
+    // class c = 2 ks + (second read): base[b][c] = address (inside a window plane) of tile b's read of that class
+    int base[TN][4], rd[TN][4], ow[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) base[b][c] = x_addr(16 * (c >> 1) + 4 * (c & 1) + pix_l + DX[b], UH[b]);
+    auto select = [&](int c) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        if (DX[b] == 1) rd[b][c] = base[b][c];                         // pw == 1: the centre tap always exists
+        else rd[b][c] = (unsigned)(ow[c] - g.pw + DX[b]) < (unsigned)g.W ? base[b][c] : ZADDR;
+      }
+    };
+    auto advance = [&](int c) {
+      ow[c] += step_ow;
+      if (ow[c] >= g.W) ow[c] -= g.W;
+    };
+    half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+    auto read_frags = [&](auto SET, int stage, int ks) {
+      constexpr int B = decltype(SET)::value;
+      const char* st = smem + stage * STAGE;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        fah[B][a] = wd_frag<ACH>(st, offA, ks * 16, a * 32);
+        if (!LP) fal[B][a] = wd_frag<ACH>(st + A_LO, offA, ks * 16, a * 32);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const short4v h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(st + wbase + rd[b][2 * ks]));
+        const short4v h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(st + wbase + rd[b][2 * ks + 1]));
+        fbh[B][b] = __builtin_bit_cast(half8, (short8v)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+        if (!LP) {
+          const short4v l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(st + wbase + B_PLANE + rd[b][2 * ks]));
+          const short4v l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(st + wbase + B_PLANE + rd[b][2 * ks + 1]));
+          fbl[B][b] = __builtin_bit_cast(half8, (short8v)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      }
+    };
+    f32x16 acc[TM][TN];
+    auto mfma_set = [&](auto SET) {          // row operand = x fragment (column tile), column operand = dy fragment (k): acc is [r][k]
+      constexpr int B = decltype(SET)::value;
+      if constexpr (!LP) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbh[B][b], fal[B][a], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbl[B][b], fah[B][a], acc[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<LP>(fbh[B][b], fah[B][a], acc[a][b]);
+    };
+    constexpr int NRD = NPL * 2 * (TM + TN), NMF = (LP ? 1 : 3) * TM * TN, RPM = (NRD + NMF - 1) / NMF;
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i * RPM < NRD) __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+      }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int stage = 0;
+    for (int t = 0; t < my_items; ++t) {
+      int tile_k, tpair, tile_c, split;
+      decode_item(t, tile_k, tpair, tile_c, split);
+      const int pbeg = split * wp.pix_per_split;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ow[c] = (pbeg + 16 * (c >> 1) + 4 * (c & 1) + pix_l) % g.OW;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+      select(0); select(1);
+      lgkm0_barrier();
+      read_frags(B0{}, stage, 0);
+      advance(0); advance(1);
+      for (int step = 0; step + 1 < wp.nsteps; ++step) {
+        select(2); select(3);
+        read_frags(B1{}, stage, 1);
+        advance(2); advance(3);
+        mfma_set(B0{});
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        select(0); select(1);
+        lgkm0_barrier();
+        read_frags(B0{}, stage, 0);
+        advance(0); advance(1);
+        mfma_set(B1{});
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      select(2); select(3);
+      read_frags(B1{}, stage, 1);
+      mfma_set(B0{});
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      mfma_set(B1{});
+      __builtin_amdgcn_sched_barrier(0);
+      // acc[a][b]: rows = run index dx C + channel (tile b -> DX[b], UH[b]; 8 (e >> 2) + 4 hh + (e & 3) inside the tile), column = k
+      const int tap = 2 * tpair + wslot;
+      if (tap < ntap) {
+        float* out = ws + ((int64_t)split * ntap + tap) * (int64_t)g.K * p.R;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          const int kk = tile_k * BM + a * 32 + li;
+          if (kk >= g.K) continue;
+          float* orow = out + (int64_t)kk * p.R;
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const int rr = DX[b] * g.C + tile_c * CT + UH[b] * 32 + 8 * e4 + 4 * hh;
+              *reinterpret_cast<float4*>(orow + rr) = make_float4(acc[a][b][4 * e4] * inv, acc[a][b][4 * e4 + 1] * inv, acc[a][b][4 * e4 + 2] * inv, acc[a][b][4 * e4 + 3] * inv);
+            }
+          }
+        }
+      }
+    }
+  };
+  if (whalf == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
 static int wd_num_cus() {
   static int n = 0;
   if (!n) {
@@ -387,10 +746,29 @@ static int wd_num_cus() {
   return n;
 }
 
+// geometries of the window kernel: stride 1, equal grids, kw == 3, whole 64-channel tiles (debug 8: never; debug 11: only for
+// K <= 64 -- with more output channels the windows are fetched once per 64-wide k tile)
+static bool wd_window_takes(const wdno_conv_geom* g) {
+  if (wdno_debug_mode == 8 || (wdno_debug_mode == 11 && g->K > 64)) return false;
+  return g->sd == 1 && g->sh == 1 && g->sw == 1 && g->OD == g->D && g->OH == g->H && g->OW == g->W && g->kw == 3 && g->pw == 1 &&
+         (g->C % 64) == 0 && (g->K % 8) == 0;
+}
 // plan shared by the workspace query and the launch (conv_h3.hip calls both)
 void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits, int* pix_per_split) {
   ConvP c;
   fill_params(c, g);
+  if (wd_window_takes(g)) {                                 // items = k tiles x tap-row pairs x channel tiles x splits, one round of the CUs
+    *bm = 64; *bn = 192;
+    const int tiles = cdiv(g->K, 64) * ((g->kd * g->kh + 1) / 2) * (g->C / 64);
+    int64_t want = 256 / tiles;
+    int64_t max_splits = cdiv64(c.P, 16 * 32);
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    int64_t pps = cdiv64(cdiv64(c.P, want), 32) * 32;
+    *pix_per_split = (int)pps;
+    *splits = (int)cdiv64(c.P, pps);
+    return;
+  }
   *bm = g->K > 64 ? 128 : 64;
   // column tile of the kw*C run: the width that pads the run least; 192 on a tie (more MFMAs per step and barrier)
   *bn = cdiv(c.R, 192) * 192 <= cdiv(c.R, 128) * 128 ? 192 : 128;
@@ -428,6 +806,30 @@ static void launch_wd(const void* xh, const void* xl, const void* dyh, const voi
                                                          sx, sdy, (const int4v*)table, wsf, wl, x_bytes, dy_bytes, tbl_bytes);
 }
 
+template <bool LP>
+static void launch_ww(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
+                      const void* table, float* wsf, const WgradDP& w, hipStream_t st) {
+  const wdno_conv_geom& g = w.c.g;
+  const unsigned x_bytes = (unsigned)((int64_t)g.N * g.D * g.H * g.W * g.C * 2);
+  const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
+  const unsigned tbl_bytes = (unsigned)(w.c.P * 16);
+  constexpr int NS = 3;
+  const size_t lds = (size_t)NS * (LP ? 1 : 2) * (4096 + 2 * 5120);
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_h3w_kernel<NS, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  int grid = wd_num_cus();
+  if (w.items < grid) grid = w.items;
+  WgradDP wl = w;
+  wl.xcd_chunk = 0;
+  if (grid >= 64 && wdno_debug_mode != 6) {
+    wl.xcd_chunk = cdiv(w.items, 8);
+    grid = wd_num_cus() & ~7;
+    if (8 * wl.xcd_chunk < grid) grid = 8 * wl.xcd_chunk;
+  }
+  conv_wgrad_h3w_kernel<NS, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh, (const _Float16*)dyl,
+                                                       sx, sdy, (const int4v*)table, wsf, wl, x_bytes, dy_bytes, tbl_bytes);
+}
+
 // wsf: split workspace [splits][ntap][K][R] (or dwp itself when splits == 1). Returns WDNO_EUNSUPPORTED for geometries the
 // DMA kernel does not take.
 int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
@@ -441,6 +843,12 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
   w.tiles_r = cdiv(w.c.R, bn);
   w.nsteps = w.pix_per_split / 32;
   w.items = w.tiles_k * w.tiles_r * g->kd * g->kh * w.splits;
+  if (wd_window_takes(g)) {      // tiles_r = C / 64 channel tiles, tap rows in pairs
+    w.items = w.tiles_k * w.tiles_r * ((g->kd * g->kh + 1) / 2) * w.splits;
+    if (xl == nullptr) launch_ww<true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);
+    else launch_ww<false>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
+    return WDNO_OK;
+  }
   if (xl == nullptr) {           // single bf16 plane per operand
     if (bm == 128 && bn == 192) launch_wd<128, 192, true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);
     else if (bm == 128) launch_wd<128, 128, true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);

@@ -631,8 +631,10 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
 
 
-def _wgrad_h3_kernel_name(k, run):
-    """Same for wdno_conv_wgrad_f16x3 (run = kw * C8)."""
+def _wgrad_h3_kernel_name(k, run, window=False):
+    """Same for wdno_conv_wgrad_f16x3 (run = kw * C8; window: the geometries of csrc/conv_wgrad_h3d.hip's wd_window_takes)."""
+    if window:
+        return 'conv_wgrad_h3w_kernel<64,384>'
     cdiv = lambda a, b: -(-a // b)
     bn = 192 if cdiv(run, 192) * 192 <= cdiv(run, 128) * 128 else 128
     return f'conv_wgrad_h3d_kernel<{128 if k > 64 else 64},{bn}>'
@@ -656,22 +658,23 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None):
         _lib.check(lib.wdno_conv_pixel_table(_p(table), C.byref(g), _stream()), 'conv_pixel_table')
         _pixel_tables[tkey] = table
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * k8 * ks[0] * ks[1] * ks[2] * c8
+    window = tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 3 and pd[2] == 1 and c8 % 64 == 0
     if xl is None:           # single bf16 plane per operand
         assert param_kc is not None
         kn, cn = param_kc
         dw = torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
-        with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8), flops):
+        with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8, window), flops):
             _lib.check(lib.wdno_conv_wgrad_bf16_param(_p(xh), _p(gh), _p(table), _p(dw), kn, cn, _p(ws), nb, C.byref(g), _stream()), 'conv_wgrad_bf16_param')
         return dw
     if param_kc is not None:
         kn, cn = param_kc
         dw = torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
-        with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8), flops):
+        with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8, window), flops):
             _lib.check(lib.wdno_conv_wgrad_f16x3_param(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dw), kn, cn, _p(ws), nb,
                                                        C.byref(g), _stream()), 'conv_wgrad_f16x3_param')
         return dw
     dwp = torch.empty((ks[0], ks[1], k8, ks[2], c8), device=xh.device, dtype=torch.float32)
-    with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8), flops):
+    with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8, window), flops):
         _lib.check(lib.wdno_conv_wgrad_f16x3(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dwp), _p(ws), nb, C.byref(g), _stream()),
                    'conv_wgrad_f16x3')
     return dwp
