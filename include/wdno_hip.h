@@ -193,6 +193,16 @@ int wdno_groupnorm_act_bwd(const float* x, const float* dy, const float* gamma, 
 int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
                                 const float* stats, float* dx, float* dgb_partial, float* dss, float* amax_rec,
                                 int64_t N, int64_t S, int C, int G, int silu, void* ws, size_t ws_bytes, wdno_stream_t s);
+/* The same backward with dx delivered as the fp16 (hi, lo) planes the split convolution kernels read (dx of the norm is the dy of
+ * the convolution in front of it, Block.forward: unet.py:80-101, conv3d.py:186-206) -- no fp32 dx, no separate amax / split passes.
+ * The scale comes from an upper bound of max|dx| that the per-sample finalize derives from per-channel maxima of the reduction pass
+ * (bound_rec: a zeroed amax record, receives the bound). dx_colsum [C] = column sums of dx (the bias gradient of that convolution).
+ * C / 8 must be a power of two <= 256 (WDNO_EUNSUPPORTED otherwise: use wdno_groupnorm_act_bwd_amax + wdno_split_f16). */
+size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G);
+int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                                  const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
+                                  float* dgb_partial, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
+                                  void* ws, size_t ws_bytes, wdno_stream_t s);
 /* Channel LayerNorm over C of CL rows [P, C], gain only (unet.py:55-65, conv3d.py:165-174) */
 int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s);
 int wdno_layernorm_fwd_amax(const float* x, const float* g, float* y, float* amax_rec, int64_t P, int C, float eps, wdno_stream_t s);
@@ -203,6 +213,9 @@ int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* d
  * conv3d.py:131-137,176-184): saves the separate accumulation pass autograd would issue. add_to may be NULL. */
 int wdno_layernorm_bwd_add(const float* x, const float* g, const float* dy, const float* add_to, float* dx, float* dg, int64_t P, int C,
                            float eps, void* ws, size_t ws_bytes, wdno_stream_t s);
+/* ... and max|dx| left in an amax record (dx is the dy of the projection in front of the next Residual block). amax_rec may be NULL. */
+int wdno_layernorm_bwd_add_amax(const float* x, const float* g, const float* dy, const float* add_to, float* dx, float* dg, float* amax_rec,
+                                int64_t P, int C, float eps, void* ws, size_t ws_bytes, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ attention
  * qkv rows are [row][3*heads*32] = (q | k | v), each [heads][32]; outputs are [row][heads*32].

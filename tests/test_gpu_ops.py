@@ -733,3 +733,43 @@ def test_relpos_bias_lookup_and_gradient(ops):
     assert torch.equal(out.detach().cpu(), ref.detach())
     out.backward(go.to(DEV))
     assert rel_l2(wd.grad, wr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('shape,k,groups,use_ss', [((2, 64, 4, 16, 16), 64, 8, True), ((1, 128, 2, 24, 24), 128, 8, False), ((4, 128, 32, 32), 256, 1, True)])
+def test_groupnorm_backward_delivers_planes(ops, shape, k, groups, use_ss):
+    """conv -> GroupNorm(+scale/shift) -> SiLU with conv_cl(grad_planes=True): the norm's backward writes the fp16 planes of dx
+    (scale from the analytic bound) and their column sums; every gradient must agree with the fp32-dx route to rounding."""
+    nd = len(shape) - 2
+    c = shape[1]
+    x = g(shape, 301)
+    w = g((k, c) + (3,) * nd, 302) * 0.05
+    b = g((k,), 303) * 0.1
+    gamma, beta = 1 + 0.2 * g((k,), 304), 0.1 * g((k,), 305)
+    ss = 0.3 * g((shape[0], 2 * k), 306) if use_ss else None
+    r = g((shape[0], k) + tuple(shape[2:]), 307)
+
+    def run(flag):
+        xs = dev(to_cl(x), grad=True)
+        ws_, bs, gs, bes = dev(w, grad=True), dev(b, grad=True), dev(gamma, grad=True), dev(beta, grad=True)
+        sss = dev(ss, grad=True) if use_ss else None
+        calls = {'n': 0}
+        orig = ops.split_f16_colsum
+
+        def counting(*a, **kw):
+            calls['n'] += 1
+            return orig(*a, **kw)
+        ops.split_f16_colsum = counting
+        try:
+            y = ops.conv_cl(xs, ws_, bs, padding=1, grad_planes=flag)
+            z = ops.groupnorm_act(y, gs, bes, groups, sss, act=True)
+            (z * dev(to_cl(r))).sum().backward()
+        finally:
+            ops.split_f16_colsum = orig
+        out = [xs.grad, ws_.grad, bs.grad, gs.grad, bes.grad] + ([sss.grad] if use_ss else [])
+        return [t.double().cpu() for t in out], calls['n']
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 1 and n_got == 0, (n_ref, n_got)          # the planes route never splits dy
+    for name, a, e in zip(['dx', 'dw', 'db', 'dgamma', 'dbeta', 'dss'], got, ref):
+        assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))

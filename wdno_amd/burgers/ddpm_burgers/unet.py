@@ -84,9 +84,9 @@ class Block(nn.Module):
 
     def forward(self, x, scale_shift=None, with_skip=False):
         if with_skip:              # block input that also feeds the skip connection: handed through the convolution (ops.conv_cl_skip)
-            x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1)
+            x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)
             return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps), xs
-        x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1)
+        x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)     # x goes to the norm and nowhere else
         return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps)
 
 

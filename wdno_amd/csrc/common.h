@@ -75,6 +75,12 @@ __device__ __forceinline__ void wave_amax_emit(float am, float* rec, int wave_li
 __device__ __forceinline__ float amax_record_read(const float* __restrict__ rec) {      // whole wave
   return wave_max(rec[(threadIdx.x & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE]);
 }
+// scale of the (hi, lo) fp16 planes of a tensor with max|x| <= amax: the power of two that puts amax into [2^14, 2^15)
+__device__ __forceinline__ float scale_from_amax(float amax) {
+  if (!(amax > 0.f) || !isfinite(amax)) return 1.0f;
+  int e = ilogbf(amax);                       // amax = m * 2^e, 1 <= m < 2
+  return ldexpf(1.0f, 14 - e);
+}
 __device__ __forceinline__ float amax4(float m, float4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }

@@ -78,11 +78,6 @@ extern "C" int wdno_amax(const float* x, int64_t n, float* amax_zeroed, wdno_str
   return wdno_check_launch();
 }
 
-__device__ __forceinline__ float scale_from_amax(float amax) {
-  if (!(amax > 0.f) || !isfinite(amax)) return 1.0f;
-  int e = ilogbf(amax);                       // amax = m * 2^e, 1 <= m < 2
-  return ldexpf(1.0f, 14 - e);                // amax * s in [2^14, 2^15)
-}
 // x [rows][C] fp32 -> hi, lo [rows][C8] fp16 (zero padded), scale_out[0] = s
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, const float* __restrict__ amax,
                                                      _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* __restrict__ scale_out,

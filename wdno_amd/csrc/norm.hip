@@ -24,8 +24,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           const float* __restrict__ cb /*[N][C][4]*/, const float* __restrict__ gb /*[N][G][4]*/,
                                                           double* __restrict__ part, int64_t S, int C, int cg, int G, int txp,
-                                                          int64_t rows_per_chunk, int silu) {
+                                                          int64_t rows_per_chunk, int silu, float* __restrict__ mx = nullptr) {
+  // mx (MODE 1, optional): per (sample, chunk) max|dz| and max|xhat| -- what gn_bwd_finalize_kernel needs to bound |dx|
   __shared__ double red[256 * 8];
+  __shared__ float redm[8];
+  float m0[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {0.f, 0.f, 0.f, 0.f};
   const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int C4 = C >> 2;
   const int tx = threadIdx.x & (txp - 1), ty = threadIdx.x / txp, nty = 256 / txp;
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
             float xh = (xv[j] - mean[j]) * rstd[j];
             s0[j] += (double)dz;
             s1[j] += (double)dz * (double)xh;
+            m0[j] = fmaxf(m0[j], fabsf(dz)); m1[j] = fmaxf(m1[j], fabsf(xh));
           }
         }
       }
@@ -92,6 +96,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     double* o = part + (((int64_t)n * nchunk + chunk) * C + tx * 4) * 2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j * 2] = s0[j]; o[j * 2 + 1] = s1[j]; }
+  }
+  if (MODE == 1 && mx) {          // block maxima of |dz| and |xhat|
+    float a = fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), b = fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3]));
+    a = wave_max(a); b = wave_max(b);
+    if ((threadIdx.x & 63) == 0) { redm[(threadIdx.x >> 6) * 2] = a; redm[(threadIdx.x >> 6) * 2 + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float* o = mx + ((int64_t)n * nchunk + chunk) * 2;
+      o[0] = fmaxf(fmaxf(redm[0], redm[2]), fmaxf(redm[4], redm[6]));
+      o[1] = fmaxf(fmaxf(redm[1], redm[3]), fmaxf(redm[5], redm[7]));
+    }
   }
 }
 
@@ -221,7 +236,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float* __restrict__ ss,
                                                                float* __restrict__ gb, float* __restrict__ dgb, float* __restrict__ dss,
-                                                               int64_t S, int C, int G, int nchunk) {
+                                                               int64_t S, int C, int G, int nchunk, const float* __restrict__ cb = nullptr,
+                                                               const float* __restrict__ mx = nullptr, float* __restrict__ bound_rec = nullptr) {
   __shared__ double chA[GN_MAXC], chB[GN_MAXC];
   const int n = blockIdx.x, cg = C / G;
   gn_chunk_totals(part, n, nchunk, C, chA, chB);
@@ -263,6 +279,30 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
     o[2] = (float)(a / m) * rstd;
     o[3] = (float)(b / m) * rstd;
   }
+  if (bound_rec) {
+    // |dx| = |k.z dz - g.z - xhat g.w| <= max|k.z| max|dz| + max|g.z| + max|xhat| max|g.w|: an upper bound of max|dx| that is known
+    // BEFORE the apply pass, so that pass can write the (hi, lo) fp16 planes of dx directly (gn_bwd_apply_planes_kernel)
+    __syncthreads();
+    float mdz = 0.f, mxh = 0.f, mk = 0.f, mz = 0.f, mw = 0.f;
+    for (int k = threadIdx.x; k < nchunk; k += 256) {
+      mdz = fmaxf(mdz, mx[((int64_t)n * nchunk + k) * 2]); mxh = fmaxf(mxh, mx[((int64_t)n * nchunk + k) * 2 + 1]);
+    }
+    for (int c = threadIdx.x; c < C; c += 256) mk = fmaxf(mk, fabsf(cb[((int64_t)n * C + c) * 4 + 2]));
+    for (int g = threadIdx.x; g < G; g += 256) {
+      mz = fmaxf(mz, fabsf(gb[((int64_t)n * G + g) * 4 + 2])); mw = fmaxf(mw, fabsf(gb[((int64_t)n * G + g) * 4 + 3]));
+    }
+    __shared__ float bm[5][4];
+    float v[5] = {wave_max(mdz), wave_max(mxh), wave_max(mk), wave_max(mz), wave_max(mw)};
+    if ((threadIdx.x & 63) == 0)
+      for (int q = 0; q < 5; ++q) bm[q][threadIdx.x >> 6] = v[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t[5];
+      for (int q = 0; q < 5; ++q) t[q] = fmaxf(fmaxf(bm[q][0], bm[q][1]), fmaxf(bm[q][2], bm[q][3]));
+      const float bound = t[2] * t[0] + t[3] + t[1] * t[4];
+      atomicMax(reinterpret_cast<unsigned*>(bound_rec) + (n & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE, __float_as_uint(bound));
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -297,6 +337,67 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     am = fmaxf(fmaxf(am, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
   if (amax_rec) amax_record_emit(am, amax_rec, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// dx as (hi, lo) fp16 planes (scale from the bound gn_bwd_finalize_kernel left in `rec`) + per-block column sums of dx (the bias
+// gradient of the convolution in front of the norm). A thread owns 8 channels: 16-byte plane stores; its channel group is fixed
+// ((gridDim.x * 256) % (C / 8) == 0), so the column sums stay in registers until the block reduces them.
+typedef _Float16 gn_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   const float* __restrict__ cb, const float* __restrict__ gb,
+                                                                   _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                                   float* __restrict__ scale_out, const float* __restrict__ rec,
+                                                                   double* __restrict__ csp, int64_t S, int C, int cg, int G, int silu) {
+  __shared__ double red[256][9];
+  const int n = blockIdx.y;
+  const int C8 = C >> 3;
+  const int64_t total8 = S * C8;
+  const float s = scale_from_amax(amax_record_read(rec));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const float* xp = x + (int64_t)n * S * C;
+  const float* dp = dy + (int64_t)n * S * C;
+  _Float16* hp = hi + (int64_t)n * S * C;
+  _Float16* lp = lo + (int64_t)n * S * C;
+  const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
+  const float4* gbp = reinterpret_cast<const float4*>(gb + (int64_t)n * G * 4);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % C8) * 8;
+  float4 kk[8], gq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { kk[j] = cbp[c0 + j]; gq[j] = gbp[(c0 + j) / cg]; }
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += stride) {
+    const float4 v0 = *reinterpret_cast<const float4*>(xp + i * 8), v1 = *reinterpret_cast<const float4*>(xp + i * 8 + 4);
+    const float4 d0 = *reinterpret_cast<const float4*>(dp + i * 8), d1 = *reinterpret_cast<const float4*>(dp + i * 8 + 4);
+    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    gn_half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float dz = dv[j];
+      if (silu) dz *= silu_grad_f(kk[j].x * xv[j] + kk[j].y);
+      const float xh = (xv[j] - gq[j].x) * gq[j].y;
+      const float o = kk[j].z * dz - gq[j].z - xh * gq[j].w;
+      acc[j] += (double)o;
+      const float t = o * s;
+      const _Float16 th = (_Float16)t;
+      h[j] = th;
+      l[j] = (_Float16)(t - (float)th);
+    }
+    *reinterpret_cast<gn_half8*>(hp + i * 8) = h;
+    *reinterpret_cast<gn_half8*>(lp + i * 8) = l;
+  }
+  // block reduction of the column sums: threads with the same channel group are C8 apart
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < C8) {
+    for (int t = threadIdx.x + C8; t < 256; t += C8)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += red[t][j];
+    double* o = csp + ((int64_t)n * gridDim.x + blockIdx.x) * C + c0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = acc[j];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- host
@@ -362,13 +463,52 @@ extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const flo
   return wdno_groupnorm_act_bwd_amax(x, dy, gamma, beta, ss, stats, dx, dgb_partial, dss, nullptr, N, S, C, G, silu, ws, ws_bytes, s);
 }
 
+
+/* ---- backward with dx delivered as fp16 (hi, lo) planes: see include/wdno_hip.h ---- */
+static inline int gn_planes_grid(int64_t S, int C) {
+  int gx = stream_grid(S * (C / 8), 256);
+  if (gx > 128) gx = 128;            // per sample; every block leaves one row of column-sum partials
+  return gx;
+}
+extern "C" size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
+  return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S) * 2 * sizeof(float) + (size_t)N * 128 * C * sizeof(double) + 64;
+}
+extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                                             const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
+                                             float* dgb_partial, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
+                                             void* ws, size_t ws_bytes, wdno_stream_t s) {
+  int rc = gn_check(N, S, C, G);
+  if (rc) return rc;
+  const int C8 = C / 8;
+  if ((C & 7) || C8 > 256 || (C8 & (C8 - 1))) return WDNO_EUNSUPPORTED;     // a thread keeps one group of 8 channels
+  if (ws_bytes < wdno_groupnorm_bwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
+  const int nchunk = gn_chunks(S);
+  double* part = (double*)ws;
+  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
+  float* gb = cb + (size_t)N * C * 4;
+  char* tail = (char*)ws + ((wdno_groupnorm_ws_bytes(N, S, C, G) + 63) & ~(size_t)63);
+  double* csp = (double*)tail;
+  float* mx = (float*)(csp + (size_t)N * 128 * C);
+  const int txp = pow2ceil(C / 4);
+  const int64_t rpc = cdiv64(S, nchunk);
+  hipStream_t st = as_stream(s);
+  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(nullptr, stats, gamma, beta, ss, nullptr, cb, gb, S, C, G, nchunk, 0.f);
+  gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, mx);
+  gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, bound_rec);
+  const int gx = gn_planes_grid(S, C);
+  gn_bwd_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp,
+                                                                   S, C, C / G, G, silu);
+  partial_rows_sum_kernel<double><<<cdiv(C, 32), PRS_THREADS, 0, st>>>(csp, dx_colsum, (int)N * gx, C);
+  return wdno_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------- channel LayerNorm
 // rows [P][C]; a row is handled by TPR lanes holding VPL float4 each. y = (x - mean) / sqrt(var + eps) * g
 template <int TPR, int VPL, bool BWD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ dy, float* __restrict__ out,
                                                          float* __restrict__ dg_part, int64_t P, int C, float eps,
-                                                         const float* __restrict__ add_to) {
+                                                         const float* __restrict__ add_to, float* __restrict__ dx_amax) {
   constexpr int RPB = 256 / TPR;
   __shared__ float red[BWD ? 256 * VPL * 4 : 1];
   const int C4 = C >> 2;
@@ -388,7 +528,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) dgacc[v][j] = 0.f;
   const float invC = 1.0f / (float)C;
   const int64_t rstride = (int64_t)gridDim.x * RPB;
-  float am = 0.f;       // forward only: max|y| of this thread's outputs, left in the amax record dg_part points to (if any)
+  float am = 0.f;       // max|y| (forward: left in the amax record dg_part points to, if any) / max|dx| (backward: in dx_amax, if any)
   // all lanes of a row group iterate together (uniform trip count per group)
   for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < P; r0 += rstride) {
     int64_t r = r0 + rloc;
@@ -448,10 +588,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
           }
           reinterpret_cast<float4*>(out + r * C)[lane + v * TPR] = o;
+          am = amax4(am, o);
         }
     }
   }
   if (!BWD && dg_part) amax_record_emit(am, dg_part, blockIdx.x);
+  if (BWD && dx_amax) amax_record_emit(am, dx_amax, blockIdx.x);
   if (BWD) {
     // reduce dg over the RPB row groups of the block, write one partial row per block
 #pragma unroll
@@ -485,11 +627,11 @@ static inline void ln_shape(int C, int& tpr, int& vpl) {
 }
 template <bool BWD>
 static int ln_launch(const float* x, const float* g, const float* dy, float* out, float* dgp, int64_t P, int C, float eps, hipStream_t st,
-                     const float* add_to = nullptr) {
+                     const float* add_to = nullptr, float* dx_amax = nullptr) {
   int tpr, vpl;
   ln_shape(C, tpr, vpl);
   int nb = ln_blocks(P, 256 / tpr);
-#define LN_CASE(T, V) layernorm_kernel<T, V, BWD><<<nb, 256, 0, st>>>(x, g, dy, out, dgp, P, C, eps, add_to)
+#define LN_CASE(T, V) layernorm_kernel<T, V, BWD><<<nb, 256, 0, st>>>(x, g, dy, out, dgp, P, C, eps, add_to, dx_amax)
   if (vpl == 1) {
     switch (tpr) {
       case 2: LN_CASE(2, 1); break;
@@ -517,18 +659,22 @@ extern "C" int wdno_layernorm_fwd(const float* x, const float* g, float* y, int6
   return wdno_layernorm_fwd_amax(x, g, y, nullptr, P, C, eps, s);
 }
 extern "C" size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C) { return (size_t)1024 * C * sizeof(float); }
-extern "C" int wdno_layernorm_bwd_add(const float* x, const float* g, const float* dy, const float* add_to, float* dx, float* dg, int64_t P,
-                                      int C, float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {
+extern "C" int wdno_layernorm_bwd_add_amax(const float* x, const float* g, const float* dy, const float* add_to, float* dx, float* dg,
+                                           float* amax_rec, int64_t P, int C, float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {
   WDNO_REQUIRE(P > 0 && C >= 4);
   if ((C & 3) || C > 1024) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_layernorm_bwd_ws_bytes(P, C)) return WDNO_EWORKSPACE;
   int tpr, vpl;
   ln_shape(C, tpr, vpl);
   int nb = ln_blocks(P, 256 / tpr);
-  int rc = ln_launch<true>(x, g, dy, dx, (float*)ws, P, C, eps, as_stream(s), add_to);
+  int rc = ln_launch<true>(x, g, dy, dx, (float*)ws, P, C, eps, as_stream(s), add_to, amax_rec);
   if (rc) return rc;
   partial_rows_sum_kernel<float><<<cdiv(C, 32), PRS_THREADS, 0, as_stream(s)>>>((const float*)ws, dg, nb, C);
   return wdno_check_launch();
+}
+extern "C" int wdno_layernorm_bwd_add(const float* x, const float* g, const float* dy, const float* add_to, float* dx, float* dg, int64_t P,
+                                      int C, float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_layernorm_bwd_add_amax(x, g, dy, add_to, dx, dg, nullptr, P, C, eps, ws, ws_bytes, s);
 }
 extern "C" int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
                                   float eps, void* ws, size_t ws_bytes, wdno_stream_t s) {

@@ -347,6 +347,7 @@ AMAX_FLOATS = 64 * 16    # WDNO_AMAX_FLOATS
 AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 
+GRAD_PLANES = os.environ.get('WDNO_GRAD_PLANES', '1') != '0'    # GroupNorm backward writes the fp16 planes of dx itself (A/B switch)
 SKIP_FUSE = os.environ.get('WDNO_SKIP_FUSE', '1') != '0'      # skip connections handed through conv / LayerNorm (A/B switch)
 _CAPTURE = None          # [pool, next index] while a HIP graph is being captured through graph_capture()
 
@@ -778,12 +779,19 @@ class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (+ residual). weight in the reference layout [K, C, (kd,) (kh, kw)] or [K, C]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, padding, with_skip=False):
+    def forward(ctx, x, weight, bias, residual, stride, padding, with_skip=False, grad_planes=False):
         ctx.with_skip = with_skip
+        y = _Conv._forward(ctx, x, weight, bias, residual, stride, padding)
+        # grad_planes: the caller states that y goes to a GroupNorm and nowhere else; if this convolution's backward reads dy
+        # only through the split kernels, the norm may deliver dy as planes (and leave the fp32 tensor unwritten)
+        if grad_planes and not ctx.rows and ctx.h3 and y.dim() in (4, 5) and residual is None:
+            ks, st = ctx.meta[0], ctx.meta[1]
+            n_, d_, h_, w_, _ = ctx.xshape
+            if not ctx.needs_input_grad[0] or (st == (1, 1, 1) and _use_h3(n_ * d_ * h_ * w_, ctx.meta[6] * ks[0] * ks[1] * ks[2])):
+                y._wdno_grad_planes = True
         if with_skip:              # second output: x itself (see conv_cl_skip); its gradient is folded into the dgrad epilogue
-            y = _Conv._forward(ctx, x, weight, bias, residual, stride, padding)
             return y, _alias_of(x)
-        return _Conv._forward(ctx, x, weight, bias, residual, stride, padding)
+        return y
 
     @staticmethod
     def _forward(ctx, x, weight, bias, residual, stride, padding):
@@ -842,8 +850,8 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gskip=None):
         if ctx.rows:
-            return _linear_rows_backward(ctx, gy) + (None,)
-        return _Conv._backward(ctx, gy, gskip) + (None,)
+            return _linear_rows_backward(ctx, gy) + (None, None)
+        return _Conv._backward(ctx, gy, gskip) + (None, None)
 
     @staticmethod
     def _backward(ctx, gy, gskip):
@@ -854,16 +862,27 @@ class _Conv(torch.autograd.Function):
             x5, weight = ctx.saved_tensors
         ks, stride, padding, k, c, cp, kp, has_bias, has_res, lead, xdim = ctx.meta
         grec = _known_amax(gy)
+        po = getattr(gy, '_wdno_planes_only', None)        # GroupNorm backward delivered dy as planes + column sums; gy itself is unwritten
         gy = _chk(gy, 'grad')
         n, d, h, w, _ = ctx.xshape
         gyplanes = None
+        gb_given = None
+        if po is not None:
+            if not (ctx.h3 and po[2] == gy._version and CONV_MATH == 'f16x3' and not has_res):
+                raise RuntimeError('wdno_amd: a planes-only gradient reached a convolution that cannot take it')
+            gyplanes, gb_given = po[0], po[1]
         osp = tuple(_out_size(a, kk, s, p) for a, kk, s, p in zip((d, h, w), ks, stride, padding))
         gy5 = gy.reshape(n, *osp, kp)
         gx = gw = gb = gr = None
         want_gb = has_bias and ctx.needs_input_grad[2]
         will_split = (ctx.needs_input_grad[1] and ctx.h3) or (ctx.needs_input_grad[0] and stride == (1, 1, 1)
                                                               and _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2]))
-        if want_gb and will_split:               # dy is split for the gradient kernels anyway: column sums from the same pass
+        if po is not None:
+            if not (will_split and (not ctx.needs_input_grad[0] or (stride == (1, 1, 1) and _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2])))):
+                raise RuntimeError('wdno_amd: a planes-only gradient reached a convolution whose backward needs fp32 dy')
+            if want_gb:
+                gb = gb_given[:k].contiguous()
+        elif want_gb and will_split:               # dy is split for the gradient kernels anyway: column sums from the same pass
             gyplanes, gbs = split_f16_colsum(gy5.reshape(-1, kp), grec)
             gb = gbs[:k].contiguous()
         if ctx.needs_input_grad[0]:
@@ -874,8 +893,9 @@ class _Conv(torch.autograd.Function):
                     # dgrad = the same kernel on dy with flipped / transposed weights; "C" role = Kp, "K" role = Cp
                     if gyplanes is None:
                         gyplanes = split_f16(gy5.reshape(-1, kp), grec)
-                    gx5 = conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, gs5,
-                                      ks, (1, 1, 1), pd, cp)
+                    drec = _new_amax_record(gy5.device)       # dx is often the dy of the next convolution (projections on a residual path)
+                    gx5 = _leave_amax(conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, gs5,
+                                                  ks, (1, 1, 1), pd, cp, amax_rec=drec), drec)
                 else:
                     wd = pack_dgrad(weight, cp, kp)
                     gx5 = conv_fwd_raw(gy5, wd, None, gs5, ks, (1, 1, 1), pd, cp)
@@ -927,7 +947,7 @@ def _patch2_dgrad(gy5, weight, cp, kp):
     return gx
 
 
-def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None, with_skip=False):
+def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None, with_skip=False, grad_planes=False):
     """Channels-last convolution / linear layer with the reference's weight layout.
 
     x: [N, D, H, W, Cp] or [N, H, W, Cp] with a conv weight [K, C, (kd,) kh, kw]; any [..., Cp] with a 2-D
@@ -939,14 +959,14 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None, with_skip=
             return (fill,) * 3
         v = (v,) * nd if isinstance(v, int) else tuple(v)
         return (fill,) * (3 - nd) + v
-    return _Conv.apply(x, weight, bias, residual, trip(stride, 1), trip(padding, 0) if nd else (0, 0, 0), with_skip)
+    return _Conv.apply(x, weight, bias, residual, trip(stride, 1), trip(padding, 0) if nd else (0, 0, 0), with_skip, grad_planes)
 
 
-def conv_cl_skip(x, weight, bias=None, stride=1, padding=0):
+def conv_cl_skip(x, weight, bias=None, stride=1, padding=0, grad_planes=False):
     """-> (conv(x), x'): x' is x handed through the operator, for blocks whose input also feeds a skip connection
     (ResnetBlock: h = block1(x) ...; out = h + x  or  res_conv(x) + h). The gradient that comes back over x' is added in the
     epilogue of this convolution's data-gradient kernel instead of by a separate accumulation launch."""
-    return conv_cl(x, weight, bias, stride, padding, None, True)
+    return conv_cl(x, weight, bias, stride, padding, None, True, grad_planes)
 
 
 class _ConvT(torch.autograd.Function):
@@ -1036,6 +1056,7 @@ def conv_transpose_cl(x, weight, bias=None):
 class _GroupNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, ss, groups, act_silu, eps):
+        x_in = x
         x = _chk(x, 'x')
         n, c = x.shape[0], x.shape[-1]
         s = x.numel() // (n * c)
@@ -1050,6 +1071,10 @@ class _GroupNormAct(torch.autograd.Function):
                                                    float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (n, s, c, groups, int(act_silu))
+        # the convolution that produced x takes its dy as fp16 planes (conv_cl(..., grad_planes=True)): deliver dx in that form
+        c8 = c // 8
+        ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH == 'f16x3' and c % 8 == 0
+                           and c8 <= 256 and (c8 & (c8 - 1)) == 0)
         return _leave_amax(y, rec)
 
     @staticmethod
@@ -1058,11 +1083,26 @@ class _GroupNormAct(torch.autograd.Function):
         n, s, c, groups, act_silu = ctx.meta
         gy = _chk(gy, 'grad')
         lib = _lib_()
+        dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
+        dss = None if ss is None else torch.empty_like(ss)
+        if ctx.grad_planes and CONV_MATH == 'f16x3':
+            nb = lib.wdno_groupnorm_bwd_planes_ws_bytes(n, s, c, groups)
+            ws = _ws(nb, x.device)
+            hi = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
+            lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
+            cs = torch.empty((c,), device=x.device, dtype=torch.float32)
+            rec = _amax_slot(x.device)
+            scale = rec[1:2]
+            _lib.check(lib.wdno_groupnorm_act_bwd_planes(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), _p(cs),
+                                                         _p(dgb), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
+                       'groupnorm_bwd_planes')
+            dx = torch.empty_like(x)              # never written: the convolution reads the planes (and fails loudly if it cannot)
+            dx._wdno_planes_only = ((hi, lo, scale), cs, dx._version)
+            red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
+            return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None
         nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
         dx = torch.empty_like(x)
-        dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
-        dss = None if ss is None else torch.empty_like(ss)
         rec = _new_amax_record(x.device)          # dx is the dy of the convolution in front of this norm
         _lib.check(lib.wdno_groupnorm_act_bwd_amax(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(dx), _p(dgb), _p(dss), _p(rec),
                                                    n, s, c, groups, act_silu, _p(ws), nb, _stream()), 'groupnorm_bwd')
@@ -1118,9 +1158,10 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty((c,), device=x.device, dtype=torch.float32)
         add_to = None if gskip is None else _chk(gskip, 'skip gradient')
-        _lib.check(lib.wdno_layernorm_bwd_add(_p(x), _p(g.reshape(-1)), _p(gy), _p(add_to), _p(dx), _p(dg), p, c, float(ctx.eps), _p(ws), nb,
-                                              _stream()), 'layernorm_bwd')
-        return dx, dg.reshape(g.shape), None, None
+        rec = _new_amax_record(x.device)
+        _lib.check(lib.wdno_layernorm_bwd_add_amax(_p(x), _p(g.reshape(-1)), _p(gy), _p(add_to), _p(dx), _p(dg), _p(rec), p, c, float(ctx.eps),
+                                                   _p(ws), nb, _stream()), 'layernorm_bwd')
+        return _leave_amax(dx, rec), dg.reshape(g.shape), None, None
 
 
 def layernorm_cl(x, g, eps=1e-5):
