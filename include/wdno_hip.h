@@ -199,6 +199,12 @@ int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, const float* ga
  * (bound_rec: a zeroed amax record, receives the bound). dx_colsum [C] = column sums of dx (the bias gradient of that convolution).
  * C / 8 must be a power of two <= 256 (WDNO_EUNSUPPORTED otherwise: use wdno_groupnorm_act_bwd_amax + wdno_split_f16). */
 size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G);
+/* Forward with y delivered as planes (the output of block1 of a ResnetBlock, read by block2's convolution only: unet.py:103-118,
+ * conv3d.py:208-230); scale from the bound max|a| max|x| + max|b| of the folded per-channel affine. Same channel restriction. */
+size_t wdno_groupnorm_fwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G);
+int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
+                                  float* y_scale, float* stats, float* bound_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                  void* ws, size_t ws_bytes, wdno_stream_t s);
 int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
                                   const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
                                   float* dgb_partial, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
@@ -206,6 +212,10 @@ int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* 
 /* Channel LayerNorm over C of CL rows [P, C], gain only (unet.py:55-65, conv3d.py:165-174) */
 int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s);
 int wdno_layernorm_fwd_amax(const float* x, const float* g, float* y, float* amax_rec, int64_t P, int C, float eps, wdno_stream_t s);
+/* y as fp16 (hi, lo) planes for the to_qkv projection that is its only reader (PreNorm: unet.py:67-78, conv3d.py:176-184); the scale
+ * follows from |y| <= sqrt(C) max|g|, no data pass. C must be a multiple of 8. */
+int wdno_layernorm_fwd_planes(const float* x, const float* g, void* y_hi, void* y_lo, float* y_scale, int64_t P, int C, float eps,
+                              wdno_stream_t s);
 size_t wdno_layernorm_bwd_ws_bytes(int64_t P, int C);
 int wdno_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* dg, int64_t P, int C,
                        float eps, void* ws, size_t ws_bytes, wdno_stream_t s);

@@ -773,3 +773,43 @@ def test_groupnorm_backward_delivers_planes(ops, shape, k, groups, use_ss):
     assert n_ref == 1 and n_got == 0, (n_ref, n_got)          # the planes route never splits dy
     for name, a, e in zip(['dx', 'dw', 'db', 'dgamma', 'dbeta', 'dss'], got, ref):
         assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))
+
+
+def test_norm_layers_write_planes_for_the_next_convolution(ops):
+    """GroupNorm / LayerNorm with out_planes=True: the following convolution must produce the same result (to rounding) as on the
+    fp32 output, in forward and in every gradient, without a split of its input."""
+    x = g((2, 64, 4, 16, 16), 311)
+    gamma, beta = 1 + 0.2 * g((64,), 312), 0.1 * g((64,), 313)
+    ss = 0.3 * g((2, 128), 314)
+    w = g((128, 64, 3, 3, 3), 315) * 0.05
+    lg = 1 + 0.2 * g((1, 64, 1, 1, 1), 316)
+    wq = g((384, 64), 317) * 0.1
+    r1, r2 = g((2, 128, 4, 16, 16), 318), g((2, 384, 4, 16, 16), 319)
+
+    def run(flag):
+        calls = {'n': 0}
+        orig = ops.split_f16
+
+        def counting(*a, **kw):
+            calls['n'] += 1
+            return orig(*a, **kw)
+        ops.split_f16 = counting
+        try:
+            xs = dev(to_cl(x), grad=True)
+            gs, bes, sss, ws_, lgs, wqs = (dev(t, grad=True) for t in (gamma, beta, ss, w, lg, wq))
+            assert ops.conv_reads_planes(2 * 4 * 16 * 16, ws_) and ops.conv_reads_planes(2 * 4 * 16 * 16, wqs)
+            z = ops.groupnorm_act(xs, gs, bes, 8, sss, act=True, out_planes=flag)
+            y1 = ops.conv_cl(z, ws_, None, padding=1)
+            q = ops.layernorm_cl(xs, lgs, 1e-5, out_planes=flag)
+            y2 = ops.conv_cl(q, wqs)
+            ((y1 * dev(to_cl(r1))).sum() + (y2 * dev(to_cl(r2))).sum()).backward()
+        finally:
+            ops.split_f16 = orig
+        outs = [y1.detach(), y2.detach(), xs.grad, gs.grad, bes.grad, sss.grad, ws_.grad, lgs.grad, wqs.grad]
+        return [t.double().cpu() for t in outs], calls['n']
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_got == n_ref - 2, (n_ref, n_got)           # the two forward splits are gone
+    for name, a, e in zip(['y1', 'y2', 'dx', 'dgamma', 'dbeta', 'dss', 'dw', 'dlg', 'dwq'], got, ref):
+        assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))

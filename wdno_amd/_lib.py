@@ -88,6 +88,9 @@ PROTOTYPES = {
     'wdno_groupnorm_act_bwd': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_groupnorm_act_bwd_amax': (I, [P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_groupnorm_bwd_planes_ws_bytes': (Z, [L, L, I, I]),
+    'wdno_groupnorm_fwd_planes_ws_bytes': (Z, [L, L, I, I]),
+    'wdno_groupnorm_act_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
+    'wdno_layernorm_fwd_planes': (I, [P, P, P, P, P, L, I, F, P]),
     'wdno_groupnorm_act_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_layernorm_fwd': (I, [P, P, P, L, I, F, P]),
     'wdno_layernorm_fwd_amax': (I, [P, P, P, P, L, I, F, P]),

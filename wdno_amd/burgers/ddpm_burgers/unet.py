@@ -45,8 +45,8 @@ class LayerNorm(nn.Module):
         super().__init__()
         self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
 
-    def forward(self, x):
-        return ops.layernorm_cl(x, self.g, 1e-5)
+    def forward(self, x, out_planes=False):
+        return ops.layernorm_cl(x, self.g, 1e-5, out_planes)
 
 
 class PreNorm(nn.Module):
@@ -58,10 +58,12 @@ class PreNorm(nn.Module):
         self.norm = LayerNorm(dim)
 
     def forward(self, x, residual=None):
+        # the normed tensor is read by fn's to_qkv projection only: where that one takes fp16 planes, the norm writes them
+        planes = hasattr(self.fn, 'to_qkv') and ops.conv_reads_planes(x.numel() // x.shape[-1], self.fn.to_qkv.weight)
         if residual is True:
-            y, xs = ops.layernorm_cl_skip(x, self.norm.g, 1e-5)
+            y, xs = ops.layernorm_cl_skip(x, self.norm.g, 1e-5, planes)
             return self.fn(y, residual=xs)
-        return self.fn(self.norm(x), residual=residual)
+        return self.fn(self.norm(x, planes), residual=residual)
 
 
 def Upsample2d(dim, dim_out=None):
@@ -82,12 +84,12 @@ class Block(nn.Module):
         self.act = nn.SiLU()
         self.groups = groups
 
-    def forward(self, x, scale_shift=None, with_skip=False):
+    def forward(self, x, scale_shift=None, with_skip=False, out_planes=False):
         if with_skip:              # block input that also feeds the skip connection: handed through the convolution (ops.conv_cl_skip)
             x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)
-            return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps), xs
+            return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes), xs
         x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)     # x goes to the norm and nowhere else
-        return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps)
+        return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes)
 
 
 class ResnetBlock(nn.Module):
@@ -104,10 +106,12 @@ class ResnetBlock(nn.Module):
         scale_shift = None
         if exists(self.mlp) and exists(time_emb):
             scale_shift = ops.conv_cl(ops.silu(time_emb), self.mlp[1].weight, self.mlp[1].bias)   # [B, 2C] = (scale | shift)
+        # block1's output is read by block2's convolution only: where that one takes fp16 planes, the norm writes them
+        planes = ops.conv_reads_planes(x.numel() // x.shape[-1], self.block2.proj.weight)
         if ops.SKIP_FUSE:
-            h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True)
+            h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True, out_planes=planes)
         else:
-            h, xs = self.block1(x, scale_shift=scale_shift), x
+            h, xs = self.block1(x, scale_shift=scale_shift, out_planes=planes), x
         h = self.block2(h)
         if isinstance(self.res_conv, nn.Identity):
             return ops.add(h, xs)

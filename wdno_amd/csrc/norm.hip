@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
                                                           const float* __restrict__ cb /*[N][C][4]*/, const float* __restrict__ gb /*[N][G][4]*/,
                                                           double* __restrict__ part, int64_t S, int C, int cg, int G, int txp,
                                                           int64_t rows_per_chunk, int silu, float* __restrict__ mx = nullptr) {
-  // mx (MODE 1, optional): per (sample, chunk) max|dz| and max|xhat| -- what gn_bwd_finalize_kernel needs to bound |dx|
+  // mx (optional): per (sample, chunk) max|dz| and max|xhat| (MODE 1) or max|x| (MODE 0) -- what the finalize kernels need to
+  // bound |dx| / |y| before the apply pass runs
   __shared__ double red[256 * 8];
   __shared__ float redm[8];
   float m0[4] = {0.f, 0.f, 0.f, 0.f}, m1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
         float xv[4] = {v.x, v.y, v.z, v.w};
         if (MODE == 0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { s0[j] += (double)xv[j]; s1[j] += (double)xv[j] * (double)xv[j]; }
+          for (int j = 0; j < 4; ++j) { s0[j] += (double)xv[j]; s1[j] += (double)xv[j] * (double)xv[j]; m0[j] = fmaxf(m0[j], fabsf(xv[j])); }
         } else {
           const float4 d = dd[u];
           float dv[4] = {d.x, d.y, d.z, d.w};
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j * 2] = s0[j]; o[j * 2 + 1] = s1[j]; }
   }
-  if (MODE == 1 && mx) {          // block maxima of |dz| and |xhat|
+  if (mx) {                       // block maxima of |dz| and |xhat| (MODE 1) / of |x| (MODE 0)
     float a = fmaxf(fmaxf(m0[0], m0[1]), fmaxf(m0[2], m0[3])), b = fmaxf(fmaxf(m1[0], m1[1]), fmaxf(m1[2], m1[3]));
     a = wave_max(a); b = wave_max(b);
     if ((threadIdx.x & 63) == 0) { redm[(threadIdx.x >> 6) * 2] = a; redm[(threadIdx.x >> 6) * 2 + 1] = b; }
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ ss, float* __restrict__ stats_out,
                                                            float* __restrict__ cb, float* __restrict__ gb, int64_t S, int C, int G,
-                                                           int nchunk, float eps) {
+                                                           int nchunk, float eps, const float* __restrict__ mx = nullptr,
+                                                           float* __restrict__ bound_rec = nullptr) {
   __shared__ double chs[GN_MAXC], chq[GN_MAXC];
   __shared__ float gmean[GN_MAXC], grstd[GN_MAXC];
   const int n = blockIdx.x, cg = C / G;
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     float* o = gb + ((int64_t)n * G + g) * 4;
     o[0] = gmean[g]; o[1] = grstd[g]; o[2] = 0.f; o[3] = 0.f;
   }
+  float ma = 0.f, mb = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
     int g = c / cg;
     float sc1 = ss ? ss[(int64_t)n * 2 * C + c] + 1.0f : 1.0f;
@@ -205,6 +208,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     float b = (beta[c] - gmean[g] * k1) * sc1 + sh;
     float* o = cb + ((int64_t)n * C + c) * 4;
     o[0] = a; o[1] = b; o[2] = a; o[3] = 0.f;   // k1*(s+1) == a
+    ma = fmaxf(ma, fabsf(a)); mb = fmaxf(mb, fabsf(b));
+  }
+  if (bound_rec) {          // |act(a x + b)| <= max|a| max|x| + max|b|: known before the apply pass (gn_apply_planes_kernel)
+    float mxx = 0.f;
+    for (int k = threadIdx.x; k < nchunk; k += 256) mxx = fmaxf(mxx, mx[((int64_t)n * nchunk + k) * 2]);
+    __shared__ float bm[3][4];
+    float v[3] = {wave_max(ma), wave_max(mb), wave_max(mxx)};
+    if ((threadIdx.x & 63) == 0)
+      for (int q = 0; q < 3; ++q) bm[q][threadIdx.x >> 6] = v[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t[3];
+      for (int q = 0; q < 3; ++q) t[q] = fmaxf(fmaxf(bm[q][0], bm[q][1]), fmaxf(bm[q][2], bm[q][3]));
+      atomicMax(reinterpret_cast<unsigned*>(bound_rec) + (n & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE, __float_as_uint(t[0] * t[2] + t[1]));
+    }
   }
 }
 
@@ -339,10 +357,48 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   if (amax_rec) amax_record_emit(am, amax_rec, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
+// y as (hi, lo) fp16 planes (scale from the bound gn_finalize_kernel left in `rec`): the output of a Block whose only reader is the
+// next convolution. A thread owns 8 channels.
+typedef _Float16 gn_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                               _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                               float* __restrict__ scale_out, const float* __restrict__ rec,
+                                                               int64_t S, int C, int silu) {
+  const int n = blockIdx.y;
+  const int C8 = C >> 3;
+  const int64_t total8 = S * C8;
+  const float s = scale_from_amax(amax_record_read(rec));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const float* xp = x + (int64_t)n * S * C;
+  _Float16* hp = hi + (int64_t)n * S * C;
+  _Float16* lp = lo + (int64_t)n * S * C;
+  const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % C8) * 8;
+  float ka[8], kb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float4 k = cbp[c0 + j]; ka[j] = k.x; kb[j] = k.y; }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += stride) {
+    const float4 v0 = *reinterpret_cast<const float4*>(xp + i * 8), v1 = *reinterpret_cast<const float4*>(xp + i * 8 + 4);
+    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    gn_half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float o = ka[j] * xv[j] + kb[j];
+      if (silu) o = silu_f(o);
+      const float t = o * s;
+      const _Float16 th = (_Float16)t;
+      h[j] = th;
+      l[j] = (_Float16)(t - (float)th);
+    }
+    *reinterpret_cast<gn_half8*>(hp + i * 8) = h;
+    *reinterpret_cast<gn_half8*>(lp + i * 8) = l;
+  }
+}
+
 // dx as (hi, lo) fp16 planes (scale from the bound gn_bwd_finalize_kernel left in `rec`) + per-block column sums of dx (the bias
 // gradient of the convolution in front of the norm). A thread owns 8 channels: 16-byte plane stores; its channel group is fixed
 // ((gridDim.x * 256) % (C / 8) == 0), so the column sums stay in registers until the block reduces them.
-typedef _Float16 gn_half8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    const float* __restrict__ cb, const float* __restrict__ gb,
                                                                    _Float16* __restrict__ hi, _Float16* __restrict__ lo,
@@ -464,6 +520,33 @@ extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const flo
 }
 
 
+extern "C" size_t wdno_groupnorm_fwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
+  return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S) * 2 * sizeof(float) + 128;
+}
+extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
+                                             float* y_scale, float* stats, float* bound_rec, int64_t N, int64_t S, int C, int G, float eps,
+                                             int silu, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  int rc = gn_check(N, S, C, G);
+  if (rc) return rc;
+  const int C8 = C / 8;
+  if ((C & 7) || C8 > 256 || (C8 & (C8 - 1))) return WDNO_EUNSUPPORTED;
+  if (ws_bytes < wdno_groupnorm_fwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
+  const int nchunk = gn_chunks(S);
+  double* part = (double*)ws;
+  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
+  float* gb = cb + (size_t)N * C * 4;
+  float* mx = (float*)((char*)ws + ((wdno_groupnorm_ws_bytes(N, S, C, G) + 63) & ~(size_t)63));
+  const int txp = pow2ceil(C / 4);
+  const int64_t rpc = cdiv64(S, nchunk);
+  hipStream_t st = as_stream(s);
+  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, mx);
+  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, bound_rec);
+  int gx = stream_grid(S * (C / 8), 256);
+  if (gx > 512) gx = 512;
+  gn_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, S, C, silu);
+  return wdno_check_launch();
+}
+
 /* ---- backward with dx delivered as fp16 (hi, lo) planes: see include/wdno_hip.h ---- */
 static inline int gn_planes_grid(int64_t S, int C) {
   int gx = stream_grid(S * (C / 8), 256);
@@ -508,7 +591,9 @@ template <int TPR, int VPL, bool BWD>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ dy, float* __restrict__ out,
                                                          float* __restrict__ dg_part, int64_t P, int C, float eps,
-                                                         const float* __restrict__ add_to, float* __restrict__ dx_amax) {
+                                                         const float* __restrict__ add_to, float* __restrict__ dx_amax,
+                                                         _Float16* __restrict__ y_hi = nullptr, _Float16* __restrict__ y_lo = nullptr,
+                                                         float* __restrict__ y_scale = nullptr) {
   constexpr int RPB = 256 / TPR;
   __shared__ float red[BWD ? 256 * VPL * 4 : 1];
   const int C4 = C >> 2;
@@ -528,6 +613,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) dgacc[v][j] = 0.f;
   const float invC = 1.0f / (float)C;
   const int64_t rstride = (int64_t)gridDim.x * RPB;
+  float ps = 1.0f;                 // forward with planes output: |y| = |xhat g| <= sqrt(C) max|g|, a scale every block derives by itself
+  if (!BWD && y_hi) {
+    float mg = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) mg = amax4(mg, gv[v]);
+    ps = scale_from_amax(sqrtf((float)C) * group_max<TPR>(mg));
+    if (blockIdx.x == 0 && threadIdx.x == 0) y_scale[0] = ps;
+  }
   float am = 0.f;       // max|y| (forward: left in the amax record dg_part points to, if any) / max|dx| (backward: in dx_amax, if any)
   // all lanes of a row group iterate together (uniform trip count per group)
   for (int64_t r0 = (int64_t)blockIdx.x * RPB; r0 < P; r0 += rstride) {
@@ -558,6 +651,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           float4 o;
           o.x = xv[v].x * rstd * gv[v].x; o.y = xv[v].y * rstd * gv[v].y;
           o.z = xv[v].z * rstd * gv[v].z; o.w = xv[v].w * rstd * gv[v].w;
+          if (y_hi) {
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+            const float t[4] = {o.x * ps, o.y * ps, o.z * ps, o.w * ps};
+            half4v h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = (_Float16)t[j]; l[j] = (_Float16)(t[j] - (float)h[j]); }
+            reinterpret_cast<half4v*>(y_hi + r * C)[lane + v * TPR] = h;
+            reinterpret_cast<half4v*>(y_lo + r * C)[lane + v * TPR] = l;
+            continue;
+          }
           reinterpret_cast<float4*>(out + r * C)[lane + v * TPR] = o;
           am = amax4(am, o);
         }
@@ -627,11 +730,12 @@ static inline void ln_shape(int C, int& tpr, int& vpl) {
 }
 template <bool BWD>
 static int ln_launch(const float* x, const float* g, const float* dy, float* out, float* dgp, int64_t P, int C, float eps, hipStream_t st,
-                     const float* add_to = nullptr, float* dx_amax = nullptr) {
+                     const float* add_to = nullptr, float* dx_amax = nullptr, _Float16* y_hi = nullptr, _Float16* y_lo = nullptr,
+                     float* y_scale = nullptr) {
   int tpr, vpl;
   ln_shape(C, tpr, vpl);
   int nb = ln_blocks(P, 256 / tpr);
-#define LN_CASE(T, V) layernorm_kernel<T, V, BWD><<<nb, 256, 0, st>>>(x, g, dy, out, dgp, P, C, eps, add_to, dx_amax)
+#define LN_CASE(T, V) layernorm_kernel<T, V, BWD><<<nb, 256, 0, st>>>(x, g, dy, out, dgp, P, C, eps, add_to, dx_amax, y_hi, y_lo, y_scale)
   if (vpl == 1) {
     switch (tpr) {
       case 2: LN_CASE(2, 1); break;
@@ -652,6 +756,14 @@ extern "C" int wdno_layernorm_fwd_amax(const float* x, const float* g, float* y,
   WDNO_REQUIRE(P > 0 && C >= 4);
   if ((C & 3) || C > 1024) return WDNO_EUNSUPPORTED;
   int rc = ln_launch<false>(x, g, nullptr, y, amax_rec, P, C, eps, as_stream(s));
+  if (rc) return rc;
+  return wdno_check_launch();
+}
+extern "C" int wdno_layernorm_fwd_planes(const float* x, const float* g, void* y_hi, void* y_lo, float* y_scale, int64_t P, int C, float eps,
+                                         wdno_stream_t s) {
+  WDNO_REQUIRE(P > 0 && C >= 8);
+  if ((C & 7) || C > 1024) return WDNO_EUNSUPPORTED;
+  int rc = ln_launch<false>(x, g, nullptr, nullptr, nullptr, P, C, eps, as_stream(s), nullptr, nullptr, (_Float16*)y_hi, (_Float16*)y_lo, y_scale);
   if (rc) return rc;
   return wdno_check_launch();
 }

@@ -347,6 +347,7 @@ AMAX_FLOATS = 64 * 16    # WDNO_AMAX_FLOATS
 AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 
+PLANES_FWD = os.environ.get('WDNO_PLANES_FWD', '1') != '0'      # norm layers in front of a convolution write its fp16 planes (A/B switch)
 GRAD_PLANES = os.environ.get('WDNO_GRAD_PLANES', '1') != '0'    # GroupNorm backward writes the fp16 planes of dx itself (A/B switch)
 SKIP_FUSE = os.environ.get('WDNO_SKIP_FUSE', '1') != '0'      # skip connections handed through conv / LayerNorm (A/B switch)
 _CAPTURE = None          # [pool, next index] while a HIP graph is being captured through graph_capture()
@@ -685,6 +686,27 @@ def _use_h3(pixels, reduction):
     return CONV_MATH in ('f16x3', 'bf16') and pixels >= H3_MIN_PIXELS and reduction >= H3_MIN_REDUCTION
 
 
+def conv_reads_planes(pixels, weight):
+    """Will conv_cl on a CL tensor with `pixels` output pixels and this weight read its input as fp16 (hi, lo) planes (and never as
+    fp32)? Norm layers whose output feeds only such a convolution write the planes themselves (out_planes=...)."""
+    if not PLANES_FWD or CONV_MATH != 'f16x3' or weight.dim() < 2:
+        return False
+    k, c = weight.shape[0], weight.shape[1]
+    vol = 1
+    for v in weight.shape[2:]:
+        vol *= v
+    if pixels <= LINEAR_ROWS_MAX and weight.dim() == 2:
+        return False
+    return pad4(c) % 8 == 0 and _use_h3(pixels, pad4(c) * vol)
+
+
+def _planes_only(t, planes):
+    """Mark t (allocated, never written) as existing only as planes."""
+    t._wdno_planes = (planes, t._version, CONV_MATH)
+    t._wdno_unwritten = True
+    return t
+
+
 def _out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
@@ -831,6 +853,10 @@ class _Conv(torch.autograd.Function):
             res5 = residual
         osp_ = tuple(_out_size(a, kk, s_, p_) for a, kk, s_, p_ in zip(x5.shape[1:4], ks, stride, padding))
         h3 = _use_h3(x5.shape[0] * osp_[0] * osp_[1] * osp_[2], cp * ks[0] * ks[1] * ks[2])
+        if getattr(x_in, '_wdno_unwritten', False):
+            hp = getattr(x_in, '_wdno_planes', None)
+            if not (h3 and hp is not None and hp[1] == x_in._version and hp[2] == CONV_MATH):
+                raise RuntimeError('wdno_amd: a planes-only tensor reached a convolution that reads fp32')
         if h3:
             planes = split_f16_of(x_in, x5.reshape(-1, cp), xrec)
             yrec = _new_amax_record(x5.device)
@@ -1055,7 +1081,7 @@ def conv_transpose_cl(x, weight, bias=None):
 # ----------------------------------------------------------------------------------------------------- normalisation
 class _GroupNormAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, ss, groups, act_silu, eps):
+    def forward(ctx, x, gamma, beta, ss, groups, act_silu, eps, out_planes=False):
         x_in = x
         x = _chk(x, 'x')
         n, c = x.shape[0], x.shape[-1]
@@ -1066,6 +1092,20 @@ class _GroupNormAct(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
         ssc = None if ss is None else _chk(ss, 'scale_shift')
+        c8_ = c // 8
+        if out_planes and CONV_MATH == 'f16x3' and c % 8 == 0 and c8_ <= 256 and (c8_ & (c8_ - 1)) == 0:
+            nbp = lib.wdno_groupnorm_fwd_planes_ws_bytes(n, s, c, groups)
+            wsp = _ws(nbp, x.device)
+            hi = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
+            lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
+            brec = _amax_slot(x.device)
+            scale = brec[1:2]
+            _lib.check(lib.wdno_groupnorm_act_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(hi), _p(lo), _p(scale), _p(stats), _p(brec),
+                                                         n, s, c, groups, float(eps), int(act_silu), _p(wsp), nbp, _stream()), 'groupnorm_fwd_planes')
+            ctx.save_for_backward(x, gamma, beta, ssc, stats)
+            ctx.meta = (n, s, c, groups, int(act_silu))
+            ctx.grad_planes = GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False)
+            return _planes_only(y, (hi, lo, scale))
         rec = _new_amax_record(x.device)
         _lib.check(lib.wdno_groupnorm_act_fwd_amax(_p(x), _p(gamma), _p(beta), _p(ssc), _p(y), _p(stats), _p(rec), n, s, c, groups,
                                                    float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
@@ -1099,7 +1139,7 @@ class _GroupNormAct(torch.autograd.Function):
             dx = torch.empty_like(x)              # never written: the convolution reads the planes (and fails loudly if it cannot)
             dx._wdno_planes_only = ((hi, lo, scale), cs, dx._version)
             red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
-            return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None
+            return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None, None
         nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
         dx = torch.empty_like(x)
@@ -1107,12 +1147,13 @@ class _GroupNormAct(torch.autograd.Function):
         _lib.check(lib.wdno_groupnorm_act_bwd_amax(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(dx), _p(dgb), _p(dss), _p(rec),
                                                    n, s, c, groups, act_silu, _p(ws), nb, _stream()), 'groupnorm_bwd')
         red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
-        return _leave_amax(dx, rec), red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None
+        return _leave_amax(dx, rec), red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None, None
 
 
-def groupnorm_act(x, gamma, beta, groups, scale_shift=None, act=True, eps=1e-5):
-    """CL GroupNorm -> optional x*(scale+1)+shift with scale_shift [N, 2C] -> optional SiLU."""
-    return _GroupNormAct.apply(x, gamma, beta, scale_shift, groups, act, eps)
+def groupnorm_act(x, gamma, beta, groups, scale_shift=None, act=True, eps=1e-5, out_planes=False):
+    """CL GroupNorm -> optional x*(scale+1)+shift with scale_shift [N, 2C] -> optional SiLU. out_planes: the caller states that the
+    result is read by one convolution that takes fp16 planes (conv_reads_planes) and by nothing else."""
+    return _GroupNormAct.apply(x, gamma, beta, scale_shift, groups, act, eps, out_planes)
 
 
 def _alias_of(x):
@@ -1131,13 +1172,22 @@ def _alias_of(x):
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, g, eps, with_skip):
+    def forward(ctx, x, g, eps, with_skip, out_planes=False):
         x_in = x
         x = _chk(x, 'x')
         c = x.shape[-1]
         p = x.numel() // c
         y = torch.empty_like(x)
         gf = g.reshape(-1)
+        if out_planes and CONV_MATH == 'f16x3' and c % 8 == 0:
+            hi = torch.empty((p, c), device=x.device, dtype=torch.float16)
+            lo = torch.empty((p, c), device=x.device, dtype=torch.float16)
+            scale = torch.empty((1,), device=x.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_layernorm_fwd_planes(_p(x), _p(gf), _p(hi), _p(lo), _p(scale), p, c, float(eps), _stream()), 'layernorm_fwd_planes')
+            ctx.save_for_backward(x, g)
+            ctx.eps = eps
+            y = _planes_only(y, (hi, lo, scale))
+            return (y, _alias_of(x_in)) if with_skip else y
         rec = _new_amax_record(x.device)
         _lib.check(_lib_().wdno_layernorm_fwd_amax(_p(x), _p(gf), _p(y), _p(rec), p, c, float(eps), _stream()), 'layernorm_fwd')
         ctx.save_for_backward(x, g)
@@ -1161,18 +1211,19 @@ class _LayerNorm(torch.autograd.Function):
         rec = _new_amax_record(x.device)
         _lib.check(lib.wdno_layernorm_bwd_add_amax(_p(x), _p(g.reshape(-1)), _p(gy), _p(add_to), _p(dx), _p(dg), _p(rec), p, c, float(ctx.eps),
                                                    _p(ws), nb, _stream()), 'layernorm_bwd')
-        return _leave_amax(dx, rec), dg.reshape(g.shape), None, None
+        return _leave_amax(dx, rec), dg.reshape(g.shape), None, None, None
 
 
-def layernorm_cl(x, g, eps=1e-5):
-    """Channel LayerNorm over the last (channel) axis of a CL tensor; g is the reference's [1, C, 1, 1(, 1)] gain."""
-    return _LayerNorm.apply(x, g, eps, False)
+def layernorm_cl(x, g, eps=1e-5, out_planes=False):
+    """Channel LayerNorm over the last (channel) axis of a CL tensor; g is the reference's [1, C, 1, 1(, 1)] gain. out_planes: see
+    groupnorm_act."""
+    return _LayerNorm.apply(x, g, eps, False, out_planes)
 
 
-def layernorm_cl_skip(x, g, eps=1e-5):
+def layernorm_cl_skip(x, g, eps=1e-5, out_planes=False):
     """-> (LayerNorm(x), x'): x' is x handed through the operator, for Residual(PreNorm(fn)): fn(norm(x), residual=x'). The gradient
     that comes back over x' is added inside the LayerNorm backward kernel (dx += skip) instead of by a separate launch."""
-    return _LayerNorm.apply(x, g, eps, True)
+    return _LayerNorm.apply(x, g, eps, True, out_planes)
 
 
 # ----------------------------------------------------------------------------------------------------- attention

@@ -76,8 +76,8 @@ class LayerNorm(nn.Module):
         self.eps = eps
         self.gamma = nn.Parameter(torch.ones(1, dim, 1, 1, 1))
 
-    def forward(self, x):
-        return ops.layernorm_cl(x, self.gamma, self.eps)
+    def forward(self, x, out_planes=False):
+        return ops.layernorm_cl(x, self.gamma, self.eps, out_planes)
 
 
 class Residual(nn.Module):
@@ -100,10 +100,13 @@ class PreNorm(nn.Module):
         self.norm = LayerNorm(dim)
 
     def forward(self, x, residual=None, **kwargs):
+        # the normed tensor is read by fn's to_qkv projection only: where that one takes fp16 planes, the norm writes them
+        att = self.fn if hasattr(self.fn, 'to_qkv') else getattr(self.fn, 'fn', None)
+        planes = hasattr(att, 'to_qkv') and ops.conv_reads_planes(x.numel() // x.shape[-1], att.to_qkv.weight)
         if residual is True:
-            y, xs = ops.layernorm_cl_skip(x, self.norm.gamma, self.norm.eps)
+            y, xs = ops.layernorm_cl_skip(x, self.norm.gamma, self.norm.eps, planes)
             return self.fn(y, residual=xs, **kwargs)
-        return self.fn(self.norm(x), residual=residual, **kwargs)
+        return self.fn(self.norm(x, planes), residual=residual, **kwargs)
 
 
 class Block(nn.Module):
@@ -114,12 +117,12 @@ class Block(nn.Module):
         self.act = nn.SiLU()
         self.groups = groups
 
-    def forward(self, x, scale_shift=None, with_skip=False):
+    def forward(self, x, scale_shift=None, with_skip=False, out_planes=False):
         if with_skip:              # block input that also feeds the skip connection: handed through the convolution (ops.conv_cl_skip)
             x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)
-            return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps), xs
+            return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes), xs
         x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)     # x goes to the norm and nowhere else
-        return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps)
+        return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes)
 
 
 class ResnetBlock(nn.Module):
@@ -136,10 +139,12 @@ class ResnetBlock(nn.Module):
             assert exists(time_emb), 'time emb must be passed in'
             # [B, 2*C]: first half = scale, second half = shift (chunk(2, dim=1) in the reference)
             scale_shift = ops.conv_cl(ops.silu(time_emb), self.mlp[1].weight, self.mlp[1].bias)
+        # block1's output is read by block2's convolution only: where that one takes fp16 planes, the norm writes them
+        planes = ops.conv_reads_planes(x.numel() // x.shape[-1], self.block2.proj.weight)
         if ops.SKIP_FUSE:
-            h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True)
+            h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True, out_planes=planes)
         else:
-            h, xs = self.block1(x, scale_shift=scale_shift), x
+            h, xs = self.block1(x, scale_shift=scale_shift, out_planes=planes), x
         h = self.block2(h)
         if isinstance(self.res_conv, nn.Identity):
             return ops.add(h, xs)
