@@ -250,6 +250,12 @@ int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const float* rot_
 int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                        const float* dout, float* dqkv, float* dbias, float* amax_rec, const wdno_attn_desc* d, float scale,
                        wdno_stream_t s);
+/* The same with dqkv delivered as fp16 (hi, lo) planes [rows][3*heads*32] for the gradient kernels of the qkv projection (its only
+ * reader: conv3d.py:232-300). The scale is derived in the kernel from the amax records of qkv and dout (an upper bound of max|dqkv|,
+ * see csrc/attention.hip) and left in dqkv_scale[0]. n_tok <= 32 only (WDNO_EUNSUPPORTED otherwise). */
+int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                         const float* dout, void* dqkv_hi, void* dqkv_lo, float* dqkv_scale, float* dbias,
+                         const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, wdno_stream_t s);
 /* Linear attention (unet.py:203-223 ; conv3d.py:241-258): q softmax over the 32 head channels, k softmax over
  * tokens, ctx = k^T v, out = ctx^T q * scale. units x n_tok rows, contiguous. ws holds k statistics and ctx. */
 size_t wdno_linattn_ws_bytes(int64_t units, int heads);
@@ -261,6 +267,11 @@ int wdno_linattn_fwd_amax(const float* qkv, float* out, float* kstats, float* ct
                           float scale, wdno_stream_t s);
 int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const float* kstats, const float* ctx, float* dqkv, float* amax_rec,
                           void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
+/* The same with dqkv delivered as fp16 (hi, lo) planes (see wdno_attn_bwd_planes); the scale bound uses the amax records of qkv and
+ * dout and the measured max|dctx| (rec_dctx: a zeroed record the call fills). */
+int wdno_linattn_bwd_planes(const float* qkv, const float* dout, const float* kstats, const float* ctx, void* dqkv_hi, void* dqkv_lo,
+                            float* dqkv_scale, const float* rec_qkv, const float* rec_dout, float* rec_dctx, void* ws, size_t ws_bytes,
+                            int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 
 /* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]
  * (nn.Embedding weight) and bucket [n, n] int64 (host-built integer table); and dW from d(bias). One launch each. */

@@ -813,3 +813,70 @@ def test_norm_layers_write_planes_for_the_next_convolution(ops):
     assert n_got == n_ref - 2, (n_ref, n_got)           # the two forward splits are gone
     for name, a, e in zip(['y1', 'y2', 'dx', 'dgamma', 'dbeta', 'dss', 'dw', 'dlg', 'dwq'], got, ref):
         assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))
+
+
+def test_attention_backward_delivers_planes(ops):
+    """to_qkv -> temporal softmax attention -> to_out with conv_cl(grad_planes=True) on the qkv projection: the attention backward
+    writes dqkv as fp16 planes (scale from the amax records of qkv and dout); gradients must agree with the fp32 route."""
+    b, f, h, w, c, heads = 2, 8, 16, 16, 64, 4
+    x = g((b, c, f, h, w), 321)
+    wq = g((3 * heads * 32, c), 322) * 0.2
+    wo = g((c, heads * 32), 323) * 0.1
+    r = g((b, c, f, h, w), 324)
+
+    def run(flag):
+        calls = {'n': 0}
+        orig = ops.split_f16
+
+        def counting(*a, **kw):
+            calls['n'] += 1
+            return orig(*a, **kw)
+        ops.split_f16 = counting
+        try:
+            xs, wqs, wos = dev(to_cl(x), grad=True), dev(wq, grad=True), dev(wo, grad=True)
+            rows = ops.conv_cl(xs, wqs, grad_planes=flag)
+            out = ops.softmax_attention(rows, heads, b, h * w, f, f * h * w, 1, h * w, 32 ** -0.5)
+            y = ops.conv_cl(out, wos)
+            (y * dev(to_cl(r))).sum().backward()
+        finally:
+            ops.split_f16 = orig
+        return [t.double().cpu() for t in (xs.grad, wqs.grad, wos.grad)], calls['n']
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_got == n_ref - 1, (n_ref, n_got)           # dqkv is never split
+    for name, a, e in zip(['dx', 'dwq', 'dwo'], got, ref):
+        assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))
+
+
+def test_linear_attention_backward_delivers_planes(ops):
+    """to_qkv -> spatial linear attention -> to_out, dqkv as fp16 planes (scale bound from the records of qkv, dout and the measured dctx)."""
+    b, f, h, w, c, heads = 2, 3, 16, 16, 64, 4
+    x = g((b, c, f, h, w), 331)
+    wq = g((3 * heads * 32, c), 332) * 0.3
+    wo = g((c, heads * 32), 333) * 0.1
+    r = g((b, c, f, h, w), 334)
+
+    def run(flag):
+        calls = {'n': 0}
+        orig = ops.split_f16
+
+        def counting(*a, **kw):
+            calls['n'] += 1
+            return orig(*a, **kw)
+        ops.split_f16 = counting
+        try:
+            xs, wqs, wos = dev(to_cl(x), grad=True), dev(wq, grad=True), dev(wo, grad=True)
+            qkv = ops.conv_cl(xs, wqs, grad_planes=flag)
+            out = ops.linear_attention(qkv, b * f, h * w, heads, 32 ** -0.5)
+            y = ops.conv_cl(out, wos)
+            (y * dev(to_cl(r))).sum().backward()
+        finally:
+            ops.split_f16 = orig
+        return [t.double().cpu() for t in (xs.grad, wqs.grad, wos.grad)], calls['n']
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_got == n_ref - 1, (n_ref, n_got)
+    for name, a, e in zip(['dx', 'dwq', 'dwo'], got, ref):
+        assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))

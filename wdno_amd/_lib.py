@@ -102,11 +102,13 @@ PROTOTYPES = {
     'wdno_attn_bwd': (I, [P, P, P, P, P, P, P, P, PA, F, P]),
     'wdno_attn_fwd_amax': (I, [P, P, P, P, P, P, PA, F, P]),
     'wdno_attn_bwd_amax': (I, [P, P, P, P, P, P, P, P, P, PA, F, P]),
+    'wdno_attn_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, PA, F, P]),
     'wdno_linattn_ws_bytes': (Z, [L, I]),
     'wdno_linattn_fwd': (I, [P, P, P, P, L, I, I, F, P]),
     'wdno_linattn_bwd': (I, [P, P, P, P, P, P, Z, L, I, I, F, P]),
     'wdno_linattn_fwd_amax': (I, [P, P, P, P, P, L, I, I, F, P]),
     'wdno_linattn_bwd_amax': (I, [P, P, P, P, P, P, P, Z, L, I, I, F, P]),
+    'wdno_linattn_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, Z, L, I, I, F, P]),
     'wdno_act_fwd': (I, [P, P, L, I, P]),
     'wdno_act_bwd': (I, [P, P, P, L, I, P]),
     'wdno_linear_rows_fwd': (I, [P, I, P, I, P, P, I, I, I, I, P]),

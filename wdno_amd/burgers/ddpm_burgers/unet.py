@@ -131,7 +131,7 @@ class LinearAttention(nn.Module):
 
     def forward(self, x, residual=None):
         b, h, w, _ = x.shape
-        qkv = ops.conv_cl(x, self.to_qkv.weight)
+        qkv = ops.conv_cl(x, self.to_qkv.weight, grad_planes=True)         # read by the attention kernels only
         out = ops.linear_attention(qkv, b, h * w, self.heads, self.scale)
         out = ops.conv_cl(out, self.to_out[0].weight, self.to_out[0].bias)
         out = self.to_out[1](out)
@@ -151,7 +151,7 @@ class Attention(nn.Module):
 
     def forward(self, x, residual=None):
         b, h, w, _ = x.shape
-        qkv = ops.conv_cl(x, self.to_qkv.weight)
+        qkv = ops.conv_cl(x, self.to_qkv.weight, grad_planes=True)         # read by the attention kernels only
         out = ops.softmax_attention(qkv, self.heads, b, 1, h * w, h * w, 0, 1, self.scale)
         return ops.conv_cl(out, self.to_out.weight, self.to_out.bias, residual=residual)
 

@@ -28,7 +28,20 @@ struct AttnP {
   int kst;  // LDS floats per item for one [n][32] matrix (padded)
   int64_t n_items;
   float* amax_rec;   // optional amax record (common.h) of the tensor the kernel writes: out (forward), dqkv (backward)
+  // backward with dqkv delivered as fp16 (hi, lo) planes (wdno_attn_bwd_planes): the plane pointers, the amax records of qkv and
+  // dout the scale bound is derived from, and where the scale is left
+  _Float16* pl_hi; _Float16* pl_lo; const float* rec_qkv; const float* rec_dout; float* pl_scale;
 };
+// dqkv as planes: store 4 consecutive values of row `row` (element offset inside the [rows][RW] tensor)
+__device__ __forceinline__ void am_store4_planes(_Float16* hi, _Float16* lo, int64_t off, float4 v, float s) {
+  typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+  const float t[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  half4v h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { h[j] = (_Float16)t[j]; l[j] = (_Float16)(t[j] - (float)h[j]); }
+  *reinterpret_cast<half4v*>(hi + off) = h;
+  *reinterpret_cast<half4v*>(lo + off) = l;
+}
 
 #define ATT_THREADS 256
 #define ATT_BWD_THREADS 128
@@ -426,6 +439,15 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
   }
   const bool tok = li < n;
   float am = 0.f;                                    // max |dqkv| this lane has stored
+  // Planes output: with A = max|qkv|, G = max|dout|, P row sums 1:  |dV| <= n G;  |dP| <= 32 G A;  sum_j |dS_ij| <= 2 * 32 G A and
+  // sum_i |dS_ij| <= n * that;  |dK| <= sqrt2 * scale * n * 64 G A^2 (the rotation keeps pair norms), |dQ| the same without n.
+  // A bound this loose (2^10 and more above the true maximum) still leaves the planes ~2^-28 max|dqkv| accurate: DESIGN.md.
+  float ps = 1.0f;
+  if (p.pl_hi) {
+    const float A = amax_record_read(p.rec_qkv), G = amax_record_read(p.rec_dout);
+    ps = scale_from_amax(1.01f * fmaxf((float)n * G, 1.4143f * p.scale * (float)n * 64.f * G * A * A));
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.pl_scale[0] = ps;
+  }
   for (int64_t item = (int64_t)blockIdx.x * AM_WAVES + wave; item < p.n_items; item += (int64_t)gridDim.x * AM_WAVES) {
     const int h = (int)(item % p.d.heads);
     const int64_t unit = item / p.d.heads;
@@ -435,6 +457,7 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
     const float* gb = am_uniform(dout + row0 * p.HD + h * DH);
     const float* fb = am_uniform(fout + row0 * p.HD + h * DH);
     float* db = const_cast<float*>(am_uniform(dqkv + row0 * p.RW + h * DH));
+    const int64_t pbase = row0 * p.RW + h * DH;                        // the same element offset inside the planes
     const unsigned lrow = (unsigned)(tok ? li : 0);
     // key / query index of step m for this lane = 8*(m>>2) + (m&3) + hz with hz = 4*hh, made opaque per item: otherwise the
     // compiler hoists all 48 per-lane row offsets (as 64-bit pairs) out of the item loop and the kernel needs 270 registers
@@ -527,7 +550,8 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
           const int d0 = 8 * e4 + 4 * hh;
           float4 gq = am_unrotate4(make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]), rcos ? rcos + li * DH : nullptr, rsin ? rsin + li * DH : nullptr, d0);
           gq = make_float4(gq.x * p.scale, gq.y * p.scale, gq.z * p.scale, gq.w * p.scale);
-          *reinterpret_cast<float4*>(drow + d0) = gq;
+          if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride) + d0, gq, ps);
+          else *reinterpret_cast<float4*>(drow + d0) = gq;
           am = amax4(am, gq);
         }
       }
@@ -567,7 +591,8 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
           const float4 gk = am_unrotate4(make_float4(dk[4 * e4], dk[4 * e4 + 1], dk[4 * e4 + 2], dk[4 * e4 + 3]), rcos ? rcos + li * DH : nullptr, rsin ? rsin + li * DH : nullptr, d0);
-          *reinterpret_cast<float4*>(drow + d0) = gk;
+          if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride + (unsigned)p.HD) + d0, gk, ps);
+          else *reinterpret_cast<float4*>(drow + d0) = gk;
           am = amax4(am, gk);
         }
       }
@@ -600,7 +625,8 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const float4 gv = make_float4(dv[4 * e4], dv[4 * e4 + 1], dv[4 * e4 + 2], dv[4 * e4 + 3]);
-          *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = gv;
+          if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride + (unsigned)(2 * p.HD)) + 8 * e4 + 4 * hh, gv, ps);
+          else *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = gv;
           am = amax4(am, gv);
         }
       }
@@ -623,6 +649,7 @@ static int attn_fill(AttnP& p, const wdno_attn_desc* d, float scale, int threads
   p.kst = d->n_tok * DH + 8;          // +8 floats: items start on different 32-byte LDS slots
   p.n_items = (int64_t)d->n_uo * d->n_ui * d->heads;
   p.amax_rec = nullptr;
+  p.pl_hi = p.pl_lo = nullptr; p.rec_qkv = p.rec_dout = nullptr; p.pl_scale = nullptr;
   return WDNO_OK;
 }
 extern "C" int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
@@ -685,6 +712,22 @@ extern "C" int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const 
     return wdno_check_launch();
   }
   return attn_amax_sweep(attn_bwd_rows(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p, d, s), dqkv, d, p.RW, amax_rec, s);
+}
+// dqkv as fp16 planes for the qkv projection's gradient kernels (MFMA path only: n_tok <= 32)
+extern "C" int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
+                                    const float* dout, void* dqkv_hi, void* dqkv_lo, float* dqkv_scale, float* dbias,
+                                    const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, wdno_stream_t s) {
+  AttnP p;
+  int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
+  if (rc) return rc;
+  const int n = d->n_tok;
+  if (n > 32 || !dqkv_hi || !dqkv_lo || !dqkv_scale || !rec_qkv || !rec_dout) return WDNO_EUNSUPPORTED;
+  size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
+  int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
+  if (nb > 2048) nb = 2048;
+  p.pl_hi = (_Float16*)dqkv_hi; p.pl_lo = (_Float16*)dqkv_lo; p.rec_qkv = rec_qkv; p.rec_dout = rec_dout; p.pl_scale = dqkv_scale;
+  attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, nullptr, dbias, p);
+  return wdno_check_launch();
 }
 static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, float* dqkv, float* dbias, AttnP& p, const wdno_attn_desc* d, wdno_stream_t s) {
@@ -1003,7 +1046,10 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
                                                                        const float* __restrict__ kstats, const float* __restrict__ ctx,
                                                                        const float* __restrict__ dctx, const float* __restrict__ tvec,
                                                                        float* __restrict__ dqkv, int n, int heads, float scale,
-                                                                       float* __restrict__ amax_rec) {
+                                                                       float* __restrict__ amax_rec, _Float16* __restrict__ pl_hi = nullptr,
+                                                                       _Float16* __restrict__ pl_lo = nullptr, const float* __restrict__ rec_qkv = nullptr,
+                                                                       const float* __restrict__ rec_dout = nullptr,
+                                                                       const float* __restrict__ rec_dctx = nullptr, float* __restrict__ pl_scale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
   float* Tc = lsm;                       // ctx  [d][e]
   float* Td = Tc + LAM_TILE;             // dctx [d][e]
@@ -1033,6 +1079,14 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
   }
   __syncthreads();
   float am = 0.f;
+  // Planes output (wdno_linattn_bwd_planes): with A = max|qkv|, G = max|dout|, D = max|dctx| (measured), ks, qsm <= 1 and |ctx| <= A:
+  // |dq| <= 2 scale 32 A G,  |dk| <= 2 * 32 A D,  |dv| <= 32 D.
+  float ps = 1.0f;
+  if (pl_hi) {
+    const float A = amax_record_read(rec_qkv), G = amax_record_read(rec_dout), D = amax_record_read(rec_dctx);
+    ps = scale_from_amax(1.01f * fmaxf(64.f * scale * A * G, fmaxf(64.f * A * D, 32.f * D)));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) pl_scale[0] = ps;
+  }
   const int t0 = (blockIdx.y * 4 + wave) * 32;
   if (t0 < n) {                                     // (no block-wide barrier below)
     const int nv = min(32, n - t0);
@@ -1041,6 +1095,7 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
     const float* qb = am_uniform(qkv + row0 * RW + h * DH);
     const float* gb = am_uniform(dout + row0 * HD + h * DH);
     float* db = const_cast<float*>(am_uniform(dqkv + row0 * RW + h * DH)) + (unsigned)(tok ? li : 0) * (unsigned)RW;
+    const int64_t pbase = row0 * RW + h * DH + (int64_t)((unsigned)(tok ? li : 0) * (unsigned)RW);
     am_stage_rows(T1, qb, (unsigned)RW, nullptr, nullptr, 1.0f, nv, lane);
     am_stage_rows(T2, qb + HD, (unsigned)RW, nullptr, nullptr, 1.0f, nv, lane);
     am_stage_rows(T3, qb + 2 * HD, (unsigned)RW, nullptr, nullptr, 1.0f, nv, lane);
@@ -1084,7 +1139,10 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
       for (int e4 = 0; e4 < 4; ++e4) {
         const float4 v = make_float4(scale * qsm[4 * e4] * (acc[4 * e4] - dot), scale * qsm[4 * e4 + 1] * (acc[4 * e4 + 1] - dot),
                                      scale * qsm[4 * e4 + 2] * (acc[4 * e4 + 2] - dot), scale * qsm[4 * e4 + 3] * (acc[4 * e4 + 3] - dot));
-        if (tok) *reinterpret_cast<float4*>(db + 8 * e4 + 4 * hh) = v;
+        if (tok) {
+          if (pl_hi) am_store4_planes(pl_hi, pl_lo, pbase + 8 * e4 + 4 * hh, v, ps);
+          else *reinterpret_cast<float4*>(db + 8 * e4 + 4 * hh) = v;
+        }
         am = amax4(am, v);
       }
     }
@@ -1105,7 +1163,10 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
         const float4 t4 = *reinterpret_cast<const float4*>(tv + d0);
         const float4 v = make_float4(expf(kk.x - m4.x) * l4.x * (acc[4 * e4] - t4.x), expf(kk.y - m4.y) * l4.y * (acc[4 * e4 + 1] - t4.y),
                                      expf(kk.z - m4.z) * l4.z * (acc[4 * e4 + 2] - t4.z), expf(kk.w - m4.w) * l4.w * (acc[4 * e4 + 3] - t4.w));
-        if (tok) *reinterpret_cast<float4*>(db + HD + d0) = v;
+        if (tok) {
+          if (pl_hi) am_store4_planes(pl_hi, pl_lo, pbase + HD + d0, v, ps);
+          else *reinterpret_cast<float4*>(db + HD + d0) = v;
+        }
         am = amax4(am, v);
       }
     }
@@ -1125,7 +1186,10 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const float4 v = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
-        if (tok) *reinterpret_cast<float4*>(db + 2 * HD + 8 * e4 + 4 * hh) = v;
+        if (tok) {
+          if (pl_hi) am_store4_planes(pl_hi, pl_lo, pbase + 2 * HD + 8 * e4 + 4 * hh, v, ps);
+          else *reinterpret_cast<float4*>(db + 2 * HD + 8 * e4 + 4 * hh) = v;
+        }
         am = amax4(am, v);
       }
     }
@@ -1253,5 +1317,29 @@ extern "C" int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const 
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)linattn_bwd_tok_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   linattn_bwd_tok_kernel<<<dim3((unsigned)units, (unsigned)cdiv(n_tok, 64)), 64 * heads, lds, st>>>(qkv, dout, kstats, ctx, dctx, tvec, dqkv,
                                                                                                 n_tok, heads, scale, amax_rec);
+  return wdno_check_launch();
+}
+
+// dqkv as fp16 planes for the gradient kernels of the qkv projection (MFMA token kernel only). rec_dctx: a zeroed amax record, receives
+// max|dctx| (a sweep over the small dctx tensor between the two launches).
+extern "C" int wdno_linattn_bwd_planes(const float* qkv, const float* dout, const float* kstats, const float* ctx, void* dqkv_hi,
+                                       void* dqkv_lo, float* dqkv_scale, const float* rec_qkv, const float* rec_dout, float* rec_dctx,
+                                       void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s) {
+  int rc = la_check(units, n_tok, heads);
+  if (rc) return rc;
+  if (!dqkv_hi || !dqkv_lo || !dqkv_scale || !rec_qkv || !rec_dout || !rec_dctx) return WDNO_EINVAL;
+  if (ws_bytes < wdno_linattn_ws_bytes(units, heads)) return WDNO_EWORKSPACE;
+  hipStream_t st = as_stream(s);
+  float* dctx = (float*)ws;
+  float* tvec = dctx + (size_t)units * heads * DH * DH;
+  linattn_ctx_kernel<1><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, dout, nullptr, ctx, dctx, tvec, n_tok, heads, scale);
+  rc = wdno_amax_record(dctx, (int64_t)units * heads * DH * DH, rec_dctx, s);
+  if (rc) return rc;
+  const size_t lds2 = ((size_t)(2 + 4 * 3) * LAM_TILE + 3 * DH) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)linattn_bwd_tok_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done = true; }
+  linattn_bwd_tok_mfma_kernel<<<dim3((unsigned)(units * heads), (unsigned)cdiv(n_tok, 128)), 256, lds2, st>>>(
+      qkv, dout, kstats, ctx, dctx, tvec, nullptr, n_tok, heads, scale, nullptr, (_Float16*)dqkv_hi, (_Float16*)dqkv_lo, rec_qkv, rec_dout, rec_dctx,
+      dqkv_scale);
   return wdno_check_launch();
 }

@@ -1230,6 +1230,7 @@ def layernorm_cl_skip(x, g, eps=1e-5, out_planes=False):
 class _Attn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, bias, rot_cos, rot_sin, desc_args, scale):
+        qkv_in = qkv
         qkv = _chk(qkv, 'qkv')
         heads = desc_args[3]
         out = torch.empty((*qkv.shape[:-1], heads * 32), device=qkv.device, dtype=torch.float32)
@@ -1240,18 +1241,30 @@ class _Attn(torch.autograd.Function):
                    'attn_fwd')
         ctx.save_for_backward(qkv, bc, rot_cos, rot_sin, out)
         ctx.meta = (desc_args, scale)
+        # the projection that produced qkv takes its dy as planes (conv_cl(..., grad_planes=True)) and left the amax of qkv
+        ctx.qrec = _known_amax(qkv_in) if (GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False) and desc_args[2] <= 32) else None
         return _leave_amax(out, rec)
 
     @staticmethod
     def backward(ctx, go):
         qkv, bias, rot_cos, rot_sin, fout = ctx.saved_tensors
         desc_args, scale = ctx.meta
+        grec = _known_amax(go)
         go = _chk(go, 'grad')
         dqkv = torch.empty_like(qkv)
         dbias = None
         if bias is not None and ctx.needs_input_grad[1]:
             dbias = torch.zeros_like(bias)
         d = AttnDesc(*desc_args)
+        if ctx.qrec is not None and grec is not None and CONV_MATH == 'f16x3':
+            rows, rw = qkv.numel() // qkv.shape[-1], qkv.shape[-1]
+            hi = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
+            lo = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
+            sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_attn_bwd_planes(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(hi), _p(lo), _p(sc),
+                                                    _p(dbias), _p(ctx.qrec), _p(grec), C.byref(d), float(scale), _stream()), 'attn_bwd_planes')
+            dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version)      # dqkv itself stays unwritten
+            return dqkv, dbias, None, None, None, None
         rec = _new_amax_record(qkv.device)        # dqkv is the dy of the qkv projection
         _lib.check(_lib_().wdno_attn_bwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(dqkv), _p(dbias), _p(rec),
                                               C.byref(d), float(scale), _stream()), 'attn_bwd')
@@ -1269,6 +1282,7 @@ def softmax_attention(qkv, heads, n_uo, n_ui, n_tok, so, si, st, scale, bias=Non
 class _LinAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, units, n_tok, heads, scale):
+        qkv_in = qkv
         qkv = _chk(qkv, 'qkv')
         hd = heads * 32
         out = torch.empty((*qkv.shape[:-1], hd), device=qkv.device, dtype=torch.float32)
@@ -1279,17 +1293,29 @@ class _LinAttn(torch.autograd.Function):
                    'linattn_fwd')
         ctx.save_for_backward(qkv, kstats, cx)
         ctx.meta = (units, n_tok, heads, scale)
+        ctx.qrec = _known_amax(qkv_in) if (GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False)) else None      # see _Attn
         return _leave_amax(out, rec)
 
     @staticmethod
     def backward(ctx, go):
         qkv, kstats, cx = ctx.saved_tensors
         units, n_tok, heads, scale = ctx.meta
+        grec = _known_amax(go)
         go = _chk(go, 'grad')
         lib = _lib_()
         nb = lib.wdno_linattn_ws_bytes(units, heads)
         ws = _ws(nb, qkv.device)
         dqkv = torch.empty_like(qkv)
+        if ctx.qrec is not None and grec is not None and CONV_MATH == 'f16x3':
+            rows, rw = qkv.numel() // qkv.shape[-1], qkv.shape[-1]
+            hi = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
+            lo = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
+            drec = _amax_slot(qkv.device)
+            sc = drec[1:2]
+            _lib.check(lib.wdno_linattn_bwd_planes(_p(qkv), _p(go), _p(kstats), _p(cx), _p(hi), _p(lo), _p(sc), _p(ctx.qrec), _p(grec), _p(drec),
+                                                   _p(ws), nb, units, n_tok, heads, float(scale), _stream()), 'linattn_bwd_planes')
+            dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version)
+            return dqkv, None, None, None, None
         rec = _new_amax_record(qkv.device)
         _lib.check(lib.wdno_linattn_bwd_amax(_p(qkv), _p(go), _p(kstats), _p(cx), _p(dqkv), _p(rec), _p(ws), nb, units, n_tok, heads,
                                              float(scale), _stream()), 'linattn_bwd')

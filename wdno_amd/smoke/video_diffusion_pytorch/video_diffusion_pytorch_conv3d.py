@@ -163,7 +163,7 @@ class SpatialLinearAttention(nn.Module):
 
     def forward(self, x, residual=None):
         b, f, h, w, _ = x.shape
-        qkv = ops.conv_cl(x, self.to_qkv.weight)
+        qkv = ops.conv_cl(x, self.to_qkv.weight, grad_planes=True)         # read by the attention kernels only
         out = ops.linear_attention(qkv, b * f, h * w, self.heads, self.scale)         # rows in CL order; same leading shape out
         return ops.conv_cl(out, self.to_out.weight, self.to_out.bias, residual=residual)
 
@@ -201,7 +201,7 @@ class EinopsToAndFrom(nn.Module):
             raise NotImplementedError('focus_present_mask is always all-False on the WDNO path (conv3d.py:304,332)')
         att = self.fn
         b, f, h, w, _ = x.shape
-        rows = ops.conv_cl(x, att.to_qkv.weight)           # [b, f, h, w, 3*hidden]: the attention kernels index its rows in place
+        rows = ops.conv_cl(x, att.to_qkv.weight, grad_planes=True)     # [b, f, h, w, 3*hidden]: the attention kernels index its rows in place; read by them only
         if self.token_axis == 'frames':
             rot = ops.rotary_tables(att.rotary_emb.freqs, f) if exists(att.rotary_emb) else None
             out = ops.softmax_attention(rows, att.heads, b, h * w, f, f * h * w, 1, h * w, att.scale, bias=pos_bias, rot=rot)
