@@ -375,10 +375,10 @@ def conv_roofline(ts_step, ops):
         sym = fam + 'I' + ''.join(f'Li{d}E' for d in dims) if all(d.isdigit() for d in dims) else None
         path = PROFILE_JSON if os.path.exists(PROFILE_JSON) else os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         with open(path) as f:
-            for kname, rec in json.load(f)['kernels'].items():
-                if sym and sym in kname:          # entries are ordered by total time: the first match is the main instantiation
-                    traffic = round(rec['hbm_bytes_per_launch'])
-                    break
+            recs = json.load(f)['kernels']
+            hit = [r for k, r in recs.items() if sym and sym in k] or [r for k, r in recs.items() if (fam + 'I') in k]
+            if hit:                               # entries are ordered by total time: the first match is the main instantiation
+                traffic = round(hit[0]['hbm_bytes_per_launch'])
     except Exception:
         traffic = None
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
