@@ -300,7 +300,7 @@ def test_linear_on_a_few_rows(ops, rows, cin, cout, bias):
         conv_case(ops, (rows, cin), (cout, cin), 1, 0, seed=300 + rows + cout, bias=bias)
     finally:
         ops._linear_rows_backward = orig
-    assert seen.get('bwd'), 'the few-rows path was not taken'
+    assert bool(seen.get('bwd')) == (rows <= ops.LINEAR_ROWS_MAX), 'few-rows path up to LINEAR_ROWS_MAX rows, the GEMM kernels beyond'
 
 
 @pytest.mark.parametrize('c', [16, 64])

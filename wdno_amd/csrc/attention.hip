@@ -35,12 +35,12 @@ struct AttnP {
 // dqkv as planes: store 4 consecutive values of row `row` (element offset inside the [rows][RW] tensor)
 __device__ __forceinline__ void am_store4_planes(_Float16* hi, _Float16* lo, int64_t off, float4 v, float s) {
   typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-  const float t[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  const float t[4] = {v.x, v.y, v.z, v.w};
   half4v h, l;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { h[j] = (_Float16)t[j]; l[j] = (_Float16)(t[j] - (float)h[j]); }
+  for (int j = 0; j < 4; ++j) { _Float16 th, tl; plane_pack(t[j], s, lo == nullptr, th, tl); h[j] = th; l[j] = tl; }
   *reinterpret_cast<half4v*>(hi + off) = h;
-  *reinterpret_cast<half4v*>(lo + off) = l;
+  if (lo) *reinterpret_cast<half4v*>(lo + off) = l;
 }
 
 #define ATT_THREADS 256
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
   // sum_i |dS_ij| <= n * that;  |dK| <= sqrt2 * scale * n * 64 G A^2 (the rotation keeps pair norms), |dQ| the same without n.
   // A bound this loose (2^10 and more above the true maximum) still leaves the planes ~2^-28 max|dqkv| accurate: DESIGN.md.
   float ps = 1.0f;
-  if (p.pl_hi) {
+  if (p.pl_hi && p.pl_lo) {
     const float A = amax_record_read(p.rec_qkv), G = amax_record_read(p.rec_dout);
     ps = scale_from_amax(1.01f * fmaxf((float)n * G, 1.4143f * p.scale * (float)n * 64.f * G * A * A));
     if (blockIdx.x == 0 && threadIdx.x == 0) p.pl_scale[0] = ps;
@@ -721,7 +721,7 @@ extern "C" int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, cons
   int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
   if (rc) return rc;
   const int n = d->n_tok;
-  if (n > 32 || !dqkv_hi || !dqkv_lo || !dqkv_scale || !rec_qkv || !rec_dout) return WDNO_EUNSUPPORTED;
+  if (n > 32 || !dqkv_hi || (dqkv_lo && (!dqkv_scale || !rec_qkv || !rec_dout))) return WDNO_EUNSUPPORTED;      // dqkv_lo == NULL: one bf16 plane, no scale
   size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
   int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
   if (nb > 2048) nb = 2048;
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
   // Planes output (wdno_linattn_bwd_planes): with A = max|qkv|, G = max|dout|, D = max|dctx| (measured), ks, qsm <= 1 and |ctx| <= A:
   // |dq| <= 2 scale 32 A G,  |dk| <= 2 * 32 A D,  |dv| <= 32 D.
   float ps = 1.0f;
-  if (pl_hi) {
+  if (pl_hi && pl_lo) {
     const float A = amax_record_read(rec_qkv), G = amax_record_read(rec_dout), D = amax_record_read(rec_dctx);
     ps = scale_from_amax(1.01f * fmaxf(64.f * scale * A * G, fmaxf(64.f * A * D, 32.f * D)));
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) pl_scale[0] = ps;
@@ -1327,14 +1327,16 @@ extern "C" int wdno_linattn_bwd_planes(const float* qkv, const float* dout, cons
                                        void* ws, size_t ws_bytes, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s) {
   int rc = la_check(units, n_tok, heads);
   if (rc) return rc;
-  if (!dqkv_hi || !dqkv_lo || !dqkv_scale || !rec_qkv || !rec_dout || !rec_dctx) return WDNO_EINVAL;
+  if (!dqkv_hi || (dqkv_lo && (!dqkv_scale || !rec_qkv || !rec_dout || !rec_dctx))) return WDNO_EINVAL;      // dqkv_lo == NULL: one bf16 plane
   if (ws_bytes < wdno_linattn_ws_bytes(units, heads)) return WDNO_EWORKSPACE;
   hipStream_t st = as_stream(s);
   float* dctx = (float*)ws;
   float* tvec = dctx + (size_t)units * heads * DH * DH;
   linattn_ctx_kernel<1><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, dout, nullptr, ctx, dctx, tvec, n_tok, heads, scale);
-  rc = wdno_amax_record(dctx, (int64_t)units * heads * DH * DH, rec_dctx, s);
-  if (rc) return rc;
+  if (dqkv_lo) {
+    rc = wdno_amax_record(dctx, (int64_t)units * heads * DH * DH, rec_dctx, s);
+    if (rc) return rc;
+  }
   const size_t lds2 = ((size_t)(2 + 4 * 3) * LAM_TILE + 3 * DH) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)linattn_bwd_tok_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr_done = true; }

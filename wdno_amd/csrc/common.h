@@ -75,6 +75,18 @@ __device__ __forceinline__ void wave_amax_emit(float am, float* rec, int wave_li
 __device__ __forceinline__ float amax_record_read(const float* __restrict__ rec) {      // whole wave
   return wave_max(rec[(threadIdx.x & (WDNO_AMAX_SLOTS - 1)) * WDNO_AMAX_STRIDE]);
 }
+__device__ __forceinline__ unsigned short bf16_rne(float v) {      // round-to-nearest-even, NaN kept quiet
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+// one value of a plane pair: (hi, lo) fp16 of v * s, or -- lo == nullptr, the single-product mode -- one bf16 in the hi plane's storage
+__device__ __forceinline__ void plane_pack(float v, float s, bool lp, _Float16& h, _Float16& l) {
+  if (lp) { const unsigned short b = bf16_rne(v); h = __builtin_bit_cast(_Float16, b); l = (_Float16)0.f; return; }
+  const float t = v * s;
+  h = (_Float16)t;
+  l = (_Float16)(t - (float)h);
+}
 // scale of the (hi, lo) fp16 planes of a tensor with max|x| <= amax: the power of two that puts amax into [2^14, 2^15)
 __device__ __forceinline__ float scale_from_amax(float amax) {
   if (!(amax > 0.f) || !isfinite(amax)) return 1.0f;

@@ -23,11 +23,6 @@ __device__ __forceinline__ f32x16 mfma_16(half8 a, half8 b, f32x16 c) {
   if constexpr (LP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ unsigned short bf16_rne(float v) {      // round-to-nearest-even, NaN kept quiet
-  unsigned u = __float_as_uint(v);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
 
 #define HBK 32   // reduction elements per step
 #define HST 40   // LDS row stride in halves

@@ -367,11 +367,12 @@ __global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __res
   const int n = blockIdx.y;
   const int C8 = C >> 3;
   const int64_t total8 = S * C8;
-  const float s = scale_from_amax(amax_record_read(rec));
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const bool single = lo == nullptr;                 // one bf16 plane, no scale (WDNO_CONV_MATH=bf16)
+  const float s = single ? 1.0f : scale_from_amax(amax_record_read(rec));
+  if (!single && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
   const float* xp = x + (int64_t)n * S * C;
   _Float16* hp = hi + (int64_t)n * S * C;
-  _Float16* lp = lo + (int64_t)n * S * C;
+  _Float16* lp = single ? nullptr : lo + (int64_t)n * S * C;
   const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % C8) * 8;
@@ -386,13 +387,12 @@ __global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __res
     for (int j = 0; j < 8; ++j) {
       float o = ka[j] * xv[j] + kb[j];
       if (silu) o = silu_f(o);
-      const float t = o * s;
-      const _Float16 th = (_Float16)t;
-      h[j] = th;
-      l[j] = (_Float16)(t - (float)th);
+      _Float16 th, tl;
+      plane_pack(o, s, single, th, tl);
+      h[j] = th; l[j] = tl;
     }
     *reinterpret_cast<gn_half8*>(hp + i * 8) = h;
-    *reinterpret_cast<gn_half8*>(lp + i * 8) = l;
+    if (!single) *reinterpret_cast<gn_half8*>(lp + i * 8) = l;
   }
 }
 
@@ -408,12 +408,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* _
   const int n = blockIdx.y;
   const int C8 = C >> 3;
   const int64_t total8 = S * C8;
-  const float s = scale_from_amax(amax_record_read(rec));
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const bool single = lo == nullptr;                 // one bf16 plane, no scale (WDNO_CONV_MATH=bf16)
+  const float s = single ? 1.0f : scale_from_amax(amax_record_read(rec));
+  if (!single && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
   const float* xp = x + (int64_t)n * S * C;
   const float* dp = dy + (int64_t)n * S * C;
   _Float16* hp = hi + (int64_t)n * S * C;
-  _Float16* lp = lo + (int64_t)n * S * C;
+  _Float16* lp = single ? nullptr : lo + (int64_t)n * S * C;
   const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
   const float4* gbp = reinterpret_cast<const float4*>(gb + (int64_t)n * G * 4);
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -434,13 +435,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* _
       const float xh = (xv[j] - gq[j].x) * gq[j].y;
       const float o = kk[j].z * dz - gq[j].z - xh * gq[j].w;
       acc[j] += (double)o;
-      const float t = o * s;
-      const _Float16 th = (_Float16)t;
-      h[j] = th;
-      l[j] = (_Float16)(t - (float)th);
+      _Float16 th, tl;
+      plane_pack(o, s, single, th, tl);
+      h[j] = th; l[j] = tl;
     }
     *reinterpret_cast<gn_half8*>(hp + i * 8) = h;
-    *reinterpret_cast<gn_half8*>(lp + i * 8) = l;
+    if (!single) *reinterpret_cast<gn_half8*>(lp + i * 8) = l;
   }
   // block reduction of the column sums: threads with the same channel group are C8 apart
 #pragma unroll
@@ -539,8 +539,8 @@ extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma,
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, mx);
-  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, bound_rec);
+  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
+  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
   gn_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, S, C, silu);
@@ -576,8 +576,8 @@ extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, co
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(nullptr, stats, gamma, beta, ss, nullptr, cb, gb, S, C, G, nchunk, 0.f);
-  gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, mx);
-  gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, bound_rec);
+  gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
+  gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, dx_lo ? bound_rec : nullptr);
   const int gx = gn_planes_grid(S, C);
   gn_bwd_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp,
                                                                    S, C, C / G, G, silu);
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const float invC = 1.0f / (float)C;
   const int64_t rstride = (int64_t)gridDim.x * RPB;
   float ps = 1.0f;                 // forward with planes output: |y| = |xhat g| <= sqrt(C) max|g|, a scale every block derives by itself
-  if (!BWD && y_hi) {
+  if (!BWD && y_hi && y_lo) {
     float mg = 0.f;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) mg = amax4(mg, gv[v]);
@@ -653,12 +653,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           o.z = xv[v].z * rstd * gv[v].z; o.w = xv[v].w * rstd * gv[v].w;
           if (y_hi) {
             typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-            const float t[4] = {o.x * ps, o.y * ps, o.z * ps, o.w * ps};
+            const float t[4] = {o.x, o.y, o.z, o.w};
             half4v h, l;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { h[j] = (_Float16)t[j]; l[j] = (_Float16)(t[j] - (float)h[j]); }
+            for (int j = 0; j < 4; ++j) { _Float16 th, tl; plane_pack(t[j], ps, y_lo == nullptr, th, tl); h[j] = th; l[j] = tl; }
             reinterpret_cast<half4v*>(y_hi + r * C)[lane + v * TPR] = h;
-            reinterpret_cast<half4v*>(y_lo + r * C)[lane + v * TPR] = l;
+            if (y_lo) reinterpret_cast<half4v*>(y_lo + r * C)[lane + v * TPR] = l;
             continue;
           }
           reinterpret_cast<float4*>(out + r * C)[lane + v * TPR] = o;

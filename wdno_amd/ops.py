@@ -689,7 +689,7 @@ def _use_h3(pixels, reduction):
 def conv_reads_planes(pixels, weight):
     """Will conv_cl on a CL tensor with `pixels` output pixels and this weight read its input as fp16 (hi, lo) planes (and never as
     fp32)? Norm layers whose output feeds only such a convolution write the planes themselves (out_planes=...)."""
-    if not PLANES_FWD or CONV_MATH != 'f16x3' or weight.dim() < 2:
+    if not PLANES_FWD or CONV_MATH not in ('f16x3', 'bf16') or weight.dim() < 2:
         return False
     k, c = weight.shape[0], weight.shape[1]
     vol = 1
@@ -771,7 +771,8 @@ def _pad_vec(v, n):
     return out
 
 
-LINEAR_ROWS_MAX = int(os.environ.get('WDNO_LINEAR_ROWS', '512'))      # at most LR_MAXROWS of csrc/linear_rows.hip; 0 = off
+LINEAR_ROWS_MAX = int(os.environ.get('WDNO_LINEAR_ROWS', '64'))       # at most LR_MAXROWS of csrc/linear_rows.hip; 0 = off. Beyond ~64 rows
+# (the time MLPs at batch 256) the GEMM kernels win: Burgers bf16 step 123.5 -> 119.5 ms
 
 
 def _linear_rows_backward(ctx, gy):
@@ -894,7 +895,7 @@ class _Conv(torch.autograd.Function):
         gyplanes = None
         gb_given = None
         if po is not None:
-            if not (ctx.h3 and po[2] == gy._version and CONV_MATH == 'f16x3' and not has_res):
+            if not (ctx.h3 and po[2] == gy._version and po[3] == CONV_MATH and not has_res):
                 raise RuntimeError('wdno_amd: a planes-only gradient reached a convolution that cannot take it')
             gyplanes, gb_given = po[0], po[1]
         osp = tuple(_out_size(a, kk, s, p) for a, kk, s, p in zip((d, h, w), ks, stride, padding))
@@ -1093,13 +1094,15 @@ class _GroupNormAct(torch.autograd.Function):
         stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
         ssc = None if ss is None else _chk(ss, 'scale_shift')
         c8_ = c // 8
-        if out_planes and CONV_MATH == 'f16x3' and c % 8 == 0 and c8_ <= 256 and (c8_ & (c8_ - 1)) == 0:
+        if out_planes and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0 and c8_ <= 256 and (c8_ & (c8_ - 1)) == 0:
             nbp = lib.wdno_groupnorm_fwd_planes_ws_bytes(n, s, c, groups)
             wsp = _ws(nbp, x.device)
             hi = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
-            lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
-            brec = _amax_slot(x.device)
-            scale = brec[1:2]
+            lo = brec = scale = None
+            if not _lp():
+                lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
+                brec = _amax_slot(x.device)
+                scale = brec[1:2]
             _lib.check(lib.wdno_groupnorm_act_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(hi), _p(lo), _p(scale), _p(stats), _p(brec),
                                                          n, s, c, groups, float(eps), int(act_silu), _p(wsp), nbp, _stream()), 'groupnorm_fwd_planes')
             ctx.save_for_backward(x, gamma, beta, ssc, stats)
@@ -1113,7 +1116,7 @@ class _GroupNormAct(torch.autograd.Function):
         ctx.meta = (n, s, c, groups, int(act_silu))
         # the convolution that produced x takes its dy as fp16 planes (conv_cl(..., grad_planes=True)): deliver dx in that form
         c8 = c // 8
-        ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH == 'f16x3' and c % 8 == 0
+        ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0
                            and c8 <= 256 and (c8 & (c8 - 1)) == 0)
         return _leave_amax(y, rec)
 
@@ -1125,19 +1128,21 @@ class _GroupNormAct(torch.autograd.Function):
         lib = _lib_()
         dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
         dss = None if ss is None else torch.empty_like(ss)
-        if ctx.grad_planes and CONV_MATH == 'f16x3':
+        if ctx.grad_planes and CONV_MATH in ('f16x3', 'bf16'):
             nb = lib.wdno_groupnorm_bwd_planes_ws_bytes(n, s, c, groups)
             ws = _ws(nb, x.device)
             hi = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
-            lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
             cs = torch.empty((c,), device=x.device, dtype=torch.float32)
-            rec = _amax_slot(x.device)
-            scale = rec[1:2]
+            lo = rec = scale = None
+            if not _lp():
+                lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
+                rec = _amax_slot(x.device)
+                scale = rec[1:2]
             _lib.check(lib.wdno_groupnorm_act_bwd_planes(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), _p(cs),
                                                          _p(dgb), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
                        'groupnorm_bwd_planes')
             dx = torch.empty_like(x)              # never written: the convolution reads the planes (and fails loudly if it cannot)
-            dx._wdno_planes_only = ((hi, lo, scale), cs, dx._version)
+            dx._wdno_planes_only = ((hi, lo, scale), cs, dx._version, CONV_MATH)
             red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
             return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None, None
         nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
@@ -1179,10 +1184,12 @@ class _LayerNorm(torch.autograd.Function):
         p = x.numel() // c
         y = torch.empty_like(x)
         gf = g.reshape(-1)
-        if out_planes and CONV_MATH == 'f16x3' and c % 8 == 0:
+        if out_planes and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0:
             hi = torch.empty((p, c), device=x.device, dtype=torch.float16)
-            lo = torch.empty((p, c), device=x.device, dtype=torch.float16)
-            scale = torch.empty((1,), device=x.device, dtype=torch.float32)
+            lo = scale = None
+            if not _lp():
+                lo = torch.empty((p, c), device=x.device, dtype=torch.float16)
+                scale = torch.empty((1,), device=x.device, dtype=torch.float32)
             _lib.check(_lib_().wdno_layernorm_fwd_planes(_p(x), _p(gf), _p(hi), _p(lo), _p(scale), p, c, float(eps), _stream()), 'layernorm_fwd_planes')
             ctx.save_for_backward(x, g)
             ctx.eps = eps
@@ -1242,7 +1249,8 @@ class _Attn(torch.autograd.Function):
         ctx.save_for_backward(qkv, bc, rot_cos, rot_sin, out)
         ctx.meta = (desc_args, scale)
         # the projection that produced qkv takes its dy as planes (conv_cl(..., grad_planes=True)) and left the amax of qkv
-        ctx.qrec = _known_amax(qkv_in) if (GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False) and desc_args[2] <= 32) else None
+        ctx.want_planes = GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False) and desc_args[2] <= 32
+        ctx.qrec = _known_amax(qkv_in) if ctx.want_planes else None
         return _leave_amax(out, rec)
 
     @staticmethod
@@ -1256,14 +1264,16 @@ class _Attn(torch.autograd.Function):
         if bias is not None and ctx.needs_input_grad[1]:
             dbias = torch.zeros_like(bias)
         d = AttnDesc(*desc_args)
-        if ctx.qrec is not None and grec is not None and CONV_MATH == 'f16x3':
+        if ctx.want_planes and (_lp() or (CONV_MATH == 'f16x3' and ctx.qrec is not None and grec is not None)):
             rows, rw = qkv.numel() // qkv.shape[-1], qkv.shape[-1]
             hi = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
-            lo = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
-            sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
+            lo = sc = None
+            if not _lp():
+                lo = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
+                sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
             _lib.check(_lib_().wdno_attn_bwd_planes(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(hi), _p(lo), _p(sc),
                                                     _p(dbias), _p(ctx.qrec), _p(grec), C.byref(d), float(scale), _stream()), 'attn_bwd_planes')
-            dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version)      # dqkv itself stays unwritten
+            dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version, CONV_MATH)      # dqkv itself stays unwritten
             return dqkv, dbias, None, None, None, None
         rec = _new_amax_record(qkv.device)        # dqkv is the dy of the qkv projection
         _lib.check(_lib_().wdno_attn_bwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(dqkv), _p(dbias), _p(rec),
@@ -1293,7 +1303,8 @@ class _LinAttn(torch.autograd.Function):
                    'linattn_fwd')
         ctx.save_for_backward(qkv, kstats, cx)
         ctx.meta = (units, n_tok, heads, scale)
-        ctx.qrec = _known_amax(qkv_in) if (GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False)) else None      # see _Attn
+        ctx.want_planes = GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False)      # see _Attn
+        ctx.qrec = _known_amax(qkv_in) if ctx.want_planes else None
         return _leave_amax(out, rec)
 
     @staticmethod
@@ -1306,15 +1317,17 @@ class _LinAttn(torch.autograd.Function):
         nb = lib.wdno_linattn_ws_bytes(units, heads)
         ws = _ws(nb, qkv.device)
         dqkv = torch.empty_like(qkv)
-        if ctx.qrec is not None and grec is not None and CONV_MATH == 'f16x3':
+        if ctx.want_planes and (_lp() or (CONV_MATH == 'f16x3' and ctx.qrec is not None and grec is not None)):
             rows, rw = qkv.numel() // qkv.shape[-1], qkv.shape[-1]
             hi = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
-            lo = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
-            drec = _amax_slot(qkv.device)
-            sc = drec[1:2]
+            lo = drec = sc = None
+            if not _lp():
+                lo = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
+                drec = _amax_slot(qkv.device)
+                sc = drec[1:2]
             _lib.check(lib.wdno_linattn_bwd_planes(_p(qkv), _p(go), _p(kstats), _p(cx), _p(hi), _p(lo), _p(sc), _p(ctx.qrec), _p(grec), _p(drec),
                                                    _p(ws), nb, units, n_tok, heads, float(scale), _stream()), 'linattn_bwd_planes')
-            dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version)
+            dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version, CONV_MATH)
             return dqkv, None, None, None, None
         rec = _new_amax_record(qkv.device)
         _lib.check(lib.wdno_linattn_bwd_amax(_p(qkv), _p(go), _p(kstats), _p(cx), _p(dqkv), _p(rec), _p(ws), nb, units, n_tok, heads,
