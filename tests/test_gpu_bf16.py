@@ -58,6 +58,7 @@ CASES = [
     ('2d_3x3', (8, 128, 16, 16), (128, 128, 3, 3), 1, 1),
     ('2d_3x3_1024', (16, 1024, 8, 8), (1024, 1024, 3, 3), 1, 1),
     ('down_144', (2, 64, 4, 32, 32), (64, 64, 1, 4, 4), (1, 2, 2), (0, 1, 1)),
+    ('2d_3x3_many_tiles', (32, 64, 64, 64), (128, 64, 3, 3), 1, 1),      # 512 tiles of 256 x 128: the wide tap-resident tiles of the bf16 mode
     ('persist_k96', (1, 16, 24, 40, 40), (96, 16, 3, 3, 3), 1, 1),
     ('persist_k32b', (4, 16, 24, 40, 40), (32, 16, 3, 3, 3), 1, 1),
 ]

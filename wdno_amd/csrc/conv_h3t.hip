@@ -359,6 +359,10 @@ static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, co
 }
 int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
+  // single-plane (bf16) mode has a third of the MFMA work per operand byte: with >= 128 output channels and enough tiles, 256 x 128
+  // tiles (64 x 128 per wave: 6 fragment reads per 8 MFMAs, 41 KB per stage) -- debug 17: the shapes of the split mode
+  if (xl == nullptr && p.g.K > 64 && cdiv64(p.P, 256) * cdiv(p.g.K, 128) >= 2 * t_num_cus() && wdno_debug_mode != 17)
+    return launch_h3t<256, 128, 4, 1, 3, true>(xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
   if (xl == nullptr) return fwd_h3t<true>(shape, xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
   return fwd_h3t<false>(shape, xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }
