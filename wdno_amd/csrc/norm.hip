@@ -548,9 +548,12 @@ extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma,
 }
 
 /* ---- backward with dx delivered as fp16 (hi, lo) planes: see include/wdno_hip.h ---- */
-static inline int gn_planes_grid(int64_t S, int C) {
+static inline int gn_planes_grid(int64_t N, int64_t S, int C) {
   int gx = stream_grid(S * (C / 8), 256);
-  if (gx > 128) gx = 128;            // per sample; every block leaves one row of column-sum partials
+  int cap = (int)(2048 / N);         // blocks per sample: every block leaves one row of column-sum partials, ~2048 rows in total
+  if (cap < 2) cap = 2;              // (at batch 256 the final reduction over 32768 rows cost 36 us per GroupNorm)
+  if (cap > 128) cap = 128;
+  if (gx > cap) gx = cap;
   return gx;
 }
 extern "C" size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
@@ -578,7 +581,7 @@ extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, co
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(nullptr, stats, gamma, beta, ss, nullptr, cb, gb, S, C, G, nchunk, 0.f);
   gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
   gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, dx_lo ? bound_rec : nullptr);
-  const int gx = gn_planes_grid(S, C);
+  const int gx = gn_planes_grid(N, S, C);
   gn_bwd_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp,
                                                                    S, C, C / G, G, silu);
   partial_rows_sum_kernel<double><<<cdiv(C, 32), PRS_THREADS, 0, st>>>(csp, dx_colsum, (int)N * gx, C);
