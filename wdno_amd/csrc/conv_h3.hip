@@ -536,6 +536,8 @@ static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const vo
   }
   if (K > 64) {
     if ((blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) && wdno_debug_mode != 3) rc = launch_h3<128, 128, 2, 2, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    // fewer 64 x 128 tiles than CUs (the 8 x 8 level of the Burgers U-Net at batch 16: 128 tiles of 288 steps each): 64 x 64 tiles
+    else if (blocks(64, 128) < 200 && wdno_debug_mode != 18) rc = launch_h3<64, 64, 2, 2, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
     else rc = launch_h3<64, 128, 1, 4, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
   } else {
     if ((blocks(128, 64) >= 512 || P <= 128) && wdno_debug_mode != 3) rc = launch_h3<128, 64, 4, 1, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
