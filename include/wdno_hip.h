@@ -256,6 +256,10 @@ int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const float* rot_
 int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, void* dqkv_hi, void* dqkv_lo, float* dqkv_scale, float* dbias,
                          const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, wdno_stream_t s);
+/* Forward that writes, next to out, the fp16 planes of out for the to_out projection (|out| <= max|qkv|: scale from rec_qkv). */
+int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, void* out_hi,
+                         void* out_lo, float* out_scale, float* amax_rec, const float* rec_qkv, const wdno_attn_desc* d, float scale,
+                         wdno_stream_t s);
 /* Linear attention (unet.py:203-223 ; conv3d.py:241-258): q softmax over the 32 head channels, k softmax over
  * tokens, ctx = k^T v, out = ctx^T q * scale. units x n_tok rows, contiguous. ws holds k statistics and ctx. */
 size_t wdno_linattn_ws_bytes(int64_t units, int heads);
@@ -272,6 +276,9 @@ int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const float* ksta
 int wdno_linattn_bwd_planes(const float* qkv, const float* dout, const float* kstats, const float* ctx, void* dqkv_hi, void* dqkv_lo,
                             float* dqkv_scale, const float* rec_qkv, const float* rec_dout, float* rec_dctx, void* ws, size_t ws_bytes,
                             int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
+/* Forward with out delivered ONLY as fp16 planes (the backward does not read out); |out| <= scale * max|qkv|. */
+int wdno_linattn_fwd_planes(const float* qkv, void* out_hi, void* out_lo, float* out_scale, float* kstats, float* ctx,
+                            const float* rec_qkv, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 
 /* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]
  * (nn.Embedding weight) and bucket [n, n] int64 (host-built integer table); and dW from d(bias). One launch each. */

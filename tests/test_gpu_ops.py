@@ -835,7 +835,7 @@ def test_attention_backward_delivers_planes(ops):
         try:
             xs, wqs, wos = dev(to_cl(x), grad=True), dev(wq, grad=True), dev(wo, grad=True)
             rows = ops.conv_cl(xs, wqs, grad_planes=flag)
-            out = ops.softmax_attention(rows, heads, b, h * w, f, f * h * w, 1, h * w, 32 ** -0.5)
+            out = ops.softmax_attention(rows, heads, b, h * w, f, f * h * w, 1, h * w, 32 ** -0.5, out_planes=flag)
             y = ops.conv_cl(out, wos)
             (y * dev(to_cl(r))).sum().backward()
         finally:
@@ -844,7 +844,7 @@ def test_attention_backward_delivers_planes(ops):
 
     ref, n_ref = run(False)
     got, n_got = run(True)
-    assert n_got == n_ref - 1, (n_ref, n_got)           # dqkv is never split
+    assert n_got == n_ref - 2, (n_ref, n_got)           # neither dqkv nor the attention output is split
     for name, a, e in zip(['dx', 'dwq', 'dwo'], got, ref):
         assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))
 
@@ -868,7 +868,7 @@ def test_linear_attention_backward_delivers_planes(ops):
         try:
             xs, wqs, wos = dev(to_cl(x), grad=True), dev(wq, grad=True), dev(wo, grad=True)
             qkv = ops.conv_cl(xs, wqs, grad_planes=flag)
-            out = ops.linear_attention(qkv, b * f, h * w, heads, 32 ** -0.5)
+            out = ops.linear_attention(qkv, b * f, h * w, heads, 32 ** -0.5, out_planes=flag)
             y = ops.conv_cl(out, wos)
             (y * dev(to_cl(r))).sum().backward()
         finally:
@@ -877,6 +877,6 @@ def test_linear_attention_backward_delivers_planes(ops):
 
     ref, n_ref = run(False)
     got, n_got = run(True)
-    assert n_got == n_ref - 1, (n_ref, n_got)
+    assert n_got == n_ref - 2, (n_ref, n_got)
     for name, a, e in zip(['dx', 'dwq', 'dwo'], got, ref):
         assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))

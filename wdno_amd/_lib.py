@@ -102,6 +102,8 @@ PROTOTYPES = {
     'wdno_attn_bwd': (I, [P, P, P, P, P, P, P, P, PA, F, P]),
     'wdno_attn_fwd_amax': (I, [P, P, P, P, P, P, PA, F, P]),
     'wdno_attn_bwd_amax': (I, [P, P, P, P, P, P, P, P, P, PA, F, P]),
+    'wdno_attn_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, PA, F, P]),
+    'wdno_linattn_fwd_planes': (I, [P, P, P, P, P, P, P, L, I, I, F, P]),
     'wdno_attn_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, PA, F, P]),
     'wdno_linattn_ws_bytes': (Z, [L, I]),
     'wdno_linattn_fwd': (I, [P, P, P, P, L, I, I, F, P]),

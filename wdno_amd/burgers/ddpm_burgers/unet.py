@@ -132,7 +132,8 @@ class LinearAttention(nn.Module):
     def forward(self, x, residual=None):
         b, h, w, _ = x.shape
         qkv = ops.conv_cl(x, self.to_qkv.weight, grad_planes=True)         # read by the attention kernels only
-        out = ops.linear_attention(qkv, b, h * w, self.heads, self.scale)
+        planes = ops.conv_reads_planes(b * h * w, self.to_out[0].weight)              # out is read by to_out only
+        out = ops.linear_attention(qkv, b, h * w, self.heads, self.scale, out_planes=planes)
         out = ops.conv_cl(out, self.to_out[0].weight, self.to_out[0].bias)
         out = self.to_out[1](out)
         return out if residual is None else ops.add(out, residual)

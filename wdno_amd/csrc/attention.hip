@@ -355,6 +355,12 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
   const int n = p.d.n_tok;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
   const bool tok = li < n;
+  // planes of out for the to_out projection next to the fp32 tensor: rows of P sum to 1, so |out| <= max|v| <= max|qkv|
+  float fps = 1.0f;
+  if (p.pl_hi && p.pl_lo) {
+    fps = scale_from_amax(amax_record_read(p.rec_qkv));
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.pl_scale[0] = fps;
+  }
   float am = 0.f;
   float* Tq = tiles[wave][0];
   float* Tk = tiles[wave][1];
@@ -395,7 +401,8 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const float4 v = make_float4(oT[4 * e4], oT[4 * e4 + 1], oT[4 * e4 + 2], oT[4 * e4 + 3]);
-        *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;
+        *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;          // the backward reads out (delta = <out, dout>)
+        if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, rowl * p.HD + h * DH + 8 * e4 + 4 * hh, v, fps);
         am = amax4(am, v);
       }
     }
@@ -677,6 +684,21 @@ extern "C" int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const 
     return wdno_check_launch();
   }
   return attn_amax_sweep(attn_fwd_rows(qkv, rot_cos, rot_sin, bias, out, p, d, s), out, d, p.HD, amax_rec, s);
+}
+// forward that also writes the fp16 planes of out for the to_out projection (MFMA path only: n_tok <= 32)
+extern "C" int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
+                                    void* out_hi, void* out_lo, float* out_scale, float* amax_rec, const float* rec_qkv,
+                                    const wdno_attn_desc* d, float scale, wdno_stream_t s) {
+  AttnP p;
+  int rc = attn_fill(p, d, scale, ATT_THREADS);
+  if (rc) return rc;
+  if (d->n_tok > 32 || !out_hi || (out_lo && (!out_scale || !rec_qkv))) return WDNO_EUNSUPPORTED;      // out_lo == NULL: one bf16 plane
+  int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
+  if (nb > 4096) nb = 4096;
+  p.amax_rec = amax_rec;
+  p.pl_hi = (_Float16*)out_hi; p.pl_lo = (_Float16*)out_lo; p.rec_qkv = rec_qkv; p.pl_scale = out_scale;
+  attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
+  return wdno_check_launch();
 }
 static int attn_fwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, AttnP& p,
                          const wdno_attn_desc* d, wdno_stream_t s) {
@@ -1202,7 +1224,9 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
 // lanes t and t + 32.
 __global__ __launch_bounds__(256, 2) void linattn_out_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
                                                                    float* __restrict__ out, int n, int heads, float scale,
-                                                                   float* __restrict__ amax_rec) {
+                                                                   float* __restrict__ amax_rec, _Float16* __restrict__ pl_hi = nullptr,
+                                                                   _Float16* __restrict__ pl_lo = nullptr, const float* __restrict__ rec_qkv = nullptr,
+                                                                   float* __restrict__ pl_scale = nullptr) {
   __shared__ __attribute__((aligned(16))) float Tc[LAM_TILE];
   __shared__ __attribute__((aligned(16))) float Tq[4][LAM_TILE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
@@ -1216,6 +1240,11 @@ __global__ __launch_bounds__(256, 2) void linattn_out_mfma_kernel(const float* _
     }
   }
   __syncthreads();
+  float ops = 1.0f;
+  if (pl_hi && pl_lo) {
+    ops = scale_from_amax(1.01f * scale * amax_record_read(rec_qkv));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) pl_scale[0] = ops;
+  }
   float am = 0.f;
   const int t0 = (blockIdx.y * 4 + wave) * 32;
   if (t0 < n) {
@@ -1247,7 +1276,12 @@ __global__ __launch_bounds__(256, 2) void linattn_out_mfma_kernel(const float* _
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
       const float4 v = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
-      if (tok) *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;
+      if (tok) {
+        // planes for the to_out projection INSTEAD of the fp32 tensor (the backward works from ctx, not from out):
+        // qs sums to `scale` over d and |ctx| <= max|v|, so |out| <= scale * max|qkv|
+        if (pl_hi) am_store4_planes(pl_hi, pl_lo, (row0 + li) * HD + h * DH + 8 * e4 + 4 * hh, v, ops);
+        else *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;
+      }
       am = amax4(am, v);
     }
   }
@@ -1343,5 +1377,27 @@ extern "C" int wdno_linattn_bwd_planes(const float* qkv, const float* dout, cons
   linattn_bwd_tok_mfma_kernel<<<dim3((unsigned)(units * heads), (unsigned)cdiv(n_tok, 128)), 256, lds2, st>>>(
       qkv, dout, kstats, ctx, dctx, tvec, nullptr, n_tok, heads, scale, nullptr, (_Float16*)dqkv_hi, (_Float16*)dqkv_lo, rec_qkv, rec_dout, rec_dctx,
       dqkv_scale);
+  return wdno_check_launch();
+}
+
+// forward with out delivered as fp16 planes only (MFMA output kernel)
+extern "C" int wdno_linattn_fwd_planes(const float* qkv, void* out_hi, void* out_lo, float* out_scale, float* kstats, float* ctx,
+                                       const float* rec_qkv, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s) {
+  int rc = la_check(units, n_tok, heads);
+  if (rc) return rc;
+  if (!out_hi || (out_lo && (!out_scale || !rec_qkv))) return WDNO_EINVAL;      // out_lo == NULL: one bf16 plane
+  hipStream_t st = as_stream(s);
+  int chunks = n_tok / 64;
+  chunks = chunks < 1 ? 1 : (chunks > 16 ? 16 : chunks);
+  if (chunks == 1) {
+    linattn_kstats_kernel<<<(unsigned)units, 256, 0, st>>>(qkv, kstats, n_tok, heads * DH, 1);
+  } else {
+    linattn_kstats_kernel<<<(unsigned)(units * chunks), 256, 0, st>>>(qkv, ctx, n_tok, heads * DH, chunks);
+    const int64_t cols = units * heads * DH;
+    linattn_kstats_merge_kernel<<<(unsigned)cdiv64(cols, 256), 256, 0, st>>>(ctx, kstats, cols, heads * DH, chunks);
+  }
+  linattn_ctx_kernel<0><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, nullptr, kstats, nullptr, ctx, nullptr, n_tok, heads, scale);
+  linattn_out_mfma_kernel<<<dim3((unsigned)(units * heads), (unsigned)cdiv(n_tok, 128)), 256, 0, st>>>(
+      qkv, ctx, nullptr, n_tok, heads, scale, nullptr, (_Float16*)out_hi, (_Float16*)out_lo, rec_qkv, out_scale);
   return wdno_check_launch();
 }

@@ -629,6 +629,8 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
         for sh in shapes[1:]:
             if cost(*sh) < cost(*best):
                 best = sh
+        if tap and _lp() and k > 64 and cdiv(pixels, 256) * cdiv(k, 128) >= 2 * cus:
+            best = (256, 128)                        # csrc/conv_h3t.hip: the wide tiles of the single-plane mode
         return f'conv_fwd_h3{"t" if tap else "d"}_kernel<{best[0]},{best[1]}>'
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
 
@@ -1236,7 +1238,7 @@ def layernorm_cl_skip(x, g, eps=1e-5, out_planes=False):
 # ----------------------------------------------------------------------------------------------------- attention
 class _Attn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, bias, rot_cos, rot_sin, desc_args, scale):
+    def forward(ctx, qkv, bias, rot_cos, rot_sin, desc_args, scale, out_planes=False):
         qkv_in = qkv
         qkv = _chk(qkv, 'qkv')
         heads = desc_args[3]
@@ -1244,14 +1246,30 @@ class _Attn(torch.autograd.Function):
         d = AttnDesc(*desc_args)
         bc = None if bias is None else _chk(bias, 'bias')
         rec = _new_amax_record(qkv.device)
-        _lib.check(_lib_().wdno_attn_fwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bc), _p(out), _p(rec), C.byref(d), float(scale), _stream()),
-                   'attn_fwd')
+        qrec_f = _known_amax(qkv_in)
+        planes = None
+        if out_planes and desc_args[2] <= 32 and (_lp() or (CONV_MATH == 'f16x3' and qrec_f is not None)):
+            rows = out.numel() // out.shape[-1]
+            hi = torch.empty((rows, heads * 32), device=qkv.device, dtype=torch.float16)
+            lo = sc = None
+            if not _lp():
+                lo = torch.empty((rows, heads * 32), device=qkv.device, dtype=torch.float16)
+                sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_attn_fwd_planes(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bc), _p(out), _p(hi), _p(lo), _p(sc), _p(rec), _p(qrec_f),
+                                                    C.byref(d), float(scale), _stream()), 'attn_fwd_planes')
+            planes = (hi, lo, sc)
+        else:
+            _lib.check(_lib_().wdno_attn_fwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bc), _p(out), _p(rec), C.byref(d), float(scale), _stream()),
+                       'attn_fwd')
         ctx.save_for_backward(qkv, bc, rot_cos, rot_sin, out)
         ctx.meta = (desc_args, scale)
         # the projection that produced qkv takes its dy as planes (conv_cl(..., grad_planes=True)) and left the amax of qkv
         ctx.want_planes = GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False) and desc_args[2] <= 32
-        ctx.qrec = _known_amax(qkv_in) if ctx.want_planes else None
-        return _leave_amax(out, rec)
+        ctx.qrec = qrec_f if ctx.want_planes else None
+        out = _leave_amax(out, rec)
+        if planes is not None:                   # out is written as well (the backward reads it); the projection finds its planes ready
+            out._wdno_planes = (planes, out._version, CONV_MATH)
+        return out
 
     @staticmethod
     def backward(ctx, go):
@@ -1274,37 +1292,49 @@ class _Attn(torch.autograd.Function):
             _lib.check(_lib_().wdno_attn_bwd_planes(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(hi), _p(lo), _p(sc),
                                                     _p(dbias), _p(ctx.qrec), _p(grec), C.byref(d), float(scale), _stream()), 'attn_bwd_planes')
             dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version, CONV_MATH)      # dqkv itself stays unwritten
-            return dqkv, dbias, None, None, None, None
+            return dqkv, dbias, None, None, None, None, None
         rec = _new_amax_record(qkv.device)        # dqkv is the dy of the qkv projection
         _lib.check(_lib_().wdno_attn_bwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(dqkv), _p(dbias), _p(rec),
                                               C.byref(d), float(scale), _stream()), 'attn_bwd')
-        return _leave_amax(dqkv, rec), dbias, None, None, None, None
+        return _leave_amax(dqkv, rec), dbias, None, None, None, None, None
 
 
-def softmax_attention(qkv, heads, n_uo, n_ui, n_tok, so, si, st, scale, bias=None, rot=None):
+def softmax_attention(qkv, heads, n_uo, n_ui, n_tok, so, si, st, scale, bias=None, rot=None, out_planes=False):
     """qkv rows [R, 3*heads*32] (any leading shape with R rows); unit (uo, ui), token j -> row uo*so + ui*si + j*st. Returns
     [..., heads*32] with the same leading shape (pass the CL tensor itself rather than a reshaped view: tensors and gradients
     then keep the amax records their kernels leave for the neighbouring projections)."""
     rc, rs = (None, None) if rot is None else rot
-    return _Attn.apply(qkv, bias, rc, rs, (n_uo, n_ui, n_tok, heads, so, si, st), scale)
+    return _Attn.apply(qkv, bias, rc, rs, (n_uo, n_ui, n_tok, heads, so, si, st), scale, out_planes)
 
 
 class _LinAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, units, n_tok, heads, scale):
+    def forward(ctx, qkv, units, n_tok, heads, scale, out_planes=False):
         qkv_in = qkv
         qkv = _chk(qkv, 'qkv')
         hd = heads * 32
         out = torch.empty((*qkv.shape[:-1], hd), device=qkv.device, dtype=torch.float32)
         kstats = torch.empty((units, hd, 2), device=qkv.device, dtype=torch.float32)
         cx = torch.empty((units, heads, 32, 32), device=qkv.device, dtype=torch.float32)
+        qrec_f = _known_amax(qkv_in)
+        ctx.meta = (units, n_tok, heads, scale)
+        ctx.want_planes = GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False)      # see _Attn
+        ctx.qrec = qrec_f if ctx.want_planes else None
+        if out_planes and (_lp() or (CONV_MATH == 'f16x3' and qrec_f is not None)):
+            rows = out.numel() // hd
+            hi = torch.empty((rows, hd), device=qkv.device, dtype=torch.float16)
+            lo = sc = None
+            if not _lp():
+                lo = torch.empty((rows, hd), device=qkv.device, dtype=torch.float16)
+                sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_linattn_fwd_planes(_p(qkv), _p(hi), _p(lo), _p(sc), _p(kstats), _p(cx), _p(qrec_f), units, n_tok, heads,
+                                                       float(scale), _stream()), 'linattn_fwd_planes')
+            ctx.save_for_backward(qkv, kstats, cx)
+            return _planes_only(out, (hi, lo, sc))          # out stays unwritten: the backward works from ctx
         rec = _new_amax_record(qkv.device)
         _lib.check(_lib_().wdno_linattn_fwd_amax(_p(qkv), _p(out), _p(kstats), _p(cx), _p(rec), units, n_tok, heads, float(scale), _stream()),
                    'linattn_fwd')
         ctx.save_for_backward(qkv, kstats, cx)
-        ctx.meta = (units, n_tok, heads, scale)
-        ctx.want_planes = GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False)      # see _Attn
-        ctx.qrec = _known_amax(qkv_in) if ctx.want_planes else None
         return _leave_amax(out, rec)
 
     @staticmethod
@@ -1328,16 +1358,16 @@ class _LinAttn(torch.autograd.Function):
             _lib.check(lib.wdno_linattn_bwd_planes(_p(qkv), _p(go), _p(kstats), _p(cx), _p(hi), _p(lo), _p(sc), _p(ctx.qrec), _p(grec), _p(drec),
                                                    _p(ws), nb, units, n_tok, heads, float(scale), _stream()), 'linattn_bwd_planes')
             dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version, CONV_MATH)
-            return dqkv, None, None, None, None
+            return dqkv, None, None, None, None, None
         rec = _new_amax_record(qkv.device)
         _lib.check(lib.wdno_linattn_bwd_amax(_p(qkv), _p(go), _p(kstats), _p(cx), _p(dqkv), _p(rec), _p(ws), nb, units, n_tok, heads,
                                              float(scale), _stream()), 'linattn_bwd')
-        return _leave_amax(dqkv, rec), None, None, None, None
+        return _leave_amax(dqkv, rec), None, None, None, None, None
 
 
-def linear_attention(qkv, units, n_tok, heads, scale):
+def linear_attention(qkv, units, n_tok, heads, scale, out_planes=False):
     """qkv [units*n_tok, 3*heads*32] rows (contiguous units; any leading shape) -> [..., heads*32], same leading shape."""
-    return _LinAttn.apply(qkv, units, n_tok, heads, scale)
+    return _LinAttn.apply(qkv, units, n_tok, heads, scale, out_planes)
 
 
 class _RelPosBias(torch.autograd.Function):

@@ -164,7 +164,8 @@ class SpatialLinearAttention(nn.Module):
     def forward(self, x, residual=None):
         b, f, h, w, _ = x.shape
         qkv = ops.conv_cl(x, self.to_qkv.weight, grad_planes=True)         # read by the attention kernels only
-        out = ops.linear_attention(qkv, b * f, h * w, self.heads, self.scale)         # rows in CL order; same leading shape out
+        planes = ops.conv_reads_planes(b * f * h * w, self.to_out.weight)             # out is read by to_out only
+        out = ops.linear_attention(qkv, b * f, h * w, self.heads, self.scale, out_planes=planes)      # rows in CL order; same leading shape out
         return ops.conv_cl(out, self.to_out.weight, self.to_out.bias, residual=residual)
 
 
@@ -202,11 +203,12 @@ class EinopsToAndFrom(nn.Module):
         att = self.fn
         b, f, h, w, _ = x.shape
         rows = ops.conv_cl(x, att.to_qkv.weight, grad_planes=True)     # [b, f, h, w, 3*hidden]: the attention kernels index its rows in place; read by them only
+        planes = ops.conv_reads_planes(b * f * h * w, att.to_out.weight)              # out is read by to_out (and the attention backward) only
         if self.token_axis == 'frames':
             rot = ops.rotary_tables(att.rotary_emb.freqs, f) if exists(att.rotary_emb) else None
-            out = ops.softmax_attention(rows, att.heads, b, h * w, f, f * h * w, 1, h * w, att.scale, bias=pos_bias, rot=rot)
+            out = ops.softmax_attention(rows, att.heads, b, h * w, f, f * h * w, 1, h * w, att.scale, bias=pos_bias, rot=rot, out_planes=planes)
         else:
-            out = ops.softmax_attention(rows, att.heads, b * f, 1, h * w, h * w, 0, 1, att.scale, bias=pos_bias, rot=None)
+            out = ops.softmax_attention(rows, att.heads, b * f, 1, h * w, h * w, 0, 1, att.scale, bias=pos_bias, rot=None, out_planes=planes)
         return ops.conv_cl(out, att.to_out.weight, None, residual=residual)
 
 
