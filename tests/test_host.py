@@ -418,3 +418,27 @@ def test_oracle_smoke_train_loop_matches_reference_t2():
         opt.step(); sch.step()
         assert abs(loss.item() - float(g[f't2::s{step}_loss'])) < 1e-5 * abs(float(g[f't2::s{step}_loss']))
         assert abs(gn.item() - float(g[f't2::s{step}_gnorm'])) < 1e-4 * float(g[f't2::s{step}_gnorm'])
+
+
+def test_planes_hand_over_predicate():
+    """ops.conv_reads_planes: the host-side contract behind out_planes=... (a norm may leave its fp32 output unwritten only when
+    the convolution behind it is certain to read fp16 planes)."""
+    from wdno_amd import ops
+    prev = ops.CONV_MATH, ops.PLANES_FWD
+    try:
+        ops.CONV_MATH, ops.PLANES_FWD = 'f16x3', True
+        w3 = torch.empty(64, 64, 3, 3, 3)
+        assert ops.conv_reads_planes(307200, w3)                                   # a level-0 ResnetBlock convolution
+        assert not ops.conv_reads_planes(ops.H3_MIN_PIXELS - 1, w3)                # too few pixels: exact-fp32 kernel, reads fp32
+        assert not ops.conv_reads_planes(307200, torch.empty(8, 4, 1, 1, 1))       # reduction below the split threshold
+        assert not ops.conv_reads_planes(ops.LINEAR_ROWS_MAX, torch.empty(256, 64))   # few-rows linear kernel reads fp32
+        assert ops.conv_reads_planes(307200, torch.empty(384, 64))                 # to_qkv on the whole level-0 tensor
+        assert not ops.conv_reads_planes(307200, torch.empty(64, 42, 7, 7, 7))     # 42 -> 44 channels: rows are not 16-byte multiples of fp16
+        ops.CONV_MATH = 'f32'
+        assert not ops.conv_reads_planes(307200, w3)
+        ops.CONV_MATH, ops.PLANES_FWD = 'bf16', True
+        assert ops.conv_reads_planes(307200, w3)                                   # single bf16 plane: the same hand-over
+        ops.PLANES_FWD = False
+        assert not ops.conv_reads_planes(307200, w3)
+    finally:
+        ops.CONV_MATH, ops.PLANES_FWD = prev
