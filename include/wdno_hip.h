@@ -256,7 +256,8 @@ int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const float* rot_
 int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, void* dqkv_hi, void* dqkv_lo, float* dqkv_scale, float* dbias,
                          const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, wdno_stream_t s);
-/* Forward that writes, next to out, the fp16 planes of out for the to_out projection (|out| <= max|qkv|: scale from rec_qkv). */
+/* Forward with out delivered ONLY as the fp16 planes of the to_out projection (|out| <= max|qkv|: scale from rec_qkv); `out` is not
+ * written. The n_tok <= 32 backward (wdno_attn_bwd*, MFMA path) does not read out: delta = sum_j P dP is formed in registers. */
 int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, void* out_hi,
                          void* out_lo, float* out_scale, float* amax_rec, const float* rec_qkv, const wdno_attn_desc* d, float scale,
                          wdno_stream_t s);

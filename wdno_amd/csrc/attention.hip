@@ -42,6 +42,29 @@ __device__ __forceinline__ void am_store4_planes(_Float16* hi, _Float16* lo, int
   *reinterpret_cast<half4v*>(hi + off) = h;
   if (lo) *reinterpret_cast<half4v*>(lo + off) = l;
 }
+// The MFMA accumulator layout gives lane (li, hh) the channel runs 8 e4 + 4 hh + (0..3) of its row: 8-byte plane stores. One
+// v_permlane32_swap per component trades the odd run of the low half-wave for the even run of the high one (tools/probes/swap_probe.hip),
+// after which a lane owns 8 CONSECUTIVE channels (16 j + 8 hh + 0..7) of each pair j: 16-byte stores. v[e4] = the four runs; off0 = element
+// offset of channel 0 of this head in the lane's row. Both lanes of a pair (l, l + 32) must be active.
+__device__ __forceinline__ void am_store_row_planes(_Float16* hi, _Float16* lo, int64_t off0, int hh, const float4* v, float s) {
+  typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float a[4] = {v[2 * j].x, v[2 * j].y, v[2 * j].z, v[2 * j].w}, b[4] = {v[2 * j + 1].x, v[2 * j + 1].y, v[2 * j + 1].z, v[2 * j + 1].w};
+    float t[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[c]), __float_as_uint(b[c]), false, false);
+      t[c] = __uint_as_float(r[0]); t[4 + c] = __uint_as_float(r[1]);
+    }
+    half8v h, l;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { _Float16 th, tl; plane_pack(t[c], s, lo == nullptr, th, tl); h[c] = th; l[c] = tl; }
+    const int64_t off = off0 + 16 * j + 8 * hh;
+    *reinterpret_cast<half8v*>(hi + off) = h;
+    if (lo) *reinterpret_cast<half8v*>(lo + off) = l;
+  }
+}
 
 #define ATT_THREADS 256
 #define ATT_BWD_THREADS 128
@@ -321,10 +344,22 @@ __device__ __forceinline__ void am_stage_rows(float* __restrict__ tile, const fl
     }
   }
 }
-// the 16 values of row `li` this lane feeds to the MFMA: channels d = 2m + hh
+// the 16 values of row `li` this lane feeds to the MFMA steps of a product that contracts over the 32 channels: step m takes the
+// channel pair (m, 16 + m), i.e. lane half hh holds channels d = 16 hh + m -- 16 CONSECUTIVE floats, four conflict-free ds_read_b128
+// (any pairing of channels into steps is valid as long as both operands use it; the first version, d = 2 m + hh, needed sixteen
+// ds_read_b32 at a row stride of 36 floats = 4-way bank conflicts, a fifth of the temporal-attention kernels' LDS cycles)
+#define AM_D(m, hh) (16 * (hh) + (m))
 __device__ __forceinline__ void am_sel(const float* __restrict__ tile, int li, int hh, float* sel) {
 #pragma unroll
-  for (int m = 0; m < 16; ++m) sel[m] = tile[li * AM_TS + 2 * m + hh];
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(tile + li * AM_TS + 16 * hh + 4 * q);
+    sel[4 * q] = v.x; sel[4 * q + 1] = v.y; sel[4 * q + 2] = v.z; sel[4 * q + 3] = v.w;
+  }
+}
+// four of them (steps 4 g .. 4 g + 3)
+__device__ __forceinline__ void am_sel4(const float* __restrict__ tile, int li, int hh, int g, float* sel) {
+  const float4 v = *reinterpret_cast<const float4*>(tile + li * AM_TS + 16 * hh + 4 * g);
+  sel[0] = v.x; sel[1] = v.y; sel[2] = v.z; sel[3] = v.w;
 }
 // softmax over the keys of query `li` from the transposed score tile (masked beyond n); returns P^T in place
 __device__ __forceinline__ void am_softmax(f32x16& sT, const float* __restrict__ brow, int n, int hh, bool tok) {
@@ -355,7 +390,8 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
   const int n = p.d.n_tok;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
   const bool tok = li < n;
-  // planes of out for the to_out projection next to the fp32 tensor: rows of P sum to 1, so |out| <= max|v| <= max|qkv|
+  // planes of out for the to_out projection instead of the fp32 tensor (the MFMA backward does not read out): rows of P sum to 1,
+  // so |out| <= max|v| <= max|qkv|
   float fps = 1.0f;
   if (p.pl_hi && p.pl_lo) {
     fps = scale_from_amax(amax_record_read(p.rec_qkv));
@@ -398,13 +434,14 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
     for (int m = 0; m < 16; ++m) oT = __builtin_amdgcn_mfma_f32_32x32x2f32(va[m], sT[m], oT, 0, 0, 0);
     if (tok) {
       float* orow = out + rowl * p.HD + h * DH;
+      float4 vv[4];
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
-        const float4 v = make_float4(oT[4 * e4], oT[4 * e4 + 1], oT[4 * e4 + 2], oT[4 * e4 + 3]);
-        *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;          // the backward reads out (delta = <out, dout>)
-        if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, rowl * p.HD + h * DH + 8 * e4 + 4 * hh, v, fps);
-        am = amax4(am, v);
+        vv[e4] = make_float4(oT[4 * e4], oT[4 * e4 + 1], oT[4 * e4 + 2], oT[4 * e4 + 3]);
+        if (!p.pl_hi) *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = vv[e4];
+        am = amax4(am, vv[e4]);
       }
+      if (p.pl_hi) am_store_row_planes(p.pl_hi, p.pl_lo, rowl * p.HD + h * DH, hh, vv, fps);      // instead of out
     }
     __builtin_amdgcn_wave_barrier();      // the next item overwrites the tiles
   }
@@ -476,33 +513,17 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
     // products need their columns. Round 1 staged Q / K first and re-read K, Q and dO column-wise from global memory for the three
     // gradient products, re-applying the rotation per element (two table loads each); now only dO is re-read. Still two tiles per wave.
     {
-      // dP^T[j][i] = sum_d V[j][d] dO[i][d]; delta_i = <dO_i, O_i> (8 lanes per row, reduced with three shuffles)
+      // dP^T[j][i] = sum_d V[j][d] dO[i][d]
       am_stage_rows(Ta, qb + 2 * p.HD, tstride, nullptr, nullptr, 1.0f, n, lane);
       am_stage_rows(Tb, gb, gstride, nullptr, nullptr, 1.0f, n, lane);
-#pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        const int idx = lane + 64 * k;
-        const int r = idx >> 3, c4 = (idx & 7) * 4;
-        float part = 0.f;
-        if (r < n) {
-          const float4 o = *reinterpret_cast<const float4*>(fb + ((unsigned)r * gstride + (unsigned)c4));
-          const float4 gg = *reinterpret_cast<const float4*>(Tb + r * AM_TS + c4);      // this lane wrote it
-          part = gg.x * o.x + gg.y * o.y + gg.z * o.z + gg.w * o.w;
-        }
-        part += __shfl_xor(part, 1); part += __shfl_xor(part, 2); part += __shfl_xor(part, 4);
-        if ((lane & 7) == 0) dl[r] = part;
-      }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e = 0; e < 16; ++e) dsT[e] = 0.f;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {          // four steps at a time: bounded live registers (the kernel runs at 128 VGPRs)
         float va[4], gg[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          va[q] = Ta[li * AM_TS + 2 * (4 * g4 + q) + hh];
-          gg[q] = Tb[li * AM_TS + 2 * (4 * g4 + q) + hh];
-        }
+        am_sel4(Ta, li, hh, g4, va);
+        am_sel4(Tb, li, hh, g4, gg);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(va[q], gg[q], dsT, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -518,17 +539,19 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         float qa[4], kb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          qa[q] = Ta[li * AM_TS + 2 * (4 * g4 + q) + hh];
-          kb[q] = Tb[li * AM_TS + 2 * (4 * g4 + q) + hh];
-        }
+        am_sel4(Ta, li, hh, g4, qa);
+        am_sel4(Tb, li, hh, g4, kb);
 #pragma unroll
         for (int q = 0; q < 4; ++q) pT = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[q], qa[q], pT, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       am_softmax(pT, bias ? bias + ((int64_t)h * n + (tok ? li : 0)) * n : nullptr, n, hh, tok);
-      const float delta = dl[li];                      // written in the first phase; the staging does not touch it
+      // delta_i = <dO_i, O_i> = sum_j P_ij dP_ij: both factors are in this lane's accumulators (16 keys here, 16 in lane ^ 32; masked
+      // keys have P = 0) -- the forward output is not read at all (round 1 re-read it: 157 MB per level-0 launch)
+      float delta = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) delta = fmaf(pT[e], dsT[e], delta);
+      delta += __shfl_xor(delta, 32);
 #pragma unroll
       for (int e = 0; e < 16; ++e) dsT[e] = pT[e] * (dsT[e] - delta);
     }
@@ -552,15 +575,17 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
       }
       if (tok) {
         float* drow = db + lrow * tstride;
+        float4 gqv[4];
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
           float4 gq = am_unrotate4(make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]), rcos ? rcos + li * DH : nullptr, rsin ? rsin + li * DH : nullptr, d0);
           gq = make_float4(gq.x * p.scale, gq.y * p.scale, gq.z * p.scale, gq.w * p.scale);
-          if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride) + d0, gq, ps);
-          else *reinterpret_cast<float4*>(drow + d0) = gq;
+          gqv[e4] = gq;
+          if (!p.pl_hi) *reinterpret_cast<float4*>(drow + d0) = gq;
           am = amax4(am, gq);
         }
+        if (p.pl_hi) am_store_row_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride), hh, gqv, ps);
       }
     }
     // dS with the lane roles swapped (lane = key) goes through LDS, over the K tile every lane has finished with; the
@@ -594,14 +619,16 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
       }
       if (tok) {
         float* drow = db + (lrow * tstride + (unsigned)p.HD);
+        float4 gkv[4];
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const int d0 = 8 * e4 + 4 * hh;
           const float4 gk = am_unrotate4(make_float4(dk[4 * e4], dk[4 * e4 + 1], dk[4 * e4 + 2], dk[4 * e4 + 3]), rcos ? rcos + li * DH : nullptr, rsin ? rsin + li * DH : nullptr, d0);
-          if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride + (unsigned)p.HD) + d0, gk, ps);
-          else *reinterpret_cast<float4*>(drow + d0) = gk;
+          gkv[e4] = gk;
+          if (!p.pl_hi) *reinterpret_cast<float4*>(drow + d0) = gk;
           am = amax4(am, gk);
         }
+        if (p.pl_hi) am_store_row_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride + (unsigned)p.HD), hh, gkv, ps);
       }
     }
     // P with the lane roles swapped, over the Q tile; dV^T[d][j] = sum_i dO[i][d] P[i][j] (dO columns are the one global re-read left)
@@ -629,13 +656,15 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
       }
       if (tok) {
         float* drow = db + (lrow * tstride + (unsigned)(2 * p.HD));
+        float4 gvv[4];
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           const float4 gv = make_float4(dv[4 * e4], dv[4 * e4 + 1], dv[4 * e4 + 2], dv[4 * e4 + 3]);
-          if (p.pl_hi) am_store4_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride + (unsigned)(2 * p.HD)) + 8 * e4 + 4 * hh, gv, ps);
-          else *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = gv;
+          gvv[e4] = gv;
+          if (!p.pl_hi) *reinterpret_cast<float4*>(drow + 8 * e4 + 4 * hh) = gv;
           am = amax4(am, gv);
         }
+        if (p.pl_hi) am_store_row_planes(p.pl_hi, p.pl_lo, pbase + (int64_t)(lrow * tstride + (unsigned)(2 * p.HD)), hh, gvv, ps);
       }
     }
     __builtin_amdgcn_wave_barrier();      // the next item overwrites this wave's tiles
@@ -685,7 +714,7 @@ extern "C" int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const 
   }
   return attn_amax_sweep(attn_fwd_rows(qkv, rot_cos, rot_sin, bias, out, p, d, s), out, d, p.HD, amax_rec, s);
 }
-// forward that also writes the fp16 planes of out for the to_out projection (MFMA path only: n_tok <= 32)
+// forward with out delivered ONLY as fp16 planes for the to_out projection (MFMA path only: n_tok <= 32; `out` is not written)
 extern "C" int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
                                     void* out_hi, void* out_lo, float* out_scale, float* amax_rec, const float* rec_qkv,
                                     const wdno_attn_desc* d, float scale, wdno_stream_t s) {
@@ -1157,16 +1186,16 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
 #pragma unroll
       for (int e = 0; e < 16; ++e) dot = fmaf(qsm[e], acc[e], dot);
       dot += __shfl_xor(dot, 32);
+      float4 vv[4];
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const float4 v = make_float4(scale * qsm[4 * e4] * (acc[4 * e4] - dot), scale * qsm[4 * e4 + 1] * (acc[4 * e4 + 1] - dot),
                                      scale * qsm[4 * e4 + 2] * (acc[4 * e4 + 2] - dot), scale * qsm[4 * e4 + 3] * (acc[4 * e4 + 3] - dot));
-        if (tok) {
-          if (pl_hi) am_store4_planes(pl_hi, pl_lo, pbase + 8 * e4 + 4 * hh, v, ps);
-          else *reinterpret_cast<float4*>(db + 8 * e4 + 4 * hh) = v;
-        }
+        vv[e4] = v;
+        if (tok && !pl_hi) *reinterpret_cast<float4*>(db + 8 * e4 + 4 * hh) = v;
         am = amax4(am, v);
       }
+      if (tok && pl_hi) am_store_row_planes(pl_hi, pl_lo, pbase, hh, vv, ps);
     }
     {   // ---- dk[d] = ks[d] * (sum_e v[e] dctx[d][e] - T[d]),  ks = exp(k - max) / sum
       float da[16], va[16];
@@ -1177,6 +1206,7 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[m], va[m], acc, 0, 0, 0);
+      float4 vk[4];
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const int d0 = 8 * e4 + 4 * hh;
@@ -1185,18 +1215,17 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
         const float4 t4 = *reinterpret_cast<const float4*>(tv + d0);
         const float4 v = make_float4(expf(kk.x - m4.x) * l4.x * (acc[4 * e4] - t4.x), expf(kk.y - m4.y) * l4.y * (acc[4 * e4 + 1] - t4.y),
                                      expf(kk.z - m4.z) * l4.z * (acc[4 * e4 + 2] - t4.z), expf(kk.w - m4.w) * l4.w * (acc[4 * e4 + 3] - t4.w));
-        if (tok) {
-          if (pl_hi) am_store4_planes(pl_hi, pl_lo, pbase + HD + d0, v, ps);
-          else *reinterpret_cast<float4*>(db + HD + d0) = v;
-        }
+        vk[e4] = v;
+        if (tok && !pl_hi) *reinterpret_cast<float4*>(db + HD + d0) = v;
         am = amax4(am, v);
       }
+      if (tok && pl_hi) am_store_row_planes(pl_hi, pl_lo, pbase + HD, hh, vk, ps);
     }
     {   // ---- dv[e] = sum_d ks[d] dctx[d][e]: row operand = dctx read by columns (lane = e), column operand = ks[t][2m + hh]
       float da[16], ka[16];
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
-        const int d = 2 * m + hh;
+        const int d = AM_D(m, hh);
         da[m] = Td[d * AM_TS + li];
         ka[m] = expf(T2[li * AM_TS + d] - km[d]) * kl[d];
       }
@@ -1205,15 +1234,15 @@ __global__ __launch_bounds__(256, 2) void linattn_bwd_tok_mfma_kernel(const floa
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[m], ka[m], acc, 0, 0, 0);
+      float4 vd[4];
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const float4 v = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
-        if (tok) {
-          if (pl_hi) am_store4_planes(pl_hi, pl_lo, pbase + 2 * HD + 8 * e4 + 4 * hh, v, ps);
-          else *reinterpret_cast<float4*>(db + 2 * HD + 8 * e4 + 4 * hh) = v;
-        }
+        vd[e4] = v;
+        if (tok && !pl_hi) *reinterpret_cast<float4*>(db + 2 * HD + 8 * e4 + 4 * hh) = v;
         am = amax4(am, v);
       }
+      if (tok && pl_hi) am_store_row_planes(pl_hi, pl_lo, pbase + 2 * HD, hh, vd, ps);
     }
   }
   if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave));
@@ -1266,24 +1295,24 @@ __global__ __launch_bounds__(256, 2) void linattn_out_mfma_kernel(const float* _
     sm += __shfl_xor(sm, 32);
     const float f = scale / sm;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) { qs[m] *= f; ca[m] = Tc[(2 * m + hh) * AM_TS + li]; }
+    for (int m = 0; m < 16; ++m) { qs[m] *= f; ca[m] = Tc[AM_D(m, hh) * AM_TS + li]; }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int m = 0; m < 16; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[m], qs[m], acc, 0, 0, 0);
     float* orow = out + (row0 + (tok ? li : 0)) * HD + h * DH;
+    float4 vo[4];
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
       const float4 v = make_float4(acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]);
-      if (tok) {
-        // planes for the to_out projection INSTEAD of the fp32 tensor (the backward works from ctx, not from out):
-        // qs sums to `scale` over d and |ctx| <= max|v|, so |out| <= scale * max|qkv|
-        if (pl_hi) am_store4_planes(pl_hi, pl_lo, (row0 + li) * HD + h * DH + 8 * e4 + 4 * hh, v, ops);
-        else *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;
-      }
+      vo[e4] = v;
+      if (tok && !pl_hi) *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = v;
       am = amax4(am, v);
     }
+    // planes for the to_out projection INSTEAD of the fp32 tensor (the backward works from ctx, not from out):
+    // qs sums to `scale` over d and |ctx| <= max|v|, so |out| <= scale * max|qkv|
+    if (tok && pl_hi) am_store_row_planes(pl_hi, pl_lo, (row0 + li) * HD + h * DH, hh, vo, ops);
   }
   if (amax_rec) wave_amax_emit(am, amax_rec, (int)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave));
 }

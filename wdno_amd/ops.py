@@ -1266,10 +1266,9 @@ class _Attn(torch.autograd.Function):
         # the projection that produced qkv takes its dy as planes (conv_cl(..., grad_planes=True)) and left the amax of qkv
         ctx.want_planes = GRAD_PLANES and getattr(qkv_in, '_wdno_grad_planes', False) and desc_args[2] <= 32
         ctx.qrec = qrec_f if ctx.want_planes else None
-        out = _leave_amax(out, rec)
-        if planes is not None:                   # out is written as well (the backward reads it); the projection finds its planes ready
-            out._wdno_planes = (planes, out._version, CONV_MATH)
-        return out
+        if planes is not None:                   # out stays unwritten: the n_tok <= 32 backward forms delta = sum_j P dP itself
+            return _planes_only(out, planes)
+        return _leave_amax(out, rec)
 
     @staticmethod
     def backward(ctx, go):
