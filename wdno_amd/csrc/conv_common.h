@@ -17,6 +17,7 @@ struct ConvP {
   int debug;      // diagnostics only (tools/bench_conv.py): 1 = skip global loads, 2 = skip MFMAs
   int tiles_n;
   int ntiles;
+  int ksplit;     // register-staged split kernels: tap rows dealt to blockIdx.y = 0 .. ksplit-1, partial sums added with atomics (1 = off)
   float* amax_rec; // optional amax record of the output (common.h), filled by the epilogue; nullptr = not wanted
 };
 
@@ -71,6 +72,7 @@ __device__ __forceinline__ void lgkm0_barrier() {
 static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.g = *g;
   p.amax_rec = nullptr;
+  p.ksplit = 1;
   p.debug = wdno_debug_mode;
   p.R = g->kw * g->C;
   p.nchunk = cdiv(p.R, BK);

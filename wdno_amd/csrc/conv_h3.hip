@@ -300,10 +300,17 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
     b_base[i] = k * p.R + c8;
   }
 
+  // Split over the tap rows (p.ksplit = 2, blockIdx.y): a wide layer with few pixels -- 8 x 8 x 16 samples x 1024 channels in the Burgers
+  // U-Net -- has fewer tiles than CUs and 288 steps per tile; two blocks per tile each take half of the (dz, dy) rows and add their
+  // partial sums with atomics onto a zeroed output (two addends: the order cannot change the result).
+  const int ntap = g.kd * g.kh;
+  const int t_first = p.ksplit > 1 ? ntap * (int)blockIdx.y / p.ksplit : 0;
+  const int t_last = p.ksplit > 1 ? ntap * ((int)blockIdx.y + 1) / p.ksplit : ntap;
+  const int nst = (t_last - t_first) * p.nchunk;          // steps of this block
   // load cursor: (tap, chunk) uniform; (dx, cc) per thread because a chunk may straddle pixels when C % 32 != 0
-  int l_chunk = 0, l_dz = 0, l_dy = 0, l_r = c8, l_dx = c8 / g.C, l_cc = c8 % g.C;
+  int l_chunk = 0, l_dz = t_first / g.kh, l_dy = t_first % g.kh, l_r = c8, l_dx = c8 / g.C, l_cc = c8 % g.C;
   const int dx0 = l_dx, cc0 = l_cc;
-  int tap_off = 0, wtap_off = 0;            // uniform element offsets of the current tap row in x and in the packed weights
+  int tap_off = (l_dz * g.H + l_dy) * g.W * g.C, wtap_off = t_first * g.K * p.R;      // uniform element offsets of the current tap row in x and in the packed weights
   const int step_dx = HBK / g.C, step_cc = HBK % g.C;
   bool row_ok[AROWS];
   auto refresh_tap = [&]() {
@@ -439,22 +446,22 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
         for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<LP>(fah[a], fbh[b], acc[a][b]);
     }
     using NXT = std::integral_constant<int, 1 - B>;
-    if (step + 1 < p.nsteps) {
-      wait_set(NXT{}, step + 2 < p.nsteps);      // the set of step+2 (issued one iteration later) may stay in flight
+    if (step + 1 < nst) {
+      wait_set(NXT{}, step + 2 < nst);      // the set of step+2 (issued one iteration later) may stay in flight
       store_tile(NXT{}, 1 - B);
     }
     __syncthreads();
-    if (step + 3 < p.nsteps) load_tile(NXT{});
+    if (step + 3 < nst) load_tile(NXT{});
   };
   load_tile(S0{});
   wait_set(S0{}, false);
   store_tile(S0{}, 0);
   __syncthreads();
-  if (p.nsteps > 1) load_tile(S1{});
-  if (p.nsteps > 2) load_tile(S0{});
-  for (int step = 0; step < p.nsteps; step += 2) {
+  if (nst > 1) load_tile(S1{});
+  if (nst > 2) load_tile(S0{});
+  for (int step = 0; step < nst; step += 2) {
     iter(S0{}, step);
-    if (step + 1 < p.nsteps) iter(S1{}, step + 1);
+    if (step + 1 < nst) iter(S1{}, step + 1);
   }
 
   const float inv = LP ? 1.0f : 1.0f / (sx[0] * sw[0]);
@@ -472,6 +479,14 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
         int kc = n0 + n_base + b * 32 + li;
         if (kc < g.K) {
           float v = acc[a][b][e] * inv;
+          if (p.ksplit > 1) {                    // partial sum: bias / residual ride on the first one
+            if (blockIdx.y == 0) {
+              if (bias) v += bias[kc];
+              if (res) v += res[yr * g.K + kc];
+            }
+            unsafeAtomicAdd(&y[yr * g.K + kc], v);
+            continue;
+          }
           if (bias) v += bias[kc];
           if (res) v += res[yr * g.K + kc];
           y[yr * g.K + kc] = v;
@@ -501,9 +516,18 @@ static int launch_h3(const void* xh, const void* xl, const void* wh, const void*
   const int64_t x_elems = (int64_t)g.N * g.D * g.H * g.W * g.C;
   const int64_t w_elems = (int64_t)g.kd * g.kh * g.K * p.R;
   if (x_elems * 2 >= OOB_OFFSET || w_elems * 2 >= OOB_OFFSET || p.P >= 0x7fffffff) return WDNO_EUNSUPPORTED;   // 32-bit buffer offsets
-  conv_fwd_h3_kernel<BM, BN, WM, WN, LP><<<p.ntiles, 256, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh,
-                                                              (const _Float16*)wl, sx, sw, bias, residual, y, p,
-                                                              (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
+  float* rec = p.amax_rec;
+  if (p.ksplit > 1) {                     // partial sums are added onto zeros; the amax record is filled by a sweep afterwards
+    if (hipMemsetAsync(y, 0, (size_t)p.P * g.K * sizeof(float), st) != hipSuccess) return WDNO_ELAUNCH;
+    p.amax_rec = nullptr;
+  }
+  conv_fwd_h3_kernel<BM, BN, WM, WN, LP><<<dim3((unsigned)p.ntiles, (unsigned)p.ksplit), 256, lds, st>>>(
+      (const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl, sx, sw, bias, residual, y, p,
+      (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
+  if (p.ksplit > 1 && rec) {
+    amax_kernel<true><<<stream_grid(p.P * g.K / 16 + 1, 256), 256, 0, st>>>(y, p.P * g.K, reinterpret_cast<unsigned*>(rec));
+    p.amax_rec = rec;
+  }
   return WDNO_OK;
 }
 
@@ -537,7 +561,11 @@ static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const vo
   if (K > 64) {
     if ((blocks(128, 128) >= 512 || blocks(64, 128) < 2 * blocks(128, 128)) && wdno_debug_mode != 3) rc = launch_h3<128, 128, 2, 2, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
     // fewer 64 x 128 tiles than CUs (the 8 x 8 level of the Burgers U-Net at batch 16: 128 tiles of 288 steps each): 64 x 64 tiles
-    else if (blocks(64, 128) < 200 && wdno_debug_mode != 18) rc = launch_h3<64, 64, 2, 2, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    else if (blocks(64, 128) < 200 && wdno_debug_mode != 18) {
+      // ... and when even those leave CUs with a single block of several hundred steps, two blocks per tile (split over the tap rows)
+      if (blocks(64, 64) <= 384 && g->kd * g->kh >= 2 && p.nsteps >= 64 && p.identity_out && residual != y && !LP && wdno_debug_mode != 19) p.ksplit = 2;
+      rc = launch_h3<64, 64, 2, 2, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
+    }
     else rc = launch_h3<64, 128, 1, 4, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
   } else {
     if ((blocks(128, 64) >= 512 || P <= 128) && wdno_debug_mode != 3) rc = launch_h3<128, 64, 4, 1, LP>(xh, xl, wph, wpl, sx, sw, bias, residual, y, p, st);
