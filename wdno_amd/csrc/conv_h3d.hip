@@ -376,7 +376,7 @@ static int fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void
   if (!narrow_only && all && cost(192, 128, 1.0) < c) { best = 1; c = cost(192, 128, 1.0); }
   if (!narrow_only && all && cost(256, 64, 1.04) < c) { best = 2; c = cost(256, 64, 1.04); }
   if (all && cost(192, 64, 1.08) < c) { best = 3; c = cost(192, 64, 1.08); }
-  if (wdno_conv_h3t_takes(g)) return wdno_conv_fwd_h3_tap(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (p.identity_out && wdno_conv_h3t_takes(g)) return wdno_conv_fwd_h3_tap(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
   // (deeper rings -- NS = 4 / 5 fill the 160 KB -- measured no faster: the 7 x 7 x 7 init convolution keeps its 3.1 M shader cycles)
   if (best == 0) return launch_h3d<128, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (best == 1) return launch_h3d<192, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);

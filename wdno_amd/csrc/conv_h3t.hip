@@ -49,37 +49,48 @@ __device__ __forceinline__ void t_piece(int4v rsrc, int off, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(off), "s"(lds_dst), "s"(rsrc) : "memory");
 }
 
-template <int BM, int BN, int KW>
+// CB = channels per stage block: 32 (LDS rows of 64 B, two 16-deep sub-steps per dx) or 16 (rows of 32 B, one sub-step per dx: the 7-wide
+// stem convolution, whose kw x BN weight rows of a 32-channel block would not leave room for two stages)
+template <int BM, int BN, int KW, int CB>
 struct TapShape {
-  static constexpr int AROWS = BM + KW - 1;                       // source pixels of a stage; the rows behind them stay zero
-  static constexpr int APIECES = (((AROWS + 3) & ~3) + 4 + 15) / 16;     // 1-KiB pieces (16 rows) per A plane, incl. four zero rows
+  static constexpr int ROWB = CB * 2;                             // bytes of an LDS row (one plane)
+  static constexpr int RPP = 1024 / ROWB;                         // rows per 1-KiB piece
+  static constexpr int ZR = CB == 32 ? 4 : 16;                    // zero rows kept behind the window (one per bank-slot class, see a_rd)
+  static constexpr int AROWS = BM + KW - 1;                       // source pixels of a stage
+  static constexpr int ZB = (AROWS + ZR - 1) / ZR * ZR;           // first zero row
+  static constexpr int APIECES = (ZB + ZR + RPP - 1) / RPP;       // 1-KiB pieces per A plane
   static constexpr int A_PLANE = APIECES * 1024;
-  static constexpr int BPIECES = KW * BN / 16;
+  static constexpr int BPIECES = (KW * BN + RPP - 1) / RPP;
   static constexpr int B_PLANE = BPIECES * 1024;
 };
 
-template <int BM, int BN, int WM, int WN, int KW, bool LP>
+template <int BM, int BN, int WM, int WN, int KW, int CB, bool LP>
 __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                             const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
                                                             const float* __restrict__ sx, const float* __restrict__ sw,
                                                             const float* __restrict__ bias, const float* __restrict__ res,
                                                             float* __restrict__ y, ConvP p, unsigned x_bytes, unsigned w_bytes) {
-  using S = TapShape<BM, BN, KW>;
+  using S = TapShape<BM, BN, KW, CB>;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int NPL = LP ? 1 : 2;
+  constexpr int ROWB = S::ROWB, RPP = S::RPP, CPR = ROWB / 16;     // row bytes, rows per piece, 16-byte chunks per row
   constexpr int A_PLANE = S::A_PLANE, B_PLANE = S::B_PLANE;
   constexpr int A_LO = A_PLANE, B_HI = NPL * A_PLANE, B_LO = B_HI + B_PLANE;
   constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
-  constexpr int PA = (S::APIECES + 3) / 4, PB = S::BPIECES / 4;      // pieces per producer wave and plane
-  static_assert(S::BPIECES % 4 == 0, "weight pieces are dealt evenly to the four producer waves");
-  constexpr int NSUB = 2 * KW;                                     // 16-deep sub-steps of a stage: (dx, ks)
+  constexpr int PA = (S::APIECES + 3) / 4, PB = (S::BPIECES + 3) / 4;      // pieces per producer wave and plane
+  constexpr int KSN = CB / 16;                                     // 16-deep sub-steps per dx
+  constexpr int NSUB = KSN * KW;                                   // sub-steps of a stage: (dx, ks)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const wdno_conv_geom& g = p.g;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int ncb = g.C >> 5;                                        // 32-channel blocks
-  const int nstages = g.kd * g.kh * ncb;                           // per tile
+  const int ncb = (g.C + CB - 1) / CB;                             // channel blocks (the last one may be ragged: CB == 16 only)
+  // stages per tile. With an odd number of sub-steps per stage (7-wide taps on 16-channel blocks) the fragment set a stage starts on
+  // alternates, so stages run in pairs: an odd count gets one all-zero stage at the end (every piece out of bounds; 1 / 148 more MFMA work
+  // on the smoke stem) rather than a second copy of the loop tail for the other parity (which cost 21 spilled registers)
+  const bool padded = (NSUB & 1) && ((g.kd * g.kh * ncb) & 1);
+  const int nstages = g.kd * g.kh * ncb + (padded ? 1 : 0);
 
   if (wave >= WM * WN) {
     // ================================================================== producer waves
@@ -87,8 +98,10 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
     int4v rxh = t_rsrc(xh, x_bytes), rxl = t_rsrc(xl, x_bytes), rwh = t_rsrc(wh, w_bytes), rwl = t_rsrc(wl, w_bytes);
     asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rwh), "+s"(rwl));
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-    const int prow = lane >> 2;
-    const int c8 = (((lane & 3) ^ ((lane >> 4) & 3))) * 8;      // logical 8-half chunk this lane fetches (source-side swizzle)
+    // lane -> (row of the piece, logical 16-byte chunk): the XOR swizzle of the fragment reads applied on the source side. 64-byte rows:
+    // chunk (L & 3) ^ ((row >> 2) & 3); 32-byte rows: chunk (L & 1) ^ ((row >> 3) & 1) (the row bits used come from the lane index alone)
+    const int prow = lane / CPR;
+    const int c8 = (CB == 32 ? ((lane & 3) ^ ((lane >> 4) & 3)) : ((lane & 1) ^ ((lane >> 4) & 1))) * 8;
     int a_off[PA], b_off[PB];
     unsigned a_mask[PA];
     bool b_ok[PB];
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
       const int64_t p0 = (int64_t)tile_m * BM;
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
-        const int r = 16 * (pq + 4 * i) + prow;
+        const int r = RPP * (pq + 4 * i) + prow;
         const int64_t pr = p0 + r - g.pw;                          // output pixel this row is the centre tap of
         const bool live = r < S::AROWS && pr >= 0 && pr < p.P;
         int q = live ? (int)pr : 0;
@@ -115,9 +128,9 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
       }
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
-        const int row = 16 * (pq + 4 * i) + prow;                  // (dx, k) = (row / BN, row % BN)
+        const int row = RPP * (pq + 4 * i) + prow;                 // (dx, k) = (row / BN, row % BN)
         const int dx = row / BN, k = tile_n * BN + (row - dx * BN);
-        b_ok[i] = k < g.K;
+        b_ok[i] = k < g.K && dx < KW;
         b_off[i] = (k * p.R + dx * g.C + c8) * 2;
       }
     };
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
     if (my_tiles > 0) setup_tile(0);
     const bool no_dma = p.debug == 21 || p.debug >= 100;                             // ablation (tools/bench_conv.py): compute waves alone
     auto issue_stage = [&](int buf) {
-      const unsigned need = (1u << s_dz) | (1u << (8 + s_dy));
+      const bool pad = s_dz == g.kd;                               // the all-zero stage (a_mask has 16 bits)
+      const unsigned need = pad ? 0x10000u : (1u << s_dz) | (1u << (8 + s_dy));
       const unsigned dst = lds0 + buf * STAGE + pq * 1024;
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -138,16 +152,17 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
       }
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
-        const int off = b_ok[i] ? b_off[i] + w_uni : T_OOB;
+        if (pq + 4 * i >= S::BPIECES) continue;                    // (the 14 weight pieces of the 7-wide stem are not a multiple of four)
+        const int off = b_ok[i] && !pad ? b_off[i] + w_uni : T_OOB;
         if (no_dma) continue;
         t_piece(rwh, off, dst + B_HI + i * 4096);
         if (!LP) t_piece(rwl, off, dst + B_LO + i * 4096);
       }
-      x_uni += 64; w_uni += 64;
-      if (++s_cb == ncb) {
+      x_uni += ROWB; w_uni += ROWB;
+      if (pad || ++s_cb == ncb) {
         s_cb = 0;
-        if (++s_dy == g.kh) { s_dy = 0; ++s_dz; }
-        if (s_dz == g.kd) {                                        // tile finished: move the cursor to the next one
+        if (!pad && ++s_dy == g.kh) { s_dy = 0; ++s_dz; }
+        if (s_dz == g.kd && (pad || !padded)) {          // tile finished: move the cursor to the next one
           s_dz = 0;
           if (++c_tile < my_tiles) setup_tile(c_tile);
         }
@@ -175,7 +190,8 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
   const int li = lane & 31, hh = lane >> 5;
   const int m_base = wm * (TM * 32), n_base = wn * (TN * 32);
   const int b_row = n_base + li;
-  const int b_rd = B_HI + b_row * 64 + ((hh ^ ((b_row >> 2) & 3)) * 16);       // dx = 0, b = 0, ks = 0 (ks = 1 is ^ 32)
+  auto swz = [](int row) { return CB == 32 ? ((row >> 2) & 3) : ((row >> 3) & 1); };      // XOR applied to the chunk index of a row
+  const int b_rd = B_HI + b_row * ROWB + ((hh ^ swz(b_row)) * 16);             // dx = 0, b = 0, ks = 0 (ks = 1 is ^ 32, 64-byte rows only)
   int a_rd[TM][KW];                                                             // per tile: A row address of (a, dx), or the zero row
   half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];                         // [set][tile]
   auto read_frags = [&](int set, int boff, int dx, int ks) {
@@ -188,8 +204,8 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      fbh[set][b] = *reinterpret_cast<const half8*>(st + dx * (BN * 64) + b * 2048 + (b_rd ^ x));
-      if (!LP) fbl[set][b] = *reinterpret_cast<const half8*>(st + B_PLANE + dx * (BN * 64) + b * 2048 + (b_rd ^ x));
+      fbh[set][b] = *reinterpret_cast<const half8*>(st + dx * (BN * ROWB) + b * (32 * ROWB) + (b_rd ^ x));
+      if (!LP) fbl[set][b] = *reinterpret_cast<const half8*>(st + B_PLANE + dx * (BN * ROWB) + b * (32 * ROWB) + (b_rd ^ x));
     }
   };
   f32x16 acc[TM][TN];
@@ -220,17 +236,22 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
     const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
+    // the tile-invariant halves of the addresses below (two candidates per (a, dx): 28 values with 7-wide taps) would otherwise be hoisted
+    // out of the tile loop and held across the stage loop -- the 7-wide kernel spilled 62 registers over that; recomputing them is
+    // ~100 VALU instructions per tile
+    int row0 = m_base + li;
+    asm volatile("" : "+v"(row0));
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      const int ow = (int)((m0 + m_base + a * 32 + li) % g.OW);
+      const int ow = ((int)m0 + row0 + a * 32) % g.OW;                  // P < 2^31 (launch_h3t)
 #pragma unroll
       for (int dx = 0; dx < KW; ++dx) {
-        const int row = m_base + a * 32 + li + (p.debug == 15 ? 0 : dx);      // debug 15 / 16: bank-conflict probes (wrong results)
+        const int row = row0 + a * 32 + (p.debug == 15 ? 0 : dx);      // debug 15 / 16: bank-conflict probes (wrong results)
         const bool ok = p.debug == 16 || (unsigned)(ow - g.pw + dx) < (unsigned)g.W;
         // the stand-in zero row keeps the bank slot of the real one (same row % 4, same swizzled chunk): a conflict-free 16-lane group
         // uses all 16 slots once, so a lane redirected anywhere else collides with a neighbour (measured: 13 % more LDS cycles)
-        const int zrow = ((S::AROWS + 3) & ~3) + (row & 3);
-        a_rd[a][dx] = (ok ? row : zrow) * 64 + ((hh ^ ((row >> 2) & 3)) * 16);
+        const int zrow = S::ZB + (row & (S::ZR - 1));
+        a_rd[a][dx] = (ok ? row : zrow) * ROWB + ((hh ^ swz(row)) * 16);
       }
     }
 #pragma unroll
@@ -238,8 +259,8 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    lgkm0_barrier();
+        for (int e = 0; e < 16; ++e) asm volatile("v_mov_b32 %0, 0" : "=v"(acc[a][b][e]));   // not `= 0.f`: the 7-wide kernel kept a second,
+    lgkm0_barrier();                                                                          // loop-invariant set of 64 zero registers to start each tile from
     read_frags(0, boff, 0, 0);
     // One scheduling region per sub-step: the fragment reads of the NEXT sub-step are dealt one per MFMA of this one (not all reads
     // first, the order the kernel was first written in) -- a wave issues in order, so a block of 8 ds_read_b128 ahead
@@ -253,27 +274,35 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
         if (i * RPM < NRD) __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
       }
     };
-    for (int s = 0; s + 1 < nstages; ++s) {
+    // a stage: sub-step `sub` (dx = sub / KSN, ks = sub % KSN) works on fragment set (PAR + sub) & 1 while the reads of sub + 1 -- at the
+    // last sub-step, behind the barrier, the first reads of the next stage -- go to the other set. With an odd number of sub-steps
+    // (7-wide taps on 16-channel blocks) the starting set alternates from stage to stage.
+    auto stage_body = [&](auto PARC, auto LASTC) {
+      constexpr int PAR = decltype(PARC)::value;
+      constexpr bool LAST = decltype(LASTC)::value;
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub) {
         if (sub + 1 < NSUB) {
-          read_frags((sub + 1) & 1, boff, (sub + 1) >> 1, (sub + 1) & 1);
-        } else {
+          read_frags((PAR + sub + 1) & 1, boff, (sub + 1) / KSN, (sub + 1) % KSN);
+        } else if (!LAST) {
           boff = STAGE - boff;
           lgkm0_barrier();
-          read_frags(0, boff, 0, 0);
+          read_frags((PAR + NSUB) & 1, boff, 0, 0);
         }
-        mfma_set(sub & 1);
-        interleave();
+        mfma_set((PAR + sub) & 1);
+        if (sub + 1 < NSUB || !LAST) interleave();
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {                        // last stage of the tile: nothing to fetch behind it
-      if (sub + 1 < NSUB) read_frags((sub + 1) & 1, boff, (sub + 1) >> 1, (sub + 1) & 1);
-      mfma_set(sub & 1);
-      if (sub + 1 < NSUB) interleave();
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if constexpr (NSUB % 2 == 0) {
+      for (int s = 0; s + 1 < nstages; ++s) stage_body(P0{}, std::false_type{});
+      stage_body(P0{}, std::true_type{});
+    } else {
+      for (int s = 0; s + 2 < nstages; s += 2) { stage_body(P0{}, std::false_type{}); stage_body(P1{}, std::false_type{}); }
+      stage_body(P0{}, std::false_type{});                         // nstages is even
+      stage_body(P1{}, std::true_type{});
     }
     boff = STAGE - boff;
     const uint64_t e_begin = stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -282,7 +311,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
     for (int a = 0; a < TM; ++a) {
       const int64_t pm = m0 + m_base + a * 32 + li;
       if (pm >= p.P) continue;
-      const int64_t yr = p.identity_out ? pm : out_row(g, pm);
+      const int64_t yr = pm;                                      // identity output placement only (conv_h3d.hip checks it before coming here)
       float* yrow = y + yr * g.K;
       const float* rrow = res ? res + yr * g.K : nullptr;
 #pragma unroll
@@ -317,10 +346,10 @@ static int t_num_cus() {
   return n;
 }
 
-template <int BM, int BN, int WM, int WN, int KW, bool LP>
+template <int BM, int BN, int WM, int WN, int KW, int CB, bool LP>
 static int launch_h3t(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                       const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
-  using S = TapShape<BM, BN, KW>;
+  using S = TapShape<BM, BN, KW, CB>;
   const wdno_conv_geom& g = p.g;
   int64_t tiles_m = cdiv64(p.P, BM);
   p.tiles_n = cdiv(g.K, BN);
@@ -336,8 +365,8 @@ static int launch_h3t(const void* xh, const void* xl, const void* wh, const void
   if (grid < 8) grid = 8;
   if (p.ntiles < grid) grid = p.ntiles;
   static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-  conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
+  if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
                                                                     sx, sw, bias, residual, y, p, (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
   return WDNO_OK;
 }
@@ -345,24 +374,32 @@ static int launch_h3t(const void* xh, const void* xl, const void* wh, const void
 // Geometries the tap-resident kernel takes: stride 1, output grid == input grid (so flat pixel indices shift by constants),
 // kw == 3, whole 32-channel blocks. `shape` = tile shape chosen by the caller (conv_h3d.hip: 0 = 128 x 128, 1 = 192 x 128,
 // 2 = 256 x 64, 3 = 192 x 64).
+// ... or kw == 7 on whole 16-channel blocks with at most 64 output channels (the stem of the smoke U-Net: 42 -> 48 channels in the planes):
+// there the weight rows of a 32-channel block (7 x 64 x 64 B per plane) would not leave room for two stages, so a stage is a 16-channel
+// block with LDS rows of 32 B and one 16-deep sub-step per dx (debug 20: the chunked kernel instead).
+static bool t_stem(const wdno_conv_geom& g) { return g.kw == 7 && (g.C % 16) == 0 && g.K <= 64 && wdno_debug_mode != 20; }
 bool wdno_conv_h3t_takes(const wdno_conv_geom& g) {
-  return g.sd == 1 && g.sh == 1 && g.sw == 1 && g.OD == g.D && g.OH == g.H && g.OW == g.W && g.kw == 3 && (g.C % 32) == 0 &&
+  return g.sd == 1 && g.sh == 1 && g.sw == 1 && g.OD == g.D && g.OH == g.H && g.OW == g.W && ((g.kw == 3 && (g.C % 32) == 0) || t_stem(g)) &&
          g.kd <= 8 && g.kh <= 8 && wdno_debug_mode != 8;
 }
 template <bool LP>
 static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                    const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
-  if (shape == 0) return launch_h3t<128, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  if (shape == 1) return launch_h3t<192, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  if (shape == 3) return launch_h3t<192, 64, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
-  return launch_h3t<256, 64, 4, 1, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 0) return launch_h3t<128, 128, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 1) return launch_h3t<192, 128, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 3) return launch_h3t<192, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  return launch_h3t<256, 64, 4, 1, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }
 int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
   // single-plane (bf16) mode has a third of the MFMA work per operand byte: with >= 128 output channels and enough tiles, 256 x 128
   // tiles (64 x 128 per wave: 6 fragment reads per 8 MFMAs, 41 KB per stage) -- debug 17: the shapes of the split mode
+  if (p.g.kw == 7) {
+    if (xl == nullptr) return launch_h3t<256, 64, 4, 1, 7, 16, true>(xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
+    return launch_h3t<256, 64, 4, 1, 7, 16, false>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  }
   if (xl == nullptr && p.g.K > 64 && cdiv64(p.P, 256) * cdiv(p.g.K, 128) >= 2 * t_num_cus() && wdno_debug_mode != 17)
-    return launch_h3t<256, 128, 4, 1, 3, true>(xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
+    return launch_h3t<256, 128, 4, 1, 3, 32, true>(xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
   if (xl == nullptr) return fwd_h3t<true>(shape, xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
   return fwd_h3t<false>(shape, xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }

@@ -604,7 +604,8 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
         y = out
         g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp, y_sp=tuple(out.shape[1:4]), ostride=ostride, ooff=ooff)
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
-    tap = tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 3 and cp8 % 32 == 0      # csrc/conv_h3t.hip: wdno_conv_h3t_takes
+    tap = (out is None and tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and max(ks) <= 8 and      # csrc/conv_h3t.hip: wdno_conv_h3t_takes
+           ((ks[2] == 3 and cp8 % 32 == 0) or (ks[2] == 7 and cp8 % 16 == 0 and kp <= 64)))
     with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks, tap), flops):
         if xl is None:       # single bf16 plane per operand
             _lib.check(_lib_().wdno_conv_fwd_bf16(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_bf16')
@@ -631,6 +632,8 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
                 best = sh
         if tap and _lp() and k > 64 and cdiv(pixels, 256) * cdiv(k, 128) >= 2 * cus:
             best = (256, 128)                        # csrc/conv_h3t.hip: the wide tiles of the single-plane mode
+        if tap and ks[2] == 7:
+            best = (256, 64)                         # ... and the 16-channel-block kernel of 7-wide taps
         return f'conv_fwd_h3{"t" if tap else "d"}_kernel<{best[0]},{best[1]}>'
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
 
