@@ -735,6 +735,258 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
   else run(std::integral_constant<int, 1>{});
 }
 
+// ====================================================================================================================
+// Seven-wide window variant: the 7x7x7 stem of the smoke U-Net (stride 1, output grid == input grid, kw == 7, pw == 3, 48 plane
+// channels, K <= 64). Ablation of conv_wgrad_h3d_kernel<64,192> on it (tools/bench_conv.py --ablate): 2.24 ms full, 1.64 ms with
+// every piece out of range, 1.04 ms without piece instructions -- the run of a tap row is 7 x 48 channels = 672 contiguous bytes
+// of x per pixel, so the chunked kernel moves every source pixel seven times (24 GB of LDS-DMA per launch). Here an item is
+// (tap row, pixel split) and a 32-pixel step receives
+//   * the 32 x 64 dy tile ([4-pixel group][32-channel unit][pixel][64 B], as above), and
+//   * ONE window of 32 + 6 consecutive source pixels x 48 channels, kept exactly as it lies in memory (38 rows of 96 B: the DMA
+//     lanes fetch 3648 contiguous bytes). The run of output pixel q is then the 336 halves starting at window row q: column tile
+//     t (32 run entries, 11 tiles; the last half tile is padding) is a transpose read at byte 96 q + 64 t, whatever dx it starts in.
+// A transpose read takes 4 pixels x 32 B per 16 lanes. With rows of 96 B (24 banks) four CONSECUTIVE pixels collide with the other
+// 16-channel half of the tile; pixels two apart (192 B = 48 banks) do not, and the MFMA does not care which pixel is which k index as
+// long as both operands agree: k index (8 hh + 4 second + j) of a 16-deep half-step is pixel 8 hh + second + 2 j. The dy tile is
+// fetched in that order (its groups of four are those pixel sets).
+//   * dx validity: per lane and column tile dx = run entry / 48; (pixel, dx) pairs off the image row read a zero slot (the
+//     window plane is 4096 B, bytes past 3648 are fetched out of range). (dz, dy) validity: per window row, from the coordinates
+//     the producer lane tracks (a row whose pixel is in another image row than the output pixel is masked by the dx test anyway).
+//   * compute wave w owns column tiles 3 w .. 3 w + 2 (wave 3: two) x 64 k; 4 DMA instructions per producer wave and step.
+template <bool LP>
+__global__ __launch_bounds__(512) void conv_wgrad_h3s_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
+                                                              const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
+                                                              const float* __restrict__ sx, const float* __restrict__ sdy,
+                                                              float* __restrict__ ws, WgradDP wp, unsigned x_bytes, unsigned dy_bytes) {
+  constexpr int KW = 7, CX = 48, NS = 3, TM = 2;
+  constexpr int ROWB = CX * 2, XROWS = 32 + KW - 1, X_DATA = XROWS * ROWB;       // 96, 38, 3648
+  constexpr int A_PLANE = 4096, X_PLANE = 4096, ZADDR = X_DATA;
+  constexpr int NPL = LP ? 1 : 2;
+  constexpr int A_LO = A_PLANE, B_HI = NPL * A_PLANE, B_LO = B_HI + X_PLANE;
+  constexpr int STAGE = NPL * (A_PLANE + X_PLANE);
+  constexpr int PER = 2 * NPL;                            // DMA instructions per producer wave and step
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const ConvP& p = wp.c;
+  const wdno_conv_geom& g = p.g;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int it_first, it_stride, my_items;                      // item order and XCD ownership: as conv_wgrad_h3d_kernel
+  if (wp.xcd_chunk > 0) {
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int beg = xcd * wp.xcd_chunk, end = min(beg + wp.xcd_chunk, wp.items);
+    it_stride = (int)gridDim.x >> 3;
+    it_first = beg + idx;
+    my_items = it_first < end ? (end - it_first + it_stride - 1) / it_stride : 0;
+  } else {
+    it_first = (int)blockIdx.x; it_stride = (int)gridDim.x;
+    my_items = (wp.items - it_first + it_stride - 1) / it_stride;
+  }
+  const int ntap = g.kd * g.kh;
+  const int total = my_items * wp.nsteps;
+
+  if (wave >= 4) {
+    // ================================================================== producer waves: lane = 16-byte slot f of every plane
+    const int pq = wave - 4;
+    int4v rxh = wd_rsrc(xh, x_bytes), rxl = wd_rsrc(xl, x_bytes), rdh = wd_rsrc(dyh, dy_bytes), rdl = wd_rsrc(dyl, dy_bytes);
+    asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rdh), "+s"(rdl));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    const int f = 64 * pq + lane;
+    const int xr = f / (ROWB / 16), xc = f - xr * (ROWB / 16);            // window row, chunk of the row
+    const bool x_slot = xr < XROWS;
+    const int gi = f >> 5, du = (f >> 4) & 1, dj = (f >> 2) & 3, dc = f & 3;
+    const int dpix = 16 * (gi >> 2) + 8 * ((gi >> 1) & 1) + (gi & 1) + 2 * dj;   // pixel of the step this dy slot holds
+    const bool d_slot = du * 32 + dc * 8 < g.K;
+    int it = 0, st = 0;                                   // cursor: item, step
+    int q = 0, qw = 0, qh = 0, qd = 0, x_off = 0, dp = 0, d_off = 0, vdz = 0, vdy = 0;
+    auto setup_item = [&]() {
+      const int id = it_first + it * it_stride;
+      const int tap = id % ntap, split = id / ntap;
+      const int dz = tap / g.kh, dy = tap - dz * g.kh;
+      vdz = dz - g.pd; vdy = dy - g.ph;
+      const int pbeg = split * wp.pix_per_split;
+      q = pbeg + xr - g.pw;                               // output-grid pixel whose centre tap this window row is
+      const int whd = g.W * g.H * g.D;
+      int qq = q + whd;                                   // >= 0 (q >= -pw)
+      qw = qq % g.W; qq /= g.W;
+      qh = qq % g.H; qq /= g.H;
+      qd = qq % g.D;
+      x_off = ((q + (vdz * g.H + vdy) * g.W) * g.C + xc * 8) * 2;
+      dp = pbeg + dpix;
+      d_off = (dp * g.K + du * 32 + dc * 8) * 2;
+    };
+    const bool no_dma = p.debug == 21;                    // ablation (tools/bench_conv.py): every piece out of range
+    auto issue_next = [&](int buf) {
+      const unsigned sb = lds0 + buf * STAGE + pq * 1024;
+      const bool xv = x_slot && q >= 0 && q < (int)p.P && (unsigned)(qd + vdz) < (unsigned)g.D && (unsigned)(qh + vdy) < (unsigned)g.H;
+      const int xo = xv && !no_dma ? x_off : WD_OOB;
+      const int d_o = d_slot && dp < (int)p.P && !no_dma ? d_off : WD_OOB;
+      wd_piece(rdh, d_o, sb);
+      if (!LP) wd_piece(rdl, d_o, sb + A_LO);
+      wd_piece(rxh, xo, sb + B_HI);
+      if (!LP) wd_piece(rxl, xo, sb + B_LO);
+      q += 32; x_off += 32 * g.C * 2; dp += 32; d_off += 32 * g.K * 2;
+      qw += 32;
+      while (qw >= g.W) { qw -= g.W; if (++qh == g.H) { qh = 0; if (++qd == g.D) qd = 0; } }
+      if (++st == wp.nsteps) { st = 0; if (++it < my_items) setup_item(); }
+    };
+    if (total > 0) { setup_item(); issue_next(0); }
+    if (total > 1) issue_next(1);
+    int nbuf = 2;
+    for (int gs = 0; gs < total; ++gs) {
+      // step gs has landed (the step after it may still be in flight) -> meet the compute waves, which have every fragment of step
+      // gs - 1 in registers by now, then refill that step's buffer with step gs + 2
+      if (gs + 1 < total) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : : : "memory");
+      if (gs + 2 < total) { issue_next(nbuf); nbuf = nbuf + 1 == NS ? 0 : nbuf + 1; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    return;
+  }
+
+  // ================================================================== compute waves
+  const int li = lane & 31, hh = lane >> 5, g1 = (lane >> 4) & 1, xq = lane & 15;
+  const int fj = xq >> 2, c4 = xq & 3;
+  typedef short short4v __attribute__((ext_vector_type(4)));
+  typedef short short8v __attribute__((ext_vector_type(8)));
+  typedef short4v __attribute__((address_space(3))) * lds_s4;
+  const float inv = LP ? 1.0f : 1.0f / (sx[0] * sdy[0]);
+  const int step_ow = 32 % g.W;
+  // dy fragment of (ks, second, a): group 4 ks + 2 hh + second, unit a, pixel slot fj, bytes 32 g1 + 8 c4 of the unit
+  const int a_base = hh * 1024 + fj * 64 + g1 * 32 + c4 * 8;
+
+  auto run = [&](auto TNC) {
+    constexpr int TN = decltype(TNC)::value;
+    const int tb0 = 3 * wave;
+    int xbase[TN][4], rd[TN][4], dlo[TN], ow[4];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int r = 32 * (tb0 + b) + 16 * g1 + 4 * c4;            // run entry of this lane's four source halves
+      const int dx = r / CX;
+      dlo[b] = dx < KW ? g.pw - dx : (1 << 20);                   // valid iff (unsigned)(ow - dlo) < W
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xbase[b][c] = (16 * (c >> 1) + 8 * hh + (c & 1) + 2 * fj) * ROWB + 2 * r;
+    }
+    auto select = [&](int c) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) rd[b][c] = (unsigned)(ow[c] - dlo[b]) < (unsigned)g.W ? xbase[b][c] : ZADDR;
+    };
+    auto advance = [&](int c) {
+      ow[c] += step_ow;
+      if (ow[c] >= g.W) ow[c] -= g.W;
+    };
+    half8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+    auto tr2 = [&](const char* a0, const char* a1) {
+      const short4v h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)a0);
+      const short4v h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)a1);
+      return __builtin_bit_cast(half8, (short8v)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto read_frags = [&](auto SET, int stage, int ks) {
+      constexpr int B = decltype(SET)::value;
+      const char* st = smem + stage * STAGE;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const char* pa = st + a_base + ks * 2048 + a * 256;
+        fah[B][a] = tr2(pa, pa + 512);
+        if (!LP) fal[B][a] = tr2(pa + A_LO, pa + A_LO + 512);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        fbh[B][b] = tr2(st + B_HI + rd[b][2 * ks], st + B_HI + rd[b][2 * ks + 1]);
+        if (!LP) fbl[B][b] = tr2(st + B_LO + rd[b][2 * ks], st + B_LO + rd[b][2 * ks + 1]);
+      }
+    };
+    f32x16 acc[TM][TN];
+    auto mfma_set = [&](auto SET) {          // row operand = x fragment (column tile), column operand = dy fragment (k): acc is [r][k]
+      constexpr int B = decltype(SET)::value;
+      if constexpr (!LP) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbh[B][b], fal[B][a], acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<false>(fbl[B][b], fah[B][a], acc[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = mfma_16<LP>(fbh[B][b], fah[B][a], acc[a][b]);
+    };
+    constexpr int NRD = NPL * 2 * (TM + TN), NMF = (LP ? 1 : 3) * TM * TN, RPM = (NRD + NMF - 1) / NMF;
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i * RPM < NRD) __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+      }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int stage = 0;
+    for (int t = 0; t < my_items; ++t) {
+      const int id = it_first + t * it_stride;
+      const int tap = id % ntap, split = id / ntap;
+      const int pbeg = split * wp.pix_per_split;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ow[c] = (pbeg + 16 * (c >> 1) + 8 * hh + (c & 1) + 2 * fj) % g.OW;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+      select(0); select(1);
+      lgkm0_barrier();
+      read_frags(B0{}, stage, 0);
+      advance(0); advance(1);
+      for (int step = 0; step + 1 < wp.nsteps; ++step) {
+        select(2); select(3);
+        read_frags(B1{}, stage, 1);
+        advance(2); advance(3);
+        mfma_set(B0{});
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        select(0); select(1);
+        lgkm0_barrier();
+        read_frags(B0{}, stage, 0);
+        advance(0); advance(1);
+        mfma_set(B1{});
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      select(2); select(3);
+      read_frags(B1{}, stage, 1);
+      mfma_set(B0{});
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      mfma_set(B1{});
+      __builtin_amdgcn_sched_barrier(0);
+      // acc[a][b]: rows = run entries 32 (tb0 + b) + 8 (e >> 2) + 4 hh + (e & 3), column = k
+      float* out = ws + ((int64_t)split * ntap + tap) * (int64_t)g.K * p.R;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int kk = a * 32 + li;
+        if (kk >= g.K) continue;
+        float* orow = out + (int64_t)kk * p.R;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int rr = 32 * (tb0 + b) + 8 * e4 + 4 * hh;
+            if (rr < p.R)
+              *reinterpret_cast<float4*>(orow + rr) = make_float4(acc[a][b][4 * e4] * inv, acc[a][b][4 * e4 + 1] * inv, acc[a][b][4 * e4 + 2] * inv, acc[a][b][4 * e4 + 3] * inv);
+          }
+        }
+      }
+    }
+  };
+  if (wave < 3) run(std::integral_constant<int, 3>{});
+  else run(std::integral_constant<int, 2>{});
+}
+
 static int wd_num_cus() {
   static int n = 0;
   if (!n) {
@@ -753,10 +1005,27 @@ static bool wd_window_takes(const wdno_conv_geom* g) {
   return g->sd == 1 && g->sh == 1 && g->sw == 1 && g->OD == g->D && g->OH == g->H && g->OW == g->W && g->kw == 3 && g->pw == 1 &&
          (g->C % 64) == 0 && (g->K % 8) == 0;
 }
+// geometries of the seven-wide window kernel (debug 8 / 28: the chunked kernel instead)
+static bool wd_stem_takes(const wdno_conv_geom* g) {
+  if (wdno_debug_mode == 8 || wdno_debug_mode == 28) return false;
+  return g->sd == 1 && g->sh == 1 && g->sw == 1 && g->OD == g->D && g->OH == g->H && g->OW == g->W && g->kw == 7 && g->pw == 3 &&
+         g->C == 48 && (g->K % 8) == 0 && g->K <= 64 && g->kd <= 8 && g->kh <= 8;
+}
 // plan shared by the workspace query and the launch (conv_h3.hip calls both)
 void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits, int* pix_per_split) {
   ConvP c;
   fill_params(c, g);
+  if (wd_stem_takes(g)) {                                   // items = tap rows x splits, one round of the CUs
+    *bm = 64; *bn = 352;
+    int64_t want = 256 / (g->kd * g->kh);
+    int64_t max_splits = cdiv64(c.P, 16 * 32);
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    int64_t pps = cdiv64(cdiv64(c.P, want), 32) * 32;
+    *pix_per_split = (int)pps;
+    *splits = (int)cdiv64(c.P, pps);
+    return;
+  }
   if (wd_window_takes(g)) {                                 // items = k tiles x tap-row pairs x channel tiles x splits, one round of the CUs
     *bm = 64; *bn = 192;
     const int tiles = cdiv(g->K, 64) * ((g->kd * g->kh + 1) / 2) * (g->C / 64);
@@ -830,6 +1099,26 @@ static void launch_ww(const void* xh, const void* xl, const void* dyh, const voi
                                                        sx, sdy, (const int4v*)table, wsf, wl, x_bytes, dy_bytes, tbl_bytes);
 }
 
+template <bool LP>
+static void launch_ws(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
+                      float* wsf, const WgradDP& w, hipStream_t st) {
+  const wdno_conv_geom& g = w.c.g;
+  const unsigned x_bytes = (unsigned)((int64_t)g.N * g.D * g.H * g.W * g.C * 2);
+  const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
+  const size_t lds = (size_t)3 * (LP ? 1 : 2) * (4096 + 4096);
+  int grid = wd_num_cus();
+  if (w.items < grid) grid = w.items;
+  WgradDP wl = w;
+  wl.xcd_chunk = 0;
+  if (grid >= 64 && wdno_debug_mode != 6) {
+    wl.xcd_chunk = cdiv(w.items, 8);
+    grid = wd_num_cus() & ~7;
+    if (8 * wl.xcd_chunk < grid) grid = 8 * wl.xcd_chunk;
+  }
+  conv_wgrad_h3s_kernel<LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)dyh, (const _Float16*)dyl,
+                                                   sx, sdy, wsf, wl, x_bytes, dy_bytes);
+}
+
 // wsf: split workspace [splits][ntap][K][R] (or dwp itself when splits == 1). Returns WDNO_EUNSUPPORTED for geometries the
 // DMA kernel does not take.
 int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
@@ -843,6 +1132,14 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
   w.tiles_r = cdiv(w.c.R, bn);
   w.nsteps = w.pix_per_split / 32;
   w.items = w.tiles_k * w.tiles_r * g->kd * g->kh * w.splits;
+  if (wd_stem_takes(g)) {
+    if ((int64_t)g->N * g->D * g->H * g->W * g->C * 2 >= WD_OOB || w.c.P * g->K * 2 >= WD_OOB) return WDNO_EUNSUPPORTED;
+    w.tiles_k = w.tiles_r = 1;
+    w.items = g->kd * g->kh * w.splits;
+    if (xl == nullptr) launch_ws<true>(xh, xh, dyh, dyh, sx, sdy, wsf, w, st);
+    else launch_ws<false>(xh, xl, dyh, dyl, sx, sdy, wsf, w, st);
+    return WDNO_OK;
+  }
   if (wd_window_takes(g)) {      // tiles_r = C / 64 channel tiles, tap rows in pairs
     w.items = w.tiles_k * w.tiles_r * ((g->kd * g->kh + 1) / 2) * w.splits;
     if (xl == nullptr) launch_ww<true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);

@@ -640,6 +640,8 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
 
 def _wgrad_h3_kernel_name(k, run, window=False):
     """Same for wdno_conv_wgrad_f16x3 (run = kw * C8; window: the geometries of csrc/conv_wgrad_h3d.hip's wd_window_takes)."""
+    if window == 'stem':
+        return 'conv_wgrad_h3s_kernel<64,352>'
     if window:
         return 'conv_wgrad_h3w_kernel<64,384>'
     cdiv = lambda a, b: -(-a // b)
@@ -666,6 +668,8 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None):
         _pixel_tables[tkey] = table
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * k8 * ks[0] * ks[1] * ks[2] * c8
     window = tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 3 and pd[2] == 1 and c8 % 64 == 0
+    if tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 7 and pd[2] == 3 and c8 == 48 and k8 <= 64 and max(ks) <= 8:
+        window = 'stem'                    # csrc/conv_wgrad_h3d.hip: wd_stem_takes
     if xl is None:           # single bf16 plane per operand
         assert param_kc is not None
         kn, cn = param_kc
