@@ -255,6 +255,19 @@ def test_conv_f16x3_tap_resident_kernels(ops, name, xs, ws, stride, padding, mod
         lib.wdno_set_debug(0)
 
 
+@pytest.mark.parametrize('mode', [30, 31], ids=['160x128', '320x64'])
+@pytest.mark.parametrize('name,xs,ws,stride,padding', [c for c in CONV_CASES_TAP if c[2][-1] == 3], ids=[c[0] for c in CONV_CASES_TAP if c[2][-1] == 3])
+def test_conv_f16x3_tap_five_row_tiles(ops, name, xs, ws, stride, padding, mode):
+    """The 160 x 128 (one wave row x four wave columns) and 320 x 64 shapes of the tap-resident kernel, which the launch plan picks for
+    layers whose tile count leaves the last round of the persistent grid mostly empty; debug 30 / 31 force them on the small cases."""
+    lib = ops._lib_()
+    lib.wdno_set_debug(mode)
+    try:
+        conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000)
+    finally:
+        lib.wdno_set_debug(0)
+
+
 def test_conv_f16x3_wide_dynamic_range(ops):
     """Gradient-like magnitudes (1e-7) and large activations (1e3) must survive the per-tensor scaling."""
     for scale in (1e-7, 1.0, 1e3):

@@ -551,9 +551,9 @@ static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const vo
   const int K = g->K;
   auto blocks = [&](int bm, int bn) { return cdiv64(P, bm) * cdiv(K, bn); };
   // problems with at least 100 tiles: persistent LDS-DMA kernels (256x64 / 128x128 tiles, 64x64 per compute wave); even with
-  // fewer tiles than CUs they beat the register-staged kernels (l2 512->128: 0.36 -> 0.24 ms). debug: 5 = never, 7 = always, 8 = always and not the tap-resident variant
+  // fewer tiles than CUs they beat the register-staged kernels (l2 512->128: 0.36 -> 0.24 ms). debug: 5 = never, 7 = always, 8 = always and not the tap-resident variant, 30 / 31 = always with the five-row tile shapes (conv_h3d.hip)
   const int dbg = wdno_debug_mode;
-  if (dbg != 5 && dbg != 3 && dbg != 1 && (dbg == 7 || dbg == 8 || (K > 64 ? blocks(128, 128) : blocks(256, 64)) >= 100)) {
+  if (dbg != 5 && dbg != 3 && dbg != 1 && (dbg == 7 || dbg == 8 || dbg == 30 || dbg == 31 || (K > 64 ? blocks(128, 128) : blocks(256, 64)) >= 100)) {
     rc = wdno_conv_fwd_h3_dma(xh, LP ? nullptr : xl, wph, LP ? nullptr : wpl, sx, sw, bias, residual, y, p, st, 3);
     if (rc == WDNO_OK) return wdno_check_launch();
     if (rc != WDNO_EUNSUPPORTED) return rc;

@@ -376,7 +376,19 @@ static int fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void
   if (!narrow_only && all && cost(192, 128, 1.0) < c) { best = 1; c = cost(192, 128, 1.0); }
   if (!narrow_only && all && cost(256, 64, 1.04) < c) { best = 2; c = cost(256, 64, 1.04); }
   if (all && cost(192, 64, 1.08) < c) { best = 3; c = cost(192, 64, 1.08); }
-  if (p.identity_out && wdno_conv_h3t_takes(g)) return wdno_conv_fwd_h3_tap(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (p.identity_out && wdno_conv_h3t_takes(g)) {
+    // tap-resident kernel only: two more shapes of 20480 outputs, five MFMA row tiles per wave. On 256 CUs the 20 x 20-level layers with 128
+    // output channels are 600 tiles of 128 x 128 (three rounds, the last with 88 tiles) but 480 of 160 x 128 (two rounds, 94 % full), the
+    // 10 x 10-level ones with 256 are 200 of 192 x 128 (78 % of one round) but 240 of 160 x 128; 320 x 64 does the same for 64 output
+    // channels at the 20 x 20 level (240 tiles instead of 400 of 192 x 64). debug 29: without them.
+    if (all && wdno_debug_mode != 29 && g.kw == 3) {
+      if (!narrow_only && cost(160, 128, 1.02) < c) { best = 4; c = cost(160, 128, 1.02); }
+      if (cost(320, 64, 1.05) < c) { best = 5; c = cost(320, 64, 1.05); }
+      if (wdno_debug_mode == 30) best = narrow_only ? 5 : 4;     // tests: the new shapes on small cases
+      if (wdno_debug_mode == 31) best = 5;
+    }
+    return wdno_conv_fwd_h3_tap(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  }
   // (deeper rings -- NS = 4 / 5 fill the 160 KB -- measured no faster: the 7 x 7 x 7 init convolution keeps its 3.1 M shader cycles)
   if (best == 0) return launch_h3d<128, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (best == 1) return launch_h3d<192, 128, 2, 2, 3, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);

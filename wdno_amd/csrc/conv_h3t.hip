@@ -373,7 +373,7 @@ static int launch_h3t(const void* xh, const void* xl, const void* wh, const void
 
 // Geometries the tap-resident kernel takes: stride 1, output grid == input grid (so flat pixel indices shift by constants),
 // kw == 3, whole 32-channel blocks. `shape` = tile shape chosen by the caller (conv_h3d.hip: 0 = 128 x 128, 1 = 192 x 128,
-// 2 = 256 x 64, 3 = 192 x 64).
+// 2 = 256 x 64, 3 = 192 x 64, 4 = 160 x 128 (one wave row, four wave columns), 5 = 320 x 64).
 // ... or kw == 7 on whole 16-channel blocks with at most 64 output channels (the stem of the smoke U-Net: 42 -> 48 channels in the planes):
 // there the weight rows of a 32-channel block (7 x 64 x 64 B per plane) would not leave room for two stages, so a stage is a 16-channel
 // block with LDS rows of 32 B and one 16-deep sub-step per dx (debug 20: the chunked kernel instead).
@@ -388,6 +388,8 @@ static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, co
   if (shape == 0) return launch_h3t<128, 128, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 1) return launch_h3t<192, 128, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 3) return launch_h3t<192, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 4) return launch_h3t<160, 128, 1, 4, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 5) return launch_h3t<320, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   return launch_h3t<256, 64, 4, 1, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }
 int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,

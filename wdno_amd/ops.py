@@ -630,6 +630,12 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
         for sh in shapes[1:]:
             if cost(*sh) < cost(*best):
                 best = sh
+        if tap and ks[2] == 3:                       # csrc/conv_h3d.hip: two more shapes for the tap-resident kernel
+            c_best = cost(*best)
+            if k > 64 and cost(160, 128, 1.02) < c_best:
+                best, c_best = (160, 128, 1.02), cost(160, 128, 1.02)
+            if cost(320, 64, 1.05) < c_best:
+                best = (320, 64, 1.05)
         if tap and _lp() and k > 64 and cdiv(pixels, 256) * cdiv(k, 128) >= 2 * cus:
             best = (256, 128)                        # csrc/conv_h3t.hip: the wide tiles of the single-plane mode
         if tap and ks[2] == 7:
