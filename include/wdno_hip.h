@@ -121,7 +121,10 @@ size_t wdno_split_colsum_ws_bytes(int64_t rows, int C8);
 int wdno_split_f16_colsum(const float* x, const float* amax_rec, void* hi, void* lo, float* scale_out, float* colsum_out,
                           void* ws, size_t ws_bytes, int64_t rows, int C, int C8, wdno_stream_t s);
 /* raw weight [K][C][kd][kh][kw] -> split planes of the packed operand in one launch. mode 0: forward operand
- * [kd][kh][A>=K][kw][B>=C]; mode 1: data-gradient operand [kd][kh][A>=C][kw][B>=K] with flipped taps. amax = max|w| (device). */
+ * [kd][kh][A>=K][kw][B>=C]; mode 1: data-gradient operand [kd][kh][A>=C][kw][B>=K] with flipped taps. amax = max|w| (device).
+ * modes 2 + 2 py + px: forward operand of parity class (py, px) of the (1,4,4) / stride (1,2,2) transposed convolution (the stride-1
+ * (1,2,2) convolution that produces the output pixels of that parity; Upsample of video_diffusion_pytorch_conv3d.py:96-98), gathered
+ * from the ConvTranspose3d weight w[C = in][K = out][1][4][4] itself; kd, kh, kw = 1, 2, 2. */
 int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh, int kw,
                            int A, int B, int mode, wdno_stream_t s);
 /* Multi-tensor forms of wdno_amax and wdno_pack_split_weight for the per-step refresh of all weights: one launch for any

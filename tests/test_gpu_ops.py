@@ -339,6 +339,22 @@ def test_conv_transpose_f16x3_path(ops, cin, cout, sp):
     assert any('h3' in k for k in n_launch) and not any(k.startswith('conv_fwd_kernel') for k in n_launch), list(n_launch)
 
 
+def test_conv_transpose_parity_operands_follow_the_weight(ops):
+    """The four parity-class operands of a transposed convolution are gathered from the ConvTranspose weight by the pack kernel and
+    refreshed with every other operand after an optimiser step: after an in-place weight change (+ weight epoch) the result must
+    follow the new weight."""
+    x, w = g((2, 64, 4, 16, 16), 410), g((64, 40, 1, 4, 4), 411) * 0.1
+    xd, wd = dev(to_cl(x)), dev(w)
+    y1 = ops.conv_transpose_cl(xd, wd)
+    assert rel_l2(from_cl(y1.cpu())[:, :40], F.conv_transpose3d(x, w, None, stride=(1, 2, 2), padding=(0, 1, 1))) < TOL
+    for k in range(2):
+        with torch.no_grad():
+            wd.mul_(-0.7).add_(0.01 * (k + 1))
+        ops.bump_weight_epoch()
+        y2 = ops.conv_transpose_cl(xd, wd)
+        assert rel_l2(from_cl(y2.cpu())[:, :40], F.conv_transpose3d(x, wd.detach().cpu().to(x.dtype), None, stride=(1, 2, 2), padding=(0, 1, 1))) < TOL
+
+
 # ----------------------------------------------------------------------------------------------------- amax records
 def _amax_chain(ops, hints, poison=False):
     """layer norm -> 1x1 conv -> group norm + SiLU -> 3x3x3 conv (residual) -> concat -> conv -> add -> conv: every producer that

@@ -1065,8 +1065,13 @@ __device__ __forceinline__ int ps_div(int n, int d, unsigned m) { return d == 1 
 __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, const float* __restrict__ amax,
                                                 _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                 float* __restrict__ scale_out, int K, int C, int kd, int kh, int kw,
-                                                int A, int B, int mode, int block, int nblocks) {
+                                                int A, int B, int mode_in, int block, int nblocks) {
   __shared__ float tile[PS_LDS_FLOATS + 16];
+  // modes 2 .. 5: forward operand of parity class (py, px) = ((mode - 2) >> 1, (mode - 2) & 1) of the (1,4,4) / stride (1,2,2) transposed
+  // convolution, read straight from its weight w[in = C][out = K][1][4][4]:  W[k][c][0][dy][dx] = w[c][k][0][3 - py - 2 dy][3 - px - 2 dx]
+  // (kd, kh, kw = 1, 2, 2). Only the gather below differs; everything after it is the forward layout.
+  const int parity = mode_in >= 2 ? mode_in - 2 : -1;
+  const int mode = mode_in == 1 ? 1 : 0;
   const bool lp = lo == nullptr;                     // one bf16 plane, no scale (amax / scale_out may be NULL)
   const float s = lp ? 1.0f : scale_from_amax(amax[0]);
   if (!lp && block == 0 && threadIdx.x == 0) scale_out[0] = s;
@@ -1089,7 +1094,10 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
       const int kk = ps_div(idx, run, m_run), r = idx - kk * run;
       const int cl = ps_div(r, T, m_T), tap = r - cl * T;
       float v = 0.f;
-      if (k0 + kk < K && cl < cvalid) v = w[((int64_t)(k0 + kk) * C + c0) * T + r];
+      if (k0 + kk < K && cl < cvalid) {
+        if (parity < 0) v = w[((int64_t)(k0 + kk) * C + c0) * T + r];
+        else v = w[((int64_t)(c0 + cl) * K + (k0 + kk)) * 16 + (3 - (parity >> 1) - 2 * (tap >> 1)) * 4 + (3 - (parity & 1) - 2 * (tap & 1))];
+      }
       tile[(tap * pt.KT + kk) * pt.CTp + cl] = v;
     }
     __syncthreads();
@@ -1168,11 +1176,12 @@ extern "C" int wdno_pack_split_weight_multi(const void* table, int n_items, int 
 }
 extern "C" int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh,
                                       int kw, int A, int B, int mode, wdno_stream_t s) {
-  WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && (mode == 0 || mode == 1));
-  WDNO_REQUIRE(mode == 0 ? (A >= K && B >= C) : (A >= C && B >= K));
+  WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && mode >= 0 && mode <= 5);
+  WDNO_REQUIRE(mode < 2 || (kd == 1 && kh == 2 && kw == 2));      // parity classes of the (1,4,4) transposed convolution
+  WDNO_REQUIRE(mode != 1 ? (A >= K && B >= C) : (A >= C && B >= K));
   WDNO_REQUIRE(lo == nullptr || (amax != nullptr && scale_out != nullptr));      // lo == NULL: one bf16 plane in `hi`
   int64_t total = (int64_t)kd * kh * A * kw * (B / 8);
-  const PackTile ptile = pack_tile(kd * kh * kw, A, B, mode);
+  const PackTile ptile = pack_tile(kd * kh * kw, A, B, mode == 1 ? 1 : 0);
   if ((int64_t)kd * kh * kw * ptile.KT * ptile.CTp > PS_LDS_FLOATS + 16) return WDNO_EUNSUPPORTED;      // > 640 taps (every operand passes here first)
   (void)total;
   pack_split_weight_kernel<<<std::min(2048, ptile.tiles_k * ptile.tiles_c), 256, 0, as_stream(s)>>>(w, amax, (_Float16*)hi, (_Float16*)lo, scale_out, K, C, kd, kh, kw,

@@ -480,6 +480,19 @@ class _WPlan:
     __slots__ = ('w', 'wd', 'kind', 'cp8', 'kp', 'hi', 'lo', 'sc', 'ver', 'used', 'lp')
 
 
+def _wmode(kind):
+    """pack mode of csrc/conv_h3.hip: 'f' forward operand, 'd' data-gradient operand, 'p{py}{px}' parity class of a transposed convolution."""
+    return 0 if kind == 'f' else 1 if kind == 'd' else 2 + 2 * int(kind[1]) + int(kind[2])
+
+
+def _wdims(kind, w5):
+    """(K, C, kd, kh, kw) the pack kernel is told for weight w5 (5-D) and operand kind."""
+    if kind[0] == 'p':              # ConvTranspose weight [in, out, 1, 4, 4] read as the [out, in, 1, 2, 2] weight of one parity class
+        assert tuple(w5.shape[2:]) == (1, 4, 4)
+        return w5.shape[1], w5.shape[0], 1, 2, 2
+    return tuple(w5.shape)
+
+
 _wplans = {}            # key -> _WPlan
 _wtables = {}           # tuple of plan keys -> (amax buffer, amax table, split table, keep-alive list)
 WEIGHT_BATCH = os.environ.get('WDNO_WEIGHT_BATCH', '1') != '0'
@@ -522,14 +535,13 @@ def _refresh_weight_plans(epoch_used):
         sitems = (_WsplitItem * len(keys))()
         for j, k in enumerate(keys):
             pl = _wplans[k]
-            w5 = _as5(pl.wd)
-            kk, cc, kd, kh, kw = w5.shape
+            kk, cc, kd, kh, kw = _wdims(pl.kind, _as5(pl.wd))
             i = wptrs.index(pl.wd.data_ptr())
             if lp:      # one bf16 plane: no amax, no lo plane, no scale
-                sitems[j] = _WsplitItem(pl.wd.data_ptr(), None, pl.hi.data_ptr(), None, None, kk, cc, kd, kh, kw, pl.kp, pl.cp8, 0 if pl.kind == 'f' else 1)
+                sitems[j] = _WsplitItem(pl.wd.data_ptr(), None, pl.hi.data_ptr(), None, None, kk, cc, kd, kh, kw, pl.kp, pl.cp8, _wmode(pl.kind))
                 continue
             sitems[j] = _WsplitItem(pl.wd.data_ptr(), amax.data_ptr() + 4 * i, pl.hi.data_ptr(), pl.lo.data_ptr(), pl.sc.data_ptr(),
-                                    kk, cc, kd, kh, kw, pl.kp, pl.cp8, 0 if pl.kind == 'f' else 1)
+                                    kk, cc, kd, kh, kw, pl.kp, pl.cp8, _wmode(pl.kind))
         at = torch.frombuffer(bytearray(bytes(aitems)), dtype=torch.uint8).to(dev)
         stt = torch.frombuffer(bytearray(bytes(sitems)), dtype=torch.uint8).to(dev)
         tabs = (amax, at, stt, len(wptrs))
@@ -567,8 +579,7 @@ def split_weight(w, kind, cp8, kp, pack=None):
         if not lp:
             amax = torch.zeros(1, device=w.device, dtype=torch.float32)
             _lib.check(_lib_().wdno_amax(_p(wc), wc.numel(), _p(amax), _stream()), 'amax')
-        w5 = _as5(wc)
-        k, c, kd, kh, kw = w5.shape
+        k, c, kd, kh, kw = _wdims(kind, _as5(wc))
         rows = kd * kh * kp * kw
         if pl is None:
             pl = _WPlan()
@@ -580,7 +591,7 @@ def split_weight(w, kind, cp8, kp, pack=None):
                 _wplans.clear(); _wtables.clear()
             _wplans[key] = pl
         _lib.check(_lib_().wdno_pack_split_weight(_p(wc), _p(amax), _p(pl.hi), _p(pl.lo), _p(pl.sc), k, c, kd, kh, kw, kp, cp8,
-                                                  0 if kind == 'f' else 1, _stream()), 'pack_split_weight')
+                                                  _wmode(kind), _stream()), 'pack_split_weight')
     pl.ver = ver
     pl.used = WEIGHT_EPOCH
     return pl.hi, pl.lo, pl.sc
@@ -1068,24 +1079,15 @@ class _ConvT(torch.autograd.Function):
         return gx, gw, gb
 
 
-def _parity_weight(w_io, py, px):
-    """The (1,2,2) stride-1 convolution weight [out, in, 1, 2, 2] of parity class (py, px) of the (1,4,4)/(1,2,2)/(0,1,1)
-    transposed convolution with weight [in, out, 1, 4, 4]: W[o][i][0][dy][dx] = w[i][o][0][3 - py - 2 dy][3 - px - 2 dx]."""
-    def build():
-        w = w_io.detach()
-        rows = torch.stack((w[:, :, :, 3 - py], w[:, :, :, 1 - py]), dim=3)                  # [in, out, 1, 2(dy), 4]
-        sub = torch.stack((rows[..., 3 - px], rows[..., 1 - px]), dim=4)                     # [in, out, 1, 2(dy), 2(dx)]
-        return sub.permute(1, 0, 2, 3, 4).contiguous()
-    return _cached(w_io, f'par{py}{px}', 0, 0, build)
-
-
 def conv_transpose_h3(xplanes, shape4, weight, bias_p, cout_p, amax_rec=None):
     """Parity-class form of the transposed convolution on the split-fp16 kernels: 4 launches writing interleaved outputs."""
     n, d, h, w = shape4
     y = torch.empty((n, d, 2 * h, 2 * w, cout_p), device=xplanes[0].device, dtype=torch.float32)
     for py in range(2):
         for px in range(2):
-            conv_fwd_h3(xplanes, shape4, _parity_weight(weight, py, px), pack_fwd, 'f', bias_p, None, (1, 2, 2), (1, 1, 1), (0, 1 - py, 1 - px),
+            # the packed operand of the parity class is gathered from the ConvTranspose weight itself (kind 'p{py}{px}'): it is refreshed
+            # with all other operands in the two launches after an optimiser step instead of ~5 small launches per class and step
+            conv_fwd_h3(xplanes, shape4, weight, pack_fwd, f'p{py}{px}', bias_p, None, (1, 2, 2), (1, 1, 1), (0, 1 - py, 1 - px),
                         cout_p, out=y, osp=(d, h, w), ostride=(1, 2, 2), ooff=(0, py, px), amax_rec=amax_rec)      # the 4 classes merge into one record
     return y
 
