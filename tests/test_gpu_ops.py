@@ -239,6 +239,7 @@ CONV_CASES_TAP = [
     ('tap_stem_k40', (1, 42, 4, 10, 33), (40, 42, 7, 7, 7), 1, 3),         # ragged output channels, odd row length
     ('tap_stem_2d', (3, 48, 20, 36), (64, 48, 7, 7), 1, 3),
     ('tap_stem_multi', (2, 42, 6, 40, 40), (64, 42, 7, 7, 7), 1, 3),       # 19200 pixels
+    ('tap_stem_c82', (1, 82, 4, 18, 18), (64, 82, 7, 7, 7), 1, 3),         # the super-resolution stem: 82 channels in planes of 96
 ]
 
 

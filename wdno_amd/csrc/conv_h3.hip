@@ -116,14 +116,14 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
   }
 }
 extern "C" int wdno_cast_bf16(const float* x, void* out, int64_t rows, int C, int C8, wdno_stream_t s) {
-  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 8);
+  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 16);      // (up to a whole 16-channel block: 7-wide stems)
   int64_t total = rows * (C8 / 8);
   split_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, nullptr, (_Float16*)out, nullptr, nullptr, rows, C, C8);
   return wdno_check_launch();
 }
 extern "C" int wdno_split_f16(const float* x, const float* amax, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8,
                               wdno_stream_t s) {
-  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 8);
+  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 16);      // (up to a whole 16-channel block: 7-wide stems)
   int64_t total = rows * (C8 / 8);
   split_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(x, amax, (_Float16*)hi, (_Float16*)lo, scale_out, rows, C, C8);
   return wdno_check_launch();
@@ -195,7 +195,7 @@ extern "C" size_t wdno_split_colsum_ws_bytes(int64_t rows, int C8) {
 }
 extern "C" int wdno_split_f16_colsum(const float* x, const float* amax, void* hi, void* lo, float* scale_out, float* colsum_out,
                                      void* ws, size_t ws_bytes, int64_t rows, int C, int C8, wdno_stream_t s) {
-  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 8);
+  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 16);      // (up to a whole 16-channel block: 7-wide stems)
   const int g8 = C8 / 8;
   if (g8 > 256 || (g8 & (g8 - 1))) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_split_colsum_ws_bytes(rows, C8)) return WDNO_EWORKSPACE;
@@ -207,7 +207,7 @@ extern "C" int wdno_split_f16_colsum(const float* x, const float* amax, void* hi
 
 extern "C" int wdno_cast_bf16_colsum(const float* x, void* out, float* colsum_out, void* ws, size_t ws_bytes, int64_t rows, int C, int C8,
                                      wdno_stream_t s) {
-  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 8);
+  WDNO_REQUIRE(rows > 0 && C > 0 && (C & 3) == 0 && (C8 & 7) == 0 && C8 >= C && C8 < C + 16);      // (up to a whole 16-channel block: 7-wide stems)
   const int g8 = C8 / 8;
   if (g8 > 256 || (g8 & (g8 - 1))) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_split_colsum_ws_bytes(rows, C8)) return WDNO_EWORKSPACE;

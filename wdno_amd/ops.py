@@ -413,13 +413,14 @@ def tensor_amax(x):
     return amax
 
 
-def split_f16_of(t, x2d, amax=None):
+def split_f16_of(t, x2d, amax=None, c8=None):
     """split_f16(x2d) for the rows of tensor t, remembered on t (with its version): a tensor that feeds two convolutions -- the
     input of a ResnetBlock with a projection skip -- is split once, and both keep the same planes for their backward."""
     h = getattr(t, '_wdno_planes', None)
-    if h is not None and h[1] == t._version and h[0][0].shape[0] == x2d.shape[0] and h[2] == CONV_MATH:
+    if (h is not None and h[1] == t._version and h[0][0].shape[0] == x2d.shape[0] and h[2] == CONV_MATH
+            and (c8 is None or h[0][0].shape[1] == c8)):
         return h[0]
-    planes = split_f16(x2d, amax)
+    planes = split_f16(x2d, amax, c8)
     try:
         t._wdno_planes = (planes, t._version, CONV_MATH)
     except Exception:
@@ -427,11 +428,12 @@ def split_f16_of(t, x2d, amax=None):
     return planes
 
 
-def split_f16(x2d, amax=None):
+def split_f16(x2d, amax=None, c8=None):
     """[rows, C] fp32 -> (hi, lo) fp16 [rows, C8] and the device scalar scale: one amax sweep (unless the producer of the
-    tensor left its amax record, `amax`) + one split pass."""
+    tensor left its amax record, `amax`) + one split pass. c8: plane width if not pad8(C) (a 7-wide stem pads to whole 16-channel blocks)."""
     rows, c = x2d.shape
-    c8 = pad8(c)
+    if c8 is None or _lp():
+        c8 = pad8(c)
     lib = _lib_()
     if _lp():                    # one bf16 plane (carried in a float16-typed tensor: 16-bit storage, the kernels reinterpret it)
         hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
@@ -885,7 +887,10 @@ class _Conv(torch.autograd.Function):
             if not (h3 and hp is not None and hp[1] == x_in._version and hp[2] == CONV_MATH):
                 raise RuntimeError('wdno_amd: a planes-only tensor reached a convolution that reads fp32')
         if h3:
-            planes = split_f16_of(x_in, x5.reshape(-1, cp), xrec)
+            # 7-wide stems run on the 16-channel-block tap-resident kernel (csrc/conv_h3t.hip: t_stem): planes padded to whole blocks
+            # (the super-resolution model's 82 channels -> 96; the base model's 42 -> 48 already are)
+            c8w = pad8(cp) + 8 if (ks[2] == 7 and kp <= 64 and tuple(stride) == (1, 1, 1) and pad8(cp) % 16) else None
+            planes = split_f16_of(x_in, x5.reshape(-1, cp), xrec, c8w)
             yrec = _new_amax_record(x5.device)
             y = _leave_amax(conv_fwd_h3(planes, tuple(x5.shape[:4]), weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp,
                                         amax_rec=yrec), yrec)
