@@ -469,7 +469,8 @@ def test_softmax_attention_thread_per_row_kernels(ops):
         lib.wdno_set_debug(0)
 
 
-@pytest.mark.parametrize('kind,b,f,h,w', [('temporal', 2, 24, 3, 5), ('temporal', 1, 7, 2, 2), ('spatial', 2, 3, 10, 10), ('spatial', 1, 1, 8, 8)])
+@pytest.mark.parametrize('kind,b,f,h,w', [('temporal', 2, 24, 3, 5), ('temporal', 1, 7, 2, 2), ('spatial', 2, 3, 10, 10), ('spatial', 1, 1, 8, 8),
+                                          ('temporal', 1, 48, 3, 4), ('temporal', 2, 33, 2, 3), ('temporal', 1, 56, 1, 2)])
 def test_softmax_attention(ops, kind, b, f, h, w):
     from oracle import unet_ref as U
     heads, dh = 4, 32
@@ -882,6 +883,41 @@ def test_attention_backward_delivers_planes(ops):
     assert n_got == n_ref - 2, (n_ref, n_got)           # neither dqkv nor the attention output is split
     for name, a, e in zip(['dx', 'dwq', 'dwo'], got, ref):
         assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))
+
+
+def test_attention_two_tile_forward_writes_planes_when_sampling(ops):
+    """33..64 tokens (the super-resolution model attends over 48 frames): the two-tile MFMA forward. Without gradients it may hand its
+    output to the to_out projection as planes only; with gradients it must not (its backward reads the fp32 output)."""
+    b, f, h, w, c, heads = 1, 48, 8, 8, 64, 4
+    x = g((b, c, f, h, w), 341)
+    wq = g((3 * heads * 32, c), 342) * 0.2
+    wo = g((c, heads * 32), 343) * 0.1
+    xs, wqs, wos = dev(to_cl(x)), dev(wq), dev(wo)
+
+    def run(flag, grad):
+        calls = {'n': 0}
+        orig = ops.split_f16
+
+        def counting(*a, **kw):
+            calls['n'] += 1
+            return orig(*a, **kw)
+        ops.split_f16 = counting
+        try:
+            with torch.set_grad_enabled(grad):
+                xin = xs.clone().requires_grad_(grad)
+                rows = ops.conv_cl(xin, wqs)
+                out = ops.softmax_attention(rows, heads, b, h * w, f, f * h * w, 1, h * w, 32 ** -0.5, out_planes=flag)
+                y = ops.conv_cl(out, wos)
+                if grad:
+                    y.sum().backward()
+        finally:
+            ops.split_f16 = orig
+        return y.detach().double().cpu(), calls['n']
+    ref, n_ref = run(False, False)
+    got, n_got = run(True, False)
+    assert n_got == n_ref - 1 and rel_l2(got, ref) < 2e-6, (n_ref, n_got, rel_l2(got, ref))
+    got_g, n_g = run(True, True)
+    assert rel_l2(got_g, ref) < 2e-6
 
 
 def test_linear_attention_backward_delivers_planes(ops):

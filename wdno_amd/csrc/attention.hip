@@ -448,6 +448,112 @@ __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const f
   if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * AM_WAVES + wave);
 }
 
+// 32 < n_tok <= 64 (the super-resolution model attends over 48 frames): the same one-wave-per-(unit, head) formulation with keys and
+// queries in two 32-wide tiles each. Q and K of all 64 rows are staged once ([64][AM_TS] per wave and operand); per query tile the two
+// score tiles (32 MFMA steps), one softmax over both, and the two P V products into one accumulator (32 steps).
+__global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_fwd_mfma64_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+                                                                            const float* __restrict__ rsin, const float* __restrict__ bias,
+                                                                            float* __restrict__ out, AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = p.d.n_tok;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+  float fps = 1.0f;
+  if (p.pl_hi && p.pl_lo) {
+    fps = scale_from_amax(amax_record_read(p.rec_qkv));
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.pl_scale[0] = fps;
+  }
+  float am = 0.f;
+  float* Tq = smem + wave * (2 * 64 * AM_TS);
+  float* Tk = Tq + 64 * AM_TS;
+  for (int64_t item = (int64_t)blockIdx.x * AM_WAVES + wave; item < p.n_items; item += (int64_t)gridDim.x * AM_WAVES) {
+    const int h = (int)(item % p.d.heads);
+    const int64_t unit = item / p.d.heads;
+    const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
+    const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
+    const float* qb = am_uniform(qkv + row0 * p.RW + h * DH);
+    const unsigned tstride = (unsigned)(p.d.st * p.RW);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float* rc = rcos ? rcos + half * 32 * DH : nullptr;
+      const float* rs = rsin ? rsin + half * 32 * DH : nullptr;
+      am_stage_rows(Tq + half * 32 * AM_TS, qb + (unsigned)(half * 32) * tstride, tstride, rc, rs, p.scale, n - half * 32, lane);
+      am_stage_rows(Tk + half * 32 * AM_TS, qb + (unsigned)(half * 32) * tstride + p.HD, tstride, rc, rs, 1.0f, n - half * 32, lane);
+    }
+    // V elements of both key tiles: step m of tile jt needs V[32 jt + key(m, hh)][d = li]
+    float va[2][16];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int j = 32 * jt + am_key(m, hh);
+        va[jt][m] = j < n ? qb[(unsigned)j * tstride + (unsigned)(2 * p.HD + li)] : 0.f;
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+      const int qi = 32 * it + li;                     // this lane's query
+      const bool tok = qi < n;
+      if (32 * it >= n) break;
+      float qs[16];
+      am_sel(Tq + it * 32 * AM_TS, li, hh, qs);
+      f32x16 sT[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        float ks[16];
+        am_sel(Tk + jt * 32 * AM_TS, li, hh, ks);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sT[jt][e] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sT[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[m], qs[m], sT[jt], 0, 0, 0);
+      }
+      // softmax over the 64 keys of query qi: 32 in this lane (two tiles x 16), 32 in lane ^ 32
+      const float* brow = bias ? bias + ((int64_t)h * n + (tok ? qi : 0)) * n : nullptr;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int j = 32 * jt + am_key(e, hh);
+          float v = sT[jt][e];
+          if (brow && tok && j < n) v += brow[j];
+          v = j < n ? v : -INFINITY;
+          sT[jt][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sT[jt][e] = expf(sT[jt][e] - mx); l += sT[jt][e]; }
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      f32x16 oT;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oT[e] = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int m = 0; m < 16; ++m) oT = __builtin_amdgcn_mfma_f32_32x32x2f32(va[jt][m], sT[jt][m] * inv, oT, 0, 0, 0);
+      // both lanes of a pair (l, l + 32) hold the same query, so `tok` is uniform over the pair (am_store_row_planes needs that)
+      if (tok) {
+        const int64_t rowl = row0 + (int64_t)qi * p.d.st;
+        float* orow = out + rowl * p.HD + h * DH;
+        float4 vv[4];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          vv[e4] = make_float4(oT[4 * e4], oT[4 * e4 + 1], oT[4 * e4 + 2], oT[4 * e4 + 3]);
+          if (!p.pl_hi) *reinterpret_cast<float4*>(orow + 8 * e4 + 4 * hh) = vv[e4];
+          am = amax4(am, vv[e4]);
+        }
+        if (p.pl_hi) am_store_row_planes(p.pl_hi, p.pl_lo, rowl * p.HD + h * DH, hh, vv, fps);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();      // the next item overwrites the tiles
+  }
+  if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * AM_WAVES + wave);
+}
+
 // element (row j, channel li) of a rotated q / k row, read column-wise (coalesced 128-byte rows): the rotation partner sits in
 // the neighbouring lane
 __device__ __forceinline__ float am_rot_elem(float x, const float* __restrict__ rc, const float* __restrict__ rs, int j, int li, bool ok) {
@@ -677,6 +783,15 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
   }
 }
 
+static void attn_fwd_mfma64_launch(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
+                                   const AttnP& p, hipStream_t st) {
+  const size_t lds = (size_t)AM_WAVES * 2 * 64 * AM_TS * sizeof(float);       // 73.7 KB: two blocks per CU
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
+  if (nb > 4096) nb = 4096;
+  attn_fwd_mfma64_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds, st>>>(qkv, rot_cos, rot_sin, bias, out, p);
+}
 static int attn_fill(AttnP& p, const wdno_attn_desc* d, float scale, int threads) {
   if (!d || d->n_uo <= 0 || d->n_ui <= 0 || d->n_tok <= 0 || d->heads <= 0) return WDNO_EINVAL;
   p.d = *d; p.scale = scale; p.HD = d->heads * DH; p.RW = 3 * p.HD;
@@ -712,6 +827,11 @@ extern "C" int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const 
     attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
     return wdno_check_launch();
   }
+  if (d->n_tok <= 64 && wdno_debug_mode != 5) {                  // two 32-wide tiles of keys and of queries per item
+    p.amax_rec = amax_rec;
+    attn_fwd_mfma64_launch(qkv, rot_cos, rot_sin, bias, out, p, as_stream(s));
+    return wdno_check_launch();
+  }
   return attn_amax_sweep(attn_fwd_rows(qkv, rot_cos, rot_sin, bias, out, p, d, s), out, d, p.HD, amax_rec, s);
 }
 // forward with out delivered ONLY as fp16 planes for the to_out projection (MFMA path only: n_tok <= 32; `out` is not written)
@@ -721,11 +841,15 @@ extern "C" int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, cons
   AttnP p;
   int rc = attn_fill(p, d, scale, ATT_THREADS);
   if (rc) return rc;
-  if (d->n_tok > 32 || !out_hi || (out_lo && (!out_scale || !rec_qkv))) return WDNO_EUNSUPPORTED;      // out_lo == NULL: one bf16 plane
+  if (d->n_tok > 64 || !out_hi || (out_lo && (!out_scale || !rec_qkv))) return WDNO_EUNSUPPORTED;      // out_lo == NULL: one bf16 plane
   int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
   if (nb > 4096) nb = 4096;
   p.amax_rec = amax_rec;
   p.pl_hi = (_Float16*)out_hi; p.pl_lo = (_Float16*)out_lo; p.rec_qkv = rec_qkv; p.pl_scale = out_scale;
+  if (d->n_tok > 32) {
+    attn_fwd_mfma64_launch(qkv, rot_cos, rot_sin, bias, out, p, as_stream(s));
+    return wdno_check_launch();
+  }
   attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
   return wdno_check_launch();
 }

@@ -1268,7 +1268,10 @@ class _Attn(torch.autograd.Function):
         rec = _new_amax_record(qkv.device)
         qrec_f = _known_amax(qkv_in)
         planes = None
-        if out_planes and desc_args[2] <= 32 and (_lp() or (CONV_MATH == 'f16x3' and qrec_f is not None)):
+        # planes only (fp32 `out` unwritten): up to 32 tokens always -- that backward does not read `out` -- and up to 64 (the two-tile
+        # forward kernel; its backward is the thread-per-row kernel, which does) when nothing here needs a gradient (sampling)
+        planes_ntok = 32 if any(ctx.needs_input_grad) else 64
+        if out_planes and desc_args[2] <= planes_ntok and (_lp() or (CONV_MATH == 'f16x3' and qrec_f is not None)):
             rows = out.numel() // out.shape[-1]
             hi = torch.empty((rows, heads * 32), device=qkv.device, dtype=torch.float16)
             lo = sc = None
