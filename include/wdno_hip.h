@@ -260,7 +260,9 @@ int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, const float* ro
                          const float* dout, void* dqkv_hi, void* dqkv_lo, float* dqkv_scale, float* dbias,
                          const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, wdno_stream_t s);
 /* Forward with out delivered ONLY as the fp16 planes of the to_out projection (|out| <= max|qkv|: scale from rec_qkv); `out` is not
- * written. The n_tok <= 32 backward (wdno_attn_bwd*, MFMA path) does not read out: delta = sum_j P dP is formed in registers. */
+ * written. n_tok <= 64 (WDNO_EUNSUPPORTED beyond). The n_tok <= 32 backward (wdno_attn_bwd*, MFMA path) does not read out: delta =
+ * sum_j P dP is formed in registers; for 33..64 tokens the backward does read it, so a caller that needs gradients keeps the fp32 form
+ * there (the super-resolution sampler, 48 frames, does not). */
 int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, void* out_hi,
                          void* out_lo, float* out_scale, float* amax_rec, const float* rec_qkv, const wdno_attn_desc* d, float scale,
                          wdno_stream_t s);
