@@ -1,6 +1,6 @@
 """GPU debugging aid: Burgers p_losses HIP vs oracle over a grid of configurations."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from wdno_amd import tree_path
