@@ -208,6 +208,15 @@ size_t wdno_groupnorm_fwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G);
 int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
                                   float* y_scale, float* stats, float* bound_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
                                   void* ws, size_t ws_bytes, wdno_stream_t s);
+/* y = act(GroupNorm(x)) + residual as BOTH the fp32 tensor y and its planes: the tail of a ResnetBlock with an identity skip
+ * (unet.py:167-176, conv3d.py:286-300: `h + self.res_conv(x)` with res_conv = Identity), whose sum is the next block's skip and the
+ * operand of its first convolution. res_rec = amax record of residual (the scale bound is the norm's bound + max|residual|);
+ * y_amax_rec (optional) receives the amax record of y. y_hi == NULL: the fp32 sum only (one pass instead of apply + add) for sums
+ * whose reader is not a convolution. Workspace: wdno_groupnorm_fwd_planes_ws_bytes. */
+int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, const float* residual,
+                                      const float* res_rec, float* y, void* y_hi, void* y_lo, float* y_scale, float* stats,
+                                      float* bound_rec, float* y_amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                      void* ws, size_t ws_bytes, wdno_stream_t s);
 int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
                                   const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
                                   float* dgb_partial, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,

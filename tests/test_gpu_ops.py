@@ -441,6 +441,33 @@ def test_groupnorm_act(ops, shape, groups, use_ss, act):
         assert rel_l2(sd.grad, sr.grad) < 5e-6
 
 
+@pytest.mark.parametrize('shape,groups,use_ss', [((2, 64, 3, 10, 10), 8, True), ((3, 128, 8, 8), 1, False), ((2, 24, 5, 5), 4, False)])
+def test_groupnorm_act_add(ops, shape, groups, use_ss):
+    """act(GroupNorm(x)) + residual in one apply pass (identity-skip ResnetBlock tail); channel counts the fused kernel does not take
+    (24: C / 8 = 3 is not a power of two) fall back to norm + add. Forward and every gradient against torch."""
+    n, c = shape[0], shape[1]
+    x, gam, bet, res = g(shape, 50, 2.0) + 0.7, g((c,), 51) * 0.3 + 1, g((c,), 52) * 0.3, g(shape, 55)
+    ss = g((n, 2 * c), 53, 0.5) if use_ss else None
+    xr, gr, br, rr = (t.clone().requires_grad_(True) for t in (x, gam, bet, res))
+    sr = ss.clone().requires_grad_(True) if use_ss else None
+    yr = F.group_norm(xr, groups, gr, br, eps=1e-5)
+    if use_ss:
+        e = sr.reshape(n, 2 * c, *([1] * (len(shape) - 2)))
+        yr = yr * (e[:, :c] + 1) + e[:, c:]
+    yr = F.silu(yr) + rr
+    go = g(shape, 54)
+    yr.backward(go)
+    xd, gd, bd, rd = dev(to_cl(x), True), dev(gam, True), dev(bet, True), dev(to_cl(res), True)
+    sd = dev(ss, True) if use_ss else None
+    y = ops.groupnorm_act_add(xd, gd, bd, groups, rd, sd, act=True)
+    assert rel_l2(from_cl(y.detach().cpu()), yr.detach()) < TOL
+    y.backward(dev(to_cl(go)))
+    assert rel_l2(from_cl(xd.grad.cpu()), xr.grad) < 5e-6 and rel_l2(from_cl(rd.grad.cpu()), rr.grad) < 1e-7
+    assert rel_l2(gd.grad, gr.grad) < 5e-6 and rel_l2(bd.grad, br.grad) < 5e-6
+    if use_ss:
+        assert rel_l2(sd.grad, sr.grad) < 5e-6
+
+
 @pytest.mark.parametrize('rows,c', [(50, 8), (300, 64), (77, 128), (40, 256), (9, 1024), (33, 96)])
 def test_layernorm(ops, rows, c):
     from oracle.unet_ref import channel_layernorm

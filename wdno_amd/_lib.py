@@ -90,6 +90,7 @@ PROTOTYPES = {
     'wdno_groupnorm_bwd_planes_ws_bytes': (Z, [L, L, I, I]),
     'wdno_groupnorm_fwd_planes_ws_bytes': (Z, [L, L, I, I]),
     'wdno_groupnorm_act_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
+    'wdno_groupnorm_act_add_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_layernorm_fwd_planes': (I, [P, P, P, P, P, L, I, F, P]),
     'wdno_groupnorm_act_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_layernorm_fwd': (I, [P, P, P, L, I, F, P]),

@@ -396,6 +396,60 @@ __global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __res
   }
 }
 
+// y = act(a x + b) + res as BOTH the fp32 tensor and its (hi, lo) fp16 planes: the tail of a ResnetBlock with an identity skip
+// (unet.py:167-176, conv3d.py:286-300). The sum is the next block's skip (fp32) and the operand of its first convolution (planes): this
+// replaces the apply pass, the add and the split (28 bytes per element over three launches) by one pass of 16. Scale from
+// max|a| max|x| + max|b| (gn_finalize_kernel, in `rec`) + max|res| (the amax record of res).
+__global__ __launch_bounds__(256) void gn_apply_add_planes_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+                                                                   const float* __restrict__ res, float* __restrict__ y,
+                                                                   _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                                   float* __restrict__ scale_out, const float* __restrict__ rec,
+                                                                   const float* __restrict__ rec_res, float* __restrict__ amax_out,
+                                                                   int64_t S, int C, int silu) {
+  const int n = blockIdx.y;
+  const int C8 = C >> 3;
+  const int64_t total8 = S * C8;
+  const bool planes = hi != nullptr;                 // hi == nullptr: the fp32 sum only (its reader is a LayerNorm, not a convolution)
+  const bool single = lo == nullptr;                 // one bf16 plane, no scale (WDNO_CONV_MATH=bf16)
+  const float s = single ? 1.0f : scale_from_amax(amax_record_read(rec) + amax_record_read(rec_res));
+  if (!single && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const float* xp = x + (int64_t)n * S * C;
+  const float* rp = res + (int64_t)n * S * C;
+  float* yp = y + (int64_t)n * S * C;
+  _Float16* hp = planes ? hi + (int64_t)n * S * C : nullptr;
+  _Float16* lp = single ? nullptr : lo + (int64_t)n * S * C;
+  const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int c0 = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % C8) * 8;      // fixed per thread: (gridDim.x * 256) % C8 == 0
+  float ka[8], kb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float4 k = cbp[c0 + j]; ka[j] = k.x; kb[j] = k.y; }
+  float am = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += stride) {
+    const float4 v0 = *reinterpret_cast<const float4*>(xp + i * 8), v1 = *reinterpret_cast<const float4*>(xp + i * 8 + 4);
+    const float4 r0 = *reinterpret_cast<const float4*>(rp + i * 8), r1 = *reinterpret_cast<const float4*>(rp + i * 8 + 4);
+    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    float ov[8];
+    gn_half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float o = ka[j] * xv[j] + kb[j];
+      if (silu) o = silu_f(o);
+      o += rv[j];
+      ov[j] = o;
+      am = fmaxf(am, fabsf(o));
+      _Float16 th, tl;
+      plane_pack(o, s, single, th, tl);
+      h[j] = th; l[j] = tl;
+    }
+    *reinterpret_cast<float4*>(yp + i * 8) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    *reinterpret_cast<float4*>(yp + i * 8 + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+    if (planes) *reinterpret_cast<gn_half8*>(hp + i * 8) = h;
+    if (planes && !single) *reinterpret_cast<gn_half8*>(lp + i * 8) = l;
+  }
+  if (amax_out) amax_record_emit(am, amax_out, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
 // dx as (hi, lo) fp16 planes (scale from the bound gn_bwd_finalize_kernel left in `rec`) + per-block column sums of dx (the bias
 // gradient of the convolution in front of the norm). A thread owns 8 channels: 16-byte plane stores; its channel group is fixed
 // ((gridDim.x * 256) % (C / 8) == 0), so the column sums stay in registers until the block reduces them.
@@ -544,6 +598,33 @@ extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma,
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
   gn_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, S, C, silu);
+  return wdno_check_launch();
+}
+
+extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, const float* residual,
+                                                 const float* res_rec, float* y, void* y_hi, void* y_lo, float* y_scale, float* stats,
+                                                 float* bound_rec, float* y_amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                                 void* ws, size_t ws_bytes, wdno_stream_t s) {
+  int rc = gn_check(N, S, C, G);
+  if (rc) return rc;
+  const int C8 = C / 8;
+  if ((C & 7) || C8 > 256 || (C8 & (C8 - 1))) return WDNO_EUNSUPPORTED;
+  if (!residual || !y || (y_lo && (!y_hi || !res_rec || !bound_rec || !y_scale))) return WDNO_EINVAL;      // y_hi == NULL: fp32 sum only
+  if (ws_bytes < wdno_groupnorm_fwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
+  const int nchunk = gn_chunks(S);
+  double* part = (double*)ws;
+  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
+  float* gb = cb + (size_t)N * C * 4;
+  float* mx = (float*)((char*)ws + ((wdno_groupnorm_ws_bytes(N, S, C, G) + 63) & ~(size_t)63));
+  const int txp = pow2ceil(C / 4);
+  const int64_t rpc = cdiv64(S, nchunk);
+  hipStream_t st = as_stream(s);
+  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
+  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
+  int gx = stream_grid(S * (C / 8), 256);
+  if (gx > 512) gx = 512;
+  gn_apply_add_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, residual, y, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, res_rec,
+                                                                   y_amax_rec, S, C, silu);
   return wdno_check_launch();
 }
 

@@ -348,6 +348,7 @@ AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 
 PLANES_FWD = os.environ.get('WDNO_PLANES_FWD', '1') != '0'      # norm layers in front of a convolution write its fp16 planes (A/B switch)
+FUSE_NORM_ADD = os.environ.get('WDNO_FUSE_NORM_ADD', '1') != '0'        # GroupNorm apply + identity-skip add in one pass (A/B switch)
 GRAD_PLANES = os.environ.get('WDNO_GRAD_PLANES', '1') != '0'    # GroupNorm backward writes the fp16 planes of dx itself (A/B switch)
 SKIP_FUSE = os.environ.get('WDNO_SKIP_FUSE', '1') != '0'      # skip connections handed through conv / LayerNorm (A/B switch)
 _CAPTURE = None          # [pool, next index] while a HIP graph is being captured through graph_capture()
@@ -1175,6 +1176,47 @@ class _GroupNormAct(torch.autograd.Function):
                                                    n, s, c, groups, act_silu, _p(ws), nb, _stream()), 'groupnorm_bwd')
         red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
         return _leave_amax(dx, rec), red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None, None
+
+
+class _GroupNormActAdd(torch.autograd.Function):
+    """y = act(GroupNorm(x)) + residual in one apply pass (csrc/norm.hip: gn_apply_add_planes_kernel), fp32 output with its amax record."""
+    @staticmethod
+    def forward(ctx, x, gamma, beta, ss, residual, groups, act_silu, eps):
+        x_in = x
+        x = _chk(x, 'x')
+        res = _chk(residual, 'residual')
+        n, c = x.shape[0], x.shape[-1]
+        s = x.numel() // (n * c)
+        lib = _lib_()
+        nb = lib.wdno_groupnorm_fwd_planes_ws_bytes(n, s, c, groups)
+        ws = _ws(nb, x.device)
+        y = torch.empty_like(x)
+        stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
+        ssc = None if ss is None else _chk(ss, 'scale_shift')
+        yrec = _new_amax_record(x.device)
+        _lib.check(lib.wdno_groupnorm_act_add_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(res), None, _p(y), None, None, None, _p(stats),
+                                                         None, _p(yrec), n, s, c, groups, float(eps), int(act_silu), _p(ws), nb, _stream()),
+                   'groupnorm_add_fwd')
+        ctx.save_for_backward(x, gamma, beta, ssc, stats)
+        ctx.meta = (n, s, c, groups, int(act_silu))
+        c8 = c // 8
+        ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0
+                           and c8 <= 256 and (c8 & (c8 - 1)) == 0)
+        return _leave_amax(y, yrec)
+
+    @staticmethod
+    def backward(ctx, gy):
+        r = _GroupNormAct.backward(ctx, gy)            # d/dx, d/dgamma, d/dbeta, d/dscale_shift of the normalised branch
+        return r[0], r[1], r[2], r[3], gy, None, None, None
+
+
+def groupnorm_act_add(x, gamma, beta, groups, residual, scale_shift=None, act=True, eps=1e-5):
+    """act(GroupNorm(x)) + residual: the tail of a ResnetBlock whose skip is the identity."""
+    c = x.shape[-1]
+    c8 = c // 8
+    if not (FUSE_NORM_ADD and c % 8 == 0 and c8 <= 256 and (c8 & (c8 - 1)) == 0 and x.shape == residual.shape):
+        return add(groupnorm_act(x, gamma, beta, groups, scale_shift, act, eps), residual)
+    return _GroupNormActAdd.apply(x, gamma, beta, scale_shift, residual, groups, act, eps)
 
 
 def groupnorm_act(x, gamma, beta, groups, scale_shift=None, act=True, eps=1e-5, out_planes=False):

@@ -117,11 +117,13 @@ class Block(nn.Module):
         self.act = nn.SiLU()
         self.groups = groups
 
-    def forward(self, x, scale_shift=None, with_skip=False, out_planes=False):
+    def forward(self, x, scale_shift=None, with_skip=False, out_planes=False, residual=None):
         if with_skip:              # block input that also feeds the skip connection: handed through the convolution (ops.conv_cl_skip)
             x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)
             return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes), xs
         x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)     # x goes to the norm and nowhere else
+        if residual is not None:   # identity skip of the ResnetBlock: added in the norm's apply pass
+            return ops.groupnorm_act_add(x, self.norm.weight, self.norm.bias, self.groups, residual, scale_shift, act=True, eps=self.norm.eps)
         return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes)
 
 
@@ -145,9 +147,9 @@ class ResnetBlock(nn.Module):
             h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True, out_planes=planes)
         else:
             h, xs = self.block1(x, scale_shift=scale_shift, out_planes=planes), x
-        h = self.block2(h)
         if isinstance(self.res_conv, nn.Identity):
-            return ops.add(h, xs)
+            return self.block2(h, residual=xs)
+        h = self.block2(h)
         return ops.conv_cl(xs, self.res_conv.weight, self.res_conv.bias, residual=h)
 
 
