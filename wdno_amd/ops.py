@@ -960,8 +960,17 @@ class _Conv(torch.autograd.Function):
                     gx5 = conv_fwd_raw(gy5, wd, None, gs5, ks, (1, 1, 1), pd, cp)
                 gs5 = None                                   # folded into the epilogue of the data-gradient convolution
             elif ks == (1, 4, 4) and stride == (1, 2, 2) and padding == (0, 1, 1):
-                wt = pack_transposed(_as5(weight), kp, cp)      # "in" = K (dy channels), "out" = C
-                gx5 = conv_transpose_raw(gy5, wt, None, cp)
+                # the data gradient of the strided Downsample convolution IS the transposed convolution of dy with the same weight read as
+                # [in = K (dy channels)][out = C][1][4][4]: four parity-class launches of the split kernels on the planes of dy
+                oh_, ow_ = gy5.shape[2], gy5.shape[3]
+                if ctx.h3 and _use_h3(n * d * oh_ * ow_, kp * 4) and _as5(weight).is_contiguous():
+                    if gyplanes is None:
+                        gyplanes = split_f16(gy5.reshape(-1, kp), grec)
+                    drec = _new_amax_record(gy5.device)
+                    gx5 = _leave_amax(conv_transpose_h3(gyplanes, tuple(gy5.shape[:4]), _as5(weight), None, cp, amax_rec=drec), drec)
+                else:
+                    wt = pack_transposed(_as5(weight), kp, cp)      # "in" = K (dy channels), "out" = C
+                    gx5 = conv_transpose_raw(gy5, wt, None, cp)
             elif ks == (1, 2, 2) and stride == (1, 2, 2) and padding == (0, 0, 0):
                 # non-overlapping patches (Burgers Downsample2d folded into a 2x2/s2 conv): each input pixel has one tap
                 gx5 = _patch2_dgrad(gy5, weight, cp, kp)
