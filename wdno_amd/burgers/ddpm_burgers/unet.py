@@ -107,7 +107,7 @@ class ResnetBlock(nn.Module):
     def forward(self, x, time_emb=None):
         scale_shift = None
         if exists(self.mlp) and exists(time_emb):
-            scale_shift = ops.conv_cl(ops.silu(time_emb), self.mlp[1].weight, self.mlp[1].bias)   # [B, 2C] = (scale | shift)
+            scale_shift = ops.conv_cl(ops.silu_shared(time_emb), self.mlp[1].weight, self.mlp[1].bias)   # [B, 2C] = (scale | shift)
         # block1's output is read by block2's convolution only: where that one takes fp16 planes, the norm writes them
         planes = ops.conv_reads_planes(x.numel() // x.shape[-1], self.block2.proj.weight)
         if ops.SKIP_FUSE:

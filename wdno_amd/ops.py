@@ -236,6 +236,22 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+def silu_shared(t):
+    """silu(t), computed once per tensor (and version): every ResnetBlock applies the same SiLU to the same time embedding in front of its
+    own projection (conv3d.py:118-133, unet.py:151-165) -- one activation forward and backward per step instead of one per block."""
+    if not (GLUE_FUSE & 1):
+        return silu(t)
+    h = getattr(t, '_wdno_silu', None)
+    if h is not None and h[1] == t._version and h[2] == torch.is_grad_enabled():
+        return h[0]
+    a = silu(t)
+    try:
+        t._wdno_silu = (a, t._version, torch.is_grad_enabled())
+    except Exception:
+        pass
+    return a
+
+
 _freq_cache = {}
 
 
@@ -349,6 +365,8 @@ AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 PLANES_FWD = os.environ.get('WDNO_PLANES_FWD', '1') != '0'      # norm layers in front of a convolution write its fp16 planes (A/B switch)
 FUSE_NORM_ADD = os.environ.get('WDNO_FUSE_NORM_ADD', '1') != '0'        # GroupNorm apply + identity-skip add in one pass (A/B switch)
+GLUE_FUSE = int(os.environ.get('WDNO_GLUE_FUSE', '5'))       # A/B switches: 1 = one shared SiLU of the time embedding, 4 = Downsample dgrad on the
+#                                                               parity-class split kernels
 GRAD_PLANES = os.environ.get('WDNO_GRAD_PLANES', '1') != '0'    # GroupNorm backward writes the fp16 planes of dx itself (A/B switch)
 SKIP_FUSE = os.environ.get('WDNO_SKIP_FUSE', '1') != '0'      # skip connections handed through conv / LayerNorm (A/B switch)
 _CAPTURE = None          # [pool, next index] while a HIP graph is being captured through graph_capture()
@@ -963,7 +981,7 @@ class _Conv(torch.autograd.Function):
                 # the data gradient of the strided Downsample convolution IS the transposed convolution of dy with the same weight read as
                 # [in = K (dy channels)][out = C][1][4][4]: four parity-class launches of the split kernels on the planes of dy
                 oh_, ow_ = gy5.shape[2], gy5.shape[3]
-                if ctx.h3 and _use_h3(n * d * oh_ * ow_, kp * 4) and _as5(weight).is_contiguous():
+                if (GLUE_FUSE & 4) and ctx.h3 and _use_h3(n * d * oh_ * ow_, kp * 4) and _as5(weight).is_contiguous():
                     if gyplanes is None:
                         gyplanes = split_f16(gy5.reshape(-1, kp), grec)
                     drec = _new_amax_record(gy5.device)

@@ -140,7 +140,7 @@ class ResnetBlock(nn.Module):
         if exists(self.mlp):
             assert exists(time_emb), 'time emb must be passed in'
             # [B, 2*C]: first half = scale, second half = shift (chunk(2, dim=1) in the reference)
-            scale_shift = ops.conv_cl(ops.silu(time_emb), self.mlp[1].weight, self.mlp[1].bias)
+            scale_shift = ops.conv_cl(ops.silu_shared(time_emb), self.mlp[1].weight, self.mlp[1].bias)
         # block1's output is read by block2's convolution only: where that one takes fp16 planes, the norm writes them
         planes = ops.conv_reads_planes(x.numel() // x.shape[-1], self.block2.proj.weight)
         if ops.SKIP_FUSE:
