@@ -76,6 +76,11 @@ int wdno_upsample_coef(const float* in, float* out, int64_t outer, int a, int mi
  * API layout [N, C, S] (S = product of spatial dims) <-> channels-last [N, S, Cp] (Cp >= C, zero padded). */
 int wdno_nc_to_cl(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s);
 int wdno_cl_to_nc(const float* src, float* dst, int64_t N, int C, int64_t S, int Cp, wdno_stream_t s);
+/* (a | b) delivered only as the fp16 planes [P][Ca + Cb] (lo == NULL: one bf16 plane) of the convolutions that read it -- the up-path
+ * torch.cat((x, h.pop()), dim=1) of conv3d.py:340-346 / unet.py:268-274, read by the next ResnetBlock's first convolution and 1 x 1 skip
+ * projection only. Scale from the amax records of a and b (left in scale_out[0]). Ca, Cb multiples of 8. */
+int wdno_concat2_cl_planes(const float* a, int Ca, const float* b, int Cb, const float* rec_a, const float* rec_b, void* hi, void* lo,
+                           float* scale_out, int64_t P, wdno_stream_t s);
 int wdno_concat2_cl(const float* a, int Ca, const float* b, int Cb, float* out, int64_t P, wdno_stream_t s);
 int wdno_concat2_cl_amax(const float* a, int Ca, const float* b, int Cb, float* out, float* amax_rec, int64_t P, wdno_stream_t s);
 int wdno_split2_cl(const float* in, float* a, int Ca, float* b, int Cb, int64_t P, wdno_stream_t s);

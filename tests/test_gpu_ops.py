@@ -878,6 +878,39 @@ def test_norm_layers_write_planes_for_the_next_convolution(ops):
         assert rel_l2(a, e) < 2e-6, (name, rel_l2(a, e))
 
 
+def test_concat_as_planes_for_a_resnet_block(ops):
+    """concat_cl(..., planes_only=True) in front of the two convolutions of a ResnetBlock input (3 x 3 x 3 and the 1 x 1 skip projection):
+    same result and gradients (to rounding) as the fp32 concat, with one split pass less and no fp32 concat tensor."""
+    a, b = g((2, 64, 4, 16, 16), 351), g((2, 64, 4, 16, 16), 352) * 3.0
+    w3, w1 = g((64, 128, 3, 3, 3), 353) * 0.03, g((64, 128, 1, 1, 1), 354) * 0.1
+    wa = g((64, 64, 1, 1, 1), 355) * 0.1
+    r = g((2, 64, 4, 16, 16), 356)
+
+    def run(flag):
+        calls = {'n': 0}
+        orig = ops.split_f16
+
+        def counting(*a_, **kw):
+            calls['n'] += 1
+            return orig(*a_, **kw)
+        ops.split_f16 = counting
+        try:
+            xa, xb, w3s, w1s, was = (dev(t, grad=True) for t in (to_cl(a), to_cl(b), w3, w1, wa))
+            ya = ops.conv_cl(xa, was)                     # a producer that leaves an amax record on its output
+            cat = ops.concat_cl(ya, ops.add(xb, xb), planes_only=flag)          # ops.add leaves a record too
+            h, xs = ops.conv_cl_skip(cat, w3s, None, padding=1)
+            y = ops.conv_cl(xs, w1s, None, residual=h)
+            (y * dev(to_cl(r))).sum().backward()
+        finally:
+            ops.split_f16 = orig
+        return [t.double().cpu() for t in (y.detach(), xa.grad, xb.grad, w3s.grad, w1s.grad, was.grad)], calls['n']
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_got == n_ref - 1, (n_ref, n_got)
+    for name, x_, e_ in zip(['y', 'da', 'db', 'dw3', 'dw1', 'dwa'], got, ref):
+        assert rel_l2(x_, e_) < 2e-6, (name, rel_l2(x_, e_))
+
+
 def test_attention_backward_delivers_planes(ops):
     """to_qkv -> temporal softmax attention -> to_out with conv_cl(grad_planes=True) on the qkv projection: the attention backward
     writes dqkv as fp16 planes (scale from the amax records of qkv and dout); gradients must agree with the fp32 route."""

@@ -55,6 +55,7 @@ PROTOTYPES = {
     'wdno_nc_to_cl': (I, [P, P, L, I, L, I, P]),
     'wdno_cl_to_nc': (I, [P, P, L, I, L, I, P]),
     'wdno_concat2_cl': (I, [P, I, P, I, P, L, P]),
+    'wdno_concat2_cl_planes': (I, [P, I, P, I, P, P, P, P, P, L, P]),
     'wdno_concat2_cl_amax': (I, [P, I, P, I, P, P, L, P]),
     'wdno_split2_cl': (I, [P, P, I, P, I, L, P]),
     'wdno_upsample2x_cl_fwd': (I, [P, P, L, I, I, I, P]),

@@ -258,13 +258,14 @@ class Unet2D(nn.Module):
         x = self.mid_attn(x)
         x = self.mid_block2(x, t)
         for block1, block2, attn, upsample in self.ups:
-            x = block1(ops.concat_cl(x, hs.pop()), t)
-            x = block2(ops.concat_cl(x, hs.pop()), t)
+            npx = x.numel() // x.shape[-1]
+            x = block1(ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(npx, block1)), t)
+            x = block2(ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(npx, block2)), t)
             x = attn(x)
             if isinstance(upsample, nn.Sequential):
                 x = ops.conv_cl(ops.upsample2x_cl(x), upsample[1].weight, upsample[1].bias, padding=1)
             else:
                 x = ops.conv_cl(x, upsample.weight, upsample.bias, padding=1)
-        x = self.final_res_block(ops.concat_cl(x, r), t)
+        x = self.final_res_block(ops.concat_cl(x, r, planes_only=ops.resnet_reads_planes(x.numel() // x.shape[-1], self.final_res_block)), t)
         x = ops.conv_cl(x, self.final_conv.weight, self.final_conv.bias)
         return ops.cl_to_nc(x, self.out_dim)

@@ -203,6 +203,40 @@ extern "C" int wdno_concat2_cl_amax(const float* a, int Ca, const float* b, int 
                                                                      total4, amax_rec);
   return wdno_check_launch();
 }
+// (a | b) delivered ONLY as the fp16 planes of the convolutions that read it (the up-path concat of a U-Net level feeds block1's
+// convolution and the 1 x 1 skip projection of the next ResnetBlock, nothing else): scale from max(max|a|, max|b|) = the exact maximum
+// of the result, known from the two amax records before the pass. A thread owns one 8-channel group (Ca, Cb multiples of 8).
+typedef _Float16 cc_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void concat2_planes_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb,
+                                                              const float* __restrict__ rec_a, const float* __restrict__ rec_b,
+                                                              _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                              float* __restrict__ scale_out, int64_t P) {
+  const bool single = lo == nullptr;                 // one bf16 plane, no scale
+  const float s = single ? 1.0f : scale_from_amax(fmaxf(amax_record_read(rec_a), amax_record_read(rec_b)));
+  if (!single && blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+  const int Ct = Ca + Cb, g8 = Ct >> 3;
+  const int64_t total = P * g8, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t p = i / g8;
+    const int c0 = (int)(i - p * g8) * 8;
+    const float* src = c0 < Ca ? a + p * Ca + c0 : b + p * Cb + (c0 - Ca);
+    const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    cc_half8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { _Float16 th, tl; plane_pack(v[e], s, single, th, tl); h[e] = th; l[e] = tl; }
+    *reinterpret_cast<cc_half8*>(hi + p * Ct + c0) = h;
+    if (!single) *reinterpret_cast<cc_half8*>(lo + p * Ct + c0) = l;
+  }
+}
+extern "C" int wdno_concat2_cl_planes(const float* a, int Ca, const float* b, int Cb, const float* rec_a, const float* rec_b, void* hi,
+                                      void* lo, float* scale_out, int64_t P, wdno_stream_t s) {
+  WDNO_REQUIRE(P > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0 && hi != nullptr);
+  WDNO_REQUIRE(lo == nullptr || (rec_a && rec_b && scale_out));
+  const int64_t total = P * ((Ca + Cb) / 8);
+  concat2_planes_kernel<<<stream_grid(total, 256), 256, 0, as_stream(s)>>>(a, Ca, b, Cb, rec_a, rec_b, (_Float16*)hi, (_Float16*)lo, scale_out, P);
+  return wdno_check_launch();
+}
 extern "C" int wdno_concat2_cl(const float* a, int Ca, const float* b, int Cb, float* out, int64_t P, wdno_stream_t s) {
   return wdno_concat2_cl_amax(a, Ca, b, Cb, out, nullptr, P, s);
 }

@@ -142,14 +142,25 @@ def cl_to_nc(x, c):
 
 class _Concat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, planes_only=False):
+        ra, rb = _known_amax(a), _known_amax(b)
         a, b = _chk(a, 'a'), _chk(b, 'b')
         ca, cb = a.shape[-1], b.shape[-1]
         p = a.numel() // ca
         out = torch.empty((*a.shape[:-1], ca + cb), device=a.device, dtype=torch.float32)
+        ctx.ca, ctx.cb = ca, cb
+        if (planes_only and PLANES_FWD and CONV_MATH in ('f16x3', 'bf16') and ca % 8 == 0 and cb % 8 == 0
+                and (_lp() or (ra is not None and rb is not None))):
+            # the caller states that only convolutions reading planes use the result: `out` stays unwritten
+            hi = torch.empty((p, ca + cb), device=a.device, dtype=torch.float16)
+            lo = sc = None
+            if not _lp():
+                lo = torch.empty((p, ca + cb), device=a.device, dtype=torch.float16)
+                sc = torch.empty((1,), device=a.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_concat2_cl_planes(_p(a), ca, _p(b), cb, _p(ra), _p(rb), _p(hi), _p(lo), _p(sc), p, _stream()), 'concat2_planes')
+            return _planes_only(out, (hi, lo, sc))
         rec = _new_amax_record(a.device)
         _lib.check(_lib_().wdno_concat2_cl_amax(_p(a), ca, _p(b), cb, _p(out), _p(rec), p, _stream()), 'concat2_cl')
-        ctx.ca, ctx.cb = ca, cb
         return _leave_amax(out, rec)
 
     @staticmethod
@@ -160,11 +171,20 @@ class _Concat(torch.autograd.Function):
         ga = torch.empty((*g.shape[:-1], ca), device=g.device, dtype=torch.float32)
         gb = torch.empty((*g.shape[:-1], cb), device=g.device, dtype=torch.float32)
         _lib.check(_lib_().wdno_split2_cl(_p(g), _p(ga), ca, _p(gb), cb, p, _stream()), 'split2_cl')
-        return ga, gb
+        return ga, gb, None
 
 
-def concat_cl(a, b):
-    return _Concat.apply(a, b)
+def concat_cl(a, b, planes_only=False):
+    """(a | b) along the channel axis. planes_only: the caller states that the result is read only by convolutions that take fp16 planes
+    (conv_reads_planes for every reader); where the amax records of a and b are known it then exists only as those planes."""
+    return _Concat.apply(a, b, planes_only and CONCAT_PLANES)
+
+
+def resnet_reads_planes(x_pixels, block):
+    """Do both readers of a ResnetBlock's input -- block1's convolution and the 1 x 1 skip projection -- take fp16 planes?"""
+    rc = getattr(block, 'res_conv', None)
+    return (SKIP_FUSE and rc is not None and hasattr(rc, 'weight') and conv_reads_planes(x_pixels, block.block1.proj.weight)
+            and conv_reads_planes(x_pixels, rc.weight))
 
 
 class _Up2x(torch.autograd.Function):
@@ -364,6 +384,7 @@ AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
 
 
 PLANES_FWD = os.environ.get('WDNO_PLANES_FWD', '1') != '0'      # norm layers in front of a convolution write its fp16 planes (A/B switch)
+CONCAT_PLANES = os.environ.get('WDNO_CONCAT_PLANES', '1') != '0'        # up-path concats exist only as the planes of their two readers (A/B switch)
 FUSE_NORM_ADD = os.environ.get('WDNO_FUSE_NORM_ADD', '1') != '0'        # GroupNorm apply + identity-skip add in one pass (A/B switch)
 GLUE_FUSE = int(os.environ.get('WDNO_GLUE_FUSE', '5'))       # A/B switches: 1 = one shared SiLU of the time embedding, 4 = Downsample dgrad on the
 #                                                               parity-class split kernels

@@ -344,7 +344,7 @@ class Unet3D_with_Conv3D(nn.Module):
         x = self.mid_block2(x, t)
 
         for block1, block2, spatial_attn, temporal_attn, upsample in self.ups:
-            x = ops.concat_cl(x, hs.pop())
+            x = ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(x.numel() // x.shape[-1], block1))
             x = block1(x, t)
             x = block2(x, t)
             if not isinstance(spatial_attn, nn.Identity):
@@ -353,7 +353,7 @@ class Unet3D_with_Conv3D(nn.Module):
             if not isinstance(upsample, nn.Identity):
                 x = ops.conv_transpose_cl(x, upsample.weight, upsample.bias)
 
-        x = ops.concat_cl(x, r)
+        x = ops.concat_cl(x, r, planes_only=ops.resnet_reads_planes(x.numel() // x.shape[-1], self.final_conv[0]))
         x = self.final_conv[0](x)
         x = ops.conv_cl(x, self.final_conv[1].weight, self.final_conv[1].bias)
         bb, ff, hh, ww, kp = x.shape
