@@ -461,6 +461,8 @@ def main():
 
     extras = {}
     roofline = cpu = None
+    if rank != 0 and world > 1:
+        ts.step(x)              # rank 0's profiled extra step below contains the gradient all-reduce: every rank has to take part in it
     if rank == 0:
         roofline = conv_roofline(lambda: ts.step(x), ops)
         if world == 1 and not args.no_extras:
@@ -512,6 +514,7 @@ def main():
         out.update(extras)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

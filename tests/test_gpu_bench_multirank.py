@@ -1,0 +1,27 @@
+"""The N > 1 control flow of bench.py on the one-GPU test box: two ranks share the GPU and exchange gradients over gloo
+(WDNO_DIST_BACKEND / WDNO_DIST_SHARE_GPU are test switches of wdno_amd.trainer.init_distributed). What is checked is what a real
+8-GPU run over RCCL needs from the script itself: every collective is entered by every rank (rank 0's profiled extra step once hung
+the other ranks' all-reduce), the max-over-ranks timing and the single JSON line of rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+    env = dict(os.environ, WDNO_DIST_BACKEND='gloo', WDNO_DIST_SHARE_GPU='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 only
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 16
+    assert len(out['per_rank']['ms_per_step']) == 2 and out['value'] > 0
+    assert out['roofline'] is not None and out['cpu_baseline'] is None

@@ -244,6 +244,8 @@ def init_distributed(backend=None):
     group -- backend "nccl" is RCCL on ROCm. Returns (rank, world, local_rank); (0, 1, LOCAL_RANK or 0) without torchrun."""
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
+        if os.environ.get('WDNO_DIST_SHARE_GPU') == '1':      # control-flow tests of the multi-rank paths on a one-GPU box (with WDNO_DIST_BACKEND=gloo)
+            local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
     if dist.is_available() and not dist.is_initialized() and world_env > 1 and 'RANK' in os.environ:
