@@ -4,6 +4,7 @@
 the other ranks' all-reduce), the max-over-ranks timing and the single JSON line of rank 0."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,11 +13,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ, WDNO_DIST_BACKEND='gloo', WDNO_DIST_SHARE_GPU='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
