@@ -753,12 +753,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
 //     window plane is 4096 B, bytes past 3648 are fetched out of range). (dz, dy) validity: per window row, from the coordinates
 //     the producer lane tracks (a row whose pixel is in another image row than the output pixel is masked by the dx test anyway).
 //   * compute wave w owns column tiles 3 w .. 3 w + 2 (wave 3: two) x 64 k; 4 DMA instructions per producer wave and step.
+#ifndef WDNO_H3S_STAGES
+#define WDNO_H3S_STAGES 4          // ring stages (16 KB each in split mode): 4 x 16 KB = the 64 KB a launch gets without a function attribute
+#endif
 template <bool LP>
 __global__ __launch_bounds__(512) void conv_wgrad_h3s_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                               const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
                                                               const float* __restrict__ sx, const float* __restrict__ sdy,
                                                               float* __restrict__ ws, WgradDP wp, unsigned x_bytes, unsigned dy_bytes) {
-  constexpr int KW = 7, CX = 48, NS = 3, TM = 2;
+  constexpr int KW = 7, CX = 48, NS = WDNO_H3S_STAGES, TM = 2;
   constexpr int ROWB = CX * 2, XROWS = 32 + KW - 1, X_DATA = XROWS * ROWB;       // 96, 38, 3648
   constexpr int A_PLANE = 4096, X_PLANE = 4096, ZADDR = X_DATA;
   constexpr int NPL = LP ? 1 : 2;
@@ -829,15 +832,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3s_kernel(const _Float16* __r
       while (qw >= g.W) { qw -= g.W; if (++qh == g.H) { qh = 0; if (++qd == g.D) qd = 0; } }
       if (++st == wp.nsteps) { st = 0; if (++it < my_items) setup_item(); }
     };
-    if (total > 0) { setup_item(); issue_next(0); }
-    if (total > 1) issue_next(1);
-    int nbuf = 2;
+    if (total > 0) setup_item();
+    int nbuf = 0;
+    for (int a = 0; a < NS - 1 && a < total; ++a) { issue_next(nbuf); nbuf = nbuf + 1 == NS ? 0 : nbuf + 1; }
     for (int gs = 0; gs < total; ++gs) {
-      // step gs has landed (the step after it may still be in flight) -> meet the compute waves, which have every fragment of step
-      // gs - 1 in registers by now, then refill that step's buffer with step gs + 2
-      if (gs + 1 < total) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(PER) : "memory");
+      // step gs has landed (the NS - 2 steps after it may still be in flight) -> meet the compute waves, which have every fragment of
+      // step gs - 1 in registers by now, then refill that step's buffer with step gs + NS - 1
+      if (gs + NS - 2 < total) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"((NS - 2) * PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" : : : "memory");
-      if (gs + 2 < total) { issue_next(nbuf); nbuf = nbuf + 1 == NS ? 0 : nbuf + 1; }
+      if (gs + NS - 1 < total) { issue_next(nbuf); nbuf = nbuf + 1 == NS ? 0 : nbuf + 1; }
     }
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     return;
@@ -1105,7 +1108,7 @@ static void launch_ws(const void* xh, const void* xl, const void* dyh, const voi
   const wdno_conv_geom& g = w.c.g;
   const unsigned x_bytes = (unsigned)((int64_t)g.N * g.D * g.H * g.W * g.C * 2);
   const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
-  const size_t lds = (size_t)3 * (LP ? 1 : 2) * (4096 + 4096);
+  const size_t lds = (size_t)WDNO_H3S_STAGES * (LP ? 1 : 2) * (4096 + 4096);
   int grid = wd_num_cus();
   if (w.items < grid) grid = w.items;
   WgradDP wl = w;
