@@ -1004,6 +1004,45 @@ __global__ __launch_bounds__(256) void wgrad_h3_reduce_nat_kernel(const float* _
     __syncthreads();
   }
 }
+// The same reduction with coalesced stores. Above, consecutive threads hold consecutive (dx, c) of one (tap row, k) and scatter them
+// ntap * kw floats apart in the parameter layout [K][C][taps]. Here a block owns one k and 64 input channels: it reads its T = ntap * kw
+// segments of 64 contiguous floats per split (one wave per segment, lane = channel), sums the splits in order, turns the [T][64] tile
+// through LDS and writes 64 * T contiguous floats of dw. T <= 64 (everything but the 7 x 7 x 7 stem).
+__global__ __launch_bounds__(256) void wgrad_h3_reduce_tile_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
+                                                                    int K8, int C8, int kw, int ntap, int Kn, int Cn) {
+  __shared__ float tile[64][65];
+  const int T = ntap * kw, R = kw * C8;
+  const int k = blockIdx.y, c0 = blockIdx.x * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int sgm = wave; sgm < T; sgm += 4) {
+    const int t = sgm / kw, dx = sgm - t * kw;
+    float a = 0.f, b = 0.f;
+    if (c0 + lane < C8) {
+      const float* src = ws + ((int64_t)t * K8 + k) * R + dx * C8 + c0 + lane;
+      int sp = 0;
+      for (; sp + 1 < splits; sp += 2) { a += src[(int64_t)sp * n]; b += src[(int64_t)(sp + 1) * n]; }
+      if (sp < splits) a += src[(int64_t)sp * n];
+    }
+    tile[lane][sgm] = a + b;
+  }
+  __syncthreads();
+  const int cn = min(64, Cn - c0);                    // channels of this tile that exist in the parameter
+  float* out = dw + ((int64_t)k * Cn + c0) * T;
+  for (int e = threadIdx.x; e < cn * T; e += 256) {
+    const int c = e / T, sgm = e - c * T;
+    out[e] = tile[c][sgm];
+  }
+}
+static void wgrad_h3_reduce_launch(const float* ws, float* dw, int64_t n, int splits, const wdno_conv_geom* g, int Kn, int Cn, hipStream_t st) {
+  const int T = g->kd * g->kh * g->kw;
+  // (layers with many splits are the small ones: K * C / 64 blocks that each walk T x splits segments are too few and too serial there --
+  // 64 -> 64 channels with 18 splits took 2x the scatter kernel's time, +1.1 ms per smoke step when used everywhere)
+  if (T <= 64 && splits <= 2 && wdno_debug_mode != 38) {             // debug 38: the scatter kernel (A/B)
+    wgrad_h3_reduce_tile_kernel<<<dim3(cdiv(Cn, 64), Kn), 256, 0, st>>>(ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
+    return;
+  }
+  wgrad_h3_reduce_nat_kernel<<<stream_grid(n / 4, 32), 256, 0, st>>>(ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
+}
 extern "C" int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
                                            const void* pixel_table, float* dw, int Kn, int Cn, void* ws, size_t ws_bytes,
                                            const wdno_conv_geom* g, wdno_stream_t s) {
@@ -1013,7 +1052,7 @@ extern "C" int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const
   int rc = wgrad_h3_partials(xh, xl, sx, dyh, dyl, sdy, pixel_table, nullptr, ws, ws_bytes, g, st, &splits);
   if (rc) return rc;
   const int64_t n = (int64_t)g->kd * g->kh * g->K * (int64_t)g->kw * g->C;
-  wgrad_h3_reduce_nat_kernel<<<stream_grid(n / 4, 32), 256, 0, st>>>((const float*)ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
+  wgrad_h3_reduce_launch((const float*)ws, dw, n, splits, g, Kn, Cn, st);
   return wdno_check_launch();
 }
 
@@ -1025,7 +1064,7 @@ extern "C" int wdno_conv_wgrad_bf16_param(const void* x16, const void* dy16, con
   int rc = wgrad_h3_partials(x16, nullptr, nullptr, dy16, nullptr, nullptr, pixel_table, nullptr, ws, ws_bytes, g, st, &splits);
   if (rc) return rc;
   const int64_t n = (int64_t)g->kd * g->kh * g->K * (int64_t)g->kw * g->C;
-  wgrad_h3_reduce_nat_kernel<<<stream_grid(n / 4, 32), 256, 0, st>>>((const float*)ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
+  wgrad_h3_reduce_launch((const float*)ws, dw, n, splits, g, Kn, Cn, st);
   return wdno_check_launch();
 }
 
