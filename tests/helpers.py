@@ -38,3 +38,13 @@ def weights(npz, prefix='w::', requires_grad=False, device='cpu'):
 def noise_seq(npz, tag):
     n = int(npz[f'{tag}_n_noise'])
     return [torch.from_numpy(npz[f'{tag}_noise_{i}']) for i in range(n)]
+
+
+def randomise(model, gen, scale=0.05):
+    """tests/golden/make_ref_golden.py::randomise: perturb every parameter with draws of a CPU generator (reproducible), so a
+    fixture can store ONE base weight set and name per-seed variants by their generator seed."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('freqs'):
+                continue
+            p.add_(scale * torch.randn(p.shape, generator=gen))

@@ -129,3 +129,50 @@ def test_explicit_guidance_gradient_and_graph_captured_guided_sampling(trees):
     a = _run(dif6, False, 42, batch_size=2, design_fn=fn, design_guidance='standard-alpha', init=init, init_u=init_u)
     b = _run(dif6, True, 42, batch_size=2, design_fn=fn, design_guidance='standard-alpha', init=init, init_u=init_u)
     assert torch.equal(a, b)
+
+
+def test_guided_graph_reads_the_per_call_tensors_of_every_call(trees):
+    """inference_2d.py calls sample() once per batch with the SAME design_fn and a NEW init_u (= state[:, 0, 0]): a cached graph must
+    replay on the new values (static buffers refreshed before the replays), never on the first call's tensors."""
+    from wdno_amd.smoke import guidance as Gd
+    from wdno_amd import diffusion_core as K
+    torch.manual_seed(1)
+    shape, ori = (3, 6, 6), (2, 8, 8)
+    resc = (torch.linspace(1.0, 5.0, 42).reshape(1, 1, 42, 1, 1)).to(DEV)
+    gz, dif = _smoke(trees, timesteps=1000, sampling_timesteps=10, ddim_sampling_eta=1.0, is_condition_control=False)
+    dif.standard_fixed_ratio = 0.05
+    fn = Gd.GuidanceFn(shape, ori, resc, w_energy=0.7, w_init=40.0)
+    init = torch.from_numpy(gz['ddim_init']).to(DEV)
+    u1 = torch.randn(2, 8, 8, device=DEV)
+    u2 = torch.randn(2, 8, 8, device=DEV) * 3.0
+    g1 = _run(dif, True, 51, batch_size=2, design_fn=fn, design_guidance='standard', init=init, init_u=u1)
+    n_graphs = len(K._graph_cache[dif])
+    u1.fill_(float('nan'))                       # the first call's tensor is gone (freed / overwritten) by the time of the second call
+    g2 = _run(dif, True, 51, batch_size=2, design_fn=fn, design_guidance='standard', init=init * 0.5, init_u=u2)
+    assert len(K._graph_cache[dif]) == n_graphs          # cache hit: the same graph replayed
+    e2 = _run(dif, False, 51, batch_size=2, design_fn=fn, design_guidance='standard', init=init * 0.5, init_u=u2)
+    assert torch.isfinite(g2).all() and torch.equal(g2, e2) and not torch.equal(g1, g2)
+    # a python scalar the captured launches bake in is part of the key
+    dif.standard_fixed_ratio = 0.02
+    g3 = _run(dif, True, 51, batch_size=2, design_fn=fn, design_guidance='standard', init=init * 0.5, init_u=u2)
+    e3 = _run(dif, False, 51, batch_size=2, design_fn=fn, design_guidance='standard', init=init * 0.5, init_u=u2)
+    assert torch.equal(g3, e3) and not torch.equal(g3, g2)
+
+
+def test_graph_cache_sees_a_plain_load_state_dict(trees):
+    """A load_state_dict (or any in-place weight edit) between two sample() calls does not pass through the trainer's weight epoch:
+    the cache key carries the parameters' version counters, so the stale graph (and its packed weight operands) is not replayed."""
+    import gc
+    import weakref
+    gz, dif = _smoke(trees, timesteps=1000, sampling_timesteps=9, ddim_sampling_eta=0.0)
+    init, control = torch.from_numpy(gz['ddim_init']).to(DEV), torch.from_numpy(gz['ddim_control']).to(DEV)
+    a = _run(dif, True, 61, batch_size=2, init=init, control=control)
+    sd = {k: (v * 1.01 if v.is_floating_point() and k.startswith('model.') and 'freqs' not in k else v) for k, v in dif.state_dict().items()}
+    dif.load_state_dict(sd)
+    b = _run(dif, True, 61, batch_size=2, init=init, control=control)
+    e = _run(dif, False, 61, batch_size=2, init=init, control=control)
+    assert torch.equal(b, e) and not torch.equal(a, b)
+    ref = weakref.ref(dif)                       # the cached graphs do not keep the module (and its activations) alive
+    del dif
+    gc.collect()
+    assert ref() is None

@@ -1,0 +1,75 @@
+"""Round-3 GPU tests: contracts the earlier rounds left implicit.
+
+* planes-only tensors (fp32 storage allocated but never written; only the fp16 planes exist): with WDNO_POISON the unwritten storage
+  is NaN-filled, so any reader outside the single-reader contract shows up as a NaN loss / gradient instead of silently reading garbage.
+GPU box only."""
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def trees():
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion as GD1
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion as GD2
+    return dict(Unet2D=Unet2D, GD1=GD1, Unet3D=Unet3D_with_Conv3D, GD2=GD2)
+
+
+def _grads(dif, x0, t, noise):
+    for p in dif.parameters():
+        p.grad = None
+    loss = dif.p_losses(x0, t, noise=noise)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in dif.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize('tree', ['smoke', 'burgers'])
+def test_unwritten_fp32_storage_is_never_read(trees, tree):
+    """Full-width models on grids large enough for the split-fp16 path (where norms / attention / concats hand over planes only):
+    a training step with every unwritten tensor NaN-poisoned gives bit-identical loss and gradients to the normal step."""
+    from wdno_amd import ops
+    torch.manual_seed(0)
+    if tree == 'smoke':
+        net = trees['Unet3D'](dim=64, dim_mults=(1, 2, 4), channels=42)
+        dif = trees['GD2'](net, torch.ones(1, 1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero', (5, 12, 12), (8, 20, 20),
+                           image_size=16, frames=6).to(DEV)
+        x0 = torch.randn(2, 6, 42, 16, 16, device=DEV) * 0.5
+    else:
+        net = trees['Unet2D'](dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+        dif = trees['GD1'](net, seq_length=(64, 64), is_wavelet=True, pad_mode='periodization', wave_type='bior2.4', padded_shape=(64, 64),
+                           ori_shape=(41, 60), is_super_model=False, upsample_t=0, upsample_x=0, timesteps=1000, sampling_timesteps=100,
+                           beta_schedule='cosine', loss_layer_weight=torch.ones(1, 9, 1, 1), is_condition_pad=True, is_condition_u0=True,
+                           is_condition_uT=False, is_condition_f=True, train_on_padded_locations=True).to(DEV)
+        x0 = torch.randn(2, 9, 64, 64, device=DEV) * 0.5
+    noise = torch.randn_like(x0)
+    t = torch.tensor([10, 700], device=DEV)
+    ops.PROFILE = {}
+    l0, g0 = _grads(dif, x0, t, noise)
+    used, ops.PROFILE = set(ops.PROFILE), None
+    assert any('h3' in k for k in used), used          # the planes path really ran
+    assert ops.POISON is False
+    ops.POISON = True
+    try:
+        l1, g1 = _grads(dif, x0, t, noise)
+    finally:
+        ops.POISON = False
+    assert torch.isfinite(l1) and torch.equal(l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 200
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        if 'relative_attention_bias' in k:          # its gradient sums per-wave partial sums with float atomics (order varies run to run)
+            assert torch.allclose(g0[k], g1[k], rtol=1e-4, atol=1e-9), k
+            continue
+        assert torch.equal(g0[k], g1[k]), k

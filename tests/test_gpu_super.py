@@ -95,3 +95,108 @@ def test_burgers_super_model_loss_and_grads(trees):
     assert abs(loss.item() - float(gz['loss'])) < TOL * abs(float(gz['loss']))
     loss.backward()
     check_grad_norms(dif, gz)
+
+
+# ------------------------------------------------------------------------------------------------ round 3: Burgers SR sampling + cascade (row f3)
+G3 = load_npz('ref_round3.npz')
+with open(os.path.join(GOLDEN, 'ref_round3_manifest.json')) as f:
+    META3 = json.load(f)
+
+
+def sub3(tag):
+    pre = tag + '::'
+    return {k[len(pre):]: G3[k] for k in G3.files if k.startswith(pre)}
+
+
+def _noises(gz, tag):
+    return iter([torch.from_numpy(gz[f'{tag}_noise_{i}']).to(DEV) for i in range(int(gz[f'{tag}_n_noise']))])
+
+
+def _burgers_dif(trees, unet, kw, sd, n_ch):
+    kw = dict(kw)
+    kw['seq_length'] = tuple(kw['seq_length'])
+    net = trees['Unet2D'](dim=unet['dim'], dim_mults=tuple(unet['dim_mults']), channels=unet['channels'], resnet_block_groups=unet['resnet_block_groups'])
+    dif = trees['GD1'](net, loss_layer_weight=torch.ones(1, n_ch, 1, 1), **kw)
+    dif.load_state_dict(sd, strict=any(not k.startswith('model.') for k in sd))       # model-only dicts keep the module's own schedule
+    return dif.to(DEV)
+
+
+def test_burgers_super_sampling_vs_reference(trees):
+    """GaussianDiffusion.sample(low=..., N_upsample=...) of the 17-channel Burgers SR model (diffusion_1d.py:462-497 -> :310-460) with
+    u0 + uT + f + pad + low conditions: DDIM-4 (eta = 1) and ancestral-3 chains against the reference's outputs on its own noise."""
+    gz, m = sub3('bsr'), META3['bsr']
+    sd = {k[3:]: torch.from_numpy(v) for k, v in gz.items() if k.startswith('w::')}
+    t = lambda k: torch.from_numpy(gz[k]).to(DEV)
+    dif = _burgers_dif(trees, m['unet'], m['diffusion'], sd, 17)
+    seq = _noises(gz, 'ddim')
+    dif.sample_noise = lambda shp, device: next(seq)
+    out = dif.sample(batch_size=m['batch'], N_upsample=m['N_upsample'], low=t('low'), u_init=t('u_init'), u_final=t('u_final'), f=t('f'))
+    e = rel_l2(out, gz['ddim_out'])
+    print('burgers SR ddim4 vs reference', e)
+    assert out.shape == gz['ddim_out'].shape and e < CHAIN_TOL
+    dif3 = _burgers_dif(trees, m['unet'], {**m['diffusion'], 'timesteps': 3, 'sampling_timesteps': None}, {k: v for k, v in sd.items() if k.startswith('model.')}, 17)
+    seq3 = _noises(gz, 'ddpm3')
+    dif3.sample_noise = lambda shp, device: next(seq3)
+    out3 = dif3.sample(batch_size=m['batch'], N_upsample=m['N_upsample'], low=t('low'), u_init=t('u_init'), u_final=t('u_final'), f=t('f'))
+    e3 = rel_l2(out3, gz['ddpm3_out'])
+    print('burgers SR ddpm3 vs reference', e3)
+    assert e3 < CHAIN_TOL
+    # the loops re-impose every condition on the result (diffusion_1d.py:349-371): index work, bit-exact
+    ps = m['diffusion']['padded_shape'][m['N_upsample'] - 1]
+    ch, cw = ps[0] + 1, ps[1]
+    for o in (out, out3):
+        assert torch.equal(o[:, 8:16, :ch, :cw].cpu(), torch.from_numpy(gz['low'])[:, :, :ch, :cw])
+        assert torch.equal(o[:, 4:8, :ch, :cw].cpu(), torch.from_numpy(gz['f'])[:, :, :ch, :cw])
+        assert torch.equal(o[:, -1, :16, :cw].cpu(), torch.from_numpy(gz['u_init'])[:, :, :cw])
+        assert torch.equal(o[:, -1, -16:, :cw].cpu(), torch.from_numpy(gz['u_final'])[:, :, :cw])
+        assert float(o[:, :-1, ch:].abs().max()) == 0.0 and float(o[:, :, :, cw:].abs().max()) == 0.0
+
+
+def test_burgers_super_resolution_cascade_vs_reference(trees):
+    """eval_ddpm_burgers.py:185-195,305-338 at a reduced size, stage by stage from the reference's own intermediates (index work
+    bit-exact), then the whole cascade chained on our side, then the inverse DWT of the result."""
+    from ddpm_burgers.wavelet_utils import upsample_coef
+    from wave_trans import tensor_to_coef_super
+    from pytorch_wavelets import DWTInverse
+    gz, m = sub3('bcas'), META3['bcas']
+    t = lambda k: torch.from_numpy(gz[k]).to(DEV)
+    W0 = {k[4:]: torch.from_numpy(v) for k, v in gz.items() if k.startswith('w0::')}
+    W1 = {k[4:]: torch.from_numpy(v) for k, v in gz.items() if k.startswith('w1::')}
+    m0 = _burgers_dif(trees, m['unet0'], m['base'], W0, 9)
+    m1 = _burgers_dif(trees, m['unet1'], m['sr'], W1, 17)
+    k, pad_size, B = m['k'], m['pad_size'], m['batch']
+    shape0, shape1, ori1 = m['base']['padded_shape'], m['sr']['padded_shape'][k - 1], m['sr']['ori_shape'][k - 1]
+    resc0, resc1 = t('resc0'), t('resc1')
+
+    def lowres(x0):
+        coef0 = x0[:, :, :shape0[-2], :shape0[-1]]
+        up = upsample_coef(coef0.contiguous(), m1.padded_shape[k - 1])
+        padded = torch.nn.functional.pad(up, (0, pad_size - up.shape[-1], 0, pad_size - up.shape[-2]), 'constant', 0)
+        return coef0, up, padded, (padded[:, :8] / resc1[:, 8:16]).contiguous()
+    # --- stage by stage, each fed with the reference's intermediate
+    coef0, up, padded, low = lowres(t('x0'))
+    for name, v in (('coef0', coef0), ('up', up), ('padded', padded), ('low', low)):
+        assert torch.equal(v.cpu(), torch.from_numpy(gz[name])), name
+    Yl, Yh = tensor_to_coef_super(t('x1'), shape1)
+    assert torch.equal(Yl.cpu(), torch.from_numpy(gz['Yl'])) and torch.equal(Yh[0].cpu(), torch.from_numpy(gz['Yh']))
+    ifm = DWTInverse(mode='periodization', wave='bior2.4')
+    u_f = ifm((Yl.contiguous(), [Yh[0].contiguous()]))[:, :, :ori1[-2], :ori1[-1]]
+    assert u_f.shape == gz['u_f'].shape and rel_l2(u_f, gz['u_f']) < 1e-6           # same coefficients in: the transform itself
+    seq = _noises(gz, 'sr')
+    m1.sample_noise = lambda shp, device: next(seq)
+    x1 = m1.sample(batch_size=B, N_upsample=k, low=t('low'), u_init=t('u0_s'), u_final=t('uT_s'), f=t('f_s')) * resc1
+    e_sr = rel_l2(x1, gz['x1'])
+    # --- the whole cascade on our side
+    seq0, seq1 = _noises(gz, 'base'), _noises(gz, 'sr')
+    m0.sample_noise = lambda shp, device: next(seq0)
+    m1.sample_noise = lambda shp, device: next(seq1)
+    x0 = m0.sample(batch_size=B, u_init=t('u0_b'), f=t('f_b')) * resc0
+    e_base = rel_l2(x0, gz['x0'])
+    _, _, _, lo = lowres(x0)
+    x1c = m1.sample(batch_size=B, N_upsample=k, low=lo, u_init=t('u0_s'), u_final=t('uT_s'), f=t('f_s')) * resc1
+    e_chain = rel_l2(x1c, gz['x1'])
+    Ylc, Yhc = tensor_to_coef_super(x1c, shape1)
+    u_fc = ifm((Ylc.contiguous(), [Yhc[0].contiguous()]))[:, :, :ori1[-2], :ori1[-1]]
+    e_field = rel_l2(u_fc, gz['u_f'])
+    print('Burgers SR cascade vs reference: base sample', e_base, 'SR sample from reference low', e_sr, 'end to end', e_chain, 'fields', e_field)
+    assert e_base < CHAIN_TOL and e_sr < CHAIN_TOL and e_chain < 2 * CHAIN_TOL and e_field < 2 * CHAIN_TOL

@@ -235,7 +235,7 @@ def burgers_full(batch=2, modes=('f16x3', 'f32')):
 
 
 # ------------------------------------------------------------------------------------------------ full-size DDIM chain A/B
-def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32')):
+def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32'), seed=7):
     """A `steps`-step DDIM chain (eta = 1, injected noise) of the full-width smoke model at the bench shape."""
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     from ddpm.diffusion_2d import GaussianDiffusion
@@ -243,7 +243,7 @@ def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32')):
     net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
     lw = torch.ones(1, 1, 42, 1, 1)
-    g = torch.Generator().manual_seed(7)
+    g = torch.Generator().manual_seed(seed)
     shape = (batch, 24, 42, 40, 40)
     ns = [torch.randn(shape, generator=g) for _ in range(steps + 1)]
     init = torch.randn(batch, 24, 40, 40, generator=g) * 0.3
@@ -276,6 +276,108 @@ def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32')):
         res[mode] = {'hip_vs_cpu32': rel_l2(o, o32), 'hip_vs_exact': rel_l2(o, o64)}
     set_math('f16x3')
     return res
+
+
+# ------------------------------------------------------------------------------------------------ DDIM-from-t=999 chains over seeds
+def chain_seeds(modes=('f16x3',), full_seeds=0):
+    """is the HIP path systematically further from the exact value of a DDIM chain that starts at t = 999 than the
+    reference's own fp32 evaluation is? tests/golden/ref_round3.npz holds, for 8 seeds x {smoke, Burgers} (different weights,
+    conditions and noise per seed), the REFERENCE's fp32 DDIM-4 output (eta = 1); here every chain is evaluated by the HIP path and by
+    the fp64 oracle (= the exact value of the chain) and three distances are recorded per seed:
+        hip_vs_exact, ref_vs_exact (reference fp32 vs exact), hip_vs_ref.
+    With full_seeds > 0 the same is done for that many seeds of the full-size 10-step smoke chain (cpu32 oracle in place of the
+    reference, which is bit-identical to it on the golden chains)."""
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion as GD1
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion as GD2
+    import json as _json
+    from tests.helpers import GOLDEN, randomise
+    g = load_npz('ref_round3.npz')
+    with open(os.path.join(GOLDEN, 'ref_round3_manifest.json')) as fh:
+        meta = _json.load(fh)['mseed']
+    base = {tree: {k[len(f'mseed_base::{tree}::'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f'mseed_base::{tree}::')}
+            for tree in ('sm', 'bu', 'buf_sm', 'buf_bu')}           # buf_*: the schedule buffers the reference outputs belong to
+    out = {'smoke': [], 'burgers': []}
+    for s in range(meta['n_seeds']):
+        # ---- smoke
+        u, d = meta['smoke']['unet'], dict(meta['smoke']['diffusion'])
+        d['padded_shape'] = tuple(d['padded_shape']); d['ori_shape'] = tuple(d['ori_shape'])
+        sub = {k[len(f'mseed_smoke{s}::'):]: g[k] for k in g.files if k.startswith(f'mseed_smoke{s}::')}
+        net = Unet3D_with_Conv3D(dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_groups=u['resnet_groups'],
+                                 init_kernel_size=u['init_kernel_size'])
+        net.load_state_dict(base['sm'])
+        randomise(net, torch.Generator().manual_seed(1000 + s))
+        sd32 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        ns = [torch.from_numpy(sub[f'ddim_noise_{i}']) for i in range(int(sub['ddim_n_noise']))]
+        init, control = torch.from_numpy(sub['init']), torch.from_numpy(sub['control'])
+        sd64 = cast_sd(sd32, f64)
+        with torch.no_grad():
+            m64 = lambda x, t: U.unet3d_forward(sd64, x, t, dim=u['dim'], dim_mults=tuple(u['dim_mults']), groups=u['resnet_groups'])
+            e = D.smoke_ddim_sample(m64, cast_buf(base['buf_sm'], f64), [n.double() for n in ns], 1000, d['sampling_timesteps'], 1.0,
+                                    padded_shape=d['padded_shape'], init=init.double(), control=control.double())
+        row = {'seed': s, 'ref_vs_exact': rel_l2(torch.from_numpy(sub['ddim_out']), e)}
+        for mode in modes:
+            set_math(mode)
+            ops.bump_weight_epoch()
+            dif = GD2(net, loss_layer_weight=torch.ones(1, 1, u['channels'], 1, 1), **d)
+            own = {k: v.clone() for k, v in dif.state_dict().items() if k in base['buf_sm']}
+            dif.load_state_dict(base['buf_sm'], strict=False)
+            dif = dif.to(DEV)
+            seq = iter([n.to(DEV) for n in ns])
+            dif.sample_noise = lambda shape, device: next(seq)
+            h = dif.sample(batch_size=2, init=init.to(DEV), control=control.to(DEV)).cpu()
+            row[mode] = {'hip_vs_exact': rel_l2(h, e), 'hip_vs_ref': rel_l2(h, sub['ddim_out'])}
+        out['smoke'].append(row)
+        # ---- Burgers
+        u, d = meta['burgers']['unet'], dict(meta['burgers']['diffusion'])
+        d['seq_length'] = tuple(d['seq_length'])
+        sub = {k[len(f'mseed_burgers{s}::'):]: g[k] for k in g.files if k.startswith(f'mseed_burgers{s}::')}
+        net = Unet2D(dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_block_groups=u['resnet_block_groups'])
+        net.load_state_dict(base['bu'])
+        randomise(net, torch.Generator().manual_seed(2000 + s))
+        if 'w_check' in sub:
+            assert torch.equal(net.init_conv.weight.detach(), torch.from_numpy(sub['w_check'])), 'per-seed weights were not re-created bit-exactly'
+        sd32 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        ns = [torch.from_numpy(sub[f'ddim_noise_{i}']) for i in range(int(sub['ddim_n_noise']))]
+        u0, ff = torch.from_numpy(sub['u_init']), torch.from_numpy(sub['f'])
+        sd64 = cast_sd(sd32, f64)
+        flags = dict(pad=True, u0=True, uT=False, f=True)
+        with torch.no_grad():
+            m64 = lambda x, t: U.unet2d_forward(sd64, x, t, dim=u['dim'], dim_mults=tuple(u['dim_mults']), groups=u['resnet_block_groups'])
+            e = D.burgers_ddim_sample(m64, cast_buf(base['buf_bu'], f64), [n.double() for n in ns], 1000, d['sampling_timesteps'], 1.0,
+                                      padded_shape=d['padded_shape'], flags=flags, u0=u0.double(), f=ff.double())
+        row = {'seed': s, 'ref_vs_exact': rel_l2(torch.from_numpy(sub['ddim_out']), e)}
+        for mode in modes:
+            set_math(mode)
+            ops.bump_weight_epoch()
+            dif = GD1(net, loss_layer_weight=torch.ones(1, u['channels'], 1, 1), **d)
+            own_b = {k: v.clone() for k, v in dif.state_dict().items() if k in base['buf_bu']}
+            dif.load_state_dict(base['buf_bu'], strict=False)
+            dif = dif.to(DEV)
+            seq = iter([n.to(DEV) for n in ns])
+            dif.sample_noise = lambda shape, device: next(seq)
+            h = dif.sample(batch_size=2, u_init=u0.to(DEV), f=ff.to(DEV)).cpu()
+            row[mode] = {'hip_vs_exact': rel_l2(h, e), 'hip_vs_ref': rel_l2(h, sub['ddim_out'])}
+        out['burgers'].append(row)
+    set_math('f16x3')
+    # how many schedule entries does THIS host compute differently (last fp32 bit) from the host the fixture was made on?
+    out['schedule_entries_differing_from_fixture_host'] = {
+        'smoke_sigmoid': {k: int((own[k].cpu() != base['buf_sm'][k]).sum()) for k in own},
+        'burgers_cosine': {k: int((own_b[k].cpu() != base['buf_bu'][k]).sum()) for k in own_b}}
+    med = lambda v: sorted(v)[len(v) // 2]
+    for tree in ('smoke', 'burgers'):
+        rows = out[tree]
+        summ = {'median_ref_vs_exact': med([r['ref_vs_exact'] for r in rows]), 'max_ref_vs_exact': max(r['ref_vs_exact'] for r in rows)}
+        for mode in modes:
+            summ[mode] = {'median_hip_vs_exact': med([r[mode]['hip_vs_exact'] for r in rows]), 'max_hip_vs_exact': max(r[mode]['hip_vs_exact'] for r in rows),
+                          'median_hip_vs_ref': med([r[mode]['hip_vs_ref'] for r in rows]), 'max_hip_vs_ref': max(r[mode]['hip_vs_ref'] for r in rows),
+                          'seeds_hip_closer_to_exact_than_ref': sum(1 for r in rows if r[mode]['hip_vs_exact'] <= r['ref_vs_exact'])}
+        out[tree + '_summary'] = summ
+    if full_seeds:
+        out['smoke_full_ddim10'] = [dict(seed=s, **{k: v for k, v in smoke_chain_full(10, 1, modes=('f16x3',), seed=7 + s).items()
+                                                    if k in ('cpu32_vs_exact', 'f16x3')}) for s in range(full_seeds)]
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ per-step errors from a common state
@@ -355,7 +457,7 @@ def main():
     for name, fn in (('smoke_golden_chains', smoke_chains), ('burgers_golden_chains', burgers_chains),
                      ('smoke_full_train_step', smoke_full), ('burgers_full_train_step', burgers_full),
                      ('smoke_full_ddim_chain', (lambda: smoke_chain_full(4)) if args.quick else smoke_chain_full),
-                     ('smoke_golden_chain_steps', smoke_chain_steps)):
+                     ('smoke_golden_chain_steps', smoke_chain_steps), ('ddim_chain_seeds', lambda: chain_seeds(('f16x3', 'f32'), 0 if args.quick else 3))):
         if args.only and name not in args.only.split(','):
             continue
         t0 = time.perf_counter()

@@ -80,7 +80,6 @@ class GaussianDiffusion(nn.Module):
         alphas, _ = K.register_schedule(self, betas, lambda snr: torch.ones_like(snr))
         self.alphas = alphas.to(torch.float32).clone()
         self.alphas_prev = torch.nn.functional.pad(alphas[:-1], (1, 0), value=1.).to(torch.float32).clone()
-        self._ac_host = self.alphas_cumprod.clone()
 
         self.normalize = normalize_to_neg_one_to_one if auto_normalize else identity
         self.unnormalize = unnormalize_to_zero_to_one if auto_normalize else identity
@@ -98,6 +97,10 @@ class GaussianDiffusion(nn.Module):
         self.use_graph = None       # None: HIP-graph replay of the unguided sampling step when the loop is long enough (WDNO_SAMPLE_GRAPH)
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def _ac_host(self):
+        return K.ac_host(self)          # host copy of the current alphas_cumprod buffer (scalar DDIM coefficients)
+
     def sample_noise(self, shape, device):
         return torch.randn(tuple(shape), device=device)
 

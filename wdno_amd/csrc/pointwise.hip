@@ -490,17 +490,29 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const float* __restrict
     out[e] = w[bucket[ij] * heads + h];
   }
 }
+// Deterministic: output (bucket, head) belongs to ONE thread that scans the nn positions in index order (an LDS float atomicAdd per
+// position summed in arrival order, so the relative_attention_bias gradient differed from run to run -- and with it every replica
+// consistency / replay check of a training run). <= 32 x heads outputs of nn terms: the operands are staged in LDS first.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void relpos_bwd_kernel(const float* __restrict__ dbias, const int64_t* __restrict__ bucket, float* __restrict__ dw,
                                                           int nn, int heads, int nb) {
-  extern __shared__ float acc[];           // [nb * heads]
-  for (int e = threadIdx.x; e < nb * heads; e += 256) acc[e] = 0.f;
-  __syncthreads();
-  for (int e = threadIdx.x; e < heads * nn; e += 256) {
-    const int h = e / nn, ij = e - h * nn;
-    atomicAdd(&acc[(int)bucket[ij] * heads + h], dbias[e]);
+  extern __shared__ float sm[];            // STAGED: [heads * nn] dbias, then [nn] bucket indices
+  int* sb = (int*)(sm + (size_t)heads * nn);
+  if (STAGED) {
+    for (int e = threadIdx.x; e < heads * nn; e += 256) sm[e] = dbias[e];
+    for (int e = threadIdx.x; e < nn; e += 256) sb[e] = (int)bucket[e];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int e = threadIdx.x; e < nb * heads; e += 256) dw[e] = acc[e];
+  for (int o = threadIdx.x; o < nb * heads; o += 256) {
+    const int bk = o / heads, h = o - bk * heads;
+    float acc = 0.f;
+    for (int ij = 0; ij < nn; ++ij) {
+      const int bb = STAGED ? sb[ij] : (int)bucket[ij];
+      const float v = STAGED ? sm[h * nn + ij] : dbias[(size_t)h * nn + ij];
+      if (bb == bk) acc += v;
+    }
+    dw[o] = acc;
+  }
 }
 extern "C" int wdno_relpos_bias_fwd(const float* w, const int64_t* bucket, float* out, int n, int heads, wdno_stream_t s) {
   WDNO_REQUIRE(n > 0 && heads > 0);
@@ -509,6 +521,8 @@ extern "C" int wdno_relpos_bias_fwd(const float* w, const int64_t* bucket, float
 }
 extern "C" int wdno_relpos_bias_bwd(const float* dbias, const int64_t* bucket, float* dw, int n, int heads, int num_buckets, wdno_stream_t s) {
   WDNO_REQUIRE(n > 0 && heads > 0 && num_buckets > 0 && num_buckets * heads <= 8192);
-  relpos_bwd_kernel<<<1, 256, (size_t)num_buckets * heads * sizeof(float), as_stream(s)>>>(dbias, bucket, dw, n * n, heads, num_buckets);
+  const size_t lds = (size_t)n * n * (heads + 1) * sizeof(float);
+  if (lds <= 48 * 1024) relpos_bwd_kernel<true><<<1, 256, lds, as_stream(s)>>>(dbias, bucket, dw, n * n, heads, num_buckets);
+  else relpos_bwd_kernel<false><<<1, 256, 0, as_stream(s)>>>(dbias, bucket, dw, n * n, heads, num_buckets);
   return wdno_check_launch();
 }

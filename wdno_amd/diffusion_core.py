@@ -167,6 +167,20 @@ def ddim_update_dev(mod, x, eps, noise, t, coef_dev):
     return x_next, x_start
 
 
+def ac_host(mod):
+    """Host copy of the module's CURRENT `alphas_cumprod` buffer (the scalar DDIM coefficients are evaluated on the host with the
+    reference's fp32 tensor arithmetic). Re-read whenever the buffer changed: `load_state_dict` of an upstream checkpoint replaces the
+    schedule buffers, and sqrt(1 - a' - sigma^2) at t = T-1 cancels so badly (c^2 ~ 1e-5 from terms ~ 1) that ONE ulp of alphas_cumprod
+    moves a 4-step eta = 1 chain by 5e-5 -- a copy taken at construction would silently mix two schedules."""
+    ac = mod.alphas_cumprod
+    key = (ac.data_ptr(), ac._version, str(ac.device))
+    c = mod.__dict__.get('_ac_cache')
+    if c is None or c[0] != key:
+        c = (key, ac.detach().to('cpu', copy=True))
+        mod.__dict__['_ac_cache'] = c
+    return c[1]
+
+
 def ddim_coefficients(alphas_cumprod_host, time, time_next, eta):
     """sigma, c, sqrt(alpha_next) as python floats from a host copy of alphas_cumprod (fp32, reference arithmetic)."""
     a, an = alphas_cumprod_host[time], alphas_cumprod_host[time_next]
@@ -184,33 +198,45 @@ _graph_cache = weakref.WeakKeyDictionary()      # diffusion module -> {key: _Ste
 
 
 class _StepGraph:
-    """One unguided sampling step -- [conditions] -> U-Net -> posterior / DDIM update -> [conditions] -- captured once in a HIP
+    """One sampling step -- [conditions] -> U-Net -> posterior / DDIM update -> [conditions] -- captured once in a HIP
     graph (ops.graph_capture) on static buffers and replayed for every step of a loop: the timestep, the DDIM coefficients and
-    the noise draw live in device memory that is refreshed between replays, so all steps are the same ~10^3-launch graph."""
+    the noise draw live in device memory that is refreshed between replays, so all steps are the same ~10^3-launch graph.
 
-    def __init__(self, mod, shape, desc, ddim, cond_first, device, guided=None):
+    Everything a replay reads is either a weight operand (keyed by the cache: weight epoch + parameter versions) or one of the
+    static buffers below. A guided step additionally reads per-call tensors (init_u, low, init of GaussianDiffusion.sample):
+    they get static buffers too (`static`, refreshed by load_static before the replays), so a second sample() call with the
+    same design_fn and a new init_u replays the same graph on the new values. The module is not kept alive by the graph."""
+
+    def __init__(self, mod, shape, desc, ddim, cond_first, device, guided_factory=None, static=None, keep=None):
         from . import ops
-        self.mod, self.ddim, self.cond_first, self.desc = mod, ddim, cond_first, desc
-        self.guided = guided              # None, or a callable (x, t, noise, coef) -> x_next for a guided step made of capturable launches
+        self.ddim, self.cond_first, self.desc = ddim, cond_first, desc
+        self.keep = keep                  # objects whose identity is part of the cache key (the design callback): held so that ids stay unique
         b = shape[0]
         self.x = torch.zeros(shape, device=device, dtype=torch.float32)
         self.src = torch.zeros(shape, device=device, dtype=torch.float32)
         self.noise = torch.zeros(shape, device=device, dtype=torch.float32)
         self.t = torch.zeros((b,), device=device, dtype=torch.long)
         self.coef = torch.zeros(3, device=device, dtype=torch.float32)
+        self.static = {k: (None if v is None else v.detach().to(device).clone()) for k, v in (static or {}).items()}
+        guided = None if guided_factory is None else guided_factory(self.static)      # a callable (x, t, noise, coef) -> x_next of capturable launches
         self.x_start = None
-        self._body()                              # eager warm-up: weight operands, pixel tables, function attributes
+        self._body(mod, guided)                   # eager warm-up: weight operands, pixel tables, function attributes
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
         with ops.graph_capture(self.graph):
-            self._body()
+            self._body(mod, guided)
 
-    def _body(self):
-        mod, x = self.mod, self.x
+    def load_static(self, static):
+        for k, v in (static or {}).items():
+            if v is not None:
+                self.static[k].copy_(v)
+
+    def _body(self, mod, guided):
+        x = self.x
         if self.cond_first:
             apply_cond(x, self.src, self.desc)
-        if self.guided is not None:
-            xn = self.guided(x, self.t, self.noise, self.coef).contiguous()
+        if guided is not None:
+            xn = guided(x, self.t, self.noise, self.coef).contiguous()
             if not self.cond_first:
                 apply_cond(xn, self.src, self.desc)
             x.copy_(xn)
@@ -226,15 +252,32 @@ class _StepGraph:
         self.x_start = xs
 
 
-def _step_graph(mod, shape, desc, ddim, cond_first, device, guided=None, guided_key=None):
+def _weight_fingerprint(mod):
+    """Changes whenever a replayed graph's weight operands could be stale: the optimiser / EMA / checkpoint writers bump
+    ops.WEIGHT_EPOCH; a plain load_state_dict or an in-place edit bumps the parameters' version counters; re-homed parameters
+    (FlatBuffers) change their addresses."""
     from . import ops
+    ver, ptr = 0, 0
+    for p in mod.parameters():
+        ver += p._version
+        ptr ^= p.data_ptr()
+    return (ops.WEIGHT_EPOCH, ver, ptr)
+
+
+def _static_sig(static):
+    return tuple((k, None if v is None else (tuple(v.shape), str(v.dtype))) for k, v in sorted((static or {}).items()))
+
+
+def _step_graph(mod, shape, desc, ddim, cond_first, device, guided_factory=None, guided_key=None, static=None, keep=None):
     cache = _graph_cache.setdefault(mod, {})
-    key = (tuple(shape), bytes(desc), bool(ddim), bool(cond_first), str(device), ops.WEIGHT_EPOCH, guided_key)
+    key = (tuple(shape), bytes(desc), bool(ddim), bool(cond_first), str(device), _weight_fingerprint(mod), guided_key, _static_sig(static))
     sg = cache.get(key)
     if sg is None:
         if len(cache) >= 2:                       # a graph pins one step's worth of activations
             cache.clear()
-        sg = cache[key] = _StepGraph(mod, tuple(shape), desc, ddim, cond_first, device, guided)
+        sg = cache[key] = _StepGraph(mod, tuple(shape), desc, ddim, cond_first, device, guided_factory, static, keep)
+    else:
+        sg.load_static(static)
     return sg
 
 
@@ -308,17 +351,24 @@ def guided_sampling_loop_smoke(mod, x, src, desc, design_fn, design_guidance, *,
         noisy = [t > 0 for t, _ in steps]
     kw = dict(design_fn=design_fn, design_guidance=design_guidance, low=low, init=init, init_u=init_u)
 
-    def guided(xx, t, noise, coef):
-        if ddim:
-            pred_noise, x_start = mod.model_predictions(shape, xx, t, None, clip_x_start=True, rederive_pred_noise=True, **kw)
-            return x_start * coef[0] + coef[1] * pred_noise + coef[2] * noise
-        mean, _, logvar, _ = mod.p_mean_variance(shape, x=xx, t=t, x_self_cond=None, clip_denoised=True, **kw)
-        return mean + (0.5 * logvar).exp() * noise
+    def guided_factory(static):
+        # the captured step reads the per-call tensors from the graph's static buffers, never from this call's tensors
+        skw = dict(design_fn=design_fn, design_guidance=design_guidance, low=static['low'], init=static['init'], init_u=static['init_u'])
+
+        def guided(xx, t, noise, coef):
+            if ddim:
+                pred_noise, x_start = mod.model_predictions(shape, xx, t, None, clip_x_start=True, rederive_pred_noise=True, **skw)
+                return x_start * coef[0] + coef[1] * pred_noise + coef[2] * noise
+            mean, _, logvar, _ = mod.p_mean_variance(shape, x=xx, t=t, x_self_cond=None, clip_denoised=True, **skw)
+            return mean + (0.5 * logvar).exp() * noise
+        return guided
     if use_graph is None:
         use_graph = SAMPLE_GRAPH and sum(noisy) >= SAMPLE_GRAPH_MIN_STEPS
     sg = None
     if use_graph and any(noisy):
-        sg = _step_graph(mod, shape, desc, ddim, False, dev, guided, ('guided', id(design_fn), design_guidance))
+        # python scalars the captured launches bake in are part of the key; the design callback is identified by object (kept alive by the graph)
+        gkey = ('guided', id(design_fn), design_guidance, float(mod.standard_fixed_ratio), float(mod.coeff_ratio))
+        sg = _step_graph(mod, shape, desc, ddim, False, dev, guided_factory, gkey, static=dict(low=low, init=init, init_u=init_u), keep=design_fn)
         sg.src.copy_(src)
         sg.x.copy_(x)
         if ddim:

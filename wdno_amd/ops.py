@@ -320,6 +320,7 @@ def _cached(w, kind, cp, kp, build):
         packed = build().contiguous()
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
+        bump_weight_epoch()          # captured graphs replay pointers into the dropped operands: the epoch is part of their cache key
     _pack_cache[key] = (ver, packed, w.detach())
     return packed
 
@@ -631,6 +632,8 @@ def split_weight(w, kind, cp8, kp, pack=None):
             pl.sc = None if lp else torch.empty(1, device=w.device, dtype=torch.float32)
             if len(_wplans) > 4096:
                 _wplans.clear(); _wtables.clear()
+                bump_weight_epoch()
+                ver = (w._version, WEIGHT_EPOCH)
             _wplans[key] = pl
         _lib.check(_lib_().wdno_pack_split_weight(_p(wc), _p(amax), _p(pl.hi), _p(pl.lo), _p(pl.sc), k, c, kd, kh, kw, kp, cp8,
                                                   _wmode(kind), _stream()), 'pack_split_weight')
@@ -768,8 +771,19 @@ def conv_reads_planes(pixels, weight):
     return pad4(c) % 8 == 0 and _use_h3(pixels, pad4(c) * vol)
 
 
+POISON = os.environ.get('WDNO_POISON', '0') == '1'      # debug / CI: fp32 tensors that exist only as planes are NaN-filled, so that any
+#                                                          reader outside the single-reader contract fails loudly instead of reading garbage
+
+
+def _poison(t):
+    if POISON:
+        t.fill_(float('nan'))
+    return t
+
+
 def _planes_only(t, planes):
     """Mark t (allocated, never written) as existing only as planes."""
+    _poison(t)
     t._wdno_planes = (planes, t._version, CONV_MATH)
     t._wdno_unwritten = True
     return t
@@ -1212,7 +1226,7 @@ class _GroupNormAct(torch.autograd.Function):
             _lib.check(lib.wdno_groupnorm_act_bwd_planes(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), _p(cs),
                                                          _p(dgb), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
                        'groupnorm_bwd_planes')
-            dx = torch.empty_like(x)              # never written: the convolution reads the planes (and fails loudly if it cannot)
+            dx = _poison(torch.empty_like(x))     # never written: the convolution reads the planes (and fails loudly if it cannot)
             dx._wdno_planes_only = ((hi, lo, scale), cs, dx._version, CONV_MATH)
             red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
             return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None, None
@@ -1277,7 +1291,7 @@ def _alias_of(x):
     """The same storage as a second autograd output (skip connections that pass THROUGH an operator so that its backward receives
     the skip gradient and folds the sum into its own output pass). Producer-side hints follow the alias."""
     xs = x.view_as(x)
-    for attr in ('_wdno_amax', '_wdno_planes'):
+    for attr in ('_wdno_amax', '_wdno_planes', '_wdno_unwritten'):
         h = getattr(x, attr, None)
         if h is not None:
             try:
@@ -1403,6 +1417,7 @@ class _Attn(torch.autograd.Function):
                 sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
             _lib.check(_lib_().wdno_attn_bwd_planes(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(hi), _p(lo), _p(sc),
                                                     _p(dbias), _p(ctx.qrec), _p(grec), C.byref(d), float(scale), _stream()), 'attn_bwd_planes')
+            _poison(dqkv)
             dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version, CONV_MATH)      # dqkv itself stays unwritten
             return dqkv, dbias, None, None, None, None, None
         rec = _new_amax_record(qkv.device)        # dqkv is the dy of the qkv projection
@@ -1469,6 +1484,7 @@ class _LinAttn(torch.autograd.Function):
                 sc = drec[1:2]
             _lib.check(lib.wdno_linattn_bwd_planes(_p(qkv), _p(go), _p(kstats), _p(cx), _p(hi), _p(lo), _p(sc), _p(ctx.qrec), _p(grec), _p(drec),
                                                    _p(ws), nb, units, n_tok, heads, float(scale), _stream()), 'linattn_bwd_planes')
+            _poison(dqkv)
             dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version, CONV_MATH)
             return dqkv, None, None, None, None, None
         rec = _new_amax_record(qkv.device)

@@ -123,7 +123,6 @@ class GaussianDiffusion(nn.Module):
                 clipped.clamp_(max=min_snr_gamma)
             return clipped / snr
         K.register_schedule(self, betas, loss_weight)
-        self._ac_host = self.alphas_cumprod.clone()      # host copy for the scalar DDIM coefficients
         self._lw_cache = None
         self.use_graph = None       # None: HIP-graph replay of the unguided sampling step when the loop is long enough (WDNO_SAMPLE_GRAPH)
 
@@ -183,6 +182,10 @@ class GaussianDiffusion(nn.Module):
             self_cond = x_start if self.self_condition else None
             img, x_start = self.p_sample(tuple(img.shape), img.contiguous(), i, self_cond)
         return img
+
+    @property
+    def _ac_host(self):
+        return K.ac_host(self)          # host copy of the current alphas_cumprod buffer (scalar DDIM coefficients)
 
     def sample_noise(self, shape, device):
         return torch.randn(shape, device=device)

@@ -145,11 +145,18 @@ class FlatBuffers:
                 for h in self._gather_hosts:
                     h[:, 1] = torch.tensor(self._view_ptrs, dtype=torch.int64)
                     h[:, 2] = torch.tensor([sp[1] for sp in self.span_list], dtype=torch.int64)
+                self._gather_events = [None] * len(self._gather_hosts)
                 self._gather_turn = 0
-            h = self._gather_hosts[self._gather_turn % len(self._gather_hosts)]
+            slot = self._gather_turn % len(self._gather_hosts)
+            h = self._gather_hosts[slot]
             self._gather_turn += 1
+            if self._gather_events[slot] is not None:      # the asynchronous copy that last read this pinned buffer must have finished
+                self._gather_events[slot].synchronize()    # (a no-op unless the host ran eight uploads ahead of the device)
             h[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
             self._gather_table.copy_(h, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._gather_events[slot] = ev
             self._gather_srcs = ptrs
         _lib.check(_lib_().wdno_gather_items(_p(self._gather_table), len(ptrs), 48, _stream()), 'gather_items')
         for p, v in zip(self.params, self._views):
@@ -218,7 +225,9 @@ class OverlappedAllReduce:
         flat = self.buf.flat_grad
         for i in self.members[b]:                     # autograd adds in place into the flat views; anything else is copied in first
             p, (o, n) = self.buf.params[i], self.spans[i]
-            if p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + 4 * o:
+            if p.grad is None:                        # no gradient in this backward: its span must not carry last step's values into the sum
+                flat[o:o + n].zero_()
+            elif p.grad.data_ptr() != flat.data_ptr() + 4 * o:
                 flat[o:o + n].view(p.shape).copy_(p.grad)
                 p.grad = flat[o:o + n].view(p.shape)
         s, e = self.bounds[b]
