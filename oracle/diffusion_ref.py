@@ -86,11 +86,30 @@ def ddim_times(T, S):
     return list(zip(times[:-1], times[1:]))
 
 
-def ddim_update(buf, x_start, eps, time, time_next, eta, noise):
-    a, an = buf['alphas_cumprod'][time], buf['alphas_cumprod'][time_next]
+def ddim_scalars(buf, time, time_next, eta):
+    """sigma, c, sqrt(alpha_next) of diffusion_2d.py:905-909 / diffusion_1d.py:423-428 in the dtype of the schedule buffers. For fp32
+    buffers every operation is an IEEE-correctly-rounded fp32 operation (numpy float32 scalars): torch's CPU fp32 sqrt is off by one
+    ulp on ~0.5 % of inputs and not on the same ones on every host, and c^2 = 1 - a' - sigma^2 at t = T-1 is ~1e-6 left over from
+    terms ~1 (quantised in 4 % steps), so with torch scalars the SAME reference code gives c = 1.196e-3 in the build container and
+    1.245e-3 on the GPU box's host, 5e-5 apart at the end of a 4-step chain (tools/ddim_coef_probe.py)."""
+    import numpy as np
+    ac = buf['alphas_cumprod']
+    if ac.dtype == torch.float32:
+        one, e = np.float32(1.0), np.float32(eta)
+        a, an = np.float32(ac[time].item()), np.float32(ac[time_next].item())
+        with np.errstate(invalid='ignore'):
+            sigma = e * np.sqrt((one - a / an) * (one - an) / (one - a))
+            c = np.sqrt(one - an - sigma * sigma)
+            return float(sigma), float(c), float(np.sqrt(an))
+    a, an = ac[time], ac[time_next]
     sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
     c = (1 - an - sigma ** 2).sqrt()
-    return x_start * an.sqrt() + c * eps + sigma * noise
+    return sigma, c, an.sqrt()
+
+
+def ddim_update(buf, x_start, eps, time, time_next, eta, noise):
+    sigma, c, sqrt_an = ddim_scalars(buf, time, time_next, eta)
+    return x_start * sqrt_an + c * eps + sigma * noise
 
 
 # ----------------------------------------------------------------------------- smoke (x is [B, F, C, H, W])

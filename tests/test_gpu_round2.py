@@ -5,7 +5,7 @@ tests/golden/make_ref_round2_golden.py from the imported reference). GPU box onl
   * D6   : sample(..., design_fn=...) / sample(..., nablaJ=..., J_scheduler=...) through model_predictions' guidance hook
            (diffusion_2d.py:723-754, diffusion_1d.py:205-227, model_utils.py:35-50)
   * 8f-3 : the super-resolution cascade of smoke/inference_2d.py:155-215, stage by stage and end to end, finished by the IDWT
-Chains that start at t = 999 (DDIM) are compared at 1e-4 (see tests/test_gpu_fullsize.py for why), everything else at 1e-5;
+Unguided chains are compared at 1e-5; the guided smoke DDIM chain and the 3-step cascade from t = 999 at the bounds stated where they are asserted;
 index / packing stages are bit-exact."""
 import json
 import os
@@ -117,7 +117,10 @@ def test_smoke_guided_sampling_vs_reference(trees):
     out6 = dif6.sample(batch_size=2, design_fn=design_fn, design_guidance='standard-alpha', init=init, init_u=init_u)
     e2 = rel_l2(out6, gz['ddpm6_out'])
     print('smoke guided chains vs reference: ddim4', e1, 'ddpm6', e2)
-    assert len(calls) == 1 + 4 + 6 and e1 < 1e-4 and e2 < 1e-5
+    # e1 (measured 2.2e-5; 7.7e-5 before the DDIM coefficients were made host independent): at t = 999 the guidance term enters pred_noise
+    # BEFORE x_start = c1 x - c2 eps (c2 = 1.8e3) is clipped, so the few entries that stay inside (-1, 1) carry 1.8e3 x the last-bit
+    # differences between the GPU's and the CPU's evaluation of the callback's autograd graph; the unguided chain of the same model is at 4e-6
+    assert len(calls) == 1 + 4 + 6 and e1 < 5e-5 and e2 < 1e-5
 
 
 def test_burgers_guided_sampling_vs_reference(trees):
@@ -143,7 +146,7 @@ def test_burgers_guided_sampling_vs_reference(trees):
     out6 = dif6.sample(batch_size=2, u_init=u_init, nablaJ=nablaJ, J_scheduler=lambda t: 0.2)
     e2 = rel_l2(out6, gz['ddpm6_out'])
     print('burgers guided chains vs reference: ddim4', e1, 'ddpm6', e2)
-    assert e1 < 1e-4 and e2 < 1e-5
+    assert e1 < 1e-5 and e2 < 1e-5
 
 
 def test_smoke_super_resolution_cascade_vs_reference(trees):
@@ -199,7 +202,27 @@ def test_smoke_super_resolution_cascade_vs_reference(trees):
     w1 = m1.sample(batch_size=N, design_fn=None, N_upsample=1, low=lo, init=t('init1'), init_u=None, control=t('control1'))
     e_chain = rel_l2(w1, gz['wave1'])
     print('SR cascade vs reference: base sample', e_base, 'SR sample from reference low', e_sr, 'end to end', e_chain)
-    assert e_base < 1e-4 and e_sr < 1e-4 and e_chain < 2e-4
+    # the base chain is DDIM-3 from t = 999 on ONE sample: its first step clips all but ~4 of 10 752 entries of x_start = c1 x - c2 eps
+    # (c2 = 1.8e3), and those few carry 1.8e3 x the last-bit differences of the U-Net between hosts. Arbiter: the oracle -- the
+    # reference's arithmetic -- in fp32 ON THIS HOST and in fp64; the HIP result may be no further from the exact chain than 1.5 x what
+    # the reference's own fp32 evaluation (the fixture, made on another host) is, and no further from the fixture than this host's fp32
+    # evaluation of the reference arithmetic is
+    from oracle import diffusion_ref as Dr, unet_ref as Ur
+    sd32 = {k[len('model.'):]: v for k, v in W(gz, 'w0::').items() if k.startswith('model.')}
+    buf32 = {k: v for k, v in W(gz, 'w0::').items() if not k.startswith('model.')}
+    ns0 = [torch.from_numpy(gz[f'base_noise_{i}']) for i in range(int(gz['base_n_noise']))]
+    chain = lambda sd, buf, dt: Dr.smoke_ddim_sample(lambda x, tt: Ur.unet3d_forward(sd, x, tt, dim=8, dim_mults=(1, 2), groups=4), buf, [n.to(dt) for n in ns0],
+                                                     1000, 3, 1.0, padded_shape=tuple(shape[0]), init=torch.from_numpy(gz['init0']).to(dt),
+                                                     control=torch.from_numpy(gz['control0']).to(dt))
+    with torch.no_grad():
+        o32 = chain(sd32, buf32, torch.float32)
+        o64 = chain({k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}, {k: v.double() for k, v in buf32.items()}, torch.float64)
+    ref_exact, hip_exact, host_ref = rel_l2(gz['wave0'], o64), rel_l2(w0, o64), rel_l2(o32, gz['wave0'])
+    print('   base chain: reference vs exact', ref_exact, 'hip vs exact', hip_exact, "this host's fp32 oracle vs reference", host_ref)
+    assert hip_exact < 1.5 * ref_exact + 2e-6 and e_base < 1.5 * host_ref + 5e-6
+    # SR stage from the reference's own low-resolution input: 1e-5. End to end: the base deviation above (arbiter-gated) carried through
+    # the SR chain, whose own t = 999 step amplifies differences of its conditioning input ~3x (measured 1.0e-4)
+    assert e_sr < 1e-5 and e_chain < 2e-4
     # --- reconstruction: our waverec3 of the unpacked coefficients vs the oracle's IDWT of the reference's coefficients
     c_ours, _ = pack(w1, shape[1], 'space')
     rec = ptwt.waverec3([c_ours[0].contiguous(), {k: v.contiguous() for k, v in c_ours[1].items()}], pywt.Wavelet('bior1.3'))

@@ -467,3 +467,28 @@ def test_ddim_coefficients_follow_the_loaded_schedule(trees):
     sdb['alphas_cumprod'] = sdb['alphas_cumprod'] * 0.5
     b.load_state_dict(sdb)
     assert torch.equal(b._ac_host, sdb['alphas_cumprod'])
+
+
+def test_ddim_coefficients_are_host_independent_and_match_the_reference_where_it_matters():
+    """K.ddim_coefficients does every fp32 operation correctly rounded (double arithmetic + rounding): equal, bit for bit, to the
+    oracle's numpy-float32 evaluation for every step pair of the three schedules, and equal to what the reference computed in the
+    build container at the one place where an ulp matters (sigmoid schedule, eta = 1, t = 999 -> 749: c^2 = 1.43e-6 left from
+    terms ~1; torch's CPU sqrt on the GPU box's host rounds sigma the other way and gets c = 1.2449e-3: tools/ddim_coef_probe.py)."""
+    from oracle import diffusion_ref as D
+    from wdno_amd import diffusion_core as K
+    same = lambda x, y: x == y or (x != x and y != y)
+    n = 0
+    for sched in (K.sigmoid_beta_schedule, K.cosine_beta_schedule, K.linear_beta_schedule):
+        ac = torch.cumprod(1 - sched(1000), 0).float()
+        for steps in (3, 4, 10, 100):
+            for eta in (0.0, 0.3, 1.0):
+                for t, tn in K.ddim_time_pairs(1000, steps):
+                    if tn >= 0:
+                        a, b = K.ddim_coefficients(ac, t, tn, eta), D.ddim_scalars({'alphas_cumprod': ac}, t, tn, eta)
+                        assert all(same(x, y) for x, y in zip(a, b)), (sched.__name__, steps, eta, t, tn, a, b)
+                        n += 1
+    assert n > 1000
+    ac = torch.cumprod(1 - K.sigmoid_beta_schedule(1000), 0).float()
+    assert K.ddim_coefficients(ac, 999, 749, 1.0) == (0.9224164485931396, 0.0011960399569943547, 0.3861948251724243)
+    ac = torch.cumprod(1 - K.cosine_beta_schedule(1000), 0).float()
+    assert math.isnan(K.ddim_coefficients(ac, 999, 665, 1.0)[1])          # Burgers DDIM-3 at eta = 1: NaN in the reference too

@@ -6,6 +6,7 @@ smoke/ddpm/diffusion_2d.py:513-547,627-685 (schedule tables are built in fp64 on
 import ctypes as C
 import math
 import os
+import struct
 import weakref
 
 import torch
@@ -181,12 +182,27 @@ def ac_host(mod):
     return c[1]
 
 
+def _f32(v):
+    """Round a python float (double) to the nearest fp32 value."""
+    return struct.unpack('<f', struct.pack('<f', v))[0]
+
+
 def ddim_coefficients(alphas_cumprod_host, time, time_next, eta):
-    """sigma, c, sqrt(alpha_next) as python floats from a host copy of alphas_cumprod (fp32, reference arithmetic)."""
-    a, an = alphas_cumprod_host[time], alphas_cumprod_host[time_next]
-    sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
-    c = (1 - an - sigma ** 2).sqrt()
-    return float(sigma), float(c), float(an.sqrt())
+    """sigma, c, sqrt(alpha_next) as python floats: the reference's fp32 tensor arithmetic (diffusion_2d.py:905-909,
+    diffusion_1d.py:423-428)
+        sigma = eta * ((1 - a / a') * (1 - a') / (1 - a)).sqrt();   c = (1 - a' - sigma ** 2).sqrt()
+    with every operation CORRECTLY ROUNDED to fp32 -- each one is done in double and rounded, which is exact for + - * / sqrt --
+    instead of by torch's CPU kernels. Reason (measured, tools/ddim_coef_probe.py): c^2 at t = T-1 is ~1e-6 left over from terms ~1, so
+    it is quantised in steps of 4 %; torch's CPU sqrt on the MI355X box's host returns 0x3f6c237b for sqrt(0x3f59d171) where the IEEE
+    result (and torch in the build container, where the reference fixtures were made) is 0x3f6c237c, which moves c from 1.196e-3 to
+    1.245e-3 and a 4-step eta = 1 chain by 5e-5. The reference on a host with a correctly rounded sqrt computes exactly these values."""
+    f = _f32
+    a, an = float(alphas_cumprod_host[time]), float(alphas_cumprod_host[time_next])
+    q = f(f(f(1.0 - f(a / an)) * f(1.0 - an)) / f(1.0 - a))
+    sigma = f(f(eta) * f(math.sqrt(q)))
+    c2 = f(f(1.0 - an) - f(sigma * sigma))
+    c = f(math.sqrt(c2)) if c2 >= 0.0 else float('nan')          # the reference's fp32 sqrt of a negative remainder is NaN too (eta = 1, huge strides)
+    return sigma, c, f(math.sqrt(an))
 
 
 # ----------------------------------------------------------------------------------------------------- sampling loops
