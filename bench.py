@@ -56,16 +56,34 @@ def build_model(device, batch=8):
     return dif.to(device)
 
 
-def build_burgers(device):
-    """The Burgers base model exactly as burgers/train_ddpm_burgers.py:128-182 builds it (scripts/burgers/train_base_sim.sh)."""
+def build_burgers(device, grid=(64, 64)):
+    """The Burgers base model exactly as burgers/train_ddpm_burgers.py:128-182 builds it (scripts/burgers/train_base_sim.sh). grid (64, 64)
+    is the reference-native tensor (41 x 60 coefficients zero-padded); (80, 64) the north-star's synthetic one: the DWT of a
+    [2, 160, 128] field fills it completely."""
     _trees()
     from ddpm_burgers.unet import Unet2D
     from ddpm_burgers.diffusion_1d import GaussianDiffusion
     torch.manual_seed(0)
     net = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
-    dif = GaussianDiffusion(net, seq_length=(64, 64), padded_shape=[41, 60], ori_shape=[81, 120], loss_layer_weight=torch.ones(1, 9, 1, 1),
+    coef, ori = ([41, 60], [81, 120]) if tuple(grid) == (64, 64) else (list(grid), [2 * grid[0], 2 * grid[1]])
+    dif = GaussianDiffusion(net, seq_length=tuple(grid), padded_shape=coef, ori_shape=ori, loss_layer_weight=torch.ones(1, 9, 1, 1),
                             is_condition_pad=True, is_condition_u0=True, is_condition_f=True, beta_schedule='cosine', timesteps=1000)
     return dif.to(device)
+
+
+def burgers_fields_to_state(fields, rescaler=None):
+    """North-star Burgers input on the GPU: fields [B, 2, 160, 128] (u, f) -> ONE fused HIP DWT launch (bior2.4 / periodization, sub-bands
+    written in coef_to_tensor order) -> [B, 8, 80, 64] + the condition channel (1-D DWT of u(t=0) and u(t=T) as four horizontal
+    stripes, data_burgers_1d.py:51-82) -> [B, 9, 80, 64] / rescaler."""
+    from wdno_amd import wavelets as Wv
+    b, _, nt, nx = fields.shape
+    packed = Wv.dwt_packed(fields, 'bior2.4', 'periodization', 2).reshape(b, 8, nt // 2, nx // 2)
+    lo, hi = Wv.DWT1DForward(J=1, mode='periodization', wave='bior2.4')(fields[:, 0, [0, nt - 1], :].contiguous())      # [B, 2, nx / 2] each
+    q = nt // 8
+    cond = torch.stack((lo[:, 0], hi[0][:, 0], lo[:, 1], hi[0][:, 1]), dim=1)            # [B, 4, nx / 2]
+    cond = cond.unsqueeze(2).expand(b, 4, q, nx // 2).reshape(b, 1, nt // 2, nx // 2)
+    x = torch.cat((packed, cond), dim=1)
+    return x if rescaler is None else x / rescaler
 
 
 # ---------------------------------------------------------------------------------------------------------------- CPU baseline
@@ -186,7 +204,7 @@ def cpu_baseline(budget_s=30.0):
     # the JSON contract's required keys: the baseline of the main metric
     s = out['smoke_train_step']['seconds_per_sample']
     out.update(value=round(1.0 / (8 * s), 4), unit='steps/s (8-sample steps)',
-               sample=f'oracle/ (CPU restatement, torch fp32) on {cores} threads of {out["cpu_model"]}: median of '
+               sample=f'oracle/ (CPU restatement, torch fp32) on {cores} of {os.cpu_count()} hardware threads of {out["cpu_model"]} (torch CPU convolutions regress beyond ~32): median of '
                       f'{out["smoke_train_step"]["iters"]} training steps at batch 1 of the same [24,42,40,40] workload after one warm-up, '
                       f'{s:.2f} s per sample; value = 1 / (8 x that). Other entries: p_sample step, the Burgers model at batch 4, and the numpy DWT oracle on 1/8 of the synthetic batch (1 thread).')
     return out
@@ -315,17 +333,20 @@ def sr_leg(device, batch=2, steps=10):
     return out
 
 
-def burgers_leg(device, batch, steps, lowp=None):
-    """Burgers base model: train step and p_sample step (BASELINE.json configs[0] shape at batch 16, configs[1] at batch 256)."""
+def burgers_leg(device, batch, steps, lowp=None, grid=(64, 64)):
+    """Burgers base model: train step and p_sample step (BASELINE.json configs[0] shape at batch 16, configs[1] at batch 256). grid
+    (80, 64): the north-star's synthetic shape; the training step then starts from FIELDS [B, 2, 160, 128] resident in HBM (HIP DWT +
+    packing inside the timed step), and the step on a pre-packed tensor is reported next to it."""
     from wdno_amd import ops
     from wdno_amd.trainer import TrainStep, cosine_annealing_lr
     prev = ops.CONV_MATH
     if lowp:
         ops.CONV_MATH = lowp
     try:
-        dif = build_burgers(device)
+        dif = build_burgers(device, grid)
         ts = TrainStep(dif, lr=1e-4, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=lambda b, s: cosine_annealing_lr(b, s, 10000))
-        x = (torch.randn(batch, 9, 64, 64) * 0.5).to(device)
+        gh, gw = grid
+        x = (torch.randn(batch, 9, gh, gw) * 0.5).to(device)
         for _ in range(3):
             ts.step(x)
         torch.cuda.synchronize()
@@ -334,8 +355,20 @@ def burgers_leg(device, batch, steps, lowp=None):
             loss, _ = ts.step(x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        pipe = None
+        if tuple(grid) != (64, 64):
+            fields = torch.randn(batch, 2, 2 * gh, 2 * gw, device=device)
+            resc = torch.full((1, 9, 1, 1), 4.0, device=device)
+            for _ in range(2):
+                ts.step(burgers_fields_to_state(fields, resc))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss, _ = ts.step(burgers_fields_to_state(fields, resc))
+            torch.cuda.synchronize()
+            pipe = (time.perf_counter() - t0) / steps
         with torch.no_grad():
-            xs = torch.randn(batch, 9, 64, 64, device=device)
+            xs = torch.randn(batch, 9, gh, gw, device=device)
             for t in (500, 499):
                 xs = dif.p_sample(xs, t)[0]
             torch.cuda.synchronize()
@@ -344,10 +377,54 @@ def burgers_leg(device, batch, steps, lowp=None):
                 xs = dif.p_sample(xs, 400 - i)[0]
             torch.cuda.synchronize()
             ds = (time.perf_counter() - t0) / steps
-        return {'batch': batch, 'conv_math': ops.CONV_MATH, 'train_ms_per_step': round(dt * 1e3, 2), 'train_steps_per_sec': round(1 / dt, 2),
-                'train_samples_per_sec': round(batch / dt, 1), 'p_sample_ms_per_step': round(ds * 1e3, 2), 'final_loss': float(loss)}
+        out = {'batch': batch, 'tensor': [batch, 9, gh, gw], 'conv_math': ops.CONV_MATH, 'train_ms_per_step': round(dt * 1e3, 2), 'train_steps_per_sec': round(1 / dt, 2),
+               'train_samples_per_sec': round(batch / dt, 1), 'p_sample_ms_per_step': round(ds * 1e3, 2), 'final_loss': float(loss)}
+        if pipe is not None:
+            out['fields_to_step'] = {'fields': [batch, 2, 2 * gh, 2 * gw], 'ms_per_step': round(pipe * 1e3, 2), 'steps_per_sec': round(1 / pipe, 2),
+                                     'note': 'HIP DWT + packing + condition channel + train step, fields resident in HBM'}
+        return out
     finally:
         ops.CONV_MATH = prev
+
+
+def smoke_pipeline_leg(ts, device, batch, steps):
+    """The smoke pipeline end to end on the GPU: fields [B, 5, 32, 64, 64] (rho, vx, vy, cx, cy) resident in HBM -> ONE fused 3-D HIP DWT
+    launch (bior1.3 / zero) -> [B*5, 8, 18, 34, 34] -> pack_smoke_batch (+ init-density and smoke-out condition channels, / RESCALER)
+    -> [B, 24, 42, 40, 40] -> the training step of the main line (data_2d.py:156-221 + diffusion_2d.py:1257-1307). The 5-field layout
+    is the reference's (its conditioning predicates sit at fixed channel positions); the north-star's 4-field synthetic tensor
+    [B, 4, 32, 64, 64] -> [B, 24, 34, 40, 40] differs in the channel count of the first and last convolution only and is timed through
+    the transform + packing as well."""
+    from wdno_amd import wavelets as Wv
+    from ddpm.data_2d import pack_smoke_batch, _RESCALERS
+    out = {}
+    resc = torch.tensor(_RESCALERS['bior1.3'], dtype=torch.float32, device=device).reshape(1, 42, 1, 1)
+
+    def to_state(fields, rs):
+        b, nf = fields.shape[:2]
+        coef = Wv.dwt_packed(fields.reshape(b * nf, 32, 64, 64), 'bior1.3', 'zero', 3).reshape(b, nf, 8, 18, 34, 34)
+        init_coef = Wv.dwt_packed(fields[:, 0, 0].reshape(b, 1, 64, 64).contiguous(), 'bior1.3', 'zero', 2).reshape(b, 4, 34, 34)
+        so = fields[:, 0].mean((-2, -1))                                       # stand-in for the smoke-out curve [B, 32]
+        lo, hi = Wv.DWT1DForward(J=1, mode='zero', wave='bior1.3')(so.unsqueeze(1).contiguous())
+        smokeout = torch.cat((lo, hi[0]), dim=1)                                # [B, 2, 18]
+        return pack_smoke_batch(coef, init_coef, smokeout, rs)
+    fields = torch.randn(batch, 5, 32, 64, 64, device=device)
+    st = to_state(fields, resc)
+    assert tuple(st.shape) == (batch, 24, 42, 40, 40)
+    out['transform_and_pack_ms'] = round(_ev_time(lambda: to_state(fields, resc), 20), 3)
+    for _ in range(2):
+        ts.step(to_state(fields, resc))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ts.step(to_state(fields, resc))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out.update(fields=[batch, 5, 32, 64, 64], state=[batch, 24, 42, 40, 40], fields_to_step_ms=round(dt * 1e3, 2), steps_per_sec=round(1 / dt, 2))
+    f4 = torch.randn(batch, 4, 32, 64, 64, device=device)
+    r4 = torch.cat((resc[:, :32], resc[:, -2:]), dim=1)
+    s4 = to_state(f4, r4)
+    out['four_field_synthetic'] = {'fields': [batch, 4, 32, 64, 64], 'state': list(s4.shape), 'transform_and_pack_ms': round(_ev_time(lambda: to_state(f4, r4), 20), 3)}
+    return out
 
 
 def conv_roofline(ts_step, ops):
@@ -393,13 +470,14 @@ def conv_roofline(ts_step, ops):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=150)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None, help='samples per GPU per step (default 8 smoke, 16 burgers, 256 burgers-bf16)')
     ap.add_argument('--workload', default='smoke', choices=['smoke', 'burgers', 'burgers-bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the sampling / DWT / Burgers side legs')
     ap.add_argument('--sample-steps', type=int, default=20)
+    ap.add_argument('--burgers-grid', default='64x64', help="tensor size of the Burgers workloads: 64x64 (reference-native) or 80x64 (north-star synthetic: fields [B,2,160,128] through the HIP DWT)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -423,9 +501,10 @@ def main():
         shape = (batch, 24, 42, 40, 40)
         grad_mb = 95.3
     else:
-        dif = build_burgers(device)
+        bgrid = tuple(int(v) for v in args.burgers_grid.split('x'))
+        dif = build_burgers(device, bgrid)
         ts = TrainStep(dif, lr=1e-4, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=lambda b, s: cosine_annealing_lr(b, s, 10000), use_ema=True)
-        shape = (batch, 9, 64, 64)
+        shape = (batch, 9, *bgrid)
         grad_mb = 563.0
     g = torch.Generator(device='cpu').manual_seed(1234 + rank)
     x = (torch.randn(shape, generator=g) * 0.5).to(device)      # resident in HBM before timing
@@ -449,7 +528,7 @@ def main():
     local_elapsed = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
-    per_rank = None
+    per_rank = {'ms_per_step': [round(local_elapsed / args.steps * 1e3, 3)], 'exposed_allreduce_ms': [0.0]}      # same schema at N = 1 (no exchange)
     if world > 1:
         comm_ms = sum(a.elapsed_time(b) for a, b in ts.comm_events) / max(1, len(ts.comm_events))
         tt = torch.tensor([elapsed, local_elapsed / args.steps * 1e3, comm_ms], device=device, dtype=torch.float64)
@@ -469,6 +548,7 @@ def main():
             try:
                 if smoke:
                     extras['sampling'] = sampling_leg(dif, device, batch, args.sample_steps)
+                    extras['fields_pipeline'] = smoke_pipeline_leg(ts, device, batch, 10)
                 extras['dwt'] = dwt_leg(device)
                 if smoke:
                     del ts, dif
@@ -476,7 +556,11 @@ def main():
                     extras['sr_sampling'] = sr_leg(device)
                     torch.cuda.empty_cache()
                     extras['burgers'] = {'fp32_equivalent_batch16': burgers_leg(device, 16, 20),
-                                         'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16') if ops.LOWP_AVAILABLE else 'bf16 path not built'}
+                                         'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16') if ops.LOWP_AVAILABLE else 'bf16 path not built',
+                                         'north_star_80x64': {'fp32_equivalent_batch16': burgers_leg(device, 16, 20, grid=(80, 64)),
+                                                              'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16', grid=(80, 64))}}
+                elif bgrid != (64, 64):
+                    extras['fields_pipeline'] = burgers_leg(device, batch, 10, lowp='bf16' if args.workload == 'burgers-bf16' else None, grid=bgrid).get('fields_to_step')
             except Exception as e:      # side legs never invalidate the main line
                 import traceback
                 extras['error'] = repr(e) + ' | ' + traceback.format_exc()[-600:]
@@ -496,8 +580,26 @@ def main():
         else:
             metric = f'diffusion train steps/sec, 1D Burgers U-Net ({batch} samples per GPU per step)'
             math = 'bf16 single-product MFMA with fp32 master weights and accumulators' if args.workload == 'burgers-bf16' else 'fp32-equivalent 3 x fp16-split MFMA'
-            wl = f'Burgers base-resolution DDPM train step: Unet2D(dim=128,(1,2,4,8),ch=9,groups=1) on [{batch},9,64,64] per GPU, convolutions: {math}, Adam+clip+EMA'
+            wl = f'Burgers base-resolution DDPM train step: Unet2D(dim=128,(1,2,4,8),ch=9,groups=1) on [{batch},9,{bgrid[0]},{bgrid[1]}] per GPU, convolutions: {math}, Adam+clip+EMA'
             dtype = 'bf16' if args.workload == 'burgers-bf16' else 'f32'
+        # whole-step roofline (SURVEY 8d counting rule: FlopCounterMode flop of the reference model, fwd + bwd = 3 x fwd; bytes = un-fused
+        # leaf-module input + output bytes, + parameters once, + the optimiser's 7 parameter-sized streams)
+        if smoke:
+            gf, gb, par_mb = 908.2, 6.06, 95.3
+        elif bgrid == (64, 64):
+            gf, gb, par_mb = 167.9, 1.05, 563.0
+        else:
+            gf, gb, par_mb = 209.8 * (bgrid[0] * bgrid[1]) / 5120.0, 1.32 * (bgrid[0] * bgrid[1]) / 5120.0, 563.0
+        step_s = ms_per_step * 1e-3
+        tfl = batch * gf / 1e3 / step_s
+        gbs = (batch * gb + 8 * par_mb / 1e3) / step_s
+        mfma_peak = PEAK_F16_MFMA_TFLOPS
+        step_roofline = {'tflops_algorithmic': round(tfl, 1), 'frac_mfma': round(tfl / mfma_peak, 4), 'mfma_peak_tflops': mfma_peak,
+                         'frac_mfma_of_fp32_equivalent_ceiling': round(tfl / (mfma_peak / 3), 4) if dtype == 'f32' else None,
+                         'hbm_GBps_unfused': round(gbs, 1), 'frac_hbm': round(gbs / (PEAK_HBM_TBS * 1e3), 4),
+                         'bound': 'mfma', 'gflop_per_sample': round(gf, 1), 'GB_per_sample_unfused': round(gb, 3),
+                         'note': 'the step is bound by matrix work (about 160 flop per un-fused byte against a ridge of 2500 / 8 = 312 flop/B for ONE '
+                                 '16-bit product and 104 flop/B for the 3-product fp32-equivalent split); both fractions are of the whole driver-timed step'}
         out = {
             'metric': metric, 'value': round(world * args.steps / elapsed, 4), 'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -505,12 +607,11 @@ def main():
             'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0},
             'samples_per_sec': round(world * args.steps * batch / elapsed, 3),
             'final_loss': final_loss,
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'step_roofline': step_roofline, 'cpu_baseline': cpu,
         }
         if 'sampling' in extras:
             out['ddpm_sample_steps_per_sec'] = extras['sampling'][f'batch{batch}']['graph_steps_per_sec']
-        if per_rank:
-            out['per_rank'] = per_rank
+        out['per_rank'] = per_rank
         out.update(extras)
         print(json.dumps(out))
     if world > 1:

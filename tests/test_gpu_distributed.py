@@ -154,3 +154,58 @@ def test_two_ranks_one_gpu_smoke_trainer(tmp_path):
     assert (seen0[0], seen0[1]) != (seen0[2], seen0[3]), 'DistributedSampler epoch was not advanced'
     files = sorted(os.listdir(tmp_path / 'res'))
     assert files.count('model-1.pt') == 1
+
+
+# ------------------------------------------------------------------------------------------------ RCCL itself, one rank (round 3)
+def _worker_rccl_one_rank(port, overlap, out):
+    """A ONE-rank "nccl" (= RCCL) process group on the box's GPU: the exchange is forced (WDNO_DP_FORCE_EXCHANGE), so every
+    torch.distributed call of the data-parallel step runs over RCCL -- broadcast of the flat parameter buffer, the async bucket
+    all-reduces on RCCL's own stream started from gradient hooks during backward, finish() ordering them against the HIP launch
+    stream -- and the result must be BIT-IDENTICAL to the same steps without a process group (a sum over one rank is the identity)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    _trees()
+    import torch.distributed as dist
+    from wdno_amd.trainer import TrainStep
+    torch.cuda.set_device(0)
+    batches = _batches()
+
+    def run():
+        dif = _model(5).to('cuda')
+        ts = TrainStep(dif, lr=1e-3, max_grad_norm=1.0, use_ema=False)
+        losses = []
+        for x0, t, noise in batches:
+            loss, gn = ts.step_with(x0.cuda(), t.cuda(), noise.cuda())
+            losses.append((loss.item(), gn.item()))
+        torch.cuda.synchronize()
+        return ts, losses, ts.opt.buf.flat_param.detach().cpu().clone()
+    ts0, l0, w0 = run()
+    assert not ts0.exchange and ts0.overlap is None
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    os.environ['WDNO_DP_FORCE_EXCHANGE'] = '1'
+    os.environ['WDNO_DP_OVERLAP'] = '1' if overlap else '0'
+    ts1, l1, w1 = run()
+    info = dict(backend=dist.get_backend(), exchange=ts1.exchange, overlap=ts1.overlap is not None,
+                buckets=0 if ts1.overlap is None else len(ts1.overlap.bounds), losses_equal=l0 == l1, weights_equal=bool(torch.equal(w0, w1)),
+                finite=bool(torch.isfinite(w1).all()))
+    # the plain collectives on device memory as well
+    v = torch.arange(1000, device='cuda', dtype=torch.float32)
+    dist.all_reduce(v)
+    dist.broadcast(v, 0)
+    dist.barrier()
+    info['allreduce_identity'] = bool(torch.equal(v.cpu(), torch.arange(1000, dtype=torch.float32)))
+    dist.destroy_process_group()
+    torch.save(info, out)
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overlap):
+    out = str(tmp_path / 'rccl.pt')
+    ctx = mp.get_context('spawn')
+    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), overlap, out))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, f'worker exit code {p.exitcode}'
+    info = torch.load(out)
+    print(info)
+    assert info['backend'] == 'nccl' and info['exchange'] and info['overlap'] == overlap and (info['buckets'] == 4) == overlap
+    assert info['losses_equal'] and info['weights_equal'] and info['finite'] and info['allreduce_identity']

@@ -492,3 +492,17 @@ def test_ddim_coefficients_are_host_independent_and_match_the_reference_where_it
     assert K.ddim_coefficients(ac, 999, 749, 1.0) == (0.9224164485931396, 0.0011960399569943547, 0.3861948251724243)
     ac = torch.cumprod(1 - K.cosine_beta_schedule(1000), 0).float()
     assert math.isnan(K.ddim_coefficients(ac, 999, 665, 1.0)[1])          # Burgers DDIM-3 at eta = 1: NaN in the reference too
+
+
+def test_batched_smoke_packer_equals_the_per_sample_packer(trees):
+    """pack_smoke_batch (the GPU-side packer used by the bench's fields -> DWT -> pack -> step pipeline) is index work: identical to
+    stacking pack_smoke_state (the reference's per-item packing, data_2d.py:156-221) over the batch."""
+    from ddpm.data_2d import pack_smoke_batch, pack_smoke_state
+    g = torch.Generator().manual_seed(3)
+    coef = torch.randn(3, 5, 8, 18, 34, 34, generator=g)
+    init_coef = torch.randn(3, 5, 4, 34, 34, generator=g)
+    smokeout = torch.randn(3, 2, 18, generator=g)
+    resc = torch.rand(1, 42, 1, 1, generator=g) + 0.5
+    one = torch.stack([pack_smoke_state(coef[i], init_coef[i], smokeout[i], resc) for i in range(3)])
+    many = pack_smoke_batch(coef, init_coef[:, 0], smokeout, resc)
+    assert many.shape == (3, 24, 42, 40, 40) and torch.equal(one, many)

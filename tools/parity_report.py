@@ -188,15 +188,26 @@ def smoke_full(batch=2, frames=24, size=40, modes=('f16x3', 'f32')):
     return res
 
 
-def burgers_full(batch=2, modes=('f16x3', 'f32')):
+def burgers_full(batch=2, modes=('f16x3', 'f32'), grid=(64, 64), coef=(41, 60), from_fields=False):
+    """grid / coef: tensor size and the coefficient region inside it. from_fields: x0 is produced ON THE GPU path from a field batch
+    [B, 2, 2 grid] through the HIP DWT (bior2.4 / periodization) + packing (+ one condition channel), the north-star's synthetic Burgers
+    input ([B, 2, 160, 128] -> [B, 8 + 1, 80, 64]); the oracle then starts from that same packed tensor."""
     from ddpm_burgers.unet import Unet2D
     from ddpm_burgers.diffusion_1d import GaussianDiffusion
     torch.manual_seed(1)
     net = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
     g = torch.Generator().manual_seed(6)
-    x0 = torch.randn(batch, 9, 64, 64, generator=g) * 0.5
-    noise = torch.randn(batch, 9, 64, 64, generator=g)
+    gh, gw = grid
+    if from_fields:
+        from wdno_amd import wavelets as Wv
+        fields = torch.randn(batch, 2, 2 * gh, 2 * gw, generator=g)
+        packed = Wv.dwt_packed(fields.to(DEV), 'bior2.4', 'periodization', 2)            # [B, 2, 4, gh, gw] in coef_to_tensor order
+        cond = torch.randn(batch, 1, gh, gw, generator=g) * 0.5
+        x0 = torch.cat((packed.reshape(batch, 8, gh, gw).cpu() * 0.25, cond), dim=1).contiguous()
+    else:
+        x0 = torch.randn(batch, 9, gh, gw, generator=g) * 0.5
+    noise = torch.randn(batch, 9, gh, gw, generator=g)
     t = torch.tensor([77, 805][:batch])
     lw = torch.ones(1, 9, 1, 1)
     flags = dict(pad=True, u0=True, uT=False, f=True)
@@ -206,7 +217,7 @@ def burgers_full(batch=2, modes=('f16x3', 'f32')):
         sd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd0.items()}
         model = lambda x, tt: U.unet2d_forward(sd, x, tt, dim=128, dim_mults=(1, 2, 4, 8), groups=1)
         t0 = time.perf_counter()
-        loss = D.burgers_p_losses(model, cast_buf(D.make_buffers('cosine', 1000), dt), x0.to(dt), t, noise.to(dt), padded_shape=[41, 60],
+        loss = D.burgers_p_losses(model, cast_buf(D.make_buffers('cosine', 1000), dt), x0.to(dt), t, noise.to(dt), padded_shape=list(coef),
                                   loss_layer_weight=lw.to(dt), flags=flags)
         loss.backward()
         return loss.item(), {k: v.grad for k, v in sd.items() if v.requires_grad}, time.perf_counter() - t0
@@ -220,7 +231,7 @@ def burgers_full(batch=2, modes=('f16x3', 'f32')):
         ops.bump_weight_epoch()
         net_h = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
         net_h.load_state_dict(sd0)
-        dif = GaussianDiffusion(net_h, seq_length=(64, 64), padded_shape=[41, 60], ori_shape=[81, 120], loss_layer_weight=lw,
+        dif = GaussianDiffusion(net_h, seq_length=tuple(grid), padded_shape=list(coef), ori_shape=[2 * coef[0] - 1, 2 * coef[1]], loss_layer_weight=lw,
                                 is_condition_pad=True, is_condition_u0=True, is_condition_f=True).to(DEV)
         ops.PROFILE = {}
         loss = dif.p_losses(x0.to(DEV), t.to(DEV), noise=noise.to(DEV))
@@ -275,6 +286,77 @@ def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32'), seed=7):
         o = dif.sample(batch_size=batch, init=init.to(DEV), control=control.to(DEV)).cpu()
         res[mode] = {'hip_vs_cpu32': rel_l2(o, o32), 'hip_vs_exact': rel_l2(o, o64)}
     set_math('f16x3')
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ configs[4] at full size
+def sr_full(batch=1):
+    """BASELINE configs[4] tensor [B, 48, 82, 80, 80] through the space-SR model Unet3D_with_Conv3D(dim=64, (1,2,4), channels=82):
+    one p_losses (loss + every parameter gradient) and one DDIM step replayed from a captured HIP graph, against the fp32 oracle on
+    the host (the fp64 evaluation of this size takes minutes and is not run)."""
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion
+    from wdno_amd import diffusion_core as K
+    avail = 0
+    with open('/proc/meminfo') as fh:
+        for line in fh:
+            if line.startswith('MemAvailable'):
+                avail = int(line.split()[1]) / 1e6          # GB
+    if avail < 96:          # the fp32 oracle's autograd tape at this size holds ~25 GB; never drive the host out of memory
+        return {'skipped': f'host has {avail:.0f} GB available, the full-size oracle step wants >= 96 GB'}
+    torch.manual_seed(3)
+    shapes = [[18, 34, 34], [34, 66, 66]]
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=82)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    lw = torch.ones(1, 1, 82, 1, 1)
+    g = torch.Generator().manual_seed(9)
+    shape = (batch, 48, 82, 80, 80)
+    x0 = torch.randn(shape, generator=g) * 0.5
+    noise = torch.randn(shape, generator=g)
+    t = torch.tensor([423] * batch)
+    coef_shape = [shapes[1][0], shapes[1][1] + 2, shapes[1][2] + 2]          # space SR: +2 border coefficients in h and w (diffusion_2d.py:860)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith('freqs') else v) for k, v in sd0.items()}
+    model = lambda x, tt: U.unet3d_forward(sd, x, tt, dim=64, dim_mults=(1, 2, 4), groups=8)
+    buf = D.make_buffers('sigmoid', 1000)
+    t0 = time.perf_counter()
+    loss = D.smoke_p_losses(model, buf, x0, t, noise, padded_shape=coef_shape, loss_layer_weight=lw, is_super_model=True)
+    loss.backward()
+    l32, g32 = loss.item(), {k: v.grad for k, v in sd.items() if v.requires_grad}
+    res = {'shape': list(shape), 'cpu_seconds_train_step': round(time.perf_counter() - t0, 1)}
+    dif = GaussianDiffusion(net, lw, True, True, True, True, 'bior1.3', 'zero', shapes, [[32, 64, 64], [64, 128, 128]], image_size=80, frames=48,
+                            timesteps=1000, sampling_timesteps=10, ddim_sampling_eta=1.0).to(DEV)
+    ops.PROFILE = {}
+    lh = dif.p_losses(x0.to(DEV), t.to(DEV), noise=noise.to(DEV))
+    lh.backward()
+    torch.cuda.synchronize()
+    kernels, ops.PROFILE = sorted(ops.PROFILE), None
+    gh = {k: p.grad.cpu() for k, p in net.named_parameters() if p.grad is not None}
+    rows = sorted((rel_l2(gh[k], g32[k]), k) for k in gh if k in g32 and g32[k] is not None)
+    res['train'] = {'loss': lh.item(), 'loss_cpu32': l32, 'loss_vs_cpu32': abs(lh.item() - l32) / abs(l32), 'n_params': len(rows), 'worst_grad_vs_cpu32': rows[-1][0],
+                    'worst_param': rows[-1][1], 'median_grad_vs_cpu32': rows[len(rows) // 2][0], 'conv_kernels_used': kernels}
+    # ---- one DDIM step (t = 500 -> 400, eta = 1) replayed from the captured graph
+    xs = torch.randn(shape, generator=g)
+    nz = torch.randn(shape, generator=g)
+    low, init, control = torch.randn(batch, 48, 40, 80, 80, generator=g) * 0.3, torch.randn(batch, 48, 80, 80, generator=g), torch.randn(batch, 48, 16, 80, 80, generator=g)
+    kw = dict(init=init, control=control, low=low, is_super_model=True)
+    D.smoke_apply_conditions(xs, coef_shape, **kw)
+    sdn = {k: v.detach() for k, v in sd.items()}
+    with torch.no_grad():
+        tt = torch.full((batch,), 500, dtype=torch.long)
+        e32, s32 = D.smoke_model_predictions(lambda x, q: U.unet3d_forward(sdn, x, q, dim=64, dim_mults=(1, 2, 4), groups=8), buf, xs, tt, clip_x_start=True, rederive=True)
+        n32 = D.smoke_apply_conditions(D.ddim_update(buf, s32, e32, 500, 400, 1.0, nz), coef_shape, **kw)
+        desc = dif._desc(shape, dif._coef_shape(shape, 1))
+        src = dif._condition_source(shape, DEV, init.to(DEV), control.to(DEV), low.to(DEV))
+        sg = K._step_graph(dif, shape, desc, True, False, torch.device(DEV))
+        for rep in range(2):            # the second replay of the same graph must reproduce the first
+            sg.src.copy_(src); sg.x.copy_(xs.to(DEV)); sg.noise.copy_(nz.to(DEV)); sg.t.fill_(500)
+            sigma, c, sqrt_an = K.ddim_coefficients(dif._ac_host, 500, 400, 1.0)
+            sg.coef.copy_(torch.tensor([sqrt_an, c, sigma]))
+            sg.graph.replay()
+            torch.cuda.synchronize()
+            res[f'ddim_step_replay{rep}'] = {'x_next_vs_cpu32': rel_l2(sg.x, n32), 'x_start_vs_cpu32': rel_l2(sg.x_start, s32)}
+        res['replays_bit_equal'] = res['ddim_step_replay0'] == res['ddim_step_replay1']
+    K._graph_cache.pop(dif, None)
     return res
 
 
@@ -457,7 +539,8 @@ def main():
     for name, fn in (('smoke_golden_chains', smoke_chains), ('burgers_golden_chains', burgers_chains),
                      ('smoke_full_train_step', smoke_full), ('burgers_full_train_step', burgers_full),
                      ('smoke_full_ddim_chain', (lambda: smoke_chain_full(4)) if args.quick else smoke_chain_full),
-                     ('smoke_golden_chain_steps', smoke_chain_steps), ('ddim_chain_seeds', lambda: chain_seeds(('f16x3', 'f32'), 0 if args.quick else 3))):
+                     ('smoke_golden_chain_steps', smoke_chain_steps), ('ddim_chain_seeds', lambda: chain_seeds(('f16x3', 'f32'), 0 if args.quick else 3)),
+                     ('burgers_north_star_train_step', lambda: burgers_full(2, ('f16x3',), (80, 64), (80, 64), True)), ('sr_full_size', sr_full)):
         if args.only and name not in args.only.split(','):
             continue
         t0 = time.perf_counter()

@@ -67,6 +67,23 @@ def pack_smoke_state(coef, init_coef, smokeout, rescaler, coef_sub=None, downsam
     return state.permute(1, 0, 2, 3) / rescaler
 
 
+def pack_smoke_batch(coef, init_coef, smokeout, rescaler, pad_t=24, pad_x=40):
+    """pack_smoke_state for a whole batch of base-resolution simulations held on one device (the GPU-side packer of SURVEY 8f-1: fields
+    -> HIP DWT -> this -> train step, no per-sample torch.load / host packing): coef [B, F, 8, t, x, x] (F fields), init_coef
+    [B, 4, x, x] (the sub-bands of the 2-D DWT of rho(t=0)), smokeout [B, 2, t]  ->  states [B, pad_t, 8 F + 2, pad_x, pad_x] /
+    rescaler. Index work only; equal to stacking pack_smoke_state per sample (tests/test_host.py)."""
+    b, nf = coef.shape[0], coef.shape[1]
+    nt, nx = coef.shape[-3], coef.shape[-1]
+    data = F.pad(coef.reshape(b, nf * 8, nt, nx, nx), (0, pad_x - nx, 0, pad_x - nx, 0, pad_t - nt))
+    cond = init_coef.unsqueeze(2).expand(b, init_coef.shape[1], pad_t // 4, nx, nx).reshape(b, -1, nx, nx)
+    cond = F.pad(cond, (0, pad_x - nx, 0, pad_x - nx))
+    so = smokeout.permute(0, 2, 1)                                         # [B, t, 2]
+    so = so.reshape(b, 1, nt, 2, 1, 1).expand(b, 1, nt, 2, pad_x // 2, pad_x).reshape(b, 1, nt, pad_x, pad_x)
+    so = F.pad(so, (0, 0, 0, 0, 0, pad_t - nt))
+    state = torch.cat((data, cond.unsqueeze(1), so), dim=1)
+    return (state.permute(0, 2, 1, 3, 4) / rescaler).contiguous()
+
+
 class Smoke_wave(Dataset):
     def __init__(self, dataset_path, wave_type, pad_mode, is_train=True, is_super_model=False, downsample_type='time', N_downsample=0):
         super().__init__()

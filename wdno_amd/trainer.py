@@ -164,14 +164,14 @@ class FlatBuffers:
         self._gathered = True
 
 
-def allreduce_sum_(flat, world_size=None, group=None):
+def allreduce_sum_(flat, world_size=None, group=None, force=False):
     """SUM over ranks, in place (no-op without a process group). The 1/world factor of DDP's mean is NOT applied here: the
     callers fold it into the clip + Adam launch (FlatAdam.step(grad_scale=1/world)). Works for CUDA tensors over RCCL and, in
     the tests, for CPU / CUDA tensors over gloo."""
     if not (dist.is_available() and dist.is_initialized()):
         return flat
     ws = world_size or dist.get_world_size(group)
-    if ws == 1:
+    if ws == 1 and not force:          # force: a one-rank group still goes through the collective (first-run test of the RCCL path on one GPU)
         return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
@@ -269,7 +269,8 @@ def init_distributed(backend=None):
 def broadcast_parameters(buf, model=None, group=None):
     """Rank 0's parameters (and buffers) to every rank, as DistributedDataParallel does at construction: replicas that were built
     from different seeds would otherwise only share gradients, never weights."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    forced = os.environ.get('WDNO_DP_FORCE_EXCHANGE', '0') == '1'
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not forced):
         return
     dist.broadcast(buf.flat_param, 0, group=group)
     if model is not None:
@@ -388,11 +389,16 @@ class TrainStep:
         self.ema = FlatEMA(self.opt.buf.flat_param, ema_decay, ema_update_every) if (use_ema and self.rank == 0) else None
         self.step_idx = 0
         self.time_comm, self.comm_events = False, []
-        # WDNO_DP_OVERLAP=1: the gradient exchange starts bucket by bucket during backward. Opt-in: it is verified on gloo
-        # (tests/test_distributed_cpu.py) but has not run over RCCL on a multi-GPU node yet; the default is one all-reduce of the
-        # whole buffer after backward (~1-2 ms of a 45 ms step at 8 GPUs).
+        # The gradient exchange. Default: ONE all-reduce of the flat buffer after backward when it is small (smoke: 95 MB, ~1-2 ms exposed at 8
+        # GPUs), bucket by bucket DURING backward (OverlappedAllReduce) when the buffer is >= 256 MB (Burgers: 563 MB = 0.9-6.4 ms on xGMI
+        # against a 24 ms step). WDNO_DP_OVERLAP=1 / 0 forces either. WDNO_DP_FORCE_EXCHANGE=1 runs the exchange even in a one-rank process
+        # group: tests/test_gpu_distributed.py drives the RCCL path (async bucket all-reduces on RCCL's stream, finish() ordering against
+        # the HIP launch stream, broadcast) on the one GPU of the test box that way.
+        self.exchange = self.world > 1 or (os.environ.get('WDNO_DP_FORCE_EXCHANGE', '0') == '1' and dist.is_available() and dist.is_initialized())
+        ov = os.environ.get('WDNO_DP_OVERLAP')
+        big = self.opt.buf.numel * 4 >= (256 << 20)
         self.overlap = (OverlappedAllReduce(self.opt.buf, group, int(os.environ.get('WDNO_DP_BUCKETS', '4')))
-                        if self.world > 1 and os.environ.get('WDNO_DP_OVERLAP', '0') == '1' else None)
+                        if self.exchange and (ov == '1' or (ov is None and big)) else None)
 
     def _backward_and_exchange(self, loss):
         if self.overlap is not None:
@@ -403,11 +409,11 @@ class TrainStep:
             return
         loss.backward()
         self.opt.buf.gather_grads()
-        if self.world > 1:
+        if self.exchange:
             if self.time_comm:                    # bench.py: the exposed part of the exchange (backward has finished), HIP events
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            allreduce_sum_(self.opt.buf.flat_grad, self.world, self.group)
+            allreduce_sum_(self.opt.buf.flat_grad, self.world, self.group, force=True)
             if self.time_comm:
                 e1.record()
                 self.comm_events.append((e0, e1))
