@@ -257,22 +257,27 @@ typedef struct {
 } wdno_attn_desc;
 int wdno_attn_fwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out,
                   const wdno_attn_desc* d, float scale, wdno_stream_t s);
-/* out = the forward result (saved); dqkv (same layout as qkv); dbias [heads][n][n] accumulated with atomics (zeroed by
- * the caller) or NULL. n_tok <= 128. */
+/* out = the forward result (saved); dqkv (same layout as qkv); dbias [heads][n][n] (written, not accumulated) or NULL. n_tok <= 128.
+ * The relative-position-bias gradient is DETERMINISTIC: every block leaves its partial sum in the workspace (wdno_attn_bwd_ws_bytes,
+ * needed only when dbias != NULL) and a second launch adds the partials in block order; with heads == 4 and n_tok <= 32 a wave sums
+ * its items in registers in item order (no atomics anywhere). */
+size_t wdno_attn_bwd_ws_bytes(const wdno_attn_desc* d);
 int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
-                  const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s);
+                  const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, void* ws, size_t ws_bytes,
+                  wdno_stream_t s);
 /* the same with an amax record (or NULL) for the tensor written: out / dqkv */
 int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, float* amax_rec,
                        const wdno_attn_desc* d, float scale, wdno_stream_t s);
 int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                        const float* dout, float* dqkv, float* dbias, float* amax_rec, const wdno_attn_desc* d, float scale,
-                       wdno_stream_t s);
+                       void* ws, size_t ws_bytes, wdno_stream_t s);
 /* The same with dqkv delivered as fp16 (hi, lo) planes [rows][3*heads*32] for the gradient kernels of the qkv projection (its only
  * reader: conv3d.py:232-300). The scale is derived in the kernel from the amax records of qkv and dout (an upper bound of max|dqkv|,
  * see csrc/attention.hip) and left in dqkv_scale[0]. n_tok <= 32 only (WDNO_EUNSUPPORTED otherwise). */
 int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, void* dqkv_hi, void* dqkv_lo, float* dqkv_scale, float* dbias,
-                         const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, wdno_stream_t s);
+                         const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, void* ws, size_t ws_bytes,
+                         wdno_stream_t s);
 /* Forward with out delivered ONLY as the fp16 planes of the to_out projection (|out| <= max|qkv|: scale from rec_qkv); `out` is not
  * written. n_tok <= 64 (WDNO_EUNSUPPORTED beyond). The n_tok <= 32 backward (wdno_attn_bwd*, MFMA path) does not read out: delta =
  * sum_j P dP is formed in registers; for 33..64 tokens the backward does read it, so a caller that needs gradients keeps the fp32 form

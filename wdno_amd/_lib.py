@@ -101,12 +101,13 @@ PROTOTYPES = {
     'wdno_layernorm_bwd_add': (I, [P, P, P, P, P, P, L, I, F, P, Z, P]),
     'wdno_layernorm_bwd_add_amax': (I, [P, P, P, P, P, P, P, L, I, F, P, Z, P]),
     'wdno_attn_fwd': (I, [P, P, P, P, P, PA, F, P]),
-    'wdno_attn_bwd': (I, [P, P, P, P, P, P, P, P, PA, F, P]),
+    'wdno_attn_bwd_ws_bytes': (Z, [PA]),
+    'wdno_attn_bwd': (I, [P, P, P, P, P, P, P, P, PA, F, P, Z, P]),
     'wdno_attn_fwd_amax': (I, [P, P, P, P, P, P, PA, F, P]),
-    'wdno_attn_bwd_amax': (I, [P, P, P, P, P, P, P, P, P, PA, F, P]),
+    'wdno_attn_bwd_amax': (I, [P, P, P, P, P, P, P, P, P, PA, F, P, Z, P]),
     'wdno_attn_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, PA, F, P]),
     'wdno_linattn_fwd_planes': (I, [P, P, P, P, P, P, P, L, I, I, F, P]),
-    'wdno_attn_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, PA, F, P]),
+    'wdno_attn_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, PA, F, P, Z, P]),
     'wdno_linattn_ws_bytes': (Z, [L, I]),
     'wdno_linattn_fwd': (I, [P, P, P, P, L, I, I, F, P]),
     'wdno_linattn_bwd': (I, [P, P, P, P, P, P, Z, L, I, I, F, P]),

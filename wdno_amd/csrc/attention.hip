@@ -284,11 +284,26 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_kernel(const float* 
       store_row32(dqkv + row * p.RW + 2 * p.HD + h * DH, dv);
     }
   }
-  if (dbias) {
+  if (dbias) {         // dbias: this block's partial [heads][n][n] (plain stores; attn_dbias_reduce_kernel sums the blocks in index order)
     __syncthreads();
-    for (int e = threadIdx.x; e < p.d.heads * n * n; e += ATT_BWD_THREADS)
-      if (dBs[e] != 0.f) atomicAdd(&dbias[e], dBs[e]);
+    float* part = dbias + (size_t)blockIdx.x * p.d.heads * n * n;
+    for (int e = threadIdx.x; e < p.d.heads * n * n; e += ATT_BWD_THREADS) part[e] = dBs[e];
   }
+}
+
+// Sum of the per-block relative-position-bias gradient partials in block order: E = heads * n * n outputs, each the sum of nb terms.
+// (Global float atomics summed them in arrival order: the gradient of relative_attention_bias differed from run to run in its last
+// bits, and with it every bit-reproducibility check of a training step.) 64 outputs per block, four partial sums per output.
+__global__ __launch_bounds__(256) void attn_dbias_reduce_kernel(const float* __restrict__ part, int nb, float* __restrict__ dbias, int E) {
+  __shared__ float red[4][64];
+  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  float acc = 0.f;
+  if (e < E)
+    for (int b = q; b < nb; b += 4) acc += part[(size_t)b * E + e];
+  red[q][el] = acc;
+  __syncthreads();
+  if (q == 0 && e < E) dbias[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
 // ------------------------------------------------------------------------------------------------ n_tok <= 32: one wave per item
@@ -583,7 +598,13 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
   float* Pt = Ta;
   float* St = Tb;
   float* dBs = smem + AM_WAVES * WAVE_LDS;            // [heads][n][n] when dbias
-  if (dbias) {
+  // Relative-position-bias gradient = sum of dS over the units. With heads == AM_WAVES a wave always works on the head `wave`
+  // (item = 4 (block + k grid) + wave), so it sums its items' dS tiles in REGISTERS, in item order; otherwise LDS atomics.
+  const bool db_regs = dbias && p.d.heads == AM_WAVES;
+  f32x16 dbacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dbacc[e] = 0.f;
+  if (dbias && !db_regs) {
     for (int e = threadIdx.x; e < p.d.heads * n * n; e += 64 * AM_WAVES) dBs[e] = 0.f;
     __syncthreads();
   }
@@ -701,7 +722,8 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
     for (int e = 0; e < 16; ++e) {
       const int j = am_key(e, hh);
       St[j * AM_TS + li] = dsT[e];
-      if (dbias && tok && j < n) atomicAdd(&dBs[(h * n + li) * n + j], dsT[e]);
+      if (db_regs) dbacc[e] += dsT[e];                 // entries with li >= n or j >= n are never written out
+      else if (dbias && tok && j < n) atomicAdd(&dBs[(h * n + li) * n + j], dsT[e]);
     }
     __builtin_amdgcn_wave_barrier();
     // dK^T[d][j] = sum_i Q[i][d] dS[i][j]: Q columns from the staged (scaled, rotated) tile
@@ -776,10 +798,20 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const f
     __builtin_amdgcn_wave_barrier();      // the next item overwrites this wave's tiles
   }
   if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * AM_WAVES + wave);
-  if (dbias) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < p.d.heads * n * n; e += 64 * AM_WAVES)
-      if (dBs[e] != 0.f) atomicAdd(&dbias[e], dBs[e]);
+  if (dbias) {         // dbias: this block's partial [heads][n][n]; attn_dbias_reduce_kernel sums the blocks in index order
+    float* part = dbias + (size_t)blockIdx.x * p.d.heads * n * n;
+    if (db_regs) {
+      if (tok) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int j = am_key(e, hh);
+          if (j < n) part[(wave * n + li) * n + j] = dbacc[e];
+        }
+      }
+    } else {
+      __syncthreads();
+      for (int e = threadIdx.x; e < p.d.heads * n * n; e += 64 * AM_WAVES) part[e] = dBs[e];
+    }
   }
 }
 
@@ -863,46 +895,74 @@ static int attn_fwd_rows(const float* qkv, const float* rot_cos, const float* ro
   attn_fwd_kernel<<<(unsigned)blocks, ATT_THREADS, lds, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
   return wdno_check_launch();
 }
+// blocks of the backward launch (= number of dbias partials) and the workspace that holds them
+static int64_t attn_bwd_blocks(const wdno_attn_desc* d) {
+  const int64_t items = (int64_t)d->n_uo * d->n_ui * d->heads;
+  if (d->n_tok <= 32 && wdno_debug_mode != 5) {
+    int64_t nb = (items + AM_WAVES - 1) / AM_WAVES;
+    return nb > 2048 ? 2048 : nb;
+  }
+  int ipb = ATT_BWD_THREADS / d->n_tok;
+  if (ipb < 1) ipb = 1;
+  int64_t groups = (items + ipb - 1) / ipb;
+  return groups > 1024 ? 1024 : groups;
+}
+extern "C" size_t wdno_attn_bwd_ws_bytes(const wdno_attn_desc* d) {
+  if (!d || d->n_tok <= 0 || d->heads <= 0) return 0;
+  return (size_t)attn_bwd_blocks(d) * d->heads * d->n_tok * d->n_tok * sizeof(float);
+}
+static int attn_dbias_reduce(const float* part, int64_t nb, float* dbias, const wdno_attn_desc* d, wdno_stream_t s) {
+  const int E = d->heads * d->n_tok * d->n_tok;
+  attn_dbias_reduce_kernel<<<(unsigned)((E + 63) / 64), 256, 0, as_stream(s)>>>(part, (int)nb, dbias, E);
+  return wdno_check_launch();
+}
 extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
-                             const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, wdno_stream_t s) {
-  return wdno_attn_bwd_amax(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, nullptr, d, scale, s);
+                             const float* dout, float* dqkv, float* dbias, const wdno_attn_desc* d, float scale, void* ws, size_t ws_bytes,
+                             wdno_stream_t s) {
+  return wdno_attn_bwd_amax(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, nullptr, d, scale, ws, ws_bytes, s);
 }
 static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, float* dqkv, float* dbias, AttnP& p, const wdno_attn_desc* d, wdno_stream_t s);
 extern "C" int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                                   const float* dout, float* dqkv, float* dbias, float* amax_rec, const wdno_attn_desc* d, float scale,
-                                  wdno_stream_t s) {
+                                  void* ws, size_t ws_bytes, wdno_stream_t s) {
   AttnP p;
   int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
   if (rc) return rc;
   const int n = d->n_tok;
+  if (dbias && (!ws || ws_bytes < wdno_attn_bwd_ws_bytes(d))) return WDNO_EWORKSPACE;
+  float* part = dbias ? (float*)ws : nullptr;           // the kernels write per-block partials; the reduce below writes dbias
   // one wave per item on MFMA tiles (debug 5: thread-per-row kernel below); 116 registers and 9 KB of LDS per wave, so four
   // waves per SIMD hide its five dependent load phases (0.94 vs 1.17 ms at the 40 x 40 level)
   if (n <= 32 && wdno_debug_mode != 5) {
     size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
-    int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
-    if (nb > 2048) nb = 2048;                                // also bounds the number of global dbias flushes
+    const int64_t nb = attn_bwd_blocks(d);                   // also the number of dbias partials
     p.amax_rec = amax_rec;
-    attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p);
-    return wdno_check_launch();
+    attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, part, p);
+    rc = wdno_check_launch();
+    return (rc || !dbias) ? rc : attn_dbias_reduce(part, nb, dbias, d, s);
   }
-  return attn_amax_sweep(attn_bwd_rows(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p, d, s), dqkv, d, p.RW, amax_rec, s);
+  rc = attn_amax_sweep(attn_bwd_rows(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, part, p, d, s), dqkv, d, p.RW, amax_rec, s);
+  return (rc || !dbias) ? rc : attn_dbias_reduce(part, attn_bwd_blocks(d), dbias, d, s);
 }
 // dqkv as fp16 planes for the qkv projection's gradient kernels (MFMA path only: n_tok <= 32)
 extern "C" int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                                     const float* dout, void* dqkv_hi, void* dqkv_lo, float* dqkv_scale, float* dbias,
-                                    const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, wdno_stream_t s) {
+                                    const float* rec_qkv, const float* rec_dout, const wdno_attn_desc* d, float scale, void* ws, size_t ws_bytes,
+                                    wdno_stream_t s) {
   AttnP p;
   int rc = attn_fill(p, d, scale, ATT_BWD_THREADS);
   if (rc) return rc;
   const int n = d->n_tok;
-  if (n > 32 || !dqkv_hi || (dqkv_lo && (!dqkv_scale || !rec_qkv || !rec_dout))) return WDNO_EUNSUPPORTED;      // dqkv_lo == NULL: one bf16 plane, no scale
+  if (n > 32 || wdno_debug_mode == 5 || !dqkv_hi || (dqkv_lo && (!dqkv_scale || !rec_qkv || !rec_dout))) return WDNO_EUNSUPPORTED;      // dqkv_lo == NULL: one bf16 plane, no scale
+  if (dbias && (!ws || ws_bytes < wdno_attn_bwd_ws_bytes(d))) return WDNO_EWORKSPACE;
+  float* part = dbias ? (float*)ws : nullptr;
   size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
-  int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
-  if (nb > 2048) nb = 2048;
+  const int64_t nb = attn_bwd_blocks(d);
   p.pl_hi = (_Float16*)dqkv_hi; p.pl_lo = (_Float16*)dqkv_lo; p.rec_qkv = rec_qkv; p.rec_dout = rec_dout; p.pl_scale = dqkv_scale;
-  attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, nullptr, dbias, p);
-  return wdno_check_launch();
+  attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, nullptr, part, p);
+  rc = wdno_check_launch();
+  return (rc || !dbias) ? rc : attn_dbias_reduce(part, nb, dbias, d, s);
 }
 static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, float* dqkv, float* dbias, AttnP& p, const wdno_attn_desc* d, wdno_stream_t s) {
@@ -912,7 +972,7 @@ static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* ro
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;
   int64_t groups = (p.n_items + p.ipb - 1) / p.ipb;
   int64_t blocks = groups;
-  if (dbias && blocks > 1024) blocks = 1024;               // bound the number of global atomic flushes
+  if (dbias && blocks > 1024) blocks = 1024;               // = attn_bwd_blocks(d): one dbias partial per block (grid-stride over the groups)
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   attn_bwd_kernel<<<(unsigned)blocks, ATT_BWD_THREADS, lds, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, dbias, p);
   return wdno_check_launch();

@@ -1404,10 +1404,13 @@ class _Attn(torch.autograd.Function):
         grec = _known_amax(go)
         go = _chk(go, 'grad')
         dqkv = torch.empty_like(qkv)
-        dbias = None
-        if bias is not None and ctx.needs_input_grad[1]:
-            dbias = torch.zeros_like(bias)
+        dbias = ws = None
+        nbw = 0
         d = AttnDesc(*desc_args)
+        if bias is not None and ctx.needs_input_grad[1]:
+            dbias = torch.empty_like(bias)            # written by the ordered sum of the per-block partials in `ws` (deterministic)
+            nbw = _lib_().wdno_attn_bwd_ws_bytes(C.byref(d))
+            ws = _ws(nbw, qkv.device)
         if ctx.want_planes and (_lp() or (CONV_MATH == 'f16x3' and ctx.qrec is not None and grec is not None)):
             rows, rw = qkv.numel() // qkv.shape[-1], qkv.shape[-1]
             hi = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
@@ -1416,13 +1419,13 @@ class _Attn(torch.autograd.Function):
                 lo = torch.empty((rows, rw), device=qkv.device, dtype=torch.float16)
                 sc = torch.empty((1,), device=qkv.device, dtype=torch.float32)
             _lib.check(_lib_().wdno_attn_bwd_planes(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(hi), _p(lo), _p(sc),
-                                                    _p(dbias), _p(ctx.qrec), _p(grec), C.byref(d), float(scale), _stream()), 'attn_bwd_planes')
+                                                    _p(dbias), _p(ctx.qrec), _p(grec), C.byref(d), float(scale), _p(ws), nbw, _stream()), 'attn_bwd_planes')
             _poison(dqkv)
             dqkv._wdno_planes_only = ((hi, lo, sc), None, dqkv._version, CONV_MATH)      # dqkv itself stays unwritten
             return dqkv, dbias, None, None, None, None, None
         rec = _new_amax_record(qkv.device)        # dqkv is the dy of the qkv projection
         _lib.check(_lib_().wdno_attn_bwd_amax(_p(qkv), _p(rot_cos), _p(rot_sin), _p(bias), _p(fout), _p(go), _p(dqkv), _p(dbias), _p(rec),
-                                              C.byref(d), float(scale), _stream()), 'attn_bwd')
+                                              C.byref(d), float(scale), _p(ws), nbw, _stream()), 'attn_bwd')
         return _leave_amax(dqkv, rec), dbias, None, None, None, None, None
 
 
