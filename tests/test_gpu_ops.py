@@ -497,7 +497,8 @@ def test_softmax_attention_thread_per_row_kernels(ops):
 
 
 @pytest.mark.parametrize('kind,b,f,h,w', [('temporal', 2, 24, 3, 5), ('temporal', 1, 7, 2, 2), ('spatial', 2, 3, 10, 10), ('spatial', 1, 1, 8, 8),
-                                          ('temporal', 1, 48, 3, 4), ('temporal', 2, 33, 2, 3), ('temporal', 1, 56, 1, 2)])
+                                          ('temporal', 1, 48, 3, 4), ('temporal', 2, 33, 2, 3), ('temporal', 1, 56, 1, 2),
+                                          ('spatial', 1, 2, 20, 20), ('spatial', 2, 1, 13, 11), ('spatial', 1, 1, 24, 24)])      # 400 / 143 / 576 tokens: attn_bwd_big_kernel
 def test_softmax_attention(ops, kind, b, f, h, w):
     from oracle import unet_ref as U
     heads, dh = 4, 32

@@ -291,6 +291,121 @@ __global__ __launch_bounds__(ATT_BWD_THREADS) void attn_bwd_kernel(const float* 
   }
 }
 
+// Backward over MANY tokens (129 .. 576; no rotation, no bias): the mid spatial attention of a model applied to a finer grid than it
+// was built for (the space super-resolution model on 80 x 80 tensors attends over 20 x 20 = 400 tokens; the reference trains it on
+// <= 40 x 40, data_2d.py:182-183, but nothing in its code stops a fine-tune at the sampling size). The n x n matrices P and dS do not
+// fit LDS any more, so nothing is stored: one block per (unit, head) item;
+//   phase A, thread = query row i: K and V rows in LDS; softmax statistics (m_i, 1 / l_i), delta_i = <dO_i, O_i>, dQ_i;
+//   phase B, thread = key row j (k_j, v_j in registers): the rows q_i, dO_i stream from global memory as wave-broadcast loads (every
+//   thread reads the same row: one line per load) and P_ij / dS_ij are recomputed from the statistics phase A left in LDS.
+#define ATT_BIG_THREADS 256
+#define ATT_BIG_MAXTOK 576
+__global__ __launch_bounds__(ATT_BIG_THREADS) void attn_bwd_big_kernel(const float* __restrict__ qkv, const float* __restrict__ fout,
+                                                                        const float* __restrict__ dout, float* __restrict__ dqkv, AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = p.d.n_tok;
+  float* Ks = smem;                                   // [n][32]
+  float* Vs = Ks + n * DH;                            // [n][32]
+  float* Ms = Vs + n * DH;                            // [n] row maximum
+  float* Ls = Ms + n;                                 // [n] 1 / row sum
+  float* Dl = Ls + n;                                 // [n] delta
+  for (int64_t item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+    const int h = (int)(item % p.d.heads);
+    const int64_t unit = item / p.d.heads;
+    const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
+    const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
+    __syncthreads();                                  // the previous item's phase B has finished with the statistics
+    for (int j = threadIdx.x; j < n; j += ATT_BIG_THREADS) {
+      float k[DH], v[DH];
+      const int64_t row = row0 + (int64_t)j * p.d.st;
+      load_row32(qkv + row * p.RW + p.HD + h * DH, k);
+      load_row32(qkv + row * p.RW + 2 * p.HD + h * DH, v);
+      store_row32(Ks + j * DH, k);
+      store_row32(Vs + j * DH, v);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += ATT_BIG_THREADS) {
+      const int64_t row = row0 + (int64_t)i * p.d.st;
+      float q[DH], go[DH], dq[DH];
+      load_row32(qkv + row * p.RW + h * DH, q);
+#pragma unroll
+      for (int e = 0; e < DH; ++e) q[e] *= p.scale;
+      load_row32(dout + row * p.HD + h * DH, go);
+      float delta = 0.f;
+      {
+        const float4* o4 = reinterpret_cast<const float4*>(fout + row * p.HD + h * DH);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float4 t = o4[e];
+          delta = fmaf(go[4 * e], t.x, delta); delta = fmaf(go[4 * e + 1], t.y, delta);
+          delta = fmaf(go[4 * e + 2], t.z, delta); delta = fmaf(go[4 * e + 3], t.w, delta);
+        }
+      }
+      float m = -INFINITY, l = 0.f;
+      for (int j = 0; j < n; ++j) {
+        const float sv = dot32_lds(q, Ks + j * DH);
+        const float mn = fmaxf(m, sv);
+        l = l * expf(m - mn) + expf(sv - mn);
+        m = mn;
+      }
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int e = 0; e < DH; ++e) dq[e] = 0.f;
+      for (int j = 0; j < n; ++j) {
+        const float4* k4 = reinterpret_cast<const float4*>(Ks + j * DH);
+        const float sv = dot32_lds(q, Ks + j * DH);
+        const float dp = dot32_lds(go, Vs + j * DH);
+        const float ds = expf(sv - m) * inv * (dp - delta);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float4 kk = k4[e];
+          dq[4 * e] = fmaf(ds, kk.x, dq[4 * e]); dq[4 * e + 1] = fmaf(ds, kk.y, dq[4 * e + 1]);
+          dq[4 * e + 2] = fmaf(ds, kk.z, dq[4 * e + 2]); dq[4 * e + 3] = fmaf(ds, kk.w, dq[4 * e + 3]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < DH; ++e) dq[e] *= p.scale;
+      store_row32(dqkv + row * p.RW + h * DH, dq);
+      Ms[i] = m; Ls[i] = inv; Dl[i] = delta;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += ATT_BIG_THREADS) {
+      float k[DH], v[DH], dk[DH], dv[DH];
+      load_row32(Ks + j * DH, k);
+      load_row32(Vs + j * DH, v);
+#pragma unroll
+      for (int e = 0; e < DH; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+      for (int i = 0; i < n; ++i) {
+        const int64_t row = row0 + (int64_t)i * p.d.st;
+        const float4* q4 = reinterpret_cast<const float4*>(qkv + row * p.RW + h * DH);
+        const float4* g4 = reinterpret_cast<const float4*>(dout + row * p.HD + h * DH);
+        float4 qq[8], gg[8];
+        float sv = 0.f, dp = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float4 a = q4[e];
+          a.x *= p.scale; a.y *= p.scale; a.z *= p.scale; a.w *= p.scale;      // the same scaled q row phase A and the forward use
+          qq[e] = a; gg[e] = g4[e];
+          sv = fmaf(a.x, k[4 * e], sv); sv = fmaf(a.y, k[4 * e + 1], sv); sv = fmaf(a.z, k[4 * e + 2], sv); sv = fmaf(a.w, k[4 * e + 3], sv);
+          dp = fmaf(gg[e].x, v[4 * e], dp); dp = fmaf(gg[e].y, v[4 * e + 1], dp); dp = fmaf(gg[e].z, v[4 * e + 2], dp); dp = fmaf(gg[e].w, v[4 * e + 3], dp);
+        }
+        const float pj = expf(sv - Ms[i]) * Ls[i];
+        const float ds = pj * (dp - Dl[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dk[4 * e] = fmaf(ds, qq[e].x, dk[4 * e]); dk[4 * e + 1] = fmaf(ds, qq[e].y, dk[4 * e + 1]);
+          dk[4 * e + 2] = fmaf(ds, qq[e].z, dk[4 * e + 2]); dk[4 * e + 3] = fmaf(ds, qq[e].w, dk[4 * e + 3]);
+          dv[4 * e] = fmaf(pj, gg[e].x, dv[4 * e]); dv[4 * e + 1] = fmaf(pj, gg[e].y, dv[4 * e + 1]);
+          dv[4 * e + 2] = fmaf(pj, gg[e].z, dv[4 * e + 2]); dv[4 * e + 3] = fmaf(pj, gg[e].w, dv[4 * e + 3]);
+        }
+      }
+      const int64_t row = row0 + (int64_t)j * p.d.st;
+      store_row32(dqkv + row * p.RW + p.HD + h * DH, dk);
+      store_row32(dqkv + row * p.RW + 2 * p.HD + h * DH, dv);
+    }
+  }
+}
+
 // Sum of the per-block relative-position-bias gradient partials in block order: E = heads * n * n outputs, each the sum of nb terms.
 // (Global float atomics summed them in arrival order: the gradient of relative_attention_bias differed from run to run in its last
 // bits, and with it every bit-reproducibility check of a training step.) 64 outputs per block, four partial sums per output.
@@ -824,6 +939,25 @@ static void attn_fwd_mfma64_launch(const float* qkv, const float* rot_cos, const
   if (nb > 4096) nb = 4096;
   attn_fwd_mfma64_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds, st>>>(qkv, rot_cos, rot_sin, bias, out, p);
 }
+static int attn_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+// Grid of the one-wave-per-item kernels: exactly the blocks that are RESIDENT together (blocks per CU x CUs), each wave walking over
+// its items with a grid stride. The first versions launched up to 4096 / 2048 blocks: several rounds of the resident set with the last
+// one partly empty (2048 blocks on 768 slots = 2.67 rounds), and waves with 3 or 4 items each (a 28 % imbalance at the 40 x 40
+// level); with 768 / 1024 blocks every wave gets 12-17 items, i.e. at most one item of imbalance. wdno_debug 41: the old caps (A/B).
+static int64_t attn_grid(int64_t items, int blocks_per_cu, int64_t old_cap) {
+  int64_t nb = (items + AM_WAVES - 1) / AM_WAVES;
+  const int64_t cap = wdno_debug_mode == 41 ? old_cap : (int64_t)blocks_per_cu * attn_num_cus();
+  return nb > cap ? cap : nb;
+}
 static int attn_fill(AttnP& p, const wdno_attn_desc* d, float scale, int threads) {
   if (!d || d->n_uo <= 0 || d->n_ui <= 0 || d->n_tok <= 0 || d->heads <= 0) return WDNO_EINVAL;
   p.d = *d; p.scale = scale; p.HD = d->heads * DH; p.RW = 3 * p.HD;
@@ -853,8 +987,7 @@ extern "C" int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const 
   if (rc) return rc;
   if (d->n_tok > 1024) return WDNO_EUNSUPPORTED;
   if (d->n_tok <= 32 && wdno_debug_mode != 5) {                  // one 32x32 MFMA tile per (unit, head): one wave per item
-    int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
-    if (nb > 4096) nb = 4096;
+    const int64_t nb = attn_grid(p.n_items, 4, 4096);
     p.amax_rec = amax_rec;
     attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
     return wdno_check_launch();
@@ -874,8 +1007,7 @@ extern "C" int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, cons
   int rc = attn_fill(p, d, scale, ATT_THREADS);
   if (rc) return rc;
   if (d->n_tok > 64 || !out_hi || (out_lo && (!out_scale || !rec_qkv))) return WDNO_EUNSUPPORTED;      // out_lo == NULL: one bf16 plane
-  int64_t nb = (p.n_items + AM_WAVES - 1) / AM_WAVES;
-  if (nb > 4096) nb = 4096;
+  const int64_t nb = attn_grid(p.n_items, 4, 4096);
   p.amax_rec = amax_rec;
   p.pl_hi = (_Float16*)out_hi; p.pl_lo = (_Float16*)out_lo; p.rec_qkv = rec_qkv; p.pl_scale = out_scale;
   if (d->n_tok > 32) {
@@ -898,10 +1030,7 @@ static int attn_fwd_rows(const float* qkv, const float* rot_cos, const float* ro
 // blocks of the backward launch (= number of dbias partials) and the workspace that holds them
 static int64_t attn_bwd_blocks(const wdno_attn_desc* d) {
   const int64_t items = (int64_t)d->n_uo * d->n_ui * d->heads;
-  if (d->n_tok <= 32 && wdno_debug_mode != 5) {
-    int64_t nb = (items + AM_WAVES - 1) / AM_WAVES;
-    return nb > 2048 ? 2048 : nb;
-  }
+  if (d->n_tok <= 32 && wdno_debug_mode != 5) return attn_grid(items, 3, 2048);
   int ipb = ATT_BWD_THREADS / d->n_tok;
   if (ipb < 1) ipb = 1;
   int64_t groups = (items + ipb - 1) / ipb;
@@ -967,7 +1096,16 @@ extern "C" int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, cons
 static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, float* dqkv, float* dbias, AttnP& p, const wdno_attn_desc* d, wdno_stream_t s) {
   const int n = d->n_tok;
-  if (n > ATT_BWD_THREADS) return WDNO_EUNSUPPORTED;      // training never attends over more than 100 tokens
+  if (n > ATT_BWD_THREADS) {                               // 129 .. 576 tokens: nothing n x n is stored (attn_bwd_big_kernel)
+    if (n > ATT_BIG_MAXTOK || rot_cos || bias || dbias) return WDNO_EUNSUPPORTED;
+    const size_t lds = ((size_t)2 * n * DH + 3 * n) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int64_t nb = p.n_items;
+    const int64_t cap = 4LL * attn_num_cus();
+    if (nb > cap) nb = cap;
+    attn_bwd_big_kernel<<<(unsigned)nb, ATT_BIG_THREADS, lds, as_stream(s)>>>(qkv, out, dout, dqkv, p);
+    return wdno_check_launch();
+  }
   size_t lds = ((size_t)p.ipb * (2 * p.kst + 2 * n * (n + 1)) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
   if (lds > 160 * 1024) return WDNO_EUNSUPPORTED;
   int64_t groups = (p.n_items + p.ipb - 1) / p.ipb;
