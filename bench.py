@@ -387,6 +387,31 @@ def burgers_leg(device, batch, steps, lowp=None, grid=(64, 64)):
         ops.CONV_MATH = prev
 
 
+def train_graph_leg(ts, x, steps):
+    """The same training step with loss -> backward -> gradient gather replayed from ONE captured HIP graph (TrainStep.capture; draws,
+    clip + Adam and EMA stay outside): host time to enqueue a step and steps/s, eager vs graph. Same kernels either way -- at batch 8
+    the GPU is the bound, so the rate barely moves; what changes is the host side (18 ms of Python per step -> a graph launch)."""
+    def measure():
+        enq = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ts.step(x)
+            enq.append((time.perf_counter() - t0) * 1e3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts.step(x)
+        torch.cuda.synchronize()
+        return round(_median(enq), 2), round((time.perf_counter() - t0) / steps * 1e3, 3)
+    e_enq, e_ms = measure()
+    ts.capture(x, warmup=1)
+    for _ in range(2):
+        ts.step(x)
+    g_enq, g_ms = measure()
+    return {'eager': {'host_enqueue_ms_per_step': e_enq, 'ms_per_step': e_ms}, 'graph': {'host_enqueue_ms_per_step': g_enq, 'ms_per_step': g_ms}}
+
+
 def smoke_pipeline_leg(ts, device, batch, steps):
     """The smoke pipeline end to end on the GPU: fields [B, 5, 32, 64, 64] (rho, vx, vy, cx, cy) resident in HBM -> ONE fused 3-D HIP DWT
     launch (bior1.3 / zero) -> [B*5, 8, 18, 34, 34] -> pack_smoke_batch (+ init-density and smoke-out condition channels, / RESCALER)
@@ -549,6 +574,7 @@ def main():
                 if smoke:
                     extras['sampling'] = sampling_leg(dif, device, batch, args.sample_steps)
                     extras['fields_pipeline'] = smoke_pipeline_leg(ts, device, batch, 10)
+                    extras['train_step_graph'] = train_graph_leg(ts, x, 20)
                 extras['dwt'] = dwt_leg(device)
                 if smoke:
                     del ts, dif

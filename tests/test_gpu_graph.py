@@ -176,3 +176,55 @@ def test_graph_cache_sees_a_plain_load_state_dict(trees):
     del dif
     gc.collect()
     assert ref() is None
+
+
+# ------------------------------------------------------------------------------------------------ the TRAINING step as one graph (round 3)
+def _train_pair(trees, tree):
+    from wdno_amd.trainer import TrainStep, multistep_lr
+    def make():
+        torch.manual_seed(4)
+        if tree == 'smoke':          # full width on a grid large enough for the split-fp16 kernels, planes hand-over, amax records
+            net = trees['Unet3D'](dim=64, dim_mults=(1, 2, 4), channels=42)
+            dif = trees['GD2'](net, torch.ones(1, 1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero', (5, 12, 12), (8, 20, 20), image_size=16, frames=6)
+        else:
+            net = trees['Unet2D'](dim=32, dim_mults=(1, 2, 4), channels=9, resnet_block_groups=1)
+            dif = trees['GD1'](net, seq_length=(32, 32), padded_shape=[21, 28], ori_shape=[41, 56], loss_layer_weight=torch.ones(1, 9, 1, 1),
+                               is_condition_pad=True, is_condition_u0=True, is_condition_f=True)
+        return TrainStep(dif.to(DEV), lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=multistep_lr, use_ema=True, ema_update_every=2)
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn((2, 6, 42, 16, 16) if tree == 'smoke' else (4, 9, 32, 32), generator=g) * 0.5).to(DEV)
+    return make, x
+
+
+@pytest.mark.parametrize('tree', ['smoke', 'burgers'])
+def test_training_step_graph_replay_equals_eager(trees, tree):
+    """TrainStep.capture: loss -> backward -> gradient gather replayed from ONE captured HIP graph (random draws, clip + Adam, EMA stay
+    outside). Five optimisation steps (two eager warm-up steps inside capture(), then three replays) must leave bit-identical losses,
+    gradient norms, weights, Adam moments and EMA weights as five eager steps consuming the same generator."""
+    from wdno_amd import ops
+    make, x = _train_pair(trees, tree)
+    xs = [x * (1.0 + 0.1 * i) for i in range(5)]
+    torch.manual_seed(99)
+    te = make()
+    ops.PROFILE = {}
+    eager = [te.step(xi) for xi in xs]
+    used, ops.PROFILE = set(ops.PROFILE), None
+    if tree == 'smoke':
+        assert any('h3' in k for k in used), used
+    torch.cuda.synchronize()
+    torch.manual_seed(99)
+    tg = make()
+    # capture() warms up on its example: feed the same two batches the eager run saw first
+    tg.step(xs[0])
+    tg.capture(xs[1], warmup=1)
+    graphed = [None, None] + [tg.step(xi) for xi in xs[2:]]
+    torch.cuda.synchronize()
+    assert tg._graph is not None
+    for i in (2, 3, 4):
+        assert torch.equal(eager[i][0], graphed[i][0]) and torch.equal(eager[i][1], graphed[i][1]), i
+    assert torch.equal(te.opt.buf.flat_param, tg.opt.buf.flat_param)
+    assert torch.equal(te.opt.exp_avg, tg.opt.exp_avg) and torch.equal(te.opt.exp_avg_sq, tg.opt.exp_avg_sq)
+    assert torch.equal(te.ema.flat, tg.ema.flat) and te.step_idx == tg.step_idx == 5
+    # a batch of another shape falls back to the eager path
+    out = tg.step(xs[0][:1])
+    assert torch.isfinite(out[0])

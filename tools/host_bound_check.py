@@ -26,3 +26,25 @@ for _ in range(5):
     enq.append((t1 - t0) * 1e3); wall.append((t2 - t0) * 1e3)
 print('host enqueue ms per step:', [round(v, 1) for v in enq])
 print('wall ms per step (single step, sync before/after):', [round(v, 1) for v in wall])
+
+# ---- the same with the step captured in one HIP graph (TrainStep.capture)
+ts.capture(batch, warmup=1)
+for _ in range(3):
+    ts.step(batch)
+torch.cuda.synchronize()
+enq, wall = [], []
+for _ in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ts.step(batch)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3); wall.append((t2 - t0) * 1e3)
+print('graph replay: host enqueue ms per step:', [round(v, 1) for v in enq])
+print('graph replay: wall ms per step (single step, sync before/after):', [round(v, 1) for v in wall])
+t0 = time.perf_counter()
+for _ in range(30):
+    ts.step(batch)
+torch.cuda.synchronize()
+print('graph replay: ms per step back to back (30 steps):', round((time.perf_counter() - t0) / 30 * 1e3, 2))

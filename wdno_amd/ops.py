@@ -177,13 +177,13 @@ class _Concat(torch.autograd.Function):
 def concat_cl(a, b, planes_only=False):
     """(a | b) along the channel axis. planes_only: the caller states that the result is read only by convolutions that take fp16 planes
     (conv_reads_planes for every reader); where the amax records of a and b are known it then exists only as those planes."""
-    return _Concat.apply(a, b, planes_only and CONCAT_PLANES)
+    return _Concat.apply(a, b, planes_only)
 
 
 def resnet_reads_planes(x_pixels, block):
     """Do both readers of a ResnetBlock's input -- block1's convolution and the 1 x 1 skip projection -- take fp16 planes?"""
     rc = getattr(block, 'res_conv', None)
-    return (SKIP_FUSE and rc is not None and hasattr(rc, 'weight') and conv_reads_planes(x_pixels, block.block1.proj.weight)
+    return (rc is not None and hasattr(rc, 'weight') and conv_reads_planes(x_pixels, block.block1.proj.weight)
             and conv_reads_planes(x_pixels, rc.weight))
 
 
@@ -259,8 +259,6 @@ def add(a, b):
 def silu_shared(t):
     """silu(t), computed once per tensor (and version): every ResnetBlock applies the same SiLU to the same time embedding in front of its
     own projection (conv3d.py:118-133, unet.py:151-165) -- one activation forward and backward per step instead of one per block."""
-    if not (GLUE_FUSE & 1):
-        return silu(t)
     h = getattr(t, '_wdno_silu', None)
     if h is not None and h[1] == t._version and h[2] == torch.is_grad_enabled():
         return h[0]
@@ -381,16 +379,14 @@ def pad8(c):
 
 _amax_pool = {}
 AMAX_FLOATS = 64 * 16    # WDNO_AMAX_FLOATS
-AMAX_HINTS = os.environ.get('WDNO_AMAX_HINTS', '1') != '0'
+AMAX_HINTS = True         # producers leave amax records on the tensors they write (test knob: results are bit-identical without)
 
 
-PLANES_FWD = os.environ.get('WDNO_PLANES_FWD', '1') != '0'      # norm layers in front of a convolution write its fp16 planes (A/B switch)
-CONCAT_PLANES = os.environ.get('WDNO_CONCAT_PLANES', '1') != '0'        # up-path concats exist only as the planes of their two readers (A/B switch)
-FUSE_NORM_ADD = os.environ.get('WDNO_FUSE_NORM_ADD', '1') != '0'        # GroupNorm apply + identity-skip add in one pass (A/B switch)
-GLUE_FUSE = int(os.environ.get('WDNO_GLUE_FUSE', '5'))       # A/B switches: 1 = one shared SiLU of the time embedding, 4 = Downsample dgrad on the
-#                                                               parity-class split kernels
-GRAD_PLANES = os.environ.get('WDNO_GRAD_PLANES', '1') != '0'    # GroupNorm backward writes the fp16 planes of dx itself (A/B switch)
-SKIP_FUSE = os.environ.get('WDNO_SKIP_FUSE', '1') != '0'      # skip connections handed through conv / LayerNorm (A/B switch)
+# Hand-over forms between layers. These were environment A/B switches while each form was being measured (every one
+# won its same-box A/B); the environment variables are gone -- the product has ONE path -- and two module attributes remain as TEST knobs:
+# the planes-vs-fp32 equivalence tests (tests/test_gpu_ops.py::test_*_planes*) evaluate a layer both ways and compare.
+PLANES_FWD = True         # norm / attention layers in front of a convolution write its fp16 planes (test knob)
+GRAD_PLANES = True        # GroupNorm / attention backward write the fp16 planes of the gradient the convolution in front reads (test knob)
 _CAPTURE = None          # [pool, next index] while a HIP graph is being captured through graph_capture()
 
 
@@ -538,7 +534,6 @@ def _wdims(kind, w5):
 
 _wplans = {}            # key -> _WPlan
 _wtables = {}           # tuple of plan keys -> (amax buffer, amax table, split table, keep-alive list)
-WEIGHT_BATCH = os.environ.get('WDNO_WEIGHT_BATCH', '1') != '0'
 
 
 class _AmaxItem(C.Structure):
@@ -610,7 +605,7 @@ def split_weight(w, kind, cp8, kp, pack=None):
     ver = (w._version, WEIGHT_EPOCH)
     pl = _wplans.get(key)
     if pl is not None:
-        if pl.ver != ver and WEIGHT_BATCH:
+        if pl.ver != ver:
             _refresh_weight_plans(WEIGHT_EPOCH)
         if pl.ver == ver:
             pl.used = WEIGHT_EPOCH
@@ -853,7 +848,7 @@ def _pad_vec(v, n):
     return out
 
 
-LINEAR_ROWS_MAX = int(os.environ.get('WDNO_LINEAR_ROWS', '64'))       # at most LR_MAXROWS of csrc/linear_rows.hip; 0 = off. Beyond ~64 rows
+LINEAR_ROWS_MAX = 64      # at most LR_MAXROWS of csrc/linear_rows.hip. Beyond ~64 rows
 # (the time MLPs at batch 256) the GEMM kernels win: Burgers bf16 step 123.5 -> 119.5 ms
 
 
@@ -1016,7 +1011,7 @@ class _Conv(torch.autograd.Function):
                 # the data gradient of the strided Downsample convolution IS the transposed convolution of dy with the same weight read as
                 # [in = K (dy channels)][out = C][1][4][4]: four parity-class launches of the split kernels on the planes of dy
                 oh_, ow_ = gy5.shape[2], gy5.shape[3]
-                if (GLUE_FUSE & 4) and ctx.h3 and _use_h3(n * d * oh_ * ow_, kp * 4) and _as5(weight).is_contiguous():
+                if ctx.h3 and _use_h3(n * d * oh_ * ow_, kp * 4) and _as5(weight).is_contiguous():
                     if gyplanes is None:
                         gyplanes = split_f16(gy5.reshape(-1, kp), grec)
                     drec = _new_amax_record(gy5.device)
@@ -1276,7 +1271,7 @@ def groupnorm_act_add(x, gamma, beta, groups, residual, scale_shift=None, act=Tr
     """act(GroupNorm(x)) + residual: the tail of a ResnetBlock whose skip is the identity."""
     c = x.shape[-1]
     c8 = c // 8
-    if not (FUSE_NORM_ADD and c % 8 == 0 and c8 <= 256 and (c8 & (c8 - 1)) == 0 and x.shape == residual.shape):
+    if not (c % 8 == 0 and c8 <= 256 and (c8 & (c8 - 1)) == 0 and x.shape == residual.shape):
         return add(groupnorm_act(x, gamma, beta, groups, scale_shift, act, eps), residual)
     return _GroupNormActAdd.apply(x, gamma, beta, scale_shift, residual, groups, act, eps)
 

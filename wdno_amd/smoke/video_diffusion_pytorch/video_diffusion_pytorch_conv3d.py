@@ -88,7 +88,7 @@ class Residual(nn.Module):
         self.fn = fn
 
     def forward(self, x, **kwargs):
-        if ops.SKIP_FUSE and isinstance(self.fn, PreNorm):          # x reaches the residual add THROUGH the norm (ops.layernorm_cl_skip)
+        if isinstance(self.fn, PreNorm):          # x reaches the residual add THROUGH the norm (ops.layernorm_cl_skip)
             return self.fn(x, residual=True, **kwargs)
         return self.fn(x, residual=x, **kwargs)
 
@@ -143,10 +143,7 @@ class ResnetBlock(nn.Module):
             scale_shift = ops.conv_cl(ops.silu_shared(time_emb), self.mlp[1].weight, self.mlp[1].bias)
         # block1's output is read by block2's convolution only: where that one takes fp16 planes, the norm writes them
         planes = ops.conv_reads_planes(x.numel() // x.shape[-1], self.block2.proj.weight)
-        if ops.SKIP_FUSE:
-            h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True, out_planes=planes)
-        else:
-            h, xs = self.block1(x, scale_shift=scale_shift, out_planes=planes), x
+        h, xs = self.block1(x, scale_shift=scale_shift, with_skip=True, out_planes=planes)
         if isinstance(self.res_conv, nn.Identity):
             return self.block2(h, residual=xs)
         h = self.block2(h)

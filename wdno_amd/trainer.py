@@ -24,7 +24,7 @@ from . import _lib, ops
 from .ops import _lib_, _p, _stream, _ws
 
 
-GRAD_GATHER = os.environ.get('WDNO_GRAD_GATHER', '1') != '0'
+GRAD_GATHER = True        # gradients are stored by autograd and gathered into the flat buffer with one launch (test knob; False = round-1 in-place accumulation)
 
 
 class _CopyItem(C.Structure):
@@ -110,10 +110,11 @@ class FlatBuffers:
             yield off, p.numel()
             off += p.numel()
 
-    def gather_grads(self):
+    def gather_grads(self, capture=False):
         """After backward: every p.grad -> its span of flat_grad (zeros where backward produced none), then p.grad becomes the
         flat view. One wdno_gather_items launch; the pointer table is re-uploaded only when an address changed (the caching
-        allocator hands out the same blocks step after step)."""
+        allocator hands out the same blocks step after step). capture=True (inside a HIP-graph capture of the step): the table upload
+        is part of the graph, from a pinned buffer that belongs to this capture alone and is never rewritten."""
         if not self.flat_grad.is_cuda:              # host buffers exist only in the gloo exchange tests (tests/test_distributed_cpu.py)
             for p, (o, n) in zip(self.params, self.span_list):
                 view = self.flat_grad[o:o + n].view(p.shape)
@@ -138,6 +139,20 @@ class FlatBuffers:
             # (src, dst, n) rows = wdno_copy_item. The upload must not block the host (a pageable-memory copy waits for the stream and
             # ends the host's run-ahead: +2 ms per step): pinned staging buffers, rotated so that a buffer is not rewritten while an
             # earlier asynchronous copy of it may still be pending.
+            if capture:
+                host = torch.empty((len(ptrs), 3), dtype=torch.int64).pin_memory()
+                host[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
+                host[:, 1] = torch.tensor(self._view_ptrs, dtype=torch.int64)
+                host[:, 2] = torch.tensor([sp[1] for sp in self.span_list], dtype=torch.int64)
+                table = torch.empty((len(ptrs), 3), dtype=torch.int64, device=self.flat_grad.device)
+                table.copy_(host, non_blocking=True)
+                self._capture_tables = getattr(self, '_capture_tables', []) + [(host, table)]      # kept alive with the graph
+                _lib.check(_lib_().wdno_gather_items(_p(table), len(ptrs), 48, _stream()), 'gather_items')
+                for p, v in zip(self.params, self._views):
+                    p.grad = v
+                self._gathered = True
+                self._gather_srcs = None                 # eager steps after a capture rebuild their own table
+                return
             if self._gather_table is None:
                 n = len(ptrs)
                 self._gather_table = torch.empty((n, 3), dtype=torch.int64, device=self.flat_grad.device)
@@ -418,7 +433,59 @@ class TrainStep:
                 e1.record()
                 self.comm_events.append((e0, e1))
 
+    # ------------------------------------------------------------------ the step as ONE captured HIP graph
+    def _draw(self, batch):
+        """(x, t, noise) exactly as GaussianDiffusion.forward draws them (diffusion_2d.py:1052-1058, diffusion_1d.py:647-654): t first,
+        then the noise, from the default generator -- so a graphed step consumes the same random numbers as an eager one."""
+        m = self.model
+        t = torch.randint(0, m.num_timesteps, (batch.shape[0],), device=batch.device).long()
+        x = m.normalize(batch) if hasattr(m, 'normalize') else batch
+        return x, t, m.sample_noise(tuple(x.shape), x.device)
+
+    def capture(self, example_batch, warmup=2):
+        """Capture loss -> backward -> gradient gather of a step on batches shaped like `example_batch` in one HIP graph
+        (ops.graph_capture); step() then replays it: ~1000 launches cost one graph launch of host time instead of ~18 ms of Python
+        per step, the GPU work is unchanged (same kernels, same order: replays are bit-identical to eager steps,
+        tests/test_gpu_graph.py). Left outside the graph on purpose: the random draws (two launches, so that eager and graphed steps
+        consume the generator identically), the gradient exchange (RCCL) and clip + Adam (two launches whose learning rate and step
+        count are host scalars). Runs `warmup` eager optimisation steps on the example first: packed weight operands, pixel tables
+        and the gradient-coverage check have to exist before a capture. Not with the overlapped bucket exchange (Python hooks)."""
+        if self.overlap is not None:
+            raise RuntimeError('wdno_amd TrainStep.capture: the overlapped bucket exchange runs Python hooks during backward; use WDNO_DP_OVERLAP=0')
+        ex = example_batch
+        for _ in range(max(1, warmup)):
+            self.step(ex)
+        x = self.model.normalize(ex) if hasattr(self.model, 'normalize') else ex
+        # static inputs of the graph (no random draw here: the generator must be consumed exactly as by eager steps)
+        self._gx, self._gt, self._gn = x.clone(), torch.zeros((x.shape[0],), device=x.device, dtype=torch.long), torch.zeros_like(x)
+        torch.cuda.synchronize()
+        self.opt.zero_grad()
+        graph = torch.cuda.CUDAGraph()
+        with ops.graph_capture(graph):
+            loss = self.model.p_losses(self._gx, self._gt, noise=self._gn)
+            loss.backward()
+            self.opt.buf.gather_grads(capture=True)
+        self._gloss, self._graph, self._gshape = loss.detach(), graph, tuple(ex.shape)
+        self.opt.buf.params_changed()          # the capture only RECORDED the refresh of the packed weight operands: nothing may pass for fresh
+        return self
+
+    def _step_graph(self, batch):
+        x, t, noise = self._draw(batch)
+        self._gx.copy_(x); self._gt.copy_(t); self._gn.copy_(noise)
+        self._graph.replay()
+        self.opt.buf._gathered = True                     # the replay left every gradient in the flat buffer
+        if self.exchange:
+            allreduce_sum_(self.opt.buf.flat_grad, self.world, self.group, force=True)
+        lr = self.lr_schedule(self.base_lr, self.step_idx)
+        gnorm = self.opt.step(lr=lr, grad_scale=1.0 / self.world)
+        self.step_idx += 1
+        if self.ema is not None:
+            self.ema.update(self.opt.buf.flat_param)
+        return self._gloss.clone(), gnorm
+
     def step(self, batch, **loss_kwargs):
+        if getattr(self, '_graph', None) is not None and tuple(batch.shape) == self._gshape and not loss_kwargs:
+            return self._step_graph(batch)
         self.opt.zero_grad()
         loss = self.model(batch, **loss_kwargs)
         self._backward_and_exchange(loss)
