@@ -391,7 +391,7 @@ _CAPTURE = None          # [pool, next index] while a HIP graph is being capture
 
 
 @contextlib.contextmanager
-def graph_capture(graph):
+def graph_capture(graph, stream=None):
     """`torch.cuda.graph(graph)` for launches of this library. Everything the library needs per launch is either a kernel
     argument or device memory, so a captured step replays unchanged; the one piece of state that eager execution renews per
     launch -- the zeroed amax records -- comes, during a capture, from a pool that is allocated AND zero-filled inside the
@@ -399,7 +399,7 @@ def graph_capture(graph):
     Run the step once eagerly first (packed / split weight operands and pixel tables are built on first use)."""
     global _CAPTURE
     assert _CAPTURE is None, 'nested graph captures are not supported'
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=stream):
         _CAPTURE = [None, 0]
         try:
             yield graph
@@ -596,6 +596,19 @@ def _refresh_weight_plans(epoch_used):
         pl.ver = (pl.w._version, WEIGHT_EPOCH)
 
 
+def prepare_graph_refresh():
+    """Before a step is captured in a HIP graph: build the device tables of the two-launch weight refresh NOW (they are uploaded from
+    host memory, which a capturing stream does not permit), then mark every operand stale so that the first convolution of the
+    captured step records the two refresh launches -- every replay then re-splits all weights before it uses them."""
+    epoch = WEIGHT_EPOCH
+    for pl in _wplans.values():
+        pl.used = epoch                       # every live operand belongs to the step that is about to be captured
+    bump_weight_epoch()
+    if _wplans:
+        _refresh_weight_plans(WEIGHT_EPOCH)   # eager: tables built (and operands refreshed) outside the capture
+    bump_weight_epoch()
+
+
 def split_weight(w, kind, cp8, kp, pack=None):
     """Split planes of the packed weight operand (cached per weight version). kind 'f': forward operand
     [kd,kh,kp,kw,cp8]; kind 'd': data-gradient operand [kd,kh,kp(=Cp of x),kw,cp8(=K8 of dy)] with flipped taps.
@@ -621,7 +634,9 @@ def split_weight(w, kind, cp8, kp, pack=None):
         rows = kd * kh * kp * kw
         if pl is None:
             pl = _WPlan()
-            pl.w, pl.wd, pl.kind, pl.cp8, pl.kp, pl.lp = w, wd, kind, cp8, kp, lp
+            # (pl.w: the DETACHED weight -- same storage and version counter; a weight that arrives as a view of a parameter (Burgers' Downsample
+            # weight) would otherwise keep its ViewBackward node, and through it the parameter's AccumulateGrad node, alive in this cache)
+            pl.w, pl.wd, pl.kind, pl.cp8, pl.kp, pl.lp = wd, wd, kind, cp8, kp, lp
             pl.hi = torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
             pl.lo = None if lp else torch.empty((rows, cp8), device=w.device, dtype=torch.float16)
             pl.sc = None if lp else torch.empty(1, device=w.device, dtype=torch.float32)

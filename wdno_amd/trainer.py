@@ -110,6 +110,15 @@ class FlatBuffers:
             yield off, p.numel()
             off += p.numel()
 
+    def prepare_capture(self):
+        """Pinned + device pointer tables of ONE upcoming graph capture (pinned host memory cannot be allocated while a stream is
+        capturing); they stay alive, unmodified, as long as this object does: the captured upload re-reads the pinned buffer at
+        every replay."""
+        n = len(self.params)
+        host = torch.empty((n, 3), dtype=torch.int64).pin_memory()
+        table = torch.empty((n, 3), dtype=torch.int64, device=self.flat_grad.device)
+        self._capture_tables = getattr(self, '_capture_tables', []) + [(host, table)]
+
     def gather_grads(self, capture=False):
         """After backward: every p.grad -> its span of flat_grad (zeros where backward produced none), then p.grad becomes the
         flat view. One wdno_gather_items launch; the pointer table is re-uploaded only when an address changed (the caching
@@ -140,13 +149,11 @@ class FlatBuffers:
             # ends the host's run-ahead: +2 ms per step): pinned staging buffers, rotated so that a buffer is not rewritten while an
             # earlier asynchronous copy of it may still be pending.
             if capture:
-                host = torch.empty((len(ptrs), 3), dtype=torch.int64).pin_memory()
+                host, table = self._capture_tables[-1]        # allocated by prepare_capture(): no host allocation inside a capture
                 host[:, 0] = torch.tensor(ptrs, dtype=torch.int64)
                 host[:, 1] = torch.tensor(self._view_ptrs, dtype=torch.int64)
                 host[:, 2] = torch.tensor([sp[1] for sp in self.span_list], dtype=torch.int64)
-                table = torch.empty((len(ptrs), 3), dtype=torch.int64, device=self.flat_grad.device)
                 table.copy_(host, non_blocking=True)
-                self._capture_tables = getattr(self, '_capture_tables', []) + [(host, table)]      # kept alive with the graph
                 _lib.check(_lib_().wdno_gather_items(_p(table), len(ptrs), 48, _stream()), 'gather_items')
                 for p, v in zip(self.params, self._views):
                     p.grad = v
@@ -453,15 +460,30 @@ class TrainStep:
         if self.overlap is not None:
             raise RuntimeError('wdno_amd TrainStep.capture: the overlapped bucket exchange runs Python hooks during backward; use WDNO_DP_OVERLAP=0')
         ex = example_batch
-        for _ in range(max(1, warmup)):
-            self.step(ex)
-        x = self.model.normalize(ex) if hasattr(self.model, 'normalize') else ex
-        # static inputs of the graph (no random draw here: the generator must be consumed exactly as by eager steps)
-        self._gx, self._gt, self._gn = x.clone(), torch.zeros((x.shape[0],), device=x.device, dtype=torch.long), torch.zeros_like(x)
+        # Warm-up AND capture on one side stream (the recipe of torch.cuda.graphs for whole-network capture): autograd binds a
+        # parameter's AccumulateGrad node to the stream that is current when the node is created; nodes left over from steps on the
+        # default stream make the engine synchronise the capturing stream with a non-capturing one, which invalidates the capture
+        # (hipErrorStreamCaptureInvalidated, or a crash inside hipStreamEndCapture).
+        # Autograd graphs of earlier eager steps can still be alive (tensor attributes such as the shared SiLU of the time embedding
+        # form reference cycles that only the cycle collector frees) and with them AccumulateGrad nodes bound to the default stream.
+        import gc
+        gc.collect()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.step(ex)
+            x = self.model.normalize(ex) if hasattr(self.model, 'normalize') else ex
+            # static inputs of the graph (no random draw here: the generator must be consumed exactly as by eager steps)
+            self._gx, self._gt, self._gn = x.clone(), torch.zeros((x.shape[0],), device=x.device, dtype=torch.long), torch.zeros_like(x)
+        torch.cuda.current_stream().wait_stream(side)
+        self.opt.buf.prepare_capture()
+        with torch.cuda.stream(side):
+            ops.prepare_graph_refresh()
         torch.cuda.synchronize()
         self.opt.zero_grad()
         graph = torch.cuda.CUDAGraph()
-        with ops.graph_capture(graph):
+        with ops.graph_capture(graph, stream=side):
             loss = self.model.p_losses(self._gx, self._gt, noise=self._gn)
             loss.backward()
             self.opt.buf.gather_grads(capture=True)
