@@ -89,3 +89,38 @@ def test_training_step_gradients_are_bit_reproducible(trees):
         assert torch.equal(l, runs[0][0])
         for k in g:
             assert torch.equal(g[k], runs[0][1][k]), k
+
+
+def test_default_kernel_selection_of_both_models():
+    """Which convolution kernel family every layer of the three bench configurations takes, frozen (tests/golden/kernel_selection.json,
+    recorded by tools/kernel_selection.py on an MI355X): the names are ops._fwd_h3_kernel_name / _wgrad_h3_kernel_name, the host-side
+    mirror of the dispatch in csrc/ (the profiling keys of bench.py). The tap-resident forward / data-gradient kernels (h3t) carry every
+    3x3(x3) ResnetBlock convolution, the window kernel (h3w) their weight gradients, the chunked kernels (h3d) the 1x1 / strided layers,
+    the exact-fp32 kernel only the [.., out_dim] 1x1 head. A change of a selection rule shows up here, not only as a timing."""
+    import json
+    import os
+    from tests.helpers import GOLDEN
+    sys.path.insert(0, os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0])
+    import bench
+    from wdno_amd import ops
+    from wdno_amd.trainer import TrainStep
+    with open(os.path.join(GOLDEN, 'kernel_selection.json')) as f:
+        want = json.load(f)
+    dev = torch.device('cuda', 0)
+    cases = (('smoke', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)), ('burgers', lambda: bench.build_burgers(dev), (16, 9, 64, 64)),
+             ('burgers80', lambda: bench.build_burgers(dev, (80, 64)), (16, 9, 80, 64)))
+    for name, build, shape in cases:
+        ts = TrainStep(build(), lr=1e-3, use_ema=False)
+        x = torch.randn(shape, device=dev) * 0.5
+        ts.step(x)
+        ops.PROFILE = {}
+        try:
+            ts.step(x)
+            torch.cuda.synchronize()
+            got = {k: len(v) for k, v in ops.PROFILE.items()}
+        finally:
+            ops.PROFILE = None
+        assert got == want[name], (name, got)
+        del ts
+        ops.drop_weight_caches()
+        torch.cuda.empty_cache()
