@@ -23,7 +23,7 @@ for hw in (1600, 400, 100):
     rot = ops.rotary_tables(freqs, n)
     go = torch.randn(R, heads * 32, device='cuda')
     args = dict(heads=heads, n_uo=B, n_ui=hw, n_tok=n, so=n * hw, si=1, st=hw, scale=32 ** -0.5, bias=bias, rot=rot)
-    for mode in (5, 0, 8):
+    for mode in (44, 0, 44, 0):
         lib.wdno_set_debug(mode)
         tf = timeit(lambda: ops.softmax_attention(qkv.detach(), **args))
         out = ops.softmax_attention(qkv, **args)
@@ -31,6 +31,6 @@ for hw in (1600, 400, 100):
             qkv.grad = None; bias.grad = None
             out.backward(go, retain_graph=True)
         tb = timeit(bw)
-        name = {5: 'old      ', 0: 'default  ', 8: 'mfma bwd '}[mode]
+        name = {44: 'generic n', 0: 'default  '}[mode]
         print(f'hw={hw:5d} mode={name} fwd {tf:7.1f} us  bwd {tb:7.1f} us')
     lib.wdno_set_debug(0)

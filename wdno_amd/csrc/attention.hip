@@ -513,11 +513,15 @@ __device__ __forceinline__ void am_softmax(f32x16& sT, const float* __restrict__
   for (int e = 0; e < 16; ++e) sT[e] *= inv;
 }
 
+// NT: the token count as a compile-time constant (24 frames: every temporal attention of the base models) or 0 = p.d.n_tok. With a
+// constant n every row / key guard below folds (row groups are 8 rows, keys come in runs of 4 per lane half): the generic kernel spends
+// 85 predicated regions and ~90 selects per item on them -- it is bound by instruction issue (~8 K cycles per item and SIMD), not by memory.
+template <int NT>
 __global__ __launch_bounds__(64 * AM_WAVES, 4) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
                                                                           const float* __restrict__ rsin, const float* __restrict__ bias,
                                                                           float* __restrict__ out, AttnP p) {
   __shared__ __attribute__((aligned(16))) float tiles[AM_WAVES][2][32 * AM_TS];
-  const int n = p.d.n_tok;
+  const int n = NT ? NT : p.d.n_tok;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
   const bool tok = li < n;
   // planes of out for the to_out projection instead of the fp32 tensor (the MFMA backward does not read out): rows of P sum to 1,
@@ -699,12 +703,13 @@ __device__ __forceinline__ float4 am_unrotate4(float4 g, const float* __restrict
   return make_float4(g.x * c.x + g.y * s.x, g.y * c.y - g.x * s.y, g.z * c.z + g.w * s.z, g.w * c.w - g.z * s.w);
 }
 
+template <int NT>
 __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
                                                                        const float* __restrict__ rsin, const float* __restrict__ bias,
                                                                        const float* __restrict__ fout, const float* __restrict__ dout,
                                                                        float* __restrict__ dqkv, float* __restrict__ dbias, AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = p.d.n_tok;
+  const int n = NT ? NT : p.d.n_tok;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
   constexpr int WAVE_LDS = 2 * 32 * AM_TS + 32;
   float* Ta = smem + wave * WAVE_LDS;                // two staged operand tiles (q, k then v, dO), then P^T / dS^T ([j][i]) in the same
@@ -989,7 +994,7 @@ extern "C" int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const 
   if (d->n_tok <= 32 && wdno_debug_mode != 5) {                  // one 32x32 MFMA tile per (unit, head): one wave per item
     const int64_t nb = attn_grid(p.n_items, 4, 4096);
     p.amax_rec = amax_rec;
-    attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
+    (d->n_tok == 24 && wdno_debug_mode != 44 ? attn_fwd_mfma_kernel<24> : attn_fwd_mfma_kernel<0>)<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
     return wdno_check_launch();
   }
   if (d->n_tok <= 64 && wdno_debug_mode != 5) {                  // two 32-wide tiles of keys and of queries per item
@@ -1014,7 +1019,7 @@ extern "C" int wdno_attn_fwd_planes(const float* qkv, const float* rot_cos, cons
     attn_fwd_mfma64_launch(qkv, rot_cos, rot_sin, bias, out, p, as_stream(s));
     return wdno_check_launch();
   }
-  attn_fwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
+  (d->n_tok == 24 && wdno_debug_mode != 44 ? attn_fwd_mfma_kernel<24> : attn_fwd_mfma_kernel<0>)<<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, p);
   return wdno_check_launch();
 }
 static int attn_fwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, float* out, AttnP& p,
@@ -1067,7 +1072,7 @@ extern "C" int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const 
     size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
     const int64_t nb = attn_bwd_blocks(d);                   // also the number of dbias partials
     p.amax_rec = amax_rec;
-    attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, part, p);
+    (d->n_tok == 24 && wdno_debug_mode != 44 ? attn_bwd_mfma_kernel<24> : attn_bwd_mfma_kernel<0>)<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, part, p);
     rc = wdno_check_launch();
     return (rc || !dbias) ? rc : attn_dbias_reduce(part, nb, dbias, d, s);
   }
@@ -1089,7 +1094,7 @@ extern "C" int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, cons
   size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
   const int64_t nb = attn_bwd_blocks(d);
   p.pl_hi = (_Float16*)dqkv_hi; p.pl_lo = (_Float16*)dqkv_lo; p.rec_qkv = rec_qkv; p.rec_dout = rec_dout; p.pl_scale = dqkv_scale;
-  attn_bwd_mfma_kernel<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, nullptr, part, p);
+  (d->n_tok == 24 && wdno_debug_mode != 44 ? attn_bwd_mfma_kernel<24> : attn_bwd_mfma_kernel<0>)<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, nullptr, part, p);
   rc = wdno_check_launch();
   return (rc || !dbias) ? rc : attn_dbias_reduce(part, nb, dbias, d, s);
 }
