@@ -48,3 +48,25 @@ def test_relative_position_buckets():
     assert b.shape == (24, 24) and int(b.min()) == 0 and int(b.max()) <= 31
     assert int(b[0, 0]) == 0 and int(b[5, 0]) == 5 and int(b[0, 5]) == 16 + 5      # sign convention: n = q - k
     assert int(b[23, 0]) == 8 + int(np.floor(np.log(23 / 8) / np.log(4) * 8))
+
+
+def test_rotary_matches_an_independent_implementation():
+    """rotary_embedding_torch is absent from /root/reference and was pinned only through restatements by the
+    builder (the oracle's and the fixture stub's). Cross-pin against an INDEPENDENT published implementation of the same scheme that
+    happens to be installed: GPT-J's rotary embedding in `transformers` (interleaved pairs -- `rotate_every_two` is lucidrains'
+    `rotate_half` on '(d r) -> d r', r = 2 -- and inv_freq = 1 / 10000^(2i / d)), applied over the token axis like
+    rotary_embedding_torch.rotate_queries_or_keys does (conv3d.py:320-322)."""
+    G = pytest.importorskip('transformers.models.gptj.modeling_gptj')
+    import torch
+    from oracle import unet_ref as U
+    g = torch.Generator().manual_seed(12)
+    b, heads, n, d = 3, 4, 24, 32
+    t = torch.randn(b, heads, n, d, generator=g, dtype=torch.float64)
+    freqs = 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].double() / d))          # RotaryEmbedding(dim).freqs (state_dict key `freqs`)
+    ours = U.rotary(t, freqs)
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, d, 2, dtype=torch.int64) / d))
+    assert torch.allclose(inv_freq.double(), freqs, rtol=1e-6)                       # the same frequency table, computed their way
+    ang = torch.arange(n).double()[:, None] * freqs[None, :]
+    sin, cos = torch.sin(ang)[None], torch.cos(ang)[None]                            # [1, n, d / 2]
+    theirs = G.apply_rotary_pos_emb(t.permute(0, 2, 1, 3), sin, cos).permute(0, 2, 1, 3)      # GPT-J layout is [b, n, heads, d]
+    assert (ours - theirs).abs().max().item() < 1e-14
