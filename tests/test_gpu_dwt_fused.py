@@ -112,3 +112,29 @@ def test_roundtrip_full_size_properties(W):
     c3 = wavelets.dwt_packed(x3, 'bior1.3', 'zero', 3)
     assert c3.shape == (32, 8, 18, 34, 34)
     assert (wavelets.idwt_packed(c3, 'bior1.3', 'zero', 3) - x3).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize('mode,wave,shape', [c[1:] for c in CASES if c[0] == 3])
+def test_streaming_3d_synthesis_equals_the_all_frames_kernel(W, mode, wave, shape):
+    """Round 3: the 3-D synthesis streams over the coefficient frames of its tile (dwt_synthesis3_stream_kernel: one frame in LDS, the T
+    pass accumulated in registers in descending frame order) -- same terms in the same order as the round-2 kernel that kept all frames
+    in LDS (debug switch 45) and as the per-axis passes: bit-exact, including the synthesis-shaped forward adjoint."""
+    wavelets, lib = W
+    g = torch.Generator().manual_seed(len(wave) + shape[-1])
+    x = torch.randn(*shape, generator=g).to(DEV)
+    coef = torch.randn_like(wavelets.dwt_packed(x, wave, mode, 3))
+
+    def run():
+        cc = coef.clone().requires_grad_(True)
+        xx = x.clone().requires_grad_(True)
+        z = wavelets.idwt_packed(cc, wave, mode, 3)
+        y = wavelets.dwt_packed(xx, wave, mode, 3)
+        (y * torch.cos(torch.arange(y.numel(), device=DEV, dtype=torch.float32)).reshape(y.shape)).sum().backward()
+        return z.detach(), xx.grad
+    a = run()
+    lib.wdno_set_debug(45)
+    try:
+        b = run()
+    finally:
+        lib.wdno_set_debug(0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -471,6 +471,136 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
   }
 }
 
+
+// Round 3: 3-D synthesis that STREAMS over the coefficient frames of its tile. The kernel above keeps the W-pass and H-pass results of
+// all ET = NQ + E coefficient frames of a tile in LDS (12 planes for bior1.3), which leaves room for 2 q-rows per tile at 40 KB: 4896 blocks
+// for [32, 8, 18, 34, 34], each coefficient read 3x through L2 and every W-pass item computed 3x (halo 6/4 in T times 4/2 in H). Here only ONE
+// frame is in LDS at a time (W pass -> S1, H pass -> S2, 20 KB for 8 q-rows); the T pass is an accumulation in registers: a thread owns
+// ITEMS output columns (ph, pw) and 2 NQ time samples of each, and every staged frame adds its lo / hi contribution to the <= L/2 q-frames it
+// belongs to. Frames are walked in DESCENDING order so that each accumulator receives its terms in the order i = 0, 1, .. of the
+// per-axis kernel (K = q - i): results stay BIT-IDENTICAL to it (tests/test_gpu_dwt_fused.py). wdno_debug 45: the kernel above (A/B).
+template <int L, int MODE, int NQ, int ITEMS>
+__global__ __launch_bounds__(256) void dwt_synthesis3_stream_kernel(const float* __restrict__ coef, float* __restrict__ x, FusedGeom g, Taps t) {
+  extern __shared__ float lds[];
+  constexpr int E = L / 2 - 1;
+  constexpr int ET = NQ + E;
+  int b = xcd_tile(blockIdx.x, g.n_blocks);
+  const int th = b % g.tiles_h;
+  b /= g.tiles_h;
+  const int tt = b % g.tiles_t;
+  const int img = b / g.tiles_t;
+  const int NW = g.FW, QW = NW >> 1, NQH = g.NH, off = g.off;
+  const int EH = NQH + E;
+  const int qh_start = g.qh0 + th * NQH;
+  const int nqh = min(NQH, g.qh0 + g.QH - qh_start);
+  const int qt_start = g.qt0 + tt * NQ;
+  const int eh_used = nqh + E;
+  const float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
+  float* __restrict__ xi = x + (int64_t)img * g.T * g.H * g.W;
+  float* S1 = lds;                              // [2 bt][2 bh][EH][NW]
+  float* S2 = lds + 4 * EH * NW;                // [2 bt][2 NQH][NW]
+  const int n_items = 2 * nqh * NW;             // output columns (ph, pw) of this tile
+  float acc[ITEMS][NQ][2];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j)
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) { acc[j][qq][0] = 0.f; acc[j][qq][1] = 0.f; }
+#pragma unroll
+  for (int e = ET - 1; e >= 0; --e) {
+    const int Kt = smap<MODE>(qt_start - E + e, g.To);
+    if (Kt < 0) continue;                       // a frame outside the tensor contributes fmaf(0, tap, acc) = acc (block-uniform)
+    // pass W: coefficient frame Kt -> S1 (branch-free body, see the kernel above)
+    for (int it = threadIdx.x; it < 4 * EH * QW; it += 256) {
+      int q = fd_div(it, g.dQW);
+      const int ql = it - q * QW;
+      const int q2 = fd_div(q, g.dEH), eh = q - q2 * EH;
+      const int bh = q2 & 1, bt = q2 >> 1;
+      const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
+      const bool rowok = Kh >= 0;
+      const int band_lo = bt * 4 + bh * 2;
+      const float* base = ci + (int64_t)Kt * g.cs0 + (rowok ? (int64_t)Kh * g.cs1 : 0);
+      const float* rl = base + band_lo * g.cs_band;
+      const float* rh = rl + g.cs_band;
+      float cl[L / 2], ch[L / 2];
+#pragma unroll
+      for (int i = 0; i < L / 2; ++i) {
+        const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
+        const bool ok = rowok && Kw >= 0;
+        const int kk = Kw >= 0 ? Kw : 0;
+        const float vl = rl[kk], vh = rh[kk];
+        cl[i] = ok ? vl : 0.f;
+        ch[i] = ok ? vh : 0.f;
+      }
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < L / 2; ++i) {
+        a0 = fmaf(cl[i], t.lo[2 * i], a0);
+        a0 = fmaf(ch[i], t.hi[2 * i], a0);
+        a1 = fmaf(cl[i], t.lo[2 * i + 1], a1);
+        a1 = fmaf(ch[i], t.hi[2 * i + 1], a1);
+      }
+      if (eh < eh_used) reinterpret_cast<float2*>(S1 + (q2 * EH + eh) * NW)[ql] = make_float2(a0, a1);
+    }
+    __syncthreads();
+    // pass H: S1 -> S2
+    for (int it = threadIdx.x; it < 2 * 2 * NQH * NW; it += 256) {
+      int q = fd_div(it, g.dFW);
+      const int pw = it - q * NW;
+      const int bt = fd_div(q, g.dNQH2), ph = q - bt * 2 * NQH;
+      if (ph >= 2 * nqh) continue;
+      const int ql = ph >> 1, r = ph & 1;
+      const float* cl = S1 + ((bt * 2 + 0) * EH + ql + E) * NW + pw;
+      const float* ch = S1 + ((bt * 2 + 1) * EH + ql + E) * NW + pw;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < L / 2; ++i) {
+        a = fmaf(cl[-i * NW], r ? t.lo[2 * i + 1] : t.lo[2 * i], a);
+        a = fmaf(ch[-i * NW], r ? t.hi[2 * i + 1] : t.hi[2 * i], a);
+      }
+      S2[(bt * 2 * NQH + ph) * NW + pw] = a;
+    }
+    __syncthreads();
+    // pass T: this frame's term of every q-frame it belongs to (i = qq + E - e in [0, E])
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int it = threadIdx.x + 256 * j;
+      if (it < n_items) {
+        const float cl = S2[it], ch = S2[2 * NQH * NW + it];        // (ph, pw) = it / NW, it % NW: S2 rows are NW wide, so the item index is the offset
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) {
+          const int i = qq + E - e;
+          if (i >= 0 && i <= E) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              acc[j][qq][r] = fmaf(cl, t.lo[r + 2 * i], acc[j][qq][r]);
+              acc[j][qq][r] = fmaf(ch, t.hi[r + 2 * i], acc[j][qq][r]);
+            }
+          }
+        }
+      }
+    }
+  }
+  const int wshift = off & 1;
+  const int64_t fs = (int64_t)g.H * g.W;
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int it = threadIdx.x + 256 * j;
+    if (it >= n_items) continue;
+    const int ph = fd_div(it, g.dFW), pw = it - ph * NW;
+    const int nw = pw - wshift;
+    const int nhh = 2 * (qh_start + (ph >> 1)) + (ph & 1) - off;
+    if (nw < 0 || nw >= g.W || nhh < 0 || nhh >= g.H) continue;
+    float* o = xi + (int64_t)nhh * g.W + nw;
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int nt = 2 * (qt_start + qq) + r - off;
+        if (nt >= 0 && nt < g.T) o[nt * fs] = acc[j][qq][r];
+      }
+  }
+}
+
 // LDS budget per block (<= 64 KB: the default dynamic-LDS limit, no function attribute needed -> graph-capture safe). Smaller
 // tiles = more blocks per CU to hide the latency of the global reads, at the price of more halo re-reads through L2.
 static size_t fused_lds_budget(long default_kb) {
@@ -543,6 +673,33 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
   g.FW = 2 * qcount(g.W);
   constexpr int NQ = (ND == 3) ? 4 : 4;
   size_t lds;
+  if (ND == 3 && wdno_debug_mode != 45) {
+    // streaming kernel: q-rows per tile from the register budget (ITEMS columns of 2 NQ samples per thread) and a 32 KB LDS budget
+    constexpr int ITEMS = 5;
+    // columns per thread actually used: 2 (measured on [32,8,18,34,34] / [10,8,34,66,66]: 5 -> 38.4 / 77.7 us, 3 -> 34.7 / 68.5, 2 -> 30.0 / 70.5, 1 -> 33.4 / 83.8;
+    // the all-frames-in-LDS kernel: 32.5-34.7 / 241): the passes are latency-bound between their barriers, so more, smaller tiles win over less halo
+    const int items_rt = wdno_debug_mode == 46 ? ITEMS : 2;
+    const int NW = g.FW;
+    int nqh = (items_rt * 256) / (2 * NW);
+    const int lds_rows = (int)(fused_lds_budget(32) / ((size_t)NW * sizeof(float)));      // 4 (NQH + E) + 4 NQH rows of NW floats
+    nqh = std::min(nqh, (lds_rows - 4 * E) / 8);
+    nqh = std::min(nqh, g.QH);
+    if (nqh >= 1) {
+      const int tiles = cdiv(g.QH, nqh);
+      g.NH = cdiv(g.QH, tiles);
+      g.tiles_h = tiles;
+      g.tiles_t = cdiv(g.QT, NQ);
+      lds = (size_t)(4 * (g.NH + E) + 4 * g.NH) * NW * sizeof(float);
+      const int64_t nbs = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
+      if (nbs <= 0x7fffffff && (int64_t)4 * (g.NH + E) * NW * (int64_t)std::max(NW, 2 * (g.NH + E)) < (1ll << 32)) {
+        g.n_blocks = (int)nbs;
+        g.dFW = make_fastdiv(NW); g.dQW = make_fastdiv(NW / 2); g.dEH = make_fastdiv(g.NH + E); g.dNQH2 = make_fastdiv(2 * g.NH);
+        g.debug = 0;
+        dwt_synthesis3_stream_kernel<L, MODE, NQ, ITEMS><<<(int)nbs, 256, lds, st>>>(src, dst, g, taps);
+        return true;
+      }
+    }
+  }
   if (ND == 3) {
     // floats: 2 ET NW (2 EH + 2 NQH), EH = NQH + E
     const size_t per_row = (size_t)2 * (NQ + E) * g.FW * sizeof(float);
