@@ -157,7 +157,7 @@ def test_two_ranks_one_gpu_smoke_trainer(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ RCCL itself, one rank (round 3)
-def _worker_rccl_one_rank(port, overlap, out):
+def _worker_rccl_one_rank(port, overlap, out, graph=False):
     """A ONE-rank "nccl" (= RCCL) process group on the box's GPU: the exchange is forced (WDNO_DP_FORCE_EXCHANGE), so every
     torch.distributed call of the data-parallel step runs over RCCL -- broadcast of the flat parameter buffer, the async bucket
     all-reduces on RCCL's own stream started from gradient hooks during backward, finish() ordering them against the HIP launch
@@ -169,10 +169,21 @@ def _worker_rccl_one_rank(port, overlap, out):
     torch.cuda.set_device(0)
     batches = _batches()
 
-    def run():
+    def run(captured=False):
         dif = _model(5).to('cuda')
         ts = TrainStep(dif, lr=1e-3, max_grad_norm=1.0, use_ema=False)
         losses = []
+        if graph:                      # draws from the default generator (same seed both runs); the second run replays a captured step
+            torch.manual_seed(123)
+            xs = [b[0].cuda() for b in batches] * 2
+            if captured:
+                ts.capture(xs[0], warmup=1)
+                xs = xs[1:]
+            for x0 in xs:
+                loss, gn = ts.step(x0)
+                losses.append((loss.item(), gn.item()))
+            torch.cuda.synchronize()
+            return ts, losses[-3:], ts.opt.buf.flat_param.detach().cpu().clone()
         for x0, t, noise in batches:
             loss, gn = ts.step_with(x0.cuda(), t.cuda(), noise.cuda())
             losses.append((loss.item(), gn.item()))
@@ -183,8 +194,8 @@ def _worker_rccl_one_rank(port, overlap, out):
     dist.init_process_group('nccl', rank=0, world_size=1)
     os.environ['WDNO_DP_FORCE_EXCHANGE'] = '1'
     os.environ['WDNO_DP_OVERLAP'] = '1' if overlap else '0'
-    ts1, l1, w1 = run()
-    info = dict(backend=dist.get_backend(), exchange=ts1.exchange, overlap=ts1.overlap is not None,
+    ts1, l1, w1 = run(captured=graph)
+    info = dict(graph=ts1._graph is not None, backend=dist.get_backend(), exchange=ts1.exchange, overlap=ts1.overlap is not None,
                 buckets=0 if ts1.overlap is None else len(ts1.overlap.bounds), losses_equal=l0 == l1, weights_equal=bool(torch.equal(w0, w1)),
                 finite=bool(torch.isfinite(w1).all()))
     # the plain collectives on device memory as well
@@ -197,15 +208,16 @@ def _worker_rccl_one_rank(port, overlap, out):
     torch.save(info, out)
 
 
-@pytest.mark.parametrize('overlap', [False, True])
-def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overlap):
+@pytest.mark.parametrize('overlap,graph', [(False, False), (True, False), (False, True)])
+def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overlap, graph):
+    """graph = True: the step replayed from a captured HIP graph with the RCCL all-reduce between the replay and clip + Adam."""
     out = str(tmp_path / 'rccl.pt')
     ctx = mp.get_context('spawn')
-    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), overlap, out))
+    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), overlap, out, graph))
     p.start()
     p.join(300)
     assert p.exitcode == 0, f'worker exit code {p.exitcode}'
     info = torch.load(out)
     print(info)
-    assert info['backend'] == 'nccl' and info['exchange'] and info['overlap'] == overlap and (info['buckets'] == 4) == overlap
+    assert info['backend'] == 'nccl' and info['exchange'] and info['overlap'] == overlap and (info['buckets'] == 4) == overlap and info['graph'] == graph
     assert info['losses_equal'] and info['weights_equal'] and info['finite'] and info['allreduce_identity']

@@ -153,3 +153,39 @@ def test_smoke_trainer_runs_and_saves(trees, tmp_path):
         assert torch.isfinite(tr2.ema.ema_model(data[:2].to(DEV)))
     p_first = next(p for p in tr2.ema.ema_model.parameters() if p.dtype == torch.float32 and p.numel() > 1)
     assert tr2.ema.flat.data_ptr() <= p_first.data_ptr() < tr2.ema.flat.data_ptr() + 4 * tr2.ema.flat.numel()
+
+
+@pytest.mark.parametrize('tree', ['smoke', 'burgers'])
+def test_trainer_with_graph_replay_is_bit_identical(trees, tmp_path, tree):
+    """Trainer.use_graph = True (a class attribute: the constructors keep the reference's parameter lists): the drop-in Trainers replay
+    loss -> backward -> gradient gather from one captured HIP graph (wdno_amd.trainer.CapturedStep) after a first launch-by-launch step.
+    Six optimisation steps of train() / optimisation_step leave bit-identical weights, Adam moments and losses as without it."""
+    def run(use_graph, sub):
+        torch.manual_seed(7)
+        if tree == 'smoke':
+            net = trees['Unet3D'](dim=8, dim_mults=(1, 2), channels=42)
+            dif = trees['GD2'](net, torch.ones(1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero', (3, 6, 6), (4, 8, 8), image_size=8, frames=4,
+                               timesteps=1000, sampling_timesteps=10, loss_type='l2')
+            data = torch.randn(4, 4, 42, 8, 8, generator=torch.Generator().manual_seed(1)) * 0.3
+            tr = trees['TS'](dif, _Fixed(data, as_tuple=True), None, train_batch_size=2, train_lr=1e-3, train_num_steps=6, save_and_sample_every=100,
+                             results_path=str(tmp_path / sub), calculate_fid=False)
+            nxt = tr._next_state
+        else:
+            dif = _burgers(trees, 3)
+            data = torch.randn(4, 9, 8, 8, generator=torch.Generator().manual_seed(1)) * 0.5
+            tr = trees['TB'](dif, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=6, results_folder=str(tmp_path / sub))
+            nxt = lambda: next(tr.dl).to(tr.device)
+        tr.use_graph = use_graph
+        torch.manual_seed(11)
+        losses = []
+        for _ in range(6):
+            losses.append(tr.optimisation_step(nxt))
+            tr.step += 1
+        torch.cuda.synchronize()
+        return tr, losses
+    te, le = run(False, 'e')
+    tg, lg = run(True, 'g')
+    assert getattr(tg, '_cap', None) is not None and getattr(te, '_cap', None) is None
+    assert le == lg
+    assert torch.equal(te.opt.buf.flat_param, tg.opt.buf.flat_param)
+    assert torch.equal(te.opt.exp_avg, tg.opt.exp_avg) and torch.equal(te.opt.exp_avg_sq, tg.opt.exp_avg_sq)

@@ -392,6 +392,54 @@ def multistep_lr(base_lr, step, milestones=(50000, 150000, 300000), gamma=0.1):
     return base_lr * gamma ** sum(1 for m in milestones if step >= m)
 
 
+class CapturedStep:
+    """loss -> backward -> gradient gather of `diffusion.p_losses` on static inputs, captured once in a HIP graph (ops.graph_capture) and
+    replayed per step. Shared by TrainStep.capture and the drop-in Trainers (TrainerCore.use_graph). What a capture needs (each item
+    found by a failed capture on the MI355X box): no host allocation / pageable upload while capturing (the pinned
+    pointer table of the gather and the device tables of the weight refresh are made before); one side stream for the capture, with no
+    autograd graph of an earlier step alive (AccumulateGrad nodes are bound to the stream they were created on); every packed weight
+    operand marked stale so that the captured step starts with the two refresh launches."""
+
+    def __init__(self, diffusion, buf, example_batch):
+        import gc
+        self.model, self.buf = diffusion, buf
+        gc.collect()                                   # drop autograd graphs of earlier steps that only the cycle collector frees
+        ex = example_batch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            x = diffusion.normalize(ex) if hasattr(diffusion, 'normalize') else ex
+            # static inputs (no random draw here: the generator must be consumed exactly as by eager steps)
+            self.x, self.t, self.noise = x.clone(), torch.zeros((x.shape[0],), device=x.device, dtype=torch.long), torch.zeros_like(x)
+            ops.prepare_graph_refresh()
+        torch.cuda.current_stream().wait_stream(side)
+        buf.prepare_capture()
+        torch.cuda.synchronize()
+        buf.zero_grad()
+        self.graph = torch.cuda.CUDAGraph()
+        with ops.graph_capture(self.graph, stream=side):
+            loss = diffusion.p_losses(self.x, self.t, noise=self.noise)
+            loss.backward()
+            buf.gather_grads(capture=True)
+        self.loss, self.shape = loss.detach(), tuple(ex.shape)
+        buf.params_changed()          # the capture only RECORDED the refresh of the packed weight operands: nothing may pass for fresh
+
+    def draw(self, batch):
+        """(x, t, noise) exactly as GaussianDiffusion.forward draws them (diffusion_2d.py:1052-1058, diffusion_1d.py:647-654): t first,
+        then the noise, from the default generator -- so a graphed step consumes the same random numbers as an eager one."""
+        m = self.model
+        t = torch.randint(0, m.num_timesteps, (batch.shape[0],), device=batch.device).long()
+        x = m.normalize(batch) if hasattr(m, 'normalize') else batch
+        return x, t, m.sample_noise(tuple(x.shape), x.device)
+
+    def run(self, batch):
+        x, t, noise = self.draw(batch)
+        self.x.copy_(x); self.t.copy_(t); self.noise.copy_(noise)
+        self.graph.replay()
+        self.buf._gathered = True                      # the replay left every gradient in the flat buffer
+        return self.loss.clone()
+
+
 class TrainStep:
     """One data-parallel optimisation step of a GaussianDiffusion module.
 
@@ -441,17 +489,9 @@ class TrainStep:
                 self.comm_events.append((e0, e1))
 
     # ------------------------------------------------------------------ the step as ONE captured HIP graph
-    def _draw(self, batch):
-        """(x, t, noise) exactly as GaussianDiffusion.forward draws them (diffusion_2d.py:1052-1058, diffusion_1d.py:647-654): t first,
-        then the noise, from the default generator -- so a graphed step consumes the same random numbers as an eager one."""
-        m = self.model
-        t = torch.randint(0, m.num_timesteps, (batch.shape[0],), device=batch.device).long()
-        x = m.normalize(batch) if hasattr(m, 'normalize') else batch
-        return x, t, m.sample_noise(tuple(x.shape), x.device)
-
     def capture(self, example_batch, warmup=2):
         """Capture loss -> backward -> gradient gather of a step on batches shaped like `example_batch` in one HIP graph
-        (ops.graph_capture); step() then replays it: ~1000 launches cost one graph launch of host time instead of ~18 ms of Python
+        (CapturedStep); step() then replays it: ~1000 launches cost one graph launch of host time instead of ~18 ms of Python
         per step, the GPU work is unchanged (same kernels, same order: replays are bit-identical to eager steps,
         tests/test_gpu_graph.py). Left outside the graph on purpose: the random draws (two launches, so that eager and graphed steps
         consume the generator identically), the gradient exchange (RCCL) and clip + Adam (two launches whose learning rate and step
@@ -459,43 +499,18 @@ class TrainStep:
         and the gradient-coverage check have to exist before a capture. Not with the overlapped bucket exchange (Python hooks)."""
         if self.overlap is not None:
             raise RuntimeError('wdno_amd TrainStep.capture: the overlapped bucket exchange runs Python hooks during backward; use WDNO_DP_OVERLAP=0')
-        ex = example_batch
-        # Warm-up AND capture on one side stream (the recipe of torch.cuda.graphs for whole-network capture): autograd binds a
-        # parameter's AccumulateGrad node to the stream that is current when the node is created; nodes left over from steps on the
-        # default stream make the engine synchronise the capturing stream with a non-capturing one, which invalidates the capture
-        # (hipErrorStreamCaptureInvalidated, or a crash inside hipStreamEndCapture).
-        # Autograd graphs of earlier eager steps can still be alive (tensor attributes such as the shared SiLU of the time embedding
-        # form reference cycles that only the cycle collector frees) and with them AccumulateGrad nodes bound to the default stream.
-        import gc
-        gc.collect()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                self.step(ex)
-            x = self.model.normalize(ex) if hasattr(self.model, 'normalize') else ex
-            # static inputs of the graph (no random draw here: the generator must be consumed exactly as by eager steps)
-            self._gx, self._gt, self._gn = x.clone(), torch.zeros((x.shape[0],), device=x.device, dtype=torch.long), torch.zeros_like(x)
-        torch.cuda.current_stream().wait_stream(side)
-        self.opt.buf.prepare_capture()
-        with torch.cuda.stream(side):
-            ops.prepare_graph_refresh()
-        torch.cuda.synchronize()
-        self.opt.zero_grad()
-        graph = torch.cuda.CUDAGraph()
-        with ops.graph_capture(graph, stream=side):
-            loss = self.model.p_losses(self._gx, self._gt, noise=self._gn)
-            loss.backward()
-            self.opt.buf.gather_grads(capture=True)
-        self._gloss, self._graph, self._gshape = loss.detach(), graph, tuple(ex.shape)
-        self.opt.buf.params_changed()          # the capture only RECORDED the refresh of the packed weight operands: nothing may pass for fresh
+        for _ in range(max(1, warmup)):
+            self.step(example_batch)
+        self._cap = CapturedStep(self.model, self.opt.buf, example_batch)
         return self
 
+    @property
+    def _graph(self):
+        cap = getattr(self, '_cap', None)
+        return None if cap is None else cap.graph
+
     def _step_graph(self, batch):
-        x, t, noise = self._draw(batch)
-        self._gx.copy_(x); self._gt.copy_(t); self._gn.copy_(noise)
-        self._graph.replay()
-        self.opt.buf._gathered = True                     # the replay left every gradient in the flat buffer
+        loss = self._cap.run(batch)
         if self.exchange:
             allreduce_sum_(self.opt.buf.flat_grad, self.world, self.group, force=True)
         lr = self.lr_schedule(self.base_lr, self.step_idx)
@@ -503,10 +518,10 @@ class TrainStep:
         self.step_idx += 1
         if self.ema is not None:
             self.ema.update(self.opt.buf.flat_param)
-        return self._gloss.clone(), gnorm
+        return loss, gnorm
 
     def step(self, batch, **loss_kwargs):
-        if getattr(self, '_graph', None) is not None and tuple(batch.shape) == self._gshape and not loss_kwargs:
+        if getattr(self, '_cap', None) is not None and tuple(batch.shape) == self._cap.shape and not loss_kwargs:
             return self._step_graph(batch)
         self.opt.zero_grad()
         loss = self.model(batch, **loss_kwargs)
@@ -716,19 +731,35 @@ class TrainerCore:
                           num_workers=num_workers, drop_last=False)
 
     # ------------------------------------------------------------------ one optimisation step (T1 / T2)
+    use_graph = False           # True: the step (loss -> backward -> gradient gather) is replayed from one captured HIP graph per batch shape
+                                # (CapturedStep; gradient_accumulate_every == 1 only). A class attribute like num_workers: the constructors keep the
+                                # reference's parameter lists. Bit-identical to the launch-by-launch step (tests/test_gpu_trainer.py).
+
     def optimisation_step(self, next_batch):
         """next_batch() -> device tensor. Returns the python float loss of this rank (the reference logs it per rank)."""
-        self.opt.zero_grad()
-        total = 0.0
-        for _ in range(self.gradient_accumulate_every):
-            loss = self.model(next_batch()) / self.gradient_accumulate_every
-            loss.backward()
-            total += float(loss.detach())
-        self.opt.buf.gather_grads()
+        total = None
+        if self.use_graph and self.gradient_accumulate_every == 1:
+            batch = next_batch()
+            cap = getattr(self, '_cap', None)
+            if cap is not None and cap.shape == tuple(batch.shape):
+                total = float(cap.run(batch))
+            else:
+                next_batch = lambda _b=batch: _b            # this step runs launch by launch (it is the warm-up), the capture follows it
+        if total is None:
+            self.opt.zero_grad()
+            total = 0.0
+            for _ in range(self.gradient_accumulate_every):
+                loss = self.model(next_batch()) / self.gradient_accumulate_every
+                loss.backward()
+                total += float(loss.detach())
+            del loss
+            self.opt.buf.gather_grads()
         if self.world > 1:
             allreduce_sum_(self.opt.buf.flat_grad, self.world)
         self.last_grad_norm = self.opt.step(lr=self.lr_schedule(self.train_lr, self.step), grad_scale=1.0 / self.world)
         self.total_loss = total
+        if self.use_graph and self.gradient_accumulate_every == 1 and (getattr(self, '_cap', None) is None or self._cap.shape != tuple(batch.shape)):
+            self._cap = CapturedStep(self.model, self.opt.buf, batch)
         return total
 
     # ------------------------------------------------------------------ checkpoints (T3)
