@@ -188,6 +188,10 @@ int wdno_conv_wgrad_bf16_param(const void* x16, const void* dy16, const void* pi
  * stats [N, G, 2] (mean, rstd) is written by fwd and read by bwd.
  */
 size_t wdno_groupnorm_ws_bytes(int64_t N, int64_t S, int C, int G);
+/* Round 3: `stats` of every GroupNorm entry point is a buffer of wdno_groupnorm_stats_floats(N, C, G) floats: the [N][G] (mean, rstd) pairs
+ * followed by the per-channel / per-group tables the forward derives from them, which the backward entry points read back (one launch
+ * fewer per norm). The forward that wrote it and the backward that reads it must see the same gamma / beta / scale_shift. */
+size_t wdno_groupnorm_stats_floats(int64_t N, int C, int G);
 int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
                            float* stats, int64_t N, int64_t S, int C, int G, float eps, int silu,
                            void* ws, size_t ws_bytes, wdno_stream_t s);
@@ -224,8 +228,10 @@ int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* gamma, const 
                                       void* ws, size_t ws_bytes, wdno_stream_t s);
 int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
                                   const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
-                                  float* dgb_partial, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
+                                  float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
                                   void* ws, size_t ws_bytes, wdno_stream_t s);
+/* dgb_sum (round 3, optional): [2 C] = the sum over the samples of dgb_partial [N][2][C] (d gamma | d beta), produced by the launch that
+ * also finishes dx_colsum; NULL = the caller reduces dgb_partial itself. */
 /* Channel LayerNorm over C of CL rows [P, C], gain only (unet.py:55-65, conv3d.py:165-174) */
 int wdno_layernorm_fwd(const float* x, const float* g, float* y, int64_t P, int C, float eps, wdno_stream_t s);
 int wdno_layernorm_fwd_amax(const float* x, const float* g, float* y, float* amax_rec, int64_t P, int C, float eps, wdno_stream_t s);

@@ -84,6 +84,7 @@ PROTOTYPES = {
     'wdno_colsum_ws_bytes': (Z, [L, I]),
     'wdno_colsum': (I, [P, P, L, I, P, Z, P]),
     'wdno_groupnorm_ws_bytes': (Z, [L, L, I, I]),
+    'wdno_groupnorm_stats_floats': (Z, [L, I, I]),
     'wdno_groupnorm_act_fwd': (I, [P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_groupnorm_act_fwd_amax': (I, [P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_groupnorm_act_bwd': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
@@ -93,7 +94,7 @@ PROTOTYPES = {
     'wdno_groupnorm_act_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_groupnorm_act_add_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_layernorm_fwd_planes': (I, [P, P, P, P, P, L, I, F, P]),
-    'wdno_groupnorm_act_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
+    'wdno_groupnorm_act_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_layernorm_fwd': (I, [P, P, P, L, I, F, P]),
     'wdno_layernorm_fwd_amax': (I, [P, P, P, P, L, I, F, P]),
     'wdno_layernorm_bwd_ws_bytes': (Z, [L, I]),

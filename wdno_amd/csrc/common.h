@@ -116,10 +116,10 @@ __device__ __forceinline__ float group_max(float v) {
 #define PRS_GROUPS 32
 #define PRS_THREADS (32 * PRS_GROUPS)
 template <typename T>
-__global__ __launch_bounds__(PRS_THREADS) void partial_rows_sum_kernel(const T* __restrict__ part, float* __restrict__ out, int nb, int C) {
+__device__ __forceinline__ void partial_rows_sum_body(const T* __restrict__ part, float* __restrict__ out, int nb, int C, int bx) {
   __shared__ double red[PRS_GROUPS][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  const int c = bx * 32 + tx;
   double acc = 0.0;
   if (c < C) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -141,6 +141,10 @@ __global__ __launch_bounds__(PRS_THREADS) void partial_rows_sum_kernel(const T* 
     for (int g = 0; g < PRS_GROUPS; ++g) a[g & 3] += red[g][tx];
     out[c] = (float)((a[0] + a[1]) + (a[2] + a[3]));
   }
+}
+template <typename T>
+__global__ __launch_bounds__(PRS_THREADS) void partial_rows_sum_kernel(const T* __restrict__ part, float* __restrict__ out, int nb, int C) {
+  partial_rows_sum_body<T>(part, out, nb, C, (int)blockIdx.x);
 }
 
 __device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }

@@ -516,6 +516,12 @@ extern "C" size_t wdno_groupnorm_ws_bytes(int64_t N, int64_t S, int C, int G) {
   size_t part = (size_t)N * gn_chunks(S) * C * 2 * sizeof(double);
   return part + (size_t)N * C * 4 * sizeof(float) + (size_t)N * G * 4 * sizeof(float) + 64;
 }
+// `stats` holds, behind the [N][G] (mean, rstd) pairs, the two tables the forward finalize derives from them -- cb [N][C][4] (per-channel affine)
+// and gb [N][G][4] -- so that the backward reads them instead of re-deriving them with one more 8-block launch per norm (30 x 6.7 us per smoke
+// training step; a launch that small costs its full duration, measured by removing the equally small column sums: -0.13 ms per step).
+extern "C" size_t wdno_groupnorm_stats_floats(int64_t N, int C, int G) { return (size_t)N * G * 2 + (size_t)N * C * 4 + (size_t)N * G * 4; }
+static inline float* gn_cb(float* stats, int64_t N, int G) { return stats + (size_t)N * G * 2; }
+static inline float* gn_gb(float* stats, int64_t N, int C, int G) { return stats + (size_t)N * G * 2 + (size_t)N * C * 4; }
 static int gn_check(int64_t N, int64_t S, int C, int G) {
   if (N <= 0 || S <= 0 || C <= 0 || G <= 0 || N > 65535) return WDNO_EINVAL;
   if ((C & 3) || C > GN_MAXC || (C % G) != 0) return WDNO_EUNSUPPORTED;
@@ -529,8 +535,8 @@ extern "C" int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, c
   if (ws_bytes < wdno_groupnorm_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
   const int nchunk = gn_chunks(S);
   double* part = (double*)ws;
-  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
-  float* gb = cb + (size_t)N * C * 4;
+  float* cb = gn_cb(stats, N, G);
+  float* gb = gn_gb(stats, N, C, G);
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
@@ -554,12 +560,11 @@ extern "C" int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, cons
   if (ws_bytes < wdno_groupnorm_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
   const int nchunk = gn_chunks(S);
   double* part = (double*)ws;
-  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
-  float* gb = cb + (size_t)N * C * 4;
+  const float* cb = gn_cb(const_cast<float*>(stats), N, G);              // the forward's tables (wdno_groupnorm_stats_floats)
+  float* gb = gn_gb(const_cast<float*>(stats), N, C, G);      // entries 2, 3 of a group are this backward's own (the two group means): written by gn_bwd_finalize_kernel
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(nullptr, stats, gamma, beta, ss, nullptr, cb, gb, S, C, G, nchunk, 0.f);
   gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu);
   gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk);
   int gx = stream_grid(S * (C / 4), 256);
@@ -587,8 +592,8 @@ extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma,
   if (ws_bytes < wdno_groupnorm_fwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
   const int nchunk = gn_chunks(S);
   double* part = (double*)ws;
-  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
-  float* gb = cb + (size_t)N * C * 4;
+  float* cb = gn_cb(stats, N, G);
+  float* gb = gn_gb(stats, N, C, G);
   float* mx = (float*)((char*)ws + ((wdno_groupnorm_ws_bytes(N, S, C, G) + 63) & ~(size_t)63));
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
@@ -613,8 +618,8 @@ extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* ga
   if (ws_bytes < wdno_groupnorm_fwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
   const int nchunk = gn_chunks(S);
   double* part = (double*)ws;
-  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
-  float* gb = cb + (size_t)N * C * 4;
+  float* cb = gn_cb(stats, N, G);
+  float* gb = gn_gb(stats, N, C, G);
   float* mx = (float*)((char*)ws + ((wdno_groupnorm_ws_bytes(N, S, C, G) + 63) & ~(size_t)63));
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
@@ -626,6 +631,19 @@ extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* ga
   gn_apply_add_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, residual, y, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, res_rec,
                                                                    y_amax_rec, S, C, silu);
   return wdno_check_launch();
+}
+
+__global__ __launch_bounds__(PRS_THREADS) void gn_bwd_tail_kernel(const double* __restrict__ csp, float* __restrict__ dx_colsum, int nb, int C, int nbx,
+                                                                     const float* __restrict__ dgb, float* __restrict__ dgb_sum, int N) {
+  if ((int)blockIdx.x < nbx) {
+    partial_rows_sum_body<double>(csp, dx_colsum, nb, C, (int)blockIdx.x);
+    return;
+  }
+  const int c = ((int)blockIdx.x - nbx) * PRS_THREADS + threadIdx.x;
+  if (c >= 2 * C) return;
+  double a = 0.0;
+  for (int p = 0; p < N; ++p) a += (double)dgb[(int64_t)p * 2 * C + c];
+  dgb_sum[c] = (float)a;
 }
 
 /* ---- backward with dx delivered as fp16 (hi, lo) planes: see include/wdno_hip.h ---- */
@@ -642,7 +660,7 @@ extern "C" size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C
 }
 extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
                                              const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
-                                             float* dgb_partial, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
+                                             float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
                                              void* ws, size_t ws_bytes, wdno_stream_t s) {
   int rc = gn_check(N, S, C, G);
   if (rc) return rc;
@@ -651,21 +669,23 @@ extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, co
   if (ws_bytes < wdno_groupnorm_bwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
   const int nchunk = gn_chunks(S);
   double* part = (double*)ws;
-  float* cb = (float*)(part + (size_t)N * nchunk * C * 2);
-  float* gb = cb + (size_t)N * C * 4;
+  const float* cb = gn_cb(const_cast<float*>(stats), N, G);
+  float* gb = gn_gb(const_cast<float*>(stats), N, C, G);      // entries 2, 3 of a group are this backward's own (the two group means): written by gn_bwd_finalize_kernel
   char* tail = (char*)ws + ((wdno_groupnorm_ws_bytes(N, S, C, G) + 63) & ~(size_t)63);
   double* csp = (double*)tail;
   float* mx = (float*)(csp + (size_t)N * 128 * C);
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(nullptr, stats, gamma, beta, ss, nullptr, cb, gb, S, C, G, nchunk, 0.f);
   gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
   gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, dx_lo ? bound_rec : nullptr);
   const int gx = gn_planes_grid(N, S, C);
   gn_bwd_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp,
                                                                    S, C, C / G, G, silu);
-  partial_rows_sum_kernel<double><<<cdiv(C, 32), PRS_THREADS, 0, st>>>(csp, dx_colsum, (int)N * gx, C);
+  // one launch for both reductions that end the backward: the column sums of dx (partials of the apply pass) and, when dgb_sum is given, the
+  // sum over the samples of the per-sample parameter-gradient pieces (was a colsum_rows launch of the caller: same fp64 sum in row order)
+  const int nbx = cdiv(C, 32), nby = dgb_sum ? cdiv(2 * C, PRS_THREADS) : 0;
+  gn_bwd_tail_kernel<<<nbx + nby, PRS_THREADS, 0, st>>>(csp, dx_colsum, (int)N * gx, C, nbx, dgb_partial, dgb_sum, (int)N);
   return wdno_check_launch();
 }
 

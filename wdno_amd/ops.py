@@ -1186,7 +1186,7 @@ class _GroupNormAct(torch.autograd.Function):
         nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
         y = torch.empty_like(x)
-        stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
+        stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
         c8_ = c // 8
         if out_planes and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0 and c8_ <= 256 and (c8_ & (c8_ - 1)) == 0:
@@ -1233,12 +1233,14 @@ class _GroupNormAct(torch.autograd.Function):
                 lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
                 rec = _amax_slot(x.device)
                 scale = rec[1:2]
+            red = torch.empty((2 * c,), device=x.device, dtype=torch.float32) if n > 1 else None      # sum over the samples, from the same launch
             _lib.check(lib.wdno_groupnorm_act_bwd_planes(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), _p(cs),
-                                                         _p(dgb), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
+                                                         _p(dgb), _p(red), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
                        'groupnorm_bwd_planes')
             dx = _poison(torch.empty_like(x))     # never written: the convolution reads the planes (and fails loudly if it cannot)
             dx._wdno_planes_only = ((hi, lo, scale), cs, dx._version, CONV_MATH)
-            red = colsum(dgb.reshape(n, 2 * c)) if n > 1 else dgb.reshape(2 * c)
+            if red is None:
+                red = dgb.reshape(2 * c)
             return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None, None
         nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
@@ -1263,7 +1265,7 @@ class _GroupNormActAdd(torch.autograd.Function):
         nb = lib.wdno_groupnorm_fwd_planes_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
         y = torch.empty_like(x)
-        stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
+        stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
         yrec = _new_amax_record(x.device)
         _lib.check(lib.wdno_groupnorm_act_add_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(res), None, _p(y), None, None, None, _p(stats),
