@@ -45,6 +45,8 @@ wrap(torch.Tensor, 'copy_')
 wrap(torch.Tensor, 'zero_')
 wrap(torch.Tensor, 'fill_')
 wrap(torch.Tensor, 'add_')
+wrap(torch.Tensor, 'new_zeros')
+wrap(torch.Tensor, '__getitem__', lambda self, *a, **k: self.is_cuda and self.dim() >= 1 and self.numel() > 1 and False)
 for fn in ('zeros', 'zeros_like', 'cat', 'stack'):
     o = getattr(torch, fn)
 
