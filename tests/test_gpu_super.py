@@ -200,3 +200,43 @@ def test_burgers_super_resolution_cascade_vs_reference(trees):
     e_field = rel_l2(u_fc, gz['u_f'])
     print('Burgers SR cascade vs reference: base sample', e_base, 'SR sample from reference low', e_sr, 'end to end', e_chain, 'fields', e_field)
     assert e_base < CHAIN_TOL and e_sr < CHAIN_TOL and e_chain < 2 * CHAIN_TOL and e_field < 2 * CHAIN_TOL
+
+
+# ------------------------------------------------------------------------------------------------ round 3: Burgers objectives pred_x0 / pred_v
+@pytest.mark.parametrize('obj', ['pred_x0', 'pred_v'])
+def test_burgers_objectives_vs_reference(trees, obj):
+    """objective = 'pred_x0' / 'pred_v' of the Burgers operator: loss weights (diffusion_1d.py:147-156), targets (:596-602) and
+    model_predictions (:229-238) -- loss, gradient norms, DDIM-4 (eta = 1) and ancestral-3 chains against the reference."""
+    gz, m = sub3('bobj_' + obj), META3['bobj_' + obj]
+    kw = dict(m['diffusion']); kw['seq_length'] = tuple(kw['seq_length'])
+    u = m['unet']
+    mk = lambda: trees['Unet2D'](dim=u['dim'], dim_mults=tuple(u['dim_mults']), channels=u['channels'], resnet_block_groups=u['resnet_block_groups'])
+    lw = torch.from_numpy(gz['lw'])
+    dif = trees['GD1'](mk(), loss_layer_weight=lw, **kw)
+    assert dif.objective == obj
+    sd = {k[3:]: torch.from_numpy(v) for k, v in gz.items() if k.startswith('w::')}
+    ref_lw = sd['loss_weight'].double()
+    assert rel_l2(dif.loss_weight.double(), ref_lw) < 1e-6            # snr / snr/(snr+1), float32 of float64 schedule arithmetic
+    dif.load_state_dict(sd, strict=True)
+    dif = dif.to(DEV)
+    t = lambda k: torch.from_numpy(gz[k]).to(DEV)
+    loss = dif.p_losses(t('x0'), t('t'), noise=t('noise'))
+    print(obj, 'loss', loss.item(), float(gz['loss']))
+    assert abs(loss.item() - float(gz['loss'])) < TOL * abs(float(gz['loss']))
+    loss.backward()
+    check_grad_norms(dif, gz)
+    seq = _noises(gz, 'ddim')
+    dif.sample_noise = lambda shp, device: next(seq)
+    out = dif.sample(batch_size=2, u_init=t('u_init'), f=t('f'))
+    e = rel_l2(out, gz['ddim_out'])
+    print(obj, 'ddim4 vs reference', e)
+    assert e < CHAIN_TOL
+    dif3 = trees['GD1'](mk(), loss_layer_weight=lw, **{**kw, 'timesteps': 3, 'sampling_timesteps': None})
+    dif3.load_state_dict({k: v for k, v in sd.items() if k.startswith('model.')}, strict=False)
+    dif3 = dif3.to(DEV)
+    seq3 = _noises(gz, 'ddpm3')
+    dif3.sample_noise = lambda shp, device: next(seq3)
+    out3 = dif3.sample(batch_size=2, u_init=t('u_init'), f=t('f'))
+    e3 = rel_l2(out3, gz['ddpm3_out'])
+    print(obj, 'ddpm3 vs reference', e3)
+    assert e3 < CHAIN_TOL
