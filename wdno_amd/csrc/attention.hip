@@ -409,16 +409,32 @@ __global__ __launch_bounds__(ATT_BIG_THREADS) void attn_bwd_big_kernel(const flo
 // Sum of the per-block relative-position-bias gradient partials in block order: E = heads * n * n outputs, each the sum of nb terms.
 // (Global float atomics summed them in arrival order: the gradient of relative_attention_bias differed from run to run in its last
 // bits, and with it every bit-reproducibility check of a training step.) 64 outputs per block, four partial sums per output.
+#define DBR_EL 8                     // outputs per block
+#define DBR_CH (256 / DBR_EL)        // partial chains per output
 __global__ __launch_bounds__(256) void attn_dbias_reduce_kernel(const float* __restrict__ part, int nb, float* __restrict__ dbias, int E) {
-  __shared__ float red[4][64];
-  const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
-  float acc = 0.f;
-  if (e < E)
-    for (int b = q; b < nb; b += 4) acc += part[(size_t)b * E + e];
-  red[q][el] = acc;
+  // 8 outputs per block (E / 8 = 288 blocks for 4 heads x 24 x 24), 32 chains per output with four independent sums each: the 768
+  // partials of an output are 6 rounds of loads per thread (64 outputs per block and 4 chains were 192 dependent rounds on 36 blocks:
+  // 50 us per launch). The order of every sum is fixed by the indices alone.
+  __shared__ float red[DBR_CH][DBR_EL];
+  const int el = threadIdx.x & (DBR_EL - 1), q = threadIdx.x / DBR_EL;
+  const int e = blockIdx.x * DBR_EL + el;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < E) {
+    int b = q;
+    for (; b + 3 * DBR_CH < nb; b += 4 * DBR_CH) {
+      a0 += part[(size_t)b * E + e]; a1 += part[(size_t)(b + DBR_CH) * E + e];
+      a2 += part[(size_t)(b + 2 * DBR_CH) * E + e]; a3 += part[(size_t)(b + 3 * DBR_CH) * E + e];
+    }
+    for (; b < nb; b += DBR_CH) a0 += part[(size_t)b * E + e];
+  }
+  red[q][el] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (q == 0 && e < E) dbias[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+  if (q == 0 && e < E) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < DBR_CH; ++k) t += red[k][el];
+    dbias[e] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ n_tok <= 32: one wave per item
@@ -1047,7 +1063,7 @@ extern "C" size_t wdno_attn_bwd_ws_bytes(const wdno_attn_desc* d) {
 }
 static int attn_dbias_reduce(const float* part, int64_t nb, float* dbias, const wdno_attn_desc* d, wdno_stream_t s) {
   const int E = d->heads * d->n_tok * d->n_tok;
-  attn_dbias_reduce_kernel<<<(unsigned)((E + 63) / 64), 256, 0, as_stream(s)>>>(part, (int)nb, dbias, E);
+  attn_dbias_reduce_kernel<<<(unsigned)((E + DBR_EL - 1) / DBR_EL), 256, 0, as_stream(s)>>>(part, (int)nb, dbias, E);
   return wdno_check_launch();
 }
 extern "C" int wdno_attn_bwd(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
