@@ -11,6 +11,7 @@
 // folded into the store/load addressing of the pass that touches the coefficient tensor, so no separate
 // packing kernel exists. Taps travel as kernel arguments (<= 16 per filter).
 #include "common.h"
+#include <type_traits>
 #include <algorithm>
 #include <cstdlib>
 
@@ -479,11 +480,17 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
 // ITEMS output columns (ph, pw) and 2 NQ time samples of each, and every staged frame adds its lo / hi contribution to the <= L/2 q-frames it
 // belongs to. Frames are walked in DESCENDING order so that each accumulator receives its terms in the order i = 0, 1, .. of the
 // per-axis kernel (K = q - i): results stay BIT-IDENTICAL to it (tests/test_gpu_dwt_fused.py). wdno_debug 45: the kernel above (A/B).
-template <int L, int MODE, int NQ, int ITEMS>
+// The kernel is bound by VALU issue, not by memory (4 blocks per CU run concurrently; ~2.5 K wave instructions per wave at 4 cycles each were 19 of
+// its 25 us): so (a) everything that does not depend on the frame -- the (band, row, column) decode of a thread's W- and H-pass items, the
+// boundary maps, the LDS offsets -- is computed once before the frame loop, (b) an H-pass item produces BOTH rows 2 ql, 2 ql + 1 from one set
+// of L reads, (c) the global loads of frame e - 1 are issued before the H / T passes of frame e. 30.0 -> 25.3 (c) -> 16.1 us (a, b) at
+// [32,8,18,34,34]; 70.5 -> 56.4 -> 32.5 us at [10,8,34,66,66].
+template <int L, int MODE, int NQ, int ITEMS, int WMAX>
 __global__ __launch_bounds__(256) void dwt_synthesis3_stream_kernel(const float* __restrict__ coef, float* __restrict__ x, FusedGeom g, Taps t) {
   extern __shared__ float lds[];
   constexpr int E = L / 2 - 1;
   constexpr int ET = NQ + E;
+  constexpr int HL = L / 2;
   int b = xcd_tile(blockIdx.x, g.n_blocks);
   const int th = b % g.tiles_h;
   b /= g.tiles_h;
@@ -500,64 +507,103 @@ __global__ __launch_bounds__(256) void dwt_synthesis3_stream_kernel(const float*
   float* S1 = lds;                              // [2 bt][2 bh][EH][NW]
   float* S2 = lds + 4 * EH * NW;                // [2 bt][2 NQH][NW]
   const int n_items = 2 * nqh * NW;             // output columns (ph, pw) of this tile
+  // W-pass items of this thread: the same (band pair, coefficient row, column pair) in every frame, so the index work is done ONCE and a
+  // frame is only its offset Kt * cs0 (the decode per frame was half of the pass's instructions). The loads of frame e - 1 are issued
+  // before the H / T passes of frame e and wait in registers: a block's chain of six exposed global-load latencies (one per frame; the
+  // blocks of a CU all run concurrently, so the kernel lasts as long as ONE block's chain) becomes one.
+  int w_dst[WMAX], w_off[WMAX][HL];
+  unsigned w_ok[WMAX];
+  const int n_w = 4 * EH * QW;
+#pragma unroll
+  for (int k = 0; k < WMAX; ++k) {
+    const int it = threadIdx.x + 256 * k;
+    int q = fd_div(it, g.dQW);
+    const int ql = it - q * QW;
+    const int q2 = fd_div(q, g.dEH), eh = q - q2 * EH;
+    const int bh = q2 & 1, bt = q2 >> 1;
+    const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
+    const bool rowok = Kh >= 0 && it < n_w;
+    const int src = rowok ? (int)((bt * 4 + bh * 2) * g.cs_band + (int64_t)Kh * g.cs1) : 0;      // (host: cs_img < 2^31)
+    w_dst[k] = (it < n_w && eh < eh_used) ? (q2 * EH + eh) * NW + 2 * ql : -1;
+    w_ok[k] = 0;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
+      w_off[k][i] = src + (rowok && Kw >= 0 ? Kw : 0);
+      w_ok[k] |= (rowok && Kw >= 0) ? (1u << i) : 0u;
+    }
+  }
+  float pl[WMAX][HL], ph_[WMAX][HL];
+  auto fetch = [&](int e) {
+    const int Kt = smap<MODE>(qt_start - E + e, g.To);
+    const float* fl = ci + (int64_t)(Kt >= 0 ? Kt : 0) * g.cs0;          // block-uniform bases: the loads are saddr + 32-bit offset
+    const float* fh = fl + g.cs_band;
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k)
+#pragma unroll
+      for (int i = 0; i < HL; ++i) { pl[k][i] = fl[w_off[k][i]]; ph_[k][i] = fh[w_off[k][i]]; }
+  };
+  // H-pass items of this thread: (bt, q-row, column) -> BOTH output rows 2 ql, 2 ql + 1 from the same L reads of S1 (each chain in the
+  // order of the per-axis kernel); offsets fixed for all frames
+  constexpr int HMAX = ITEMS;                   // 2 NQH NW <= 256 ITEMS by the host's choice of NQH
+  int h_src[HMAX], h_dst[HMAX];
+#pragma unroll
+  for (int k = 0; k < HMAX; ++k) {
+    const int it = threadIdx.x + 256 * k;
+    const int q = fd_div(it, g.dFW);            // bt * NQH + ql
+    const int pw = it - q * NW;
+    const int bt = q >= NQH ? 1 : 0, ql = q - bt * NQH;
+    const bool ok = it < 2 * NQH * NW && ql < nqh;
+    h_src[k] = ok ? ((bt * 2) * EH + ql + E) * NW + pw : -1;
+    h_dst[k] = (bt * 2 * NQH + 2 * ql) * NW + pw;
+  }
   float acc[ITEMS][NQ][2];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j)
 #pragma unroll
     for (int qq = 0; qq < NQ; ++qq) { acc[j][qq][0] = 0.f; acc[j][qq][1] = 0.f; }
+  fetch(ET - 1);
 #pragma unroll
   for (int e = ET - 1; e >= 0; --e) {
     const int Kt = smap<MODE>(qt_start - E + e, g.To);
-    if (Kt < 0) continue;                       // a frame outside the tensor contributes fmaf(0, tap, acc) = acc (block-uniform)
-    // pass W: coefficient frame Kt -> S1 (branch-free body, see the kernel above)
-    for (int it = threadIdx.x; it < 4 * EH * QW; it += 256) {
-      int q = fd_div(it, g.dQW);
-      const int ql = it - q * QW;
-      const int q2 = fd_div(q, g.dEH), eh = q - q2 * EH;
-      const int bh = q2 & 1, bt = q2 >> 1;
-      const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
-      const bool rowok = Kh >= 0;
-      const int band_lo = bt * 4 + bh * 2;
-      const float* base = ci + (int64_t)Kt * g.cs0 + (rowok ? (int64_t)Kh * g.cs1 : 0);
-      const float* rl = base + band_lo * g.cs_band;
-      const float* rh = rl + g.cs_band;
-      float cl[L / 2], ch[L / 2];
+    const bool live = Kt >= 0;                  // a frame outside the tensor contributes fmaf(0, tap, acc) = acc (block-uniform)
+    if (live) {
+      // pass W: the prefetched coefficients of frame Kt -> S1
 #pragma unroll
-      for (int i = 0; i < L / 2; ++i) {
-        const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
-        const bool ok = rowok && Kw >= 0;
-        const int kk = Kw >= 0 ? Kw : 0;
-        const float vl = rl[kk], vh = rh[kk];
-        cl[i] = ok ? vl : 0.f;
-        ch[i] = ok ? vh : 0.f;
-      }
-      float a0 = 0.f, a1 = 0.f;
+      for (int k = 0; k < WMAX; ++k) {
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-      for (int i = 0; i < L / 2; ++i) {
-        a0 = fmaf(cl[i], t.lo[2 * i], a0);
-        a0 = fmaf(ch[i], t.hi[2 * i], a0);
-        a1 = fmaf(cl[i], t.lo[2 * i + 1], a1);
-        a1 = fmaf(ch[i], t.hi[2 * i + 1], a1);
+        for (int i = 0; i < HL; ++i) {
+          const bool ok = (w_ok[k] >> i) & 1u;
+          const float cl = ok ? pl[k][i] : 0.f, ch = ok ? ph_[k][i] : 0.f;
+          a0 = fmaf(cl, t.lo[2 * i], a0);
+          a0 = fmaf(ch, t.hi[2 * i], a0);
+          a1 = fmaf(cl, t.lo[2 * i + 1], a1);
+          a1 = fmaf(ch, t.hi[2 * i + 1], a1);
+        }
+        if (w_dst[k] >= 0) *reinterpret_cast<float2*>(S1 + w_dst[k]) = make_float2(a0, a1);
       }
-      if (eh < eh_used) reinterpret_cast<float2*>(S1 + (q2 * EH + eh) * NW)[ql] = make_float2(a0, a1);
     }
+    if (e > 0) fetch(e - 1);
+    if (!live) continue;
     __syncthreads();
     // pass H: S1 -> S2
-    for (int it = threadIdx.x; it < 2 * 2 * NQH * NW; it += 256) {
-      int q = fd_div(it, g.dFW);
-      const int pw = it - q * NW;
-      const int bt = fd_div(q, g.dNQH2), ph = q - bt * 2 * NQH;
-      if (ph >= 2 * nqh) continue;
-      const int ql = ph >> 1, r = ph & 1;
-      const float* cl = S1 + ((bt * 2 + 0) * EH + ql + E) * NW + pw;
-      const float* ch = S1 + ((bt * 2 + 1) * EH + ql + E) * NW + pw;
-      float a = 0.f;
 #pragma unroll
-      for (int i = 0; i < L / 2; ++i) {
-        a = fmaf(cl[-i * NW], r ? t.lo[2 * i + 1] : t.lo[2 * i], a);
-        a = fmaf(ch[-i * NW], r ? t.hi[2 * i + 1] : t.hi[2 * i], a);
+    for (int k = 0; k < HMAX; ++k) {
+      if (h_src[k] < 0) continue;
+      const float* cl = S1 + h_src[k];
+      const float* ch = cl + EH * NW;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < HL; ++i) {
+        const float vl = cl[-i * NW], vh = ch[-i * NW];
+        a0 = fmaf(vl, t.lo[2 * i], a0);
+        a0 = fmaf(vh, t.hi[2 * i], a0);
+        a1 = fmaf(vl, t.lo[2 * i + 1], a1);
+        a1 = fmaf(vh, t.hi[2 * i + 1], a1);
       }
-      S2[(bt * 2 * NQH + ph) * NW + pw] = a;
+      S2[h_dst[k]] = a0;
+      S2[h_dst[k] + NW] = a1;
     }
     __syncthreads();
     // pass T: this frame's term of every q-frame it belongs to (i = qq + E - e in [0, E])
@@ -675,30 +721,33 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
   size_t lds;
   if (ND == 3 && wdno_debug_mode != 45) {
     // streaming kernel: q-rows per tile from the register budget (ITEMS columns of 2 NQ samples per thread) and a 32 KB LDS budget
-    constexpr int ITEMS = 5;
-    // columns per thread actually used: 2 (measured on [32,8,18,34,34] / [10,8,34,66,66]: 5 -> 38.4 / 77.7 us, 3 -> 34.7 / 68.5, 2 -> 30.0 / 70.5, 1 -> 33.4 / 83.8;
-    // the all-frames-in-LDS kernel: 32.5-34.7 / 241): the passes are latency-bound between their barriers, so more, smaller tiles win over less halo
-    const int items_rt = wdno_debug_mode == 46 ? ITEMS : 2;
-    const int NW = g.FW;
-    int nqh = (items_rt * 256) / (2 * NW);
-    const int lds_rows = (int)(fused_lds_budget(32) / ((size_t)NW * sizeof(float)));      // 4 (NQH + E) + 4 NQH rows of NW floats
-    nqh = std::min(nqh, (lds_rows - 4 * E) / 8);
-    nqh = std::min(nqh, g.QH);
-    if (nqh >= 1) {
+    auto stream = [&](auto ITEMS_C, auto NQ_C) -> bool {
+      constexpr int ITEMS = decltype(ITEMS_C)::value, NQS = decltype(NQ_C)::value;
+      const int NW = g.FW;
+      int nqh = (ITEMS * 256) / (2 * NW);
+      const int lds_rows = (int)(fused_lds_budget(32) / ((size_t)NW * sizeof(float)));      // 4 (NQH + E) + 4 NQH rows of NW floats
+      nqh = std::min(nqh, (lds_rows - 4 * E) / 8);
+      nqh = std::min(nqh, g.QH);
+      if (nqh < 1 || g.cs_img >= (1ll << 31)) return false;
       const int tiles = cdiv(g.QH, nqh);
       g.NH = cdiv(g.QH, tiles);
       g.tiles_h = tiles;
-      g.tiles_t = cdiv(g.QT, NQ);
-      lds = (size_t)(4 * (g.NH + E) + 4 * g.NH) * NW * sizeof(float);
+      g.tiles_t = cdiv(g.QT, NQS);
+      const size_t lds = (size_t)(4 * (g.NH + E) + 4 * g.NH) * NW * sizeof(float);
       const int64_t nbs = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
-      if (nbs <= 0x7fffffff && (int64_t)4 * (g.NH + E) * NW * (int64_t)std::max(NW, 2 * (g.NH + E)) < (1ll << 32)) {
-        g.n_blocks = (int)nbs;
-        g.dFW = make_fastdiv(NW); g.dQW = make_fastdiv(NW / 2); g.dEH = make_fastdiv(g.NH + E); g.dNQH2 = make_fastdiv(2 * g.NH);
-        g.debug = 0;
-        dwt_synthesis3_stream_kernel<L, MODE, NQ, ITEMS><<<(int)nbs, 256, lds, st>>>(src, dst, g, taps);
-        return true;
-      }
-    }
+      const int n_w = 4 * (g.NH + E) * (NW / 2);               // W-pass items of a frame: WMAX per thread, held in registers
+      if (nbs > 0x7fffffff || n_w > 8 * 256 || (int64_t)4 * (g.NH + E) * NW * (int64_t)std::max(NW, 2 * (g.NH + E)) >= (1ll << 32)) return false;
+      g.n_blocks = (int)nbs;
+      g.dFW = make_fastdiv(NW); g.dQW = make_fastdiv(NW / 2); g.dEH = make_fastdiv(g.NH + E); g.dNQH2 = make_fastdiv(2 * g.NH);
+      g.debug = 0;
+      if (n_w <= 4 * 256) dwt_synthesis3_stream_kernel<L, MODE, NQS, ITEMS, 4><<<(int)nbs, 256, lds, st>>>(src, dst, g, taps);
+      else dwt_synthesis3_stream_kernel<L, MODE, NQS, ITEMS, 8><<<(int)nbs, 256, lds, st>>>(src, dst, g, taps);
+      return true;
+    };
+    // tile shape: 2 columns per thread, NQ = 4 q-frames per tile. Measured on [32,8,18,34,34] / [10,8,34,66,66] with this kernel (us):
+    // 2 col NQ 4: 16.1 / 33.3; 3 col: 17.2 / 42.0; 4 col: 19.7 / 37.4; 2 col NQ 8: 17.8 / 31.8; 3 col NQ 8: 21.5 / 47.1
+    const bool ok = stream(std::integral_constant<int, 2>{}, std::integral_constant<int, NQ>{});
+    if (ok) return true;
   }
   if (ND == 3) {
     // floats: 2 ET NW (2 EH + 2 NQH), EH = NQH + E
