@@ -1,4 +1,4 @@
-"""DWT / IDWT throughput on the two BASELINE.json shapes (HIP events on the launch stream, inputs resident in HBM).
+"""DWT / IDWT kernel time on the two BASELINE.json shapes (HIP events around graph replays of 20 launches, inputs resident in HBM).
 Algorithmic bytes = input + output of one transform: 2-D per/bior2.4 [64,2,160,128]: 20.97 MB; 3-D zero/bior1.3
 [32,32,64,64]: 38.1 MB."""
 import json
@@ -12,17 +12,21 @@ sys.path.insert(0, ROOT)
 from wdno_amd import wavelets  # noqa: E402
 
 
-def timed(fn, iters=50, warm=5):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+def timed(fn, n=20):
+    """us per launch: n launches captured in one graph (no host gaps between them), 10 replays."""
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(10):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3      # us
+    return e0.elapsed_time(e1) / 10 / n * 1e3
 
 
 def run():

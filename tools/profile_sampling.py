@@ -1,23 +1,24 @@
-"""A few eager DDPM sampling steps of the smoke model at the bench batch (for rocprofv3 --kernel-trace --stats)."""
-import os, sys
+"""Eager DDPM sampling steps of the smoke base model at batch 8 for a kernel trace (rocprofv3 --kernel-trace -- python tools/profile_sampling.py)."""
+import os
+import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-from wdno_amd import _lib, diffusion_core as K
+from wdno_amd import diffusion_core as K
 
-dev = torch.device('cuda', 0)
-_lib.load()
-b = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-dif = bench.build_model(dev, b)
-shape = (b, 24, 42, 40, 40)
+dev = 'cuda'
+dif = bench.build_model(dev)
+shape = (8, 24, 42, 40, 40)
 x = torch.randn(shape, device=dev)
-init = torch.randn(b, 24, 40, 40, device=dev)
-control = torch.randn(b, 24, 16, 40, 40, device=dev)
+init = torch.randn(8, 24, 40, 40, device=dev)
+control = torch.randn(8, 24, 16, 40, 40, device=dev)
 desc = dif._desc(shape, dif.padded_shape)
 src = dif._condition_source(shape, dev, init, control, None)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 with torch.no_grad():
-    for i in range(6):
+    for i in range(n):
         x, _ = dif.p_sample(shape, x, 500 - i)
         x = K.apply_cond(x, src, desc)
 torch.cuda.synchronize()
+print('done', n)

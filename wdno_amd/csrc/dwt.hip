@@ -156,7 +156,7 @@ static inline FastDiv make_fastdiv(int d) {
 __device__ __forceinline__ int fd_div(int n, FastDiv f) { return f.d == 1 ? n : (int)__umulhi((unsigned)n, f.m); }
 
 struct FusedGeom {
-  FastDiv dFW, dNH, dWo, dQW, dEH, dNQH2;
+  FastDiv dFW, dNH, dWo, dQW, dEH, dNQH2, dRW, dQW4;      // (dRW, dQW4: the staged W pass of the 2-D synthesis)
   int n_img, T, H, W, To, Ho, Wo;
   int64_t cs_img, cs_band, cs0, cs1;
   int off, odd_t, odd_h, odd_w;
@@ -262,8 +262,13 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
       S2[((p * 2 + 1) * NH + kh) * FW + c] = hi;
     }
   } else {
+    // 2-D: register pass along H straight from global memory. With periodization (MODE 0) a row of S2 holds ONE period (FW = 2 Wo columns,
+    // set by the host): column c <-> w = (c - off) mod period, and the W pass below wraps its reads -- the L - 2 boundary columns of the
+    // extended row were 272 items for 256 threads at W = 128 (a second round of global loads for 16 threads). The source rows of an item
+    // are consecutive modulo the period: one wrap, then increments (16 boundary maps and 64-bit address products per item before).
     S2 = lds;
     const int ngroups = (nh + NK - 1) / NK;
+    const int PH = g.H + g.odd_h;
     for (int it = threadIdx.x; it < ngroups * FW; it += 256) {
       const int gq = fd_div(it, g.dFW);
       const int c = it - gq * FW, k0 = gq * NK;
@@ -272,16 +277,24 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
 #pragma unroll
       for (int k = 0; k < NK; ++k) { lo[k] = 0.f; hi[k] = 0.f; }
       if (w >= 0) {
+        const int hb = 2 * (kh0 + k0) - off;
+        int hv = MODE == 0 ? wrap_period(hb, PH) : hb;              // MODE 0: position within the period; MODE 1: the row index itself
+        float v[2 * NK + L - 2];
 #pragma unroll
         for (int jj = 0; jj < 2 * NK + L - 2; ++jj) {
-          const int hj = amap<MODE>(2 * (kh0 + k0) - off + jj, g.H, g.odd_h);
-          const float v = hj >= 0 ? xi[(int64_t)hj * g.W + w] : 0.f;
+          int hj;
+          if (MODE == 0) { hj = min(hv, g.H - 1); hv = hv + 1 == PH ? 0 : hv + 1; }
+          else { hj = (hv >= 0 && hv < g.H) ? hv : -1; ++hv; }
+          v[jj] = hj >= 0 ? xi[hj * g.W + w] : 0.f;                  // (host: an image has < 2^31 elements)
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2 * NK + L - 2; ++jj) {
 #pragma unroll
           for (int k = 0; k < NK; ++k) {
             const int m = jj - 2 * k;
             if (m >= 0 && m < L) {
-              lo[k] = fmaf(t.lo[L - 1 - m], v, lo[k]);
-              hi[k] = fmaf(t.hi[L - 1 - m], v, hi[k]);
+              lo[k] = fmaf(t.lo[L - 1 - m], v[jj], lo[k]);
+              hi[k] = fmaf(t.hi[L - 1 - m], v[jj], hi[k]);
             }
           }
         }
@@ -298,6 +311,7 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
   // pass W: LDS -> packed coefficients. float2 reads (index 2 kw + m): conflict-free, and m ascends inside each pair
   float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
   const int Wo = g.Wo;
+  constexpr bool PERIOD_ROWS = ND == 2 && MODE == 0;          // S2 rows hold one period: float2 index kw + i wraps at Wo
   for (int it = threadIdx.x; it < NP * 2 * NH * Wo; it += 256) {
     int q = fd_div(it, g.dWo);
     const int kw = it - q * Wo;
@@ -307,11 +321,13 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
     const int bt = (ND == 3) ? p / NK : 0;
     const int kt = (ND == 3) ? kt0 + p % NK : 0;
     if (ND == 3 && kt >= g.To) continue;
-    const float2* row = reinterpret_cast<const float2*>(S2 + ((p * 2 + bh) * NH + kh) * FW) + kw;
+    const float2* row0 = reinterpret_cast<const float2*>(S2 + ((p * 2 + bh) * NH + kh) * FW);
     float lo = 0.f, hi = 0.f;
 #pragma unroll
     for (int i = 0; i < L / 2; ++i) {
-      const float2 v = row[i];
+      int idx = kw + i;
+      if (PERIOD_ROWS) idx = idx >= Wo ? idx - Wo : idx;
+      const float2 v = row0[idx];
       lo = fmaf(t.lo[L - 1 - 2 * i], v.x, lo);
       hi = fmaf(t.hi[L - 1 - 2 * i], v.x, hi);
       lo = fmaf(t.lo[L - 2 - 2 * i], v.y, lo);
@@ -351,41 +367,57 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
   // Branch-free body: every load is issued unconditionally from a clamped (always valid) address and masked by a select, so that
   // the loads of several items are in flight together (with early-outs the loop was a chain of dependent L2 round trips: 22 of the
   // kernel's 42 us at [32, 8, 18, 34, 34]). A masked term contributes fmaf(0, tap, a) = a, i.e. the skipped fmaf of the per-axis kernel.
+  // WB items per round: their WB * L loads are all requested before the first is used (a thread has 6 items at the Burgers shape; with the
+  // compiler's 2-item unroll that was three dependent round trips to L2 / HBM per block).
+  constexpr int WB = (ND == 2) ? 3 : 2;
+  constexpr int HL = L / 2;
+  const int n_w = NP * 2 * EH * QW;
   if (g.debug != 12)
-#pragma unroll 2
-  for (int it = threadIdx.x; it < NP * 2 * EH * QW; it += 256) {
-    int q = fd_div(it, g.dQW);
-    const int ql = it - q * QW;
-    const int q2 = fd_div(q, g.dEH), eh = q - q2 * EH;
-    const int bh = q2 & 1, p = q2 >> 1;
-    const int bt = (ND == 3) ? p / ET : 0;
-    const int Kt = (ND == 3) ? smap<MODE>(qt_start - E + p % ET, g.To) : 0;
-    const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
-    const bool rowok = Kt >= 0 && Kh >= 0;
-    const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
-    const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
-    const float* base = ci + (rowok ? (int64_t)Kt * g.cs0 + (int64_t)Kh * g.cs1 : 0);
-    const float* rl = base + band_lo * g.cs_band;
-    const float* rh = base + band_hi * g.cs_band;
-    float cl[L / 2], ch[L / 2];
+  for (int it0 = threadIdx.x; it0 < n_w; it0 += 256 * WB) {
+    float cl[WB][HL], ch[WB][HL];
+    unsigned okm[WB];
+    int dst[WB];
 #pragma unroll
-    for (int i = 0; i < L / 2; ++i) {
-      const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
-      const bool ok = rowok && Kw >= 0;
-      const int kk = Kw >= 0 ? Kw : 0;
-      const float vl = rl[kk], vh = rh[kk];
-      cl[i] = ok ? vl : 0.f;
-      ch[i] = ok ? vh : 0.f;
-    }
-    float a0 = 0.f, a1 = 0.f;
+    for (int u = 0; u < WB; ++u) {
+      const bool live = it0 + 256 * u < n_w;
+      const int it = live ? it0 + 256 * u : 0;                  // (a slot past the end decodes item 0: every address stays inside the image)
+      int q = fd_div(it, g.dQW);
+      const int ql = it - q * QW;
+      const int q2 = fd_div(q, g.dEH), eh = q - q2 * EH;
+      const int bh = q2 & 1, p = q2 >> 1;
+      const int bt = (ND == 3) ? p / ET : 0;
+      const int Kt = (ND == 3) ? smap<MODE>(qt_start - E + p % ET, g.To) : 0;
+      const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
+      const bool rowok = live && Kt >= 0 && Kh >= 0;
+      const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
+      const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
+      const int base = rowok ? (int)((int64_t)Kt * g.cs0 + (int64_t)Kh * g.cs1) : 0;        // (host: cs_img < 2^31)
+      const float* rl = ci + band_lo * g.cs_band;
+      const float* rh = ci + band_hi * g.cs_band;
+      okm[u] = 0;
+      dst[u] = (live && eh < eh_used) ? ((p * 2 + bh) * EH + eh) * NW + 2 * ql : -1;
 #pragma unroll
-    for (int i = 0; i < L / 2; ++i) {
-      a0 = fmaf(cl[i], t.lo[2 * i], a0);
-      a0 = fmaf(ch[i], t.hi[2 * i], a0);
-      a1 = fmaf(cl[i], t.lo[2 * i + 1], a1);
-      a1 = fmaf(ch[i], t.hi[2 * i + 1], a1);
+      for (int i = 0; i < HL; ++i) {
+        const int Kw = smap<MODE>(g.qw0 + ql - i, g.Wo);
+        const int o = base + (Kw >= 0 ? Kw : 0);
+        cl[u][i] = rl[o]; ch[u][i] = rh[o];
+        okm[u] |= (rowok && Kw >= 0) ? (1u << i) : 0u;
+      }
     }
-    if (eh < eh_used) reinterpret_cast<float2*>(S1 + ((p * 2 + bh) * EH + eh) * NW)[ql] = make_float2(a0, a1);
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < HL; ++i) {
+        const bool ok = (okm[u] >> i) & 1u;
+        const float vl = ok ? cl[u][i] : 0.f, vh = ok ? ch[u][i] : 0.f;
+        a0 = fmaf(vl, t.lo[2 * i], a0);
+        a0 = fmaf(vh, t.hi[2 * i], a0);
+        a1 = fmaf(vl, t.lo[2 * i + 1], a1);
+        a1 = fmaf(vh, t.hi[2 * i + 1], a1);
+      }
+      if (dst[u] >= 0) *reinterpret_cast<float2*>(S1 + dst[u]) = make_float2(a0, a1);
+    }
   }
   __syncthreads();
   const int wshift = off & 1;                                // position pw <-> n_w = pw - (off & 1)
@@ -473,6 +505,163 @@ __global__ __launch_bounds__(256) void dwt_synthesis_fused_kernel(const float* _
 }
 
 
+// Round 3: 2-D synthesis with the W pass fed from LDS. Ablation of the kernel above at the Burgers shape ([128, 4, 80, 64] -> [128, 160, 128],
+// bior2.4, periodization; 14.8 us for 21 MB; tools/bench_dwt.py): without its loads 8.1 us, without the H pass 9.3, without the W pass 5.6.
+// All 1280 blocks are resident at once (5 per CU) and the kernel lasts as long as ONE block's chain load -> W pass -> H pass -> store:
+// what shortens it is fewer dependent round trips, not fewer instructions (a variant whose blocks walk several tiles with the next tile's
+// rows prefetched into registers was slower for every tile count: 15.3 / 17.2 / 19.8 / 24.5 us at 1 / 2 / 3 / 5 tiles per block).
+//   * staging: the tile's raw coefficient rows go to LDS -- row (band pair bh, coefficient row eh, lo / hi) holds the RW = 4 ceil(QW / 4)
+//     + L / 2 - 1 coefficients K = qw0 - (L / 2 - 1) + p with the boundary rule applied (wrapped or zero). A wave takes whole rows (row
+//     index and map are wave-uniform), a lane the same columns of every row; all loads of a thread are in flight together.
+//   * W pass: an item is FOUR consecutive output pairs of one row: a window of L / 2 + 3 values per band from LDS instead of 4 * L / 2
+//     global loads with a boundary map each.
+//   * H pass: as above (register pass over NQ q-rows per item).
+// Every sum keeps the order i = 0, 1, .. of the per-axis kernel: bit-identical (tests/test_gpu_dwt_fused.py).
+template <int L, int MODE, int NQ, int PMAX>
+__global__ __launch_bounds__(256) void dwt_synthesis2_kernel(const float* __restrict__ coef, float* __restrict__ x, FusedGeom g, Taps t) {
+  extern __shared__ float lds[];
+  constexpr int E = L / 2 - 1, ET = NQ + E, HL = L / 2, RMAX = 2 * NQ + E;       // rows per wave: 4 EH / 4, EH <= 2 NQ + E (host)
+  const int NW = g.FW, QW = NW >> 1, NQH = g.NH, off = g.off;
+  const int EH = NQH + E;
+  const int QW4 = (QW + 3) >> 2, RW = 4 * QW4 + HL - 1;
+  float* S1 = lds;                                            // [2 bh][EH][NW]
+  float* R = lds + 2 * EH * NW;                               // [2 bh][EH][lo, hi][RW]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wshift = off & 1;
+  // columns of this lane in a staged row (two per pass of 128; RW <= 128 PMAX by the host's choice): the same for every tile
+  int kw[PMAX][2];
+  bool colok[PMAX][2];
+#pragma unroll
+  for (int pp = 0; pp < PMAX; ++pp)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pidx = 128 * pp + 64 * h + lane;
+      const int Kw = smap<MODE>(g.qw0 - (HL - 1) + min(pidx, RW - 1), g.Wo);
+      colok[pp][h] = Kw >= 0 && pidx < RW;
+      kw[pp][h] = Kw >= 0 ? Kw : 0;
+    }
+  constexpr int npp = PMAX;
+  float v[PMAX][2][RMAX];
+  auto tile_of = [&](int tile, int& img, int& qh_start) {
+    const int b = xcd_tile(tile, g.n_blocks);
+    const int th = b % g.tiles_h;
+    img = b / g.tiles_h;
+    qh_start = g.qh0 + th * NQH;
+  };
+  auto fetch = [&](int tile) {
+    int img, qh_start;
+    tile_of(tile, img, qh_start);
+    const float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
+#pragma unroll
+    for (int pp = 0; pp < PMAX; ++pp) {
+      if (pp >= npp) break;
+#pragma unroll
+      for (int rr = 0; rr < RMAX; ++rr) {
+        const int r = wave + 4 * rr;                          // r = (bh * EH + eh) * 2 + band
+        if (r >= 4 * EH) break;
+        const int band = r & 1, q2 = r >> 1;
+        const int bh = q2 >= EH ? 1 : 0, eh = q2 - bh * EH;
+        const int Kh = smap<MODE>(qh_start - E + eh, g.Ho);
+        const float* row = ci + (bh + 2 * band) * g.cs_band + (int64_t)(Kh >= 0 ? Kh : 0) * g.cs1;
+        v[pp][0][rr] = row[kw[pp][0]];
+        v[pp][1][rr] = row[kw[pp][1]];
+      }
+    }
+  };
+  const int tile = blockIdx.x;
+  fetch(tile);
+  {
+    int img, qh_start;
+    tile_of(tile, img, qh_start);
+    const int nqh = min(NQH, g.qh0 + g.QH - qh_start);
+    const int eh_used = nqh + E;
+    float* __restrict__ xi = x + (int64_t)img * g.T * g.H * g.W;
+    // registers -> R
+#pragma unroll
+    for (int pp = 0; pp < PMAX; ++pp) {
+      if (pp >= npp) break;
+#pragma unroll
+      for (int rr = 0; rr < RMAX; ++rr) {
+        const int r = wave + 4 * rr;
+        if (r >= 4 * EH) break;
+        const int q2 = r >> 1;
+        const int eh = q2 >= EH ? q2 - EH : q2;
+        const bool rowok = smap<MODE>(qh_start - E + eh, g.Ho) >= 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pidx = 128 * pp + 64 * h + lane;
+          if (pidx < RW) R[r * RW + pidx] = (colok[pp][h] && rowok) ? v[pp][h][rr] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // pass W: R -> S1
+    for (int it = threadIdx.x; it < 2 * EH * QW4; it += 256) {
+      const int q2 = fd_div(it, g.dQW4), j = it - q2 * QW4;    // q2 = bh * EH + eh
+      const int eh = q2 >= EH ? q2 - EH : q2;
+      if (eh >= eh_used) continue;
+      const float* wl = R + (q2 * 2) * RW + 4 * j;
+      const float* wh = wl + RW;
+      float cl[HL + 3], ch[HL + 3];
+#pragma unroll
+      for (int e = 0; e < HL + 3; ++e) { cl[e] = wl[e]; ch[e] = wh[e]; }
+      float o8[8];
+#pragma unroll
+      for (int tq = 0; tq < 4; ++tq) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < HL; ++i) {
+          const float vl = cl[tq + HL - 1 - i], vh = ch[tq + HL - 1 - i];
+          a0 = fmaf(vl, t.lo[2 * i], a0);
+          a0 = fmaf(vh, t.hi[2 * i], a0);
+          a1 = fmaf(vl, t.lo[2 * i + 1], a1);
+          a1 = fmaf(vh, t.hi[2 * i + 1], a1);
+        }
+        o8[2 * tq] = a0; o8[2 * tq + 1] = a1;
+      }
+      float* d = S1 + q2 * NW + 8 * j;
+      if (4 * j + 3 < QW && (NW & 3) == 0) {
+        *reinterpret_cast<float4*>(d) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+      } else {
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+          if (4 * j + tq < QW) { d[2 * tq] = o8[2 * tq]; d[2 * tq + 1] = o8[2 * tq + 1]; }
+      }
+    }
+    __syncthreads();
+    // pass H (registers): items (group of NQ q-rows, pw)
+    const int ngroups = (nqh + NQ - 1) / NQ;
+    for (int it = threadIdx.x; it < ngroups * NW; it += 256) {
+      const int gq = fd_div(it, g.dFW);
+      const int pw = it - gq * NW, q0 = gq * NQ;
+      const int nw = pw - wshift;
+      if (nw < 0 || nw >= g.W) continue;
+      float cl[ET], ch[ET];
+#pragma unroll
+      for (int e = 0; e < ET; ++e) {
+        const bool ok = q0 + e < eh_used;
+        cl[e] = ok ? S1[(q0 + e) * NW + pw] : 0.f;
+        ch[e] = ok ? S1[(EH + q0 + e) * NW + pw] : 0.f;
+      }
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i < L / 2; ++i) {
+            acc = fmaf(cl[qq - i + E], t.lo[r + 2 * i], acc);
+            acc = fmaf(ch[qq - i + E], t.hi[r + 2 * i], acc);
+          }
+          const int nhh = 2 * (qh_start + q0 + qq) + r - off;
+          if (q0 + qq < nqh && nhh >= 0 && nhh < g.H) xi[nhh * g.W + nw] = acc;
+        }
+      }
+    }
+  }
+}
+
 // Round 3: 3-D synthesis that STREAMS over the coefficient frames of its tile. The kernel above keeps the W-pass and H-pass results of
 // all ET = NQ + E coefficient frames of a tile in LDS (12 planes for bior1.3), which leaves room for 2 q-rows per tile at 40 KB: 4896 blocks
 // for [32, 8, 18, 34, 34], each coefficient read 3x through L2 and every W-pass item computed 3x (halo 6/4 in T times 4/2 in H). Here only ONE
@@ -539,9 +728,11 @@ __global__ __launch_bounds__(256) void dwt_synthesis3_stream_kernel(const float*
     const float* fl = ci + (int64_t)(Kt >= 0 ? Kt : 0) * g.cs0;          // block-uniform bases: the loads are saddr + 32-bit offset
     const float* fh = fl + g.cs_band;
 #pragma unroll
-    for (int k = 0; k < WMAX; ++k)
+    for (int k = 0; k < WMAX; ++k) {
+      if (256 * k >= n_w) continue;             // block-uniform: item slots past the tile's count neither load nor compute
 #pragma unroll
       for (int i = 0; i < HL; ++i) { pl[k][i] = fl[w_off[k][i]]; ph_[k][i] = fh[w_off[k][i]]; }
+    }
   };
   // H-pass items of this thread: (bt, q-row, column) -> BOTH output rows 2 ql, 2 ql + 1 from the same L reads of S1 (each chain in the
   // order of the per-axis kernel); offsets fixed for all frames
@@ -571,6 +762,7 @@ __global__ __launch_bounds__(256) void dwt_synthesis3_stream_kernel(const float*
       // pass W: the prefetched coefficients of frame Kt -> S1
 #pragma unroll
       for (int k = 0; k < WMAX; ++k) {
+        if (256 * k >= n_w) continue;
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
@@ -671,7 +863,8 @@ static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d,
   g.off = MODE == 1 ? L - 2 : L / 2 - 1;
   const bool odd = MODE == 0 && odd_rule;
   g.odd_t = odd && (g.T & 1); g.odd_h = odd && (g.H & 1); g.odd_w = odd && (g.W & 1);
-  g.FW = 2 * g.Wo + L - 2;
+  g.FW = (ND == 2 && MODE == 0) ? 2 * g.Wo : 2 * g.Wo + L - 2;        // 2-D periodization: one period per LDS row (see the kernel)
+  if ((int64_t)g.T * g.H * g.W >= (1ll << 31)) return false;
   constexpr int NK = (ND == 3) ? 3 : 4;
   size_t lds;
   if (ND == 3) {
@@ -717,6 +910,7 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
   g.QH = qcount(g.H);
   g.QT = qcount(g.T);
   g.FW = 2 * qcount(g.W);
+  if (g.cs_img >= (1ll << 31) || (int64_t)g.T * g.H * g.W >= (1ll << 31)) return false;      // 32-bit offsets within an image
   constexpr int NQ = (ND == 3) ? 4 : 4;
   size_t lds;
   if (ND == 3 && wdno_debug_mode != 45) {
@@ -764,16 +958,26 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
     long nq_max = (long)(fused_lds_budget(40) / per_row) - E;
     nq_max = std::min<long>(nq_max / NQ * NQ, 2 * NQ);
     if (nq_max < NQ) return false;
-    g.NH = (int)nq_max;
+    g.NH = (int)nq_max;                                       // NH + E <= 2 NQ + E <= 16: the staged W pass keeps one register per row of a wave
     g.tiles_h = cdiv(g.QH, g.NH);
     g.tiles_t = 1;
-    lds = per_row * (size_t)(g.NH + E);
+    lds = per_row * (size_t)(g.NH + E) + (size_t)4 * (g.NH + E) * (4 * ((g.FW / 2 + 3) / 4) + L / 2 - 1) * sizeof(float);      // S1 + the staged raw rows
   }
   const int64_t nb = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
   if (nb > 0x7fffffff) return false;
   g.n_blocks = (int)nb;
   g.dFW = make_fastdiv(g.FW); g.dQW = make_fastdiv(g.FW / 2); g.dEH = make_fastdiv(g.NH + E); g.dNQH2 = make_fastdiv(2 * g.NH);
+  g.dQW4 = make_fastdiv((g.FW / 2 + 3) / 4); g.dRW = make_fastdiv(4 * ((g.FW / 2 + 3) / 4) + L / 2 - 1);
   g.debug = wdno_debug_mode;
+  if (ND == 2 && wdno_debug_mode != 50) {                     // debug 50: the one-tile-per-block kernel (A/B)
+    const int RW = 4 * ((g.FW / 2 + 3) / 4) + L / 2 - 1;
+    if (g.NH + E <= 2 * NQ + E && RW <= 256) {
+      const int grid = (int)nb;
+      if (RW <= 128) dwt_synthesis2_kernel<L, MODE, NQ, 1><<<grid, 256, lds, st>>>(src, dst, g, taps);
+      else dwt_synthesis2_kernel<L, MODE, NQ, 2><<<grid, 256, lds, st>>>(src, dst, g, taps);
+      return true;
+    }
+  }
   if ((int64_t)2 * (NQ + E) * 2 * (g.NH + E) * g.FW * (int64_t)std::max(g.FW, 2 * (g.NH + E)) >= (1ll << 32)) return false;   // fd_div range
   dwt_synthesis_fused_kernel<ND, L, MODE, NQ><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
   return true;
