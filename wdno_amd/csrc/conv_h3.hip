@@ -1129,15 +1129,27 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
     __syncthreads();
     // load: row kk of the tile = w[(k0 + kk)*C*T + c0*T ...], `run` contiguous floats ([c][tap]); zero where k >= K or c >= C
     const int cvalid = min(pt.CT, C - c0);           // may be <= 0 for padding tiles
-    for (int idx = threadIdx.x; idx < pt.KT * run; idx += 256) {
-      const int kk = ps_div(idx, run, m_run), r = idx - kk * run;
-      const int cl = ps_div(r, T, m_T), tap = r - cl * T;
-      float v = 0.f;
-      if (k0 + kk < K && cl < cvalid) {
-        if (parity < 0) v = w[((int64_t)(k0 + kk) * C + c0) * T + r];
-        else v = w[((int64_t)(c0 + cl) * K + (k0 + kk)) * 16 + (3 - (parity >> 1) - 2 * (tap >> 1)) * 4 + (3 - (parity & 1) - 2 * (tap & 1))];
+    // eight loads per thread in flight (one at a time, behind a branch, the 36 loads of a thread per 8 x 128 x 9 tile were a chain of
+    // round trips: 1.17 ms per step for the 563 MB of Burgers weights = 1.45 TB/s over read + write)
+    const int nload = pt.KT * run;
+    for (int idx0 = threadIdx.x; idx0 < nload; idx0 += 256 * 8) {
+      float v[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = min(idx0 + 256 * u, nload - 1);
+        const int kk = ps_div(idx, run, m_run), r = idx - kk * run;
+        const int cl = ps_div(r, T, m_T), tap = r - cl * T;
+        const bool ok = k0 + kk < K && cl < cvalid;
+        const int64_t off = !ok ? 0 : parity < 0 ? ((int64_t)(k0 + kk) * C + c0) * T + r
+                            : ((int64_t)(c0 + cl) * K + (k0 + kk)) * 16 + (3 - (parity >> 1) - 2 * (tap >> 1)) * 4 + (3 - (parity & 1) - 2 * (tap & 1));
+        v[u] = w[off];
+        if (!ok) v[u] = 0.f;
+        dst[u] = idx0 + 256 * u < nload ? (tap * pt.KT + kk) * pt.CTp + cl : -1;
       }
-      tile[(tap * pt.KT + kk) * pt.CTp + cl] = v;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) tile[dst[u]] = v[u];
     }
     __syncthreads();
     // store: items (tap, a_local, group of 8 b's), the group index fastest: 16 contiguous bytes per plane per thread
@@ -1189,7 +1201,12 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const wdno_amax_item* _
   const int64_t n = it.n;
   float m = 0.f;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) m = fmaxf(m, fabsf(x[k]));
+  int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; k + 3 * stride < n; k += 4 * stride) {            // four loads in flight (weights sit at 4-byte-aligned offsets of the flat buffer: no float4)
+    const float a = x[k], b = x[k + stride], c = x[k + 2 * stride], d = x[k + 3 * stride];
+    m = fmaxf(fmaxf(m, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+  }
+  for (; k < n; k += stride) m = fmaxf(m, fabsf(x[k]));
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
