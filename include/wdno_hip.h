@@ -325,6 +325,24 @@ int wdno_linear_rows_fwd(const float* x, int x_stride, const float* w, int w_str
 int wdno_linear_rows_wgrad(const float* x, int x_stride, const float* dy, int dy_stride, float* dw, float* db, int P, int C, int K,
                            wdno_stream_t s);
 
+/* All projections of ONE input x [P][C] (contiguous) in one launch: the scale/shift projections of every ResnetBlock read the same
+ * activated time embedding (conv3d.py:118-133 `self.mlp`, unet.py:151-165). The layers are a device-resident table; k_start = number of
+ * output features of the layers before this one, F = their total. Outputs are concatenations:
+ *   y  : block i = [P][K_i] at float offset P * k_start_i          dy: the same layout
+ *   dw : [F][C] (rows k_start_i .. + K_i = the gradient of weight i),  db: [F]
+ *   dx : [P][C] = sum over all layers; ws of wdno_linear_multi_dgrad_ws_bytes(F, P, C) bytes (partial sums, added in a fixed order). */
+typedef struct wdno_linear_item {
+  const void* w;        /* [K][C] fp32, contiguous */
+  const void* bias;     /* [K] or NULL */
+  int K, k_start;
+} wdno_linear_item;
+int wdno_linear_multi_fwd(const void* table, int n_items, int F, const float* x, float* y, int P, int C, wdno_stream_t s);
+int wdno_linear_multi_wgrad(const void* table, int n_items, int F, const float* x, const float* dy, float* dw, float* db, int P, int C,
+                            wdno_stream_t s);
+size_t wdno_linear_multi_dgrad_ws_bytes(int F, int P, int C);
+int wdno_linear_multi_dgrad(const void* table, int n_items, int F, const float* dy, float* dx, int P, int C, void* ws, size_t ws_bytes,
+                            wdno_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------ pointwise
  * act: 0 = SiLU, 1 = GELU(erf). */
 int wdno_act_fwd(const float* x, float* y, int64_t n, int act, wdno_stream_t s);

@@ -8,6 +8,8 @@ import sys
 import pytest
 import torch
 
+from tests.helpers import rel_l2
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
@@ -124,3 +126,55 @@ def test_default_kernel_selection_of_both_models():
         del ts
         ops.drop_weight_caches()
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('p,c,ks', [(8, 256, (128, 128, 256, 512, 512)), (16, 512, (256, 2048, 1024, 256)), (37, 64, (8, 24, 40))])
+def test_linear_multi_equals_per_layer(p, c, ks):
+    """ops.linear_multi (every ResnetBlock's scale/shift projection of the time embedding in one launch, csrc/linear_rows.hip) against the
+    per-layer path: outputs and weight / bias gradients bit-equal (same sums in the same order), the data gradient -- a sum over the layers
+    in a different order -- to rounding; with the gradient arriving through the hand-over slot, as a fresh tensor, and not at all."""
+    import torch.nn as nn
+    from wdno_amd import ops
+    g = torch.Generator().manual_seed(5)
+    layers = [nn.Linear(c, k).to(DEV) for k in ks]
+    for l in layers:
+        l.weight.data = torch.randn(l.weight.shape, generator=g).to(DEV) * 0.1
+        l.bias.data = torch.randn(l.bias.shape, generator=g).to(DEV)
+    x = torch.randn(p, c, generator=g).to(DEV).requires_grad_(True)
+    gys = [torch.randn(p, k, generator=g).to(DEV) for k in ks]
+    outs = ops.linear_multi(x, layers)
+    assert outs is not None and len(outs) == len(ks)
+    # layer 0: gradient written into the slot (what the GroupNorm backward does); layer 1: a fresh tensor; last layer: unused output
+    slot = outs[0]._wdno_grad_slot
+    assert slot.shape == outs[0].shape
+
+    class ViaSlot(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a):
+            return a.clone()
+
+        @staticmethod
+        def backward(ctx, gy):
+            slot.copy_(gy)
+            return slot
+    loss = (ViaSlot.apply(outs[0]) * gys[0]).sum()
+    for o, gy in zip(outs[1:-1], gys[1:-1]):
+        loss = loss + (o * gy).sum()
+    loss.backward()
+    got = dict(x=x.grad.clone(), w=[l.weight.grad.clone() for l in layers], b=[l.bias.grad.clone() for l in layers], y=[o.detach().clone() for o in outs])
+    x.grad = None
+    for l in layers:
+        l.weight.grad = None; l.bias.grad = None
+    refs = [ops.conv_cl(x, l.weight, l.bias) for l in layers]
+    loss = sum((o * gy).sum() for o, gy in zip(refs[:-1], gys[:-1]))
+    loss.backward()
+    for i, l in enumerate(layers):
+        assert torch.equal(got['y'][i], refs[i].detach()), i
+        if i < len(layers) - 1:
+            assert torch.equal(got['w'][i], l.weight.grad), i
+            assert torch.equal(got['b'][i], l.bias.grad), i
+        else:
+            assert float(got['w'][i].abs().max()) == 0.0 and float(got['b'][i].abs().max()) == 0.0
+    e = rel_l2(got['x'], x.grad)
+    print('linear_multi dgrad vs per-layer', e)
+    assert e < 2e-6

@@ -119,6 +119,10 @@ PROTOTYPES = {
     'wdno_act_bwd': (I, [P, P, P, L, I, P]),
     'wdno_linear_rows_fwd': (I, [P, I, P, I, P, P, I, I, I, I, P]),
     'wdno_linear_rows_wgrad': (I, [P, I, P, I, P, P, I, I, I, P]),
+    'wdno_linear_multi_fwd': (I, [P, I, I, P, P, I, I, P]),
+    'wdno_linear_multi_wgrad': (I, [P, I, I, P, P, P, P, I, I, P]),
+    'wdno_linear_multi_dgrad_ws_bytes': (Z, [I, I, I]),
+    'wdno_linear_multi_dgrad': (I, [P, I, I, P, P, I, I, P, Z, P]),
     'wdno_add': (I, [P, P, P, L, P]),
     'wdno_add_amax': (I, [P, P, P, P, L, P]),
     'wdno_sinusoidal_emb': (I, [P, P, P, I, I, P]),

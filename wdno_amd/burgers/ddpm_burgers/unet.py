@@ -104,9 +104,10 @@ class ResnetBlock(nn.Module):
         self.res_conv = nn.Conv2d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
         self.conv_2d = conv_2d
 
-    def forward(self, x, time_emb=None):
-        scale_shift = None
-        if exists(self.mlp) and exists(time_emb):
+    def forward(self, x, time_emb=None, scale_shift=None):
+        """scale_shift: this block's projection of the time embedding when the caller computed all blocks' projections in one launch
+        (Unet2D.time_projections); otherwise it is computed here."""
+        if scale_shift is None and exists(self.mlp) and exists(time_emb):
             scale_shift = ops.conv_cl(ops.silu_shared(time_emb), self.mlp[1].weight, self.mlp[1].bias)   # [B, 2C] = (scale | shift)
         # block1's output is read by block2's convolution only: where that one takes fp16 planes, the norm writes them
         planes = ops.conv_reads_planes(x.numel() // x.shape[-1], self.block2.proj.weight)
@@ -230,6 +231,17 @@ class Unet2D(nn.Module):
         e = ops.gelu(e)
         return ops.conv_cl(e, self.time_mlp[3].weight, self.time_mlp[3].bias)
 
+    def time_projections(self, t):
+        """The scale/shift projections of all ResnetBlocks, in the order forward() runs them, from one grouped launch (ops.linear_multi: they
+        all read silu(t)); an iterator of Nones when the grouped kernels do not take the shapes (each block then projects for itself)."""
+        blocks = getattr(self, '_time_blocks', None)
+        if blocks is None:
+            blocks = ([b for lv in self.downs for b in lv[:2]] + [self.mid_block1, self.mid_block2] + [b for lv in self.ups for b in lv[:2]]
+                      + [self.final_res_block])
+            object.__setattr__(self, '_time_blocks', blocks)         # (not a submodule list: the blocks are registered where the reference has them)
+        out = ops.linear_multi(ops.silu_shared(t), [b.mlp[1] for b in blocks]) if all(exists(b.mlp) for b in blocks) else None
+        return iter(out if out is not None else [None] * len(blocks))
+
     def forward(self, x, time, x_self_cond=None):
         """x: [B, C, H, W] -> [B, out_dim, H, W]"""
         if self.self_condition:
@@ -239,11 +251,12 @@ class Unet2D(nn.Module):
         x = ops.conv_cl(x, self.init_conv.weight, self.init_conv.bias, padding=3)
         r = x
         t = self.time_embedding(time)
+        ss = self.time_projections(t)
         hs = []
         for block1, block2, attn, downsample in self.downs:
-            x = block1(x, t)
+            x = block1(x, t, next(ss))
             hs.append(x)
-            x = block2(x, t)
+            x = block2(x, t, next(ss))
             x = attn(x)
             hs.append(x)
             if isinstance(downsample, nn.Sequential):
@@ -251,18 +264,18 @@ class Unet2D(nn.Module):
                 x = ops.conv_cl(x, wgt.view(wgt.shape[0], wgt.shape[1] // 4, 2, 2), downsample[1].bias, stride=2, padding=0)
             else:
                 x = ops.conv_cl(x, downsample.weight, downsample.bias, padding=1)
-        x = self.mid_block1(x, t)
+        x = self.mid_block1(x, t, next(ss))
         x = self.mid_attn(x)
-        x = self.mid_block2(x, t)
+        x = self.mid_block2(x, t, next(ss))
         for block1, block2, attn, upsample in self.ups:
             npx = x.numel() // x.shape[-1]
-            x = block1(ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(npx, block1)), t)
-            x = block2(ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(npx, block2)), t)
+            x = block1(ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(npx, block1)), t, next(ss))
+            x = block2(ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(npx, block2)), t, next(ss))
             x = attn(x)
             if isinstance(upsample, nn.Sequential):
                 x = ops.conv_cl(ops.upsample2x_cl(x), upsample[1].weight, upsample[1].bias, padding=1)
             else:
                 x = ops.conv_cl(x, upsample.weight, upsample.bias, padding=1)
-        x = self.final_res_block(ops.concat_cl(x, r, planes_only=ops.resnet_reads_planes(x.numel() // x.shape[-1], self.final_res_block)), t)
+        x = self.final_res_block(ops.concat_cl(x, r, planes_only=ops.resnet_reads_planes(x.numel() // x.shape[-1], self.final_res_block)), t, next(ss))
         x = ops.conv_cl(x, self.final_conv.weight, self.final_conv.bias)
         return ops.cl_to_nc(x, self.out_dim)

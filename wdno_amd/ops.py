@@ -1157,6 +1157,94 @@ class _ConvT(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _LinearItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('K', C.c_int), ('k_start', C.c_int)]
+
+
+_lin_tables = {}          # (weight / bias pointers, C) -> (device table, K list, k_start list, F)
+
+
+def _linear_table(weights, biases, c):
+    key = (tuple(w.data_ptr() for w in weights), tuple(0 if b is None else b.data_ptr() for b in biases), c)
+    tab = _lin_tables.get(key)
+    if tab is None:
+        if len(_lin_tables) > 64:
+            _lin_tables.clear()
+        items = (_LinearItem * len(weights))()
+        ks, start = [], 0
+        for i, (w, b) in enumerate(zip(weights, biases)):
+            items[i] = _LinearItem(w.data_ptr(), None if b is None else b.data_ptr(), w.shape[0], start)
+            ks.append((w.shape[0], start))
+            start += w.shape[0]
+        dev = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(weights[0].device)
+        tab = (dev, ks, start)
+        _lin_tables[key] = tab
+    return tab
+
+
+class _LinearMulti(torch.autograd.Function):
+    """Every ResnetBlock's scale/shift projection of the same activated time embedding in ONE launch (csrc/linear_rows.hip,
+    wdno_linear_multi_*), forward and backward. Outputs are views of one buffer; the gradient buffer is handed to the consumers
+    (`_wdno_grad_slot`: the GroupNorm backward writes d(scale_shift) straight into its slot), so that the backward is three launches
+    -- weight / bias gradients, partial data gradients, their sum -- instead of ~5 per layer."""
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        weights, biases = wb[:n], wb[n:]
+        x = _chk(x, 'x')
+        p, c = x.shape
+        tab, ks, f = _linear_table(weights, biases, c)
+        ybuf = torch.empty((p * f,), device=x.device, dtype=torch.float32)
+        _lib.check(_lib_().wdno_linear_multi_fwd(_p(tab), len(ks), f, _p(x), _p(ybuf), p, c, _stream()), 'linear_multi_fwd')
+        gbuf = torch.empty_like(ybuf)
+        outs = []
+        for k, start in ks:
+            o = ybuf[p * start:p * (start + k)].view(p, k)
+            o._wdno_grad_slot = gbuf[p * start:p * (start + k)].view(p, k)
+            outs.append(o)
+        ctx.save_for_backward(x, *[w for w in weights])
+        ctx.meta = (tab, ks, f, p, c, [b is not None for b in biases])
+        ctx.gbuf = gbuf
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        x = ctx.saved_tensors[0]
+        tab, ks, f, p, c, has_bias = ctx.meta
+        gbuf = ctx.gbuf
+        for (k, start), g in zip(ks, gys):
+            slot = gbuf[p * start:p * (start + k)].view(p, k)
+            if g is None:
+                slot.zero_()
+            elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
+                slot.copy_(g)                      # a gradient that did not come through the slot (another consumer, an accumulated sum)
+        lib = _lib_()
+        n = len(ks)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((p, c), device=x.device, dtype=torch.float32)
+            nb = lib.wdno_linear_multi_dgrad_ws_bytes(f, p, c)
+            ws = _ws(nb, x.device)
+            _lib.check(lib.wdno_linear_multi_dgrad(_p(tab), n, f, _p(gbuf), _p(gx), p, c, _p(ws), nb, _stream()), 'linear_multi_dgrad')
+        gw = torch.empty((f, c), device=x.device, dtype=torch.float32)
+        gb = torch.empty((f,), device=x.device, dtype=torch.float32)
+        _lib.check(lib.wdno_linear_multi_wgrad(_p(tab), n, f, _p(x), _p(gbuf), _p(gw), _p(gb), p, c, _stream()), 'linear_multi_wgrad')
+        gws = tuple(gw[start:start + k] if ctx.needs_input_grad[2 + i] else None for i, (k, start) in enumerate(ks))
+        gbs = tuple(gb[start:start + k] if hb and ctx.needs_input_grad[2 + n + i] else None for i, ((k, start), hb) in enumerate(zip(ks, has_bias)))
+        return (gx, None) + gws + gbs
+
+
+def linear_multi(x, layers):
+    """[layer(x) for layer in layers] for nn.Linear layers that all read x [P, C] (P <= LINEAR_ROWS_MAX): one launch. Returns None when the
+    shapes are not the ones the grouped kernels take (the caller then projects layer by layer)."""
+    if not layers or x.dim() != 2 or x.shape[0] > LINEAR_ROWS_MAX or x.shape[1] % 4 or x.shape[1] > 512 or x.dtype != torch.float32:
+        return None
+    ws = [l.weight for l in layers]
+    if any(w.dim() != 2 or w.shape[1] != x.shape[1] or w.shape[0] % 4 or not w.is_contiguous() or w.dtype != torch.float32 for w in ws):
+        return None
+    bs = [l.bias for l in layers]
+    return list(_LinearMulti.apply(x, len(ws), *ws, *bs))
+
+
 def conv_transpose_h3(xplanes, shape4, weight, bias_p, cout_p, amax_rec=None):
     """Parity-class form of the transposed convolution on the split-fp16 kernels: 4 launches writing interleaved outputs."""
     n, d, h, w = shape4
@@ -1188,6 +1276,7 @@ class _GroupNormAct(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
+        ctx.ss_slot = getattr(ss, '_wdno_grad_slot', None) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
         c8_ = c // 8
         if out_planes and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0 and c8_ <= 256 and (c8_ & (c8_ - 1)) == 0:
             nbp = lib.wdno_groupnorm_fwd_planes_ws_bytes(n, s, c, groups)
@@ -1222,7 +1311,7 @@ class _GroupNormAct(torch.autograd.Function):
         gy = _chk(gy, 'grad')
         lib = _lib_()
         dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
-        dss = None if ss is None else torch.empty_like(ss)
+        dss = None if ss is None else (ctx.ss_slot if getattr(ctx, 'ss_slot', None) is not None else torch.empty_like(ss))
         if ctx.grad_planes and CONV_MATH in ('f16x3', 'bf16'):
             nb = lib.wdno_groupnorm_bwd_planes_ws_bytes(n, s, c, groups)
             ws = _ws(nb, x.device)
@@ -1267,6 +1356,7 @@ class _GroupNormActAdd(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
+        ctx.ss_slot = getattr(ss, '_wdno_grad_slot', None) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
         yrec = _new_amax_record(x.device)
         _lib.check(lib.wdno_groupnorm_act_add_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(res), None, _p(y), None, None, None, _p(stats),
                                                          None, _p(yrec), n, s, c, groups, float(eps), int(act_silu), _p(ws), nb, _stream()),

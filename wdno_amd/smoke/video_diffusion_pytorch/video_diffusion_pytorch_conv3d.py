@@ -135,9 +135,10 @@ class ResnetBlock(nn.Module):
         self.block2 = Block(dim_out, dim_out, groups=groups)
         self.res_conv = nn.Conv3d(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
-    def forward(self, x, time_emb=None):
-        scale_shift = None
-        if exists(self.mlp):
+    def forward(self, x, time_emb=None, scale_shift=None):
+        """scale_shift: this block's projection of the time embedding when the caller has computed the projections of all blocks in one
+        launch (Unet3D_with_Conv3D.time_projections); otherwise it is computed here."""
+        if exists(self.mlp) and scale_shift is None:
             assert exists(time_emb), 'time emb must be passed in'
             # [B, 2*C]: first half = scale, second half = shift (chunk(2, dim=1) in the reference)
             scale_shift = ops.conv_cl(ops.silu_shared(time_emb), self.mlp[1].weight, self.mlp[1].bias)
@@ -309,6 +310,16 @@ class Unet3D_with_Conv3D(nn.Module):
         e = ops.gelu(e)
         return ops.conv_cl(e, self.time_mlp[3].weight, self.time_mlp[3].bias)
 
+    def time_projections(self, t):
+        """The scale/shift projections of all ResnetBlocks, in the order forward() runs them, from one grouped launch (ops.linear_multi: they
+        all read silu(t)); an iterator of Nones when the grouped kernels do not take the shapes (each block then projects for itself)."""
+        blocks = getattr(self, '_time_blocks', None)
+        if blocks is None:
+            blocks = [b for lv in self.downs for b in lv[:2]] + [self.mid_block1, self.mid_block2] + [b for lv in self.ups for b in lv[:2]]
+            object.__setattr__(self, '_time_blocks', blocks)         # (not a submodule list: the blocks are registered where the reference has them)
+        out = ops.linear_multi(ops.silu_shared(t), [b.mlp[1] for b in blocks]) if all(exists(b.mlp) for b in blocks) else None
+        return iter(out if out is not None else [None] * len(blocks))
+
     def forward(self, x, time, cond=None, null_cond_prob=0., focus_present_mask=None, prob_focus_present=0.):
         """x: [B, F, C, H, W] (frames before channels, as handed over by GaussianDiffusion) -> same shape."""
         assert cond is None, 'cond must be None (has_cond is False on the WDNO path)'
@@ -323,11 +334,12 @@ class Unet3D_with_Conv3D(nn.Module):
         x = self.init_temporal_attn(x, pos_bias=pos_bias)
         r = x
         t = self.time_embedding(time)
+        ss = self.time_projections(t)
 
         hs = []
         for block1, block2, spatial_attn, temporal_attn, downsample in self.downs:
-            x = block1(x, t)
-            x = block2(x, t)
+            x = block1(x, t, next(ss))
+            x = block2(x, t, next(ss))
             if not isinstance(spatial_attn, nn.Identity):
                 x = spatial_attn(x)
             x = temporal_attn(x, pos_bias=pos_bias, focus_present_mask=focus_present_mask)
@@ -335,15 +347,15 @@ class Unet3D_with_Conv3D(nn.Module):
             if not isinstance(downsample, nn.Identity):
                 x = ops.conv_cl(x, downsample.weight, downsample.bias, stride=(1, 2, 2), padding=(0, 1, 1))
 
-        x = self.mid_block1(x, t)
+        x = self.mid_block1(x, t, next(ss))
         x = self.mid_spatial_attn(x)
         x = self.mid_temporal_attn(x, pos_bias=pos_bias, focus_present_mask=focus_present_mask)
-        x = self.mid_block2(x, t)
+        x = self.mid_block2(x, t, next(ss))
 
         for block1, block2, spatial_attn, temporal_attn, upsample in self.ups:
             x = ops.concat_cl(x, hs.pop(), planes_only=ops.resnet_reads_planes(x.numel() // x.shape[-1], block1))
-            x = block1(x, t)
-            x = block2(x, t)
+            x = block1(x, t, next(ss))
+            x = block2(x, t, next(ss))
             if not isinstance(spatial_attn, nn.Identity):
                 x = spatial_attn(x)
             x = temporal_attn(x, pos_bias=pos_bias, focus_present_mask=focus_present_mask)
