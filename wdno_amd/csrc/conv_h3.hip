@@ -1037,7 +1037,10 @@ static void wgrad_h3_reduce_launch(const float* ws, float* dw, int64_t n, int sp
   const int T = g->kd * g->kh * g->kw;
   // (layers with many splits are the small ones: K * C / 64 blocks that each walk T x splits segments are too few and too serial there --
   // 64 -> 64 channels with 18 splits took 2x the scatter kernel's time, +1.1 ms per smoke step when used everywhere)
-  if (T <= 64 && splits <= 2 && wdno_debug_mode != 38) {             // debug 38: the scatter kernel (A/B)
+  // ... but a layer with >= 512 (k, 64-channel) blocks and a handful of splits (256 -> 256 at level 2: 1024 blocks, 3 splits) has enough of them, and
+  // the scatter kernel's 4-byte stores 27 floats apart are what it pays for (31-33 us per launch, 7 launches per smoke step)
+  const bool big = (int64_t)Kn * cdiv(Cn, 64) >= 512 && splits <= 8 && wdno_debug_mode != 39;
+  if (T <= 64 && (splits <= 2 || big) && wdno_debug_mode != 38) {             // debug 38: the scatter kernel (A/B)
     wgrad_h3_reduce_tile_kernel<<<dim3(cdiv(Cn, 64), Kn), 256, 0, st>>>(ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
     return;
   }
