@@ -446,6 +446,9 @@ __global__ __launch_bounds__(256) void attn_dbias_reduce_kernel(const float* __r
 //   them (step m <-> e = m), so P^T feeds the second MFMA without moving data; V is read as coalesced 128-byte rows.
 // The backward needs P and dS with the roles of the lanes swapped (lane = key) for dK / dV: two 32x33 tiles per wave in LDS.
 #define AM_WAVES 4
+#ifndef ATT_BWD_BLOCKS_PER_CU
+#define ATT_BWD_BLOCKS_PER_CU 3      /* 4 (128 registers, 22 spilled): 457 / 139 / 70 us vs 458 / 126 / 75 at hw = 1600 / 400 / 100: no gain */
+#endif
 // wave-uniform pointer in SGPRs: the per-lane part of an address stays a 32-bit offset (global_load saddr + voffset)
 __device__ __forceinline__ const float* am_uniform(const float* p) {
   uint64_t a = reinterpret_cast<uint64_t>(p);
@@ -720,7 +723,7 @@ __device__ __forceinline__ float4 am_unrotate4(float4 g, const float* __restrict
 }
 
 template <int NT>
-__global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
+__global__ __launch_bounds__(64 * AM_WAVES, ATT_BWD_BLOCKS_PER_CU) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ rcos,
                                                                        const float* __restrict__ rsin, const float* __restrict__ bias,
                                                                        const float* __restrict__ fout, const float* __restrict__ dout,
                                                                        float* __restrict__ dqkv, float* __restrict__ dbias, AttnP p) {
@@ -1051,7 +1054,7 @@ static int attn_fwd_rows(const float* qkv, const float* rot_cos, const float* ro
 // blocks of the backward launch (= number of dbias partials) and the workspace that holds them
 static int64_t attn_bwd_blocks(const wdno_attn_desc* d) {
   const int64_t items = (int64_t)d->n_uo * d->n_ui * d->heads;
-  if (d->n_tok <= 32 && wdno_debug_mode != 5) return attn_grid(items, 3, 2048);
+  if (d->n_tok <= 32 && wdno_debug_mode != 5) return attn_grid(items, ATT_BWD_BLOCKS_PER_CU, 2048);
   int ipb = ATT_BWD_THREADS / d->n_tok;
   if (ipb < 1) ipb = 1;
   int64_t groups = (items + ipb - 1) / ipb;
@@ -1085,7 +1088,7 @@ extern "C" int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const 
   // one wave per item on MFMA tiles (debug 5: thread-per-row kernel below); 116 registers and 9 KB of LDS per wave, so four
   // waves per SIMD hide its five dependent load phases (0.94 vs 1.17 ms at the 40 x 40 level)
   if (n <= 32 && wdno_debug_mode != 5) {
-    size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
+    size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias && d->heads != AM_WAVES ? (size_t)d->heads * n * n : 0)) * sizeof(float);      // (heads == AM_WAVES: the partial lives in registers)
     const int64_t nb = attn_bwd_blocks(d);                   // also the number of dbias partials
     p.amax_rec = amax_rec;
     (d->n_tok == 24 && wdno_debug_mode != 44 ? attn_bwd_mfma_kernel<24> : attn_bwd_mfma_kernel<0>)<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, part, p);
@@ -1107,7 +1110,7 @@ extern "C" int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, cons
   if (n > 32 || wdno_debug_mode == 5 || !dqkv_hi || (dqkv_lo && (!dqkv_scale || !rec_qkv || !rec_dout))) return WDNO_EUNSUPPORTED;      // dqkv_lo == NULL: one bf16 plane, no scale
   if (dbias && (!ws || ws_bytes < wdno_attn_bwd_ws_bytes(d))) return WDNO_EWORKSPACE;
   float* part = dbias ? (float*)ws : nullptr;
-  size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias ? (size_t)d->heads * n * n : 0)) * sizeof(float);
+  size_t lds2 = ((size_t)AM_WAVES * (2 * 32 * AM_TS + 32) + (dbias && d->heads != AM_WAVES ? (size_t)d->heads * n * n : 0)) * sizeof(float);      // (heads == AM_WAVES: the partial lives in registers)
   const int64_t nb = attn_bwd_blocks(d);
   p.pl_hi = (_Float16*)dqkv_hi; p.pl_lo = (_Float16*)dqkv_lo; p.rec_qkv = rec_qkv; p.rec_dout = rec_dout; p.pl_scale = dqkv_scale;
   (d->n_tok == 24 && wdno_debug_mode != 44 ? attn_bwd_mfma_kernel<24> : attn_bwd_mfma_kernel<0>)<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, nullptr, part, p);
