@@ -863,6 +863,7 @@ def _pad_vec(v, n):
     return out
 
 
+LINEAR_MULTI_ROWS_MAX = 256    # the grouped projections (linear_multi) still beat ~40 GEMM launches at batch 256 (Burgers bf16: 103.5 -> 102.3 ms)
 LINEAR_ROWS_MAX = 64      # at most LR_MAXROWS of csrc/linear_rows.hip. Beyond ~64 rows
 # (the time MLPs at batch 256) the GEMM kernels win: Burgers bf16 step 123.5 -> 119.5 ms
 
@@ -1236,7 +1237,7 @@ class _LinearMulti(torch.autograd.Function):
 def linear_multi(x, layers):
     """[layer(x) for layer in layers] for nn.Linear layers that all read x [P, C] (P <= LINEAR_ROWS_MAX): one launch. Returns None when the
     shapes are not the ones the grouped kernels take (the caller then projects layer by layer)."""
-    if not layers or x.dim() != 2 or x.shape[0] > LINEAR_ROWS_MAX or x.shape[1] % 4 or x.shape[1] > 512 or x.dtype != torch.float32:
+    if not layers or x.dim() != 2 or x.shape[0] > LINEAR_MULTI_ROWS_MAX or x.shape[1] % 4 or x.shape[1] > 512 or x.dtype != torch.float32:
         return None
     ws = [l.weight for l in layers]
     if any(w.dim() != 2 or w.shape[1] != x.shape[1] or w.shape[0] % 4 or not w.is_contiguous() or w.dtype != torch.float32 for w in ws):
