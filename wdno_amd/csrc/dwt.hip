@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
     S2 = lds + 2 * NK * FH * FW;
     kt0 = tt * NK;
     const int64_t fs = (int64_t)g.H * g.W;
+    // (measured and dropped: batches of 2 / 3 items with all their frame loads requested first and 32-bit offsets: 25.4-25.9 us against 17.8)
     for (int it = threadIdx.x; it < rows * FW; it += 256) {
       const int r = fd_div(it, g.dFW), c = it - r * FW;
       const int h = amap<MODE>(2 * kh0 - off + r, g.H, g.odd_h);
@@ -245,21 +246,30 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
       }
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < NP * NH * FW; it += 256) {
-      int q = fd_div(it, g.dFW);
-      const int c = it - q * FW;
-      const int p = fd_div(q, g.dNH), kh = q - p * NH;
-      if (kh >= nh) continue;
-      const float* col = S1 + (p * FH + 2 * kh) * FW + c;
-      float lo = 0.f, hi = 0.f;
+    // pass H: an item is a COLUMN (plane p, column c) of S1: its nh outputs slide a window of L values down the column (two new reads per
+    // output instead of L, one index decode per column instead of one per output); every sum in the order m = 0 .. L - 1 as before
+    for (int it = threadIdx.x; it < NP * FW; it += 256) {
+      const int p = fd_div(it, g.dFW), c = it - p * FW;
+      const float* col = S1 + p * FH * FW + c;
+      float* o0 = S2 + (p * 2 * NH) * FW + c;
+      float w[L];
 #pragma unroll
-      for (int m = 0; m < L; ++m) {
-        const float v = col[m * FW];
-        lo = fmaf(t.lo[L - 1 - m], v, lo);
-        hi = fmaf(t.hi[L - 1 - m], v, hi);
+      for (int m = 0; m < L - 2; ++m) w[m + 2] = col[m * FW];
+      col += (L - 2) * FW;
+      for (int kh = 0; kh < nh; ++kh) {
+#pragma unroll
+        for (int m = 0; m < L - 2; ++m) w[m] = w[m + 2];
+        w[L - 2] = col[0]; w[L - 1] = col[FW];
+        col += 2 * FW;
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int m = 0; m < L; ++m) {
+          lo = fmaf(t.lo[L - 1 - m], w[m], lo);
+          hi = fmaf(t.hi[L - 1 - m], w[m], hi);
+        }
+        o0[kh * FW] = lo;
+        o0[(NH + kh) * FW] = hi;
       }
-      S2[((p * 2 + 0) * NH + kh) * FW + c] = lo;
-      S2[((p * 2 + 1) * NH + kh) * FW + c] = hi;
     }
   } else {
     // 2-D: register pass along H straight from global memory. With periodization (MODE 0) a row of S2 holds ONE period (FW = 2 Wo columns,
@@ -312,9 +322,13 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
   float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
   const int Wo = g.Wo;
   constexpr bool PERIOD_ROWS = ND == 2 && MODE == 0;          // S2 rows hold one period: float2 index kw + i wraps at Wo
-  for (int it = threadIdx.x; it < NP * 2 * NH * Wo; it += 256) {
-    int q = fd_div(it, g.dWo);
-    const int kw = it - q * Wo;
+  // an item = FOUR consecutive coefficients of one row: a window of L / 2 + 3 float2 reads (instead of 4 L / 2) and one row decode
+  constexpr int HLW = L / 2;
+  const int Wo4 = (Wo + 3) >> 2;
+  const int rmax = PERIOD_ROWS ? Wo - 1 : (FW >> 1) - 1;       // last float2 of a row
+  for (int it = threadIdx.x; it < NP * 2 * NH * Wo4; it += 256) {
+    int q = fd_div(it, g.dQW4);
+    const int kw0 = (it - q * Wo4) * 4;
     const int q2 = fd_div(q, g.dNH), kh = q - q2 * NH;
     if (kh >= nh) continue;
     const int bh = q2 & 1, p = q2 >> 1;
@@ -322,22 +336,31 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
     const int kt = (ND == 3) ? kt0 + p % NK : 0;
     if (ND == 3 && kt >= g.To) continue;
     const float2* row0 = reinterpret_cast<const float2*>(S2 + ((p * 2 + bh) * NH + kh) * FW);
-    float lo = 0.f, hi = 0.f;
+    float2 v[HLW + 3];
 #pragma unroll
-    for (int i = 0; i < L / 2; ++i) {
-      int idx = kw + i;
+    for (int i = 0; i < HLW + 3; ++i) {
+      int idx = kw0 + i;
       if (PERIOD_ROWS) idx = idx >= Wo ? idx - Wo : idx;
-      const float2 v = row0[idx];
-      lo = fmaf(t.lo[L - 1 - 2 * i], v.x, lo);
-      hi = fmaf(t.hi[L - 1 - 2 * i], v.x, hi);
-      lo = fmaf(t.lo[L - 2 - 2 * i], v.y, lo);
-      hi = fmaf(t.hi[L - 2 - 2 * i], v.y, hi);
+      v[i] = row0[min(idx, rmax)];                             // (past the row only for the coefficients kw >= Wo of a ragged last group: not stored)
     }
     const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
     const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
-    float* o = ci + (int64_t)kt * g.cs0 + (int64_t)(kh0 + kh) * g.cs1 + kw;
-    o[band_lo * g.cs_band] = lo;
-    o[band_hi * g.cs_band] = hi;
+    float* o = ci + (int64_t)kt * g.cs0 + (int64_t)(kh0 + kh) * g.cs1 + kw0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int i = 0; i < HLW; ++i) {
+        lo = fmaf(t.lo[L - 1 - 2 * i], v[u + i].x, lo);
+        hi = fmaf(t.hi[L - 1 - 2 * i], v[u + i].x, hi);
+        lo = fmaf(t.lo[L - 2 - 2 * i], v[u + i].y, lo);
+        hi = fmaf(t.hi[L - 2 - 2 * i], v[u + i].y, hi);
+      }
+      if (kw0 + u < Wo) {
+        o[band_lo * g.cs_band + u] = lo;
+        o[band_hi * g.cs_band + u] = hi;
+      }
+    }
   }
 }
 
@@ -890,7 +913,7 @@ static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d,
   const int64_t nb = (int64_t)g.n_img * g.tiles_t * g.tiles_h;
   if (nb > 0x7fffffff) return false;
   g.n_blocks = (int)nb;
-  g.dFW = make_fastdiv(g.FW); g.dNH = make_fastdiv(g.NH); g.dWo = make_fastdiv(g.Wo);
+  g.dFW = make_fastdiv(g.FW); g.dNH = make_fastdiv(g.NH); g.dWo = make_fastdiv(g.Wo); g.dQW4 = make_fastdiv((g.Wo + 3) / 4);
   if ((int64_t)2 * NK * 2 * g.NH * std::max(g.FW, g.Wo) * (int64_t)std::max(g.FW, g.NH) >= (1ll << 32)) return false;   // fd_div range
   dwt_analysis_fused_kernel<ND, L, MODE, NK><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
   return true;
