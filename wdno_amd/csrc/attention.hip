@@ -1202,10 +1202,15 @@ template <int MODE>
 __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restrict__ qkv, const float* __restrict__ other,
                                                            const float* __restrict__ kstats, const float* __restrict__ ctx_in,
                                                            float* __restrict__ ctx_out, float* __restrict__ tvec,
-                                                           int n, int heads, float scale) {
+                                                           int n, int heads, float scale, int chunks = 1, float* __restrict__ part = nullptr) {
+  // chunks > 1 (few (unit, head) pairs, many tokens: the Burgers U-Net has 16 x 4 of them over 4096 tokens -- 64 blocks on 256 CUs): the
+  // token range is cut into `chunks` pieces, one block each, partial sums go to part[block][32][32] and linattn_ctx_merge_kernel adds them
   __shared__ float red[4][DH][KST];
   const int HD = heads * DH, RW = 3 * HD;
-  const int unit = blockIdx.x / heads, h = blockIdx.x - unit * heads;
+  const int uh = blockIdx.x / chunks, chunk = blockIdx.x - uh * chunks;
+  const int unit = uh / heads, h = uh - unit * heads;
+  const int clen = ((n + chunks - 1) / chunks + 7) & ~7;
+  const int t0 = chunk * clen, t1 = min(n, t0 + clen);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, dd = lane & 31, hh = lane >> 5;
   float km = 0.f, kinvl = 1.f;
   if (MODE == 0) {
@@ -1220,12 +1225,12 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
   // eight token pairs per round: all sixteen row loads of a round are requested before the first is used (one pair per
   // iteration leaves a single 256-byte request in flight per wave and the kernel at ~1.5 TB/s)
   constexpr int UN = 8;
-  for (int j0 = wave * 2; j0 < n; j0 += 8 * UN) {
+  for (int j0 = t0 + wave * 2; j0 < t1; j0 += 8 * UN) {
     float ra[UN], rb[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int j = j0 + 8 * u + hh;
-      const bool ok = j < n;
+      const bool ok = j < t1;
       if (MODE == 0) {
         ra[u] = ok ? base[(int64_t)j * RW + HD] : 0.f;
         rb[u] = ok ? base[(int64_t)j * RW + 2 * HD] : 0.f;
@@ -1236,7 +1241,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const bool ok = j0 + 8 * u + hh < n;
+      const bool ok = j0 + 8 * u + hh < t1;
       float a;
       if (MODE == 0) {
         a = ok ? expf(ra[u] - km) * kinvl : 0.f;
@@ -1253,6 +1258,14 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
   for (int e = 0; e < 16; ++e) red[wave][(e & 3) + 8 * (e >> 2) + 4 * hh][dd] = acc[e];
   __syncthreads();
   // 1024 outputs / 256 threads
+  if (chunks > 1) {
+    float* po = part + (int64_t)blockIdx.x * DH * DH;
+    for (int o = threadIdx.x; o < DH * DH; o += 256) {
+      int r = o >> 5, c = o & 31;
+      po[o] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+    }
+    return;
+  }
   float* co = ctx_out + ((int64_t)unit * heads + h) * DH * DH;
   const float* ci = MODE == 1 ? ctx_in + ((int64_t)unit * heads + h) * DH * DH : nullptr;
   for (int o = threadIdx.x; o < DH * DH; o += 256) {
@@ -1269,6 +1282,48 @@ __global__ __launch_bounds__(256) void linattn_ctx_kernel(const float* __restric
       tvec[((int64_t)unit * heads + h) * DH + threadIdx.x] = t;
     }
   }
+}
+
+// sum of the chunk partials of linattn_ctx_kernel in chunk order; MODE 1 also T[d] = sum_e dctx[d][e] ctx[d][e]
+template <int MODE>
+__global__ __launch_bounds__(256) void linattn_ctx_merge_kernel(const float* __restrict__ part, const float* __restrict__ ctx_in,
+                                                                 float* __restrict__ ctx_out, float* __restrict__ tvec, int chunks) {
+  __shared__ float red[DH][KST];
+  const int64_t uh = blockIdx.x;
+  const float* p0 = part + uh * chunks * DH * DH;
+  float* co = ctx_out + uh * DH * DH;
+  const float* ci = MODE == 1 ? ctx_in + uh * DH * DH : nullptr;
+  for (int o = threadIdx.x; o < DH * DH; o += 256) {
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += p0[c * DH * DH + o];
+    co[o] = v;
+    if (MODE == 1) red[o >> 5][o & 31] = v * ci[o];
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    if (threadIdx.x < DH) {
+      float t = 0.f;
+      for (int c = 0; c < DH; ++c) t += red[threadIdx.x][c];
+      tvec[uh * DH + threadIdx.x] = t;
+    }
+  }
+}
+// pieces of the token range per (unit, head): enough blocks for ~2 per CU, at least 128 tokens each, at most LA_MAXCHUNKS
+#define LA_MAXCHUNKS 16
+static int la_ctx_chunks(int64_t units, int heads, int n_tok) {
+  const int64_t uh = units * heads;
+  int64_t c = (2 * (int64_t)attn_num_cus() + uh - 1) / uh;
+  if (c > n_tok / 128) c = n_tok / 128;
+  if (c > LA_MAXCHUNKS) c = LA_MAXCHUNKS;
+  if (c < 1 || wdno_debug_mode == 52) c = 1;                  // debug 52: one block per (unit, head) (A/B)
+  return (int)c;
+}
+template <int MODE>
+static void la_ctx_launch(const float* qkv, const float* other, const float* kstats, const float* ctx_in, float* ctx_out, float* tvec, float* part,
+                          int64_t units, int n_tok, int heads, float scale, hipStream_t st) {
+  const int chunks = part ? la_ctx_chunks(units, heads, n_tok) : 1;
+  linattn_ctx_kernel<MODE><<<(unsigned)(units * heads * chunks), 256, 0, st>>>(qkv, other, kstats, ctx_in, ctx_out, tvec, n_tok, heads, scale, chunks, part);
+  if (chunks > 1) linattn_ctx_merge_kernel<MODE><<<(unsigned)(units * heads), 256, 0, st>>>(part, ctx_in, ctx_out, tvec, chunks);
 }
 
 // pass 3: out[n][e] = scale * sum_d ctx[d][e] * softmax_d(q[n])[d]; one thread per (token, head)
@@ -1670,7 +1725,8 @@ static int la_check(int64_t units, int n, int heads) {
 }
 // backward workspace: dctx [units,heads,32,32] + T [units,heads,32]
 extern "C" size_t wdno_linattn_ws_bytes(int64_t units, int heads) {
-  return ((size_t)units * heads * DH * DH + (size_t)units * heads * DH) * sizeof(float);
+  const size_t chunk_part = units * heads <= 2 * (int64_t)attn_num_cus() ? (size_t)units * heads * LA_MAXCHUNKS * DH * DH : 0;      // partial contexts of a chunked token range
+  return ((size_t)units * heads * DH * DH + (size_t)units * heads * DH + chunk_part) * sizeof(float);
 }
 extern "C" int wdno_linattn_fwd(const float* qkv, float* out, float* kstats, float* ctx, int64_t units, int n_tok, int heads,
                                 float scale, wdno_stream_t s) {
@@ -1691,7 +1747,9 @@ extern "C" int wdno_linattn_fwd_amax(const float* qkv, float* out, float* kstats
     const int64_t cols = units * heads * DH;
     linattn_kstats_merge_kernel<<<(unsigned)cdiv64(cols, 256), 256, 0, st>>>(ctx, kstats, cols, heads * DH, chunks);
   }
-  linattn_ctx_kernel<0><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, nullptr, kstats, nullptr, ctx, nullptr, n_tok, heads, scale);
+  // (chunk partials of the context go through `out`, which only the output kernel below writes: units * heads * chunks * 1024 floats
+  // <= units * n_tok * HD because chunks <= n_tok / 128)
+  la_ctx_launch<0>(qkv, nullptr, kstats, nullptr, ctx, nullptr, out, units, n_tok, heads, scale, st);
   if (wdno_debug_mode != 5) {            // debug 5: the thread-per-token kernel
     linattn_out_mfma_kernel<<<dim3((unsigned)(units * heads), (unsigned)cdiv(n_tok, 128)), 256, 0, st>>>(qkv, ctx, out, n_tok, heads, scale, amax_rec);
     return wdno_check_launch();
@@ -1713,7 +1771,8 @@ extern "C" int wdno_linattn_bwd_amax(const float* qkv, const float* dout, const 
   hipStream_t st = as_stream(s);
   float* dctx = (float*)ws;
   float* tvec = dctx + (size_t)units * heads * DH * DH;
-  linattn_ctx_kernel<1><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, dout, nullptr, ctx, dctx, tvec, n_tok, heads, scale);
+  float* cpart = ws_bytes >= wdno_linattn_ws_bytes(units, heads) && units * heads <= 2 * (int64_t)attn_num_cus() ? tvec + (size_t)units * heads * DH : nullptr;
+  la_ctx_launch<1>(qkv, dout, nullptr, ctx, dctx, tvec, cpart, units, n_tok, heads, scale, st);
   if (wdno_debug_mode != 5) {            // debug 5: the thread-per-token kernel
     const size_t lds2 = ((size_t)(2 + 4 * 3) * LAM_TILE + 3 * DH) * sizeof(float);
     static bool attr_done = false;
@@ -1741,7 +1800,8 @@ extern "C" int wdno_linattn_bwd_planes(const float* qkv, const float* dout, cons
   hipStream_t st = as_stream(s);
   float* dctx = (float*)ws;
   float* tvec = dctx + (size_t)units * heads * DH * DH;
-  linattn_ctx_kernel<1><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, dout, nullptr, ctx, dctx, tvec, n_tok, heads, scale);
+  float* cpart = ws_bytes >= wdno_linattn_ws_bytes(units, heads) && units * heads <= 2 * (int64_t)attn_num_cus() ? tvec + (size_t)units * heads * DH : nullptr;
+  la_ctx_launch<1>(qkv, dout, nullptr, ctx, dctx, tvec, cpart, units, n_tok, heads, scale, st);
   if (dqkv_lo) {
     rc = wdno_amax_record(dctx, (int64_t)units * heads * DH * DH, rec_dctx, s);
     if (rc) return rc;
@@ -1771,7 +1831,8 @@ extern "C" int wdno_linattn_fwd_planes(const float* qkv, void* out_hi, void* out
     const int64_t cols = units * heads * DH;
     linattn_kstats_merge_kernel<<<(unsigned)cdiv64(cols, 256), 256, 0, st>>>(ctx, kstats, cols, heads * DH, chunks);
   }
-  linattn_ctx_kernel<0><<<(unsigned)(units * heads), 256, 0, st>>>(qkv, nullptr, kstats, nullptr, ctx, nullptr, n_tok, heads, scale);
+  // (chunk partials go through the hi plane: units * heads * chunks * 4096 bytes <= units * n_tok * HD * 2 because chunks <= n_tok / 128)
+  la_ctx_launch<0>(qkv, nullptr, kstats, nullptr, ctx, nullptr, (float*)out_hi, units, n_tok, heads, scale, st);
   linattn_out_mfma_kernel<<<dim3((unsigned)(units * heads), (unsigned)cdiv(n_tok, 128)), 256, 0, st>>>(
       qkv, ctx, nullptr, n_tok, heads, scale, nullptr, (_Float16*)out_hi, (_Float16*)out_lo, rec_qkv, out_scale);
   return wdno_check_launch();
