@@ -11,10 +11,16 @@
 #define GN_MAXC 1024
 
 static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-static inline int gn_chunks(int64_t S) {
+static inline int gn_chunks(int64_t S, int64_t N, int C) {
   int64_t c = cdiv64(S, 64);
   if (c > 64) c = 64;
   if (c < 1) c = 1;
+  // few samples x few rows of many channels (the deep levels of the Burgers U-Net: 16 samples x 64 pixels x 1024 channels was 16 blocks,
+  // 34 us per backward reduction): finer chunks, down to one round of loads (4 rows per row group) each, until ~256 blocks exist
+  int txp = pow2ceil(C >> 2);
+  if (txp > 256) txp = 256;
+  const int nty = 256 / (txp < 1 ? 1 : txp);
+  while (c < 64 && N * c < 256 && S / (2 * c) >= 4 * nty) c *= 2;
   return (int)c;
 }
 
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* _
 // ---------------------------------------------------------------------------------------------- host
 // ws layout: [ double part[N][nchunk][C][2] | float cb[N][C][4] | float gb[N][G][4] ]
 extern "C" size_t wdno_groupnorm_ws_bytes(int64_t N, int64_t S, int C, int G) {
-  size_t part = (size_t)N * gn_chunks(S) * C * 2 * sizeof(double);
+  size_t part = (size_t)N * gn_chunks(S, N, C) * C * 2 * sizeof(double);
   return part + (size_t)N * C * 4 * sizeof(float) + (size_t)N * G * 4 * sizeof(float) + 64;
 }
 // `stats` holds, behind the [N][G] (mean, rstd) pairs, the two tables the forward finalize derives from them -- cb [N][C][4] (per-channel affine)
@@ -543,7 +549,7 @@ extern "C" int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, c
   int rc = gn_check(N, S, C, G);
   if (rc) return rc;
   if (ws_bytes < wdno_groupnorm_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
-  const int nchunk = gn_chunks(S);
+  const int nchunk = gn_chunks(S, N, C);
   double* part = (double*)ws;
   float* cb = gn_cb(stats, N, G);
   float* gb = gn_gb(stats, N, C, G);
@@ -568,7 +574,7 @@ extern "C" int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, cons
   int rc = gn_check(N, S, C, G);
   if (rc) return rc;
   if (ws_bytes < wdno_groupnorm_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
-  const int nchunk = gn_chunks(S);
+  const int nchunk = gn_chunks(S, N, C);
   double* part = (double*)ws;
   const float* cb = gn_cb(const_cast<float*>(stats), N, G);              // the forward's tables (wdno_groupnorm_stats_floats)
   float* gb = gn_gb(const_cast<float*>(stats), N, C, G);      // entries 2, 3 of a group are this backward's own (the two group means): written by gn_bwd_finalize_kernel
@@ -590,7 +596,7 @@ extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const flo
 
 
 extern "C" size_t wdno_groupnorm_fwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
-  return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S) * 2 * sizeof(float) + 128;
+  return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S, N, C) * 2 * sizeof(float) + 128;
 }
 extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
                                              float* y_scale, float* stats, float* bound_rec, int64_t N, int64_t S, int C, int G, float eps,
@@ -600,7 +606,7 @@ extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma,
   const int C8 = C / 8;
   if ((C & 7) || C8 > 256 || (C8 & (C8 - 1))) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_groupnorm_fwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
-  const int nchunk = gn_chunks(S);
+  const int nchunk = gn_chunks(S, N, C);
   double* part = (double*)ws;
   float* cb = gn_cb(stats, N, G);
   float* gb = gn_gb(stats, N, C, G);
@@ -626,7 +632,7 @@ extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* ga
   if ((C & 7) || C8 > 256 || (C8 & (C8 - 1))) return WDNO_EUNSUPPORTED;
   if (!residual || !y || (y_lo && (!y_hi || !res_rec || !bound_rec || !y_scale))) return WDNO_EINVAL;      // y_hi == NULL: fp32 sum only
   if (ws_bytes < wdno_groupnorm_fwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
-  const int nchunk = gn_chunks(S);
+  const int nchunk = gn_chunks(S, N, C);
   double* part = (double*)ws;
   float* cb = gn_cb(stats, N, G);
   float* gb = gn_gb(stats, N, C, G);
@@ -664,7 +670,7 @@ static inline int gn_planes_grid(int64_t N, int64_t S, int C) {
   return gx;
 }
 extern "C" size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
-  return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S) * 2 * sizeof(float) + (size_t)N * 128 * C * sizeof(double) + 64;
+  return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S, N, C) * 2 * sizeof(float) + (size_t)N * 128 * C * sizeof(double) + 64;
 }
 extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
                                              const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
@@ -675,7 +681,7 @@ extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, co
   const int C8 = C / 8;
   if ((C & 7) || C8 > 256 || (C8 & (C8 - 1))) return WDNO_EUNSUPPORTED;     // a thread keeps one group of 8 channels
   if (ws_bytes < wdno_groupnorm_bwd_planes_ws_bytes(N, S, C, G)) return WDNO_EWORKSPACE;
-  const int nchunk = gn_chunks(S);
+  const int nchunk = gn_chunks(S, N, C);
   double* part = (double*)ws;
   const float* cb = gn_cb(const_cast<float*>(stats), N, G);
   float* gb = gn_gb(const_cast<float*>(stats), N, C, G);      // entries 2, 3 of a group are this backward's own (the two group means): written by gn_bwd_finalize_kernel
