@@ -542,7 +542,7 @@ def test_softmax_attention(ops, kind, b, f, h, w):
         assert rel_l2(bd.grad, br.grad) < 5e-6
 
 
-@pytest.mark.parametrize('units,n', [(3, 100), (2, 1600), (1, 37), (4, 16)])
+@pytest.mark.parametrize('units,n', [(3, 100), (2, 1600), (1, 37), (4, 16), (16, 4096), (2, 1000)])      # the last three pairs run with a chunked token range
 def test_linear_attention(ops, units, n):
     heads, dh = 4, 32
     qkv = g((units, n, 3 * heads * dh), 50)
