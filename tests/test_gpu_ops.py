@@ -42,7 +42,8 @@ def from_cl(x):
 
 
 # ----------------------------------------------------------------------------------------------------- layout (bit exact)
-@pytest.mark.parametrize('shape,cp', [((3, 42, 5, 7), 44), ((2, 9, 16, 16), 12), ((1, 64, 33), 64), ((4, 3, 8, 12), 4)])
+@pytest.mark.parametrize('shape,cp', [((3, 42, 5, 7), 44), ((2, 9, 16, 16), 12), ((1, 64, 33), 64), ((4, 3, 8, 12), 4), ((5, 42, 40, 40), 44), ((2, 82, 9, 13), 96),
+                                      ((2, 128, 70), 128), ((1, 200, 65), 256), ((3, 1, 130), 1)])
 def test_layout_roundtrip(ops, shape, cp):
     x = g(shape, 1).float()
     y = ops.nc_to_cl(x.to(DEV), cp)
