@@ -145,8 +145,8 @@ def test_linear_multi_equals_per_layer(p, c, ks):
     outs = ops.linear_multi(x, layers)
     assert outs is not None and len(outs) == len(ks)
     # layer 0: gradient written into the slot (what the GroupNorm backward does); layer 1: a fresh tensor; last layer: unused output
-    slot = outs[0]._wdno_grad_slot
-    assert slot.shape == outs[0].shape
+    slot = ops._claim_grad_slot(outs[0])
+    assert slot.shape == outs[0].shape and ops._claim_grad_slot(outs[0]) is None      # one consumer only
 
     class ViaSlot(torch.autograd.Function):
         @staticmethod
@@ -178,3 +178,24 @@ def test_linear_multi_equals_per_layer(p, c, ks):
     e = rel_l2(got['x'], x.grad)
     print('linear_multi dgrad vs per-layer', e)
     assert e < 2e-6
+
+
+def test_linear_multi_output_with_two_norm_consumers():
+    """A scale/shift tensor read by TWO GroupNorms: only the first may write its gradient into the hand-over slot; the sum must still be right."""
+    import torch.nn as nn
+    from wdno_amd import ops
+    g = torch.Generator().manual_seed(9)
+    lin = nn.Linear(64, 32).to(DEV)
+    x = torch.randn(4, 64, generator=g).to(DEV).requires_grad_(True)
+    a, b = (torch.randn(4, 6, 10, 16, generator=g).to(DEV).requires_grad_(True) for _ in range(2))
+    gamma, beta = torch.ones(16, device=DEV, requires_grad=True), torch.zeros(16, device=DEV, requires_grad=True)
+
+    def run(ss):
+        y = ops.groupnorm_act(a, gamma, beta, 4, ss) + ops.groupnorm_act(b, gamma, beta, 4, ss)
+        (y * y).sum().backward()
+        out = (x.grad.clone(), lin.weight.grad.clone())
+        x.grad = None; lin.weight.grad = None; lin.bias.grad = None; a.grad = None; b.grad = None; gamma.grad = None; beta.grad = None
+        return out
+    got = run(ops.linear_multi(x, [lin])[0])
+    ref = run(ops.conv_cl(x, lin.weight, lin.bias))
+    assert rel_l2(got[0], ref[0]) < 2e-6 and rel_l2(got[1], ref[1]) < 2e-6

@@ -1264,6 +1264,18 @@ def conv_transpose_cl(x, weight, bias=None):
 
 
 # ----------------------------------------------------------------------------------------------------- normalisation
+def _claim_grad_slot(t):
+    """The gradient hand-over slot of a tensor produced by ops.linear_multi, for its FIRST consumer only: a second consumer of the same
+    tensor gets None, returns a fresh gradient, autograd adds the two and _LinearMulti.backward copies the sum into the slot."""
+    slot = getattr(t, '_wdno_grad_slot', None)
+    if slot is not None:
+        try:
+            del t._wdno_grad_slot
+        except AttributeError:
+            pass
+    return slot
+
+
 class _GroupNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, ss, groups, act_silu, eps, out_planes=False):
@@ -1277,7 +1289,7 @@ class _GroupNormAct(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
-        ctx.ss_slot = getattr(ss, '_wdno_grad_slot', None) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
+        ctx.ss_slot = _claim_grad_slot(ss) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
         c8_ = c // 8
         if out_planes and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0 and c8_ <= 256 and (c8_ & (c8_ - 1)) == 0:
             nbp = lib.wdno_groupnorm_fwd_planes_ws_bytes(n, s, c, groups)
@@ -1357,7 +1369,7 @@ class _GroupNormActAdd(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
-        ctx.ss_slot = getattr(ss, '_wdno_grad_slot', None) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
+        ctx.ss_slot = _claim_grad_slot(ss) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
         yrec = _new_amax_record(x.device)
         _lib.check(lib.wdno_groupnorm_act_add_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(res), None, _p(y), None, None, None, _p(stats),
                                                          None, _p(yrec), n, s, c, groups, float(eps), int(act_silu), _p(ws), nb, _stream()),
