@@ -721,7 +721,22 @@ def _wgrad_h3_kernel_name(k, run, window=False):
     return f'conv_wgrad_h3d_kernel<{128 if k > 64 else 64},{bn}>'
 
 
-def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None):
+FLAT_WGRAD = True         # weight gradients of split convolutions land in the trainer's flat gradient buffer (no gather copy for them)
+
+
+def _flat_grad_out(w, shape):
+    """The span of the trainer's flat gradient buffer that belongs to parameter w (trainer.FlatBuffers registers it), as a fresh tensor
+    of `shape`, when the weight-gradient kernel may write there directly: this is the first gradient of w since zero_grad() (w.grad is
+    None and no other node of this backward has claimed the span), so autograd will STORE the returned tensor -- which then already is
+    the flat view gather_grads() would have copied into. None otherwise (the caller allocates)."""
+    v = getattr(w, '_wdno_flat_grad', None)
+    if v is None or not FLAT_WGRAD or w.grad is not None or getattr(w, '_wdno_flat_busy', True) or v.numel() != math.prod(shape) or v.device != w.device:
+        return None
+    w._wdno_flat_busy = True
+    return v.view(shape)
+
+
+def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None, out=None):
     """-> dwp [kd, kh, K8, kw, C8] fp32 from the split planes of x (C8 channels) and dy (K8 channels); with param_kc = (K, C)
     the result comes back as [K, C, kd, kh, kw] (the parameter's layout, padding dropped) straight from the split reduction."""
     xh, xl, sx = xplanes
@@ -745,13 +760,13 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None):
     if xl is None:           # single bf16 plane per operand
         assert param_kc is not None
         kn, cn = param_kc
-        dw = torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
+        dw = out if out is not None else torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
         with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8, window), flops):
             _lib.check(lib.wdno_conv_wgrad_bf16_param(_p(xh), _p(gh), _p(table), _p(dw), kn, cn, _p(ws), nb, C.byref(g), _stream()), 'conv_wgrad_bf16_param')
         return dw
     if param_kc is not None:
         kn, cn = param_kc
-        dw = torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
+        dw = out if out is not None else torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
         with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8, window), flops):
             _lib.check(lib.wdno_conv_wgrad_f16x3_param(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dw), kn, cn, _p(ws), nb,
                                                        C.byref(g), _stream()), 'conv_wgrad_f16x3_param')
@@ -1049,7 +1064,8 @@ class _Conv(torch.autograd.Function):
             if ctx.h3:
                 if gyplanes is None:
                     gyplanes = split_f16(gy5.reshape(-1, kp), grec)
-                gw = conv_wgrad_h3((xh, xl, sx), (n, d, h, w), gyplanes, osp, ks, stride, padding, param_kc=(k, c)).reshape(weight.shape)
+                gw = conv_wgrad_h3((xh, xl, sx), (n, d, h, w), gyplanes, osp, ks, stride, padding, param_kc=(k, c),
+                                   out=_flat_grad_out(weight, (k, c, *ks))).reshape(weight.shape)
             else:
                 dwp = conv_wgrad_raw(x5, gy5, ks, stride, padding)
                 gw = dwp[:, :, :k, :, :c].permute(2, 4, 0, 1, 3).reshape(weight.shape).contiguous()

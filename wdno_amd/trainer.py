@@ -55,6 +55,8 @@ class FlatBuffers:
         self._gather_srcs, self._gather_table, self._gathered = None, None, False
         self._views = [self.flat_grad[o:o + n].view(p.shape) for p, (o, n) in zip(self.params, self.span_list)]
         self._view_ptrs = [v.data_ptr() for v in self._views]
+        for prm, v in zip(self.params, self._views):      # ops._flat_grad_out: weight-gradient kernels write their span of flat_grad directly
+            prm._wdno_flat_grad, prm._wdno_flat_busy = v, False
 
     def params_changed(self):
         """Call after ANY write to flat_param (optimiser step, broadcast, checkpoint load, EMA copy): the packed / split weight
@@ -103,6 +105,7 @@ class FlatBuffers:
             return
         for p in self.params:
             p.grad = None
+            p._wdno_flat_busy = False
 
     def _spans(self):
         off = 0
