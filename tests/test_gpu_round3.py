@@ -199,3 +199,43 @@ def test_linear_multi_output_with_two_norm_consumers():
     got = run(ops.linear_multi(x, [lin])[0])
     ref = run(ops.conv_cl(x, lin.weight, lin.bias))
     assert rel_l2(got[0], ref[0]) < 2e-6 and rel_l2(got[1], ref[1]) < 2e-6
+
+
+def test_weight_gradients_land_in_the_flat_buffer(trees):
+    """ops.FLAT_WGRAD: the split-convolution weight gradients are written into their spans of the trainer's flat gradient buffer (autograd stores
+    the returned view, gather_grads skips it); two optimiser steps are bit-identical to the gather-copy path, and a second backward without
+    zero_grad (gradient accumulation) falls back to fresh tensors."""
+    import copy
+    from wdno_amd import ops
+    from wdno_amd.trainer import TrainStep
+    torch.manual_seed(4)
+    net = trees['Unet2D'](dim=32, dim_mults=(1, 2), channels=9, resnet_block_groups=1)
+    dif0 = trees['GD1'](net, seq_length=(16, 16), is_wavelet=True, pad_mode='periodization', wave_type='bior2.4', padded_shape=[11, 14], ori_shape=[21, 28],
+                        is_super_model=False, timesteps=1000, sampling_timesteps=4, is_condition_pad=True, is_condition_u0=True, is_condition_uT=False,
+                        is_condition_f=True).to(DEV)
+    x = torch.randn(4, 9, 16, 16, device=DEV) * 0.5
+    res = []
+    try:
+        for flag in (True, False):
+            ops.FLAT_WGRAD = flag
+            dif = copy.deepcopy(dif0)
+            ts = TrainStep(dif, lr=1e-3)
+            torch.manual_seed(11)
+            for _ in range(2):
+                ts.step(x)
+            res.append(ts.opt.buf.flat_param.clone())
+            if flag:
+                buf = ts.opt.buf
+                buf.zero_grad()
+                torch.manual_seed(12)
+                dif(x).backward()
+                alias = [p.grad is not None and p.grad.data_ptr() == vp for p, vp in zip(buf.params, buf._view_ptrs)]
+                assert sum(alias) >= 8, sum(alias)
+                g1 = [p.grad.clone() for p in buf.params]
+                torch.manual_seed(12)
+                dif(x).backward()                                    # accumulation: no zero_grad in between
+                for p, a in zip(buf.params, g1):
+                    assert torch.allclose(p.grad, 2 * a, rtol=1e-6, atol=1e-9)
+    finally:
+        ops.FLAT_WGRAD = True
+    assert torch.equal(res[0], res[1])
