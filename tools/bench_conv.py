@@ -17,6 +17,10 @@ CASES = [  # name, x [N,D,H,W,C], weight [K,C,kd,kh,kw], stride, pad
     ('l0 qkv 1x1 64->384', (8, 24, 40, 40, 64), (384, 64), (1, 1, 1), (0, 0, 0)),
     ('l0 out 1x1 128->64', (8, 24, 40, 40, 128), (64, 128), (1, 1, 1), (0, 0, 0)),
     ('l0 down 1x4x4 64->64', (8, 24, 40, 40, 64), (64, 64, 1, 4, 4), (1, 2, 2), (0, 1, 1)),
+    ('burgers l0 3x3 128->128', (16, 1, 64, 64, 128), (128, 128, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('burgers l1 3x3 256->256', (16, 1, 32, 32, 256), (256, 256, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('burgers l2 3x3 512->512', (16, 1, 16, 16, 512), (512, 512, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('burgers l3 3x3 1024->1024', (16, 1, 8, 8, 1024), (1024, 1024, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ]
 only = [a for a in sys.argv[1:] if not a.startswith('-')]
 fp32_too = '--fp32' in sys.argv
