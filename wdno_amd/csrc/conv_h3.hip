@@ -553,7 +553,9 @@ static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const vo
   // problems with at least 100 tiles: persistent LDS-DMA kernels (256x64 / 128x128 tiles, 64x64 per compute wave); even with
   // fewer tiles than CUs they beat the register-staged kernels (l2 512->128: 0.36 -> 0.24 ms). debug: 5 = never, 7 = always, 8 = always and not the tap-resident variant, 30 / 31 = always with the five-row tile shapes (conv_h3d.hip)
   const int dbg = wdno_debug_mode;
-  if (dbg != 5 && dbg != 3 && dbg != 1 && (dbg == 7 || dbg == 8 || dbg == 30 || dbg == 31 || (K > 64 ? blocks(128, 128) : blocks(256, 64)) >= 100)) {
+  // ... and the tap-resident kernel (stride 1, equal grids, 3-wide) has 64 x 64 / 128 x 64 tiles for problems of fewer tiles (debug 53: not)
+  const bool small_tap = p.identity_out && wdno_conv_h3t_takes(*g) && g->kw == 3 && dbg != 53 && blocks(64, 64) >= 64;
+  if (dbg != 5 && dbg != 3 && dbg != 1 && (dbg == 7 || dbg == 8 || dbg == 30 || dbg == 31 || dbg == 54 || dbg == 55 || small_tap || (K > 64 ? blocks(128, 128) : blocks(256, 64)) >= 100)) {
     rc = wdno_conv_fwd_h3_dma(xh, LP ? nullptr : xl, wph, LP ? nullptr : wpl, sx, sw, bias, residual, y, p, st, 3);
     if (rc == WDNO_OK) return wdno_check_launch();
     if (rc != WDNO_EUNSUPPORTED) return rc;

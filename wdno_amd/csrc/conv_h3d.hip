@@ -384,6 +384,14 @@ static int fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void
     if (all && wdno_debug_mode != 29 && g.kw == 3) {
       if (!narrow_only && cost(160, 128, 1.02) < c) { best = 4; c = cost(160, 128, 1.02); }
       if (cost(320, 64, 1.05) < c) { best = 5; c = cost(320, 64, 1.05); }
+      // few pixels x many channels (the 16 x 16 and 8 x 8 levels of the Burgers U-Net at batch 16: 176 tiles of 192 x 64, 64 of 128 x 128):
+      // 128 x 64 and 64 x 64 tiles fill the chip; their operand traffic per MFMA is higher (weights 1.15 / 1.35). debug 53: without them.
+      if (wdno_debug_mode != 53) {
+        if (cost(128, 64, 1.15) < c) { best = 7; c = cost(128, 64, 1.15); }
+        if (cost(64, 64, 1.35) < c) { best = 6; c = cost(64, 64, 1.35); }
+      }
+      if (wdno_debug_mode == 54) best = 6;
+      if (wdno_debug_mode == 55) best = 7;
       if (wdno_debug_mode == 30) best = narrow_only ? 5 : 4;     // tests: the new shapes on small cases
       if (wdno_debug_mode == 31) best = 5;
     }

@@ -390,6 +390,8 @@ static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, co
   if (shape == 3) return launch_h3t<192, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 4) return launch_h3t<160, 128, 1, 4, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 5) return launch_h3t<320, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  if (shape == 6) return launch_h3t<64, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);      // few pixels x many channels (Burgers 8 x 8 level)
+  if (shape == 7) return launch_h3t<128, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   return launch_h3t<256, 64, 4, 1, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }
 int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,

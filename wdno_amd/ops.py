@@ -688,7 +688,8 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
     """Kernel family wdno_conv_fwd_f16x3 picks (mirrors the dispatch in csrc/conv_h3.hip; used as the profiling key)."""
     cdiv = lambda a, b: -(-a // b)
     tiles = cdiv(pixels, 128) * cdiv(k, 128) if k > 64 else cdiv(pixels, 256)
-    if tiles >= 100 and max(ks) <= 8:
+    small_tap = tap and ks[2] == 3 and cdiv(pixels, 64) * cdiv(k, 64) >= 64      # csrc/conv_h3.hip: the tap-resident kernel's 64-row / 128 x 64 tiles
+    if (tiles >= 100 or small_tap) and max(ks) <= 8:
         cus = 256                                    # the tile shape is chosen for the device's CU count (csrc/conv_h3d.hip)
         cost = lambda bm, bn, wgt: cdiv(cdiv(pixels, bm) * cdiv(k, bn), cus) * bm * bn * wgt
         shapes = [(256, 64, 1.04), (192, 64, 1.08)] if k <= 64 else [(128, 128, 1.0), (192, 128, 1.0), (256, 64, 1.04), (192, 64, 1.08)]
@@ -701,7 +702,11 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
             if k > 64 and cost(160, 128, 1.02) < c_best:
                 best, c_best = (160, 128, 1.02), cost(160, 128, 1.02)
             if cost(320, 64, 1.05) < c_best:
-                best = (320, 64, 1.05)
+                best, c_best = (320, 64, 1.05), cost(320, 64, 1.05)
+            if cost(128, 64, 1.15) < c_best:
+                best, c_best = (128, 64, 1.15), cost(128, 64, 1.15)
+            if cost(64, 64, 1.35) < c_best:
+                best = (64, 64, 1.35)
         if tap and _lp() and k > 64 and cdiv(pixels, 256) * cdiv(k, 128) >= 2 * cus:
             best = (256, 128)                        # csrc/conv_h3t.hip: the wide tiles of the single-plane mode
         if tap and ks[2] == 7:
