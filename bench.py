@@ -16,6 +16,7 @@ Reported next to it in the same JSON line (never part of `value`):
   roofline : the dominant convolution kernel of the main workload; cpu_baseline: the oracle on the host cores.
 
     python bench.py --gpus 1 --steps 100 --warmup 5
+    python bench.py --gpus N ...          (no launcher: re-executes itself as N ranks under torch.distributed.run on a free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -493,6 +494,29 @@ def conv_roofline(ts_step, ops):
             'conv_ms_per_step': {k: round(v[0], 3) for k, v in agg.items()}}
 
 
+def _rccl_version():
+    try:
+        return list(torch.cuda.nccl.version())
+    except Exception as e:
+        return repr(e)
+
+
+def self_launch(n):
+    """Re-execute this script as n ranks under torch.distributed.run on a free local port; rank 0's JSON line passes through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -506,12 +530,19 @@ def main():
     ap.add_argument('--burgers-grid', default='64x64', help="tensor size of the Burgers workloads: 64x64 (reference-native) or 80x64 (north-star synthetic: fields [B,2,160,128] through the HIP DWT)")
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the reference's
+        # `accelerate launch --num_processes N`, scripts/smoke/train_base_sim.sh:3-9) and hand their exit code back.
+        sys.exit(self_launch(args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback on the product path)'
     from wdno_amd.trainer import init_distributed
     rank, world, local = init_distributed()                # torchrun: set_device(LOCAL_RANK) + RCCL ("nccl") process group
     import torch.distributed as dist
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the process group has {world} rank(s) '
+                         f'(WORLD_SIZE={os.environ.get("WORLD_SIZE")}, RANK={os.environ.get("RANK")}): refusing to report a {world}-rank number as {args.gpus}')
+    if world > 1 and os.environ.get('WDNO_DIST_SHARE_GPU') != '1' and torch.cuda.device_count() < world:
+        raise SystemExit(f'bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible')
     device = torch.device('cuda', local)
 
     from wdno_amd import _lib, ops
@@ -631,7 +662,10 @@ def main():
             'metric': metric, 'value': round(world * args.steps / elapsed, 4), 'unit': 'steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
-            'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0},
+            'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0,
+                       'process_group': ({'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                                          'rccl_version': _rccl_version() if dist.get_backend() == 'nccl' else None,
+                                          'devices_visible': torch.cuda.device_count()} if world > 1 else None)},
             'samples_per_sec': round(world * args.steps * batch / elapsed, 3),
             'final_loss': final_loss,
             'roofline': roofline, 'step_roofline': step_roofline, 'cpu_baseline': cpu,

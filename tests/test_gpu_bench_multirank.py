@@ -34,3 +34,38 @@ def test_bench_two_ranks_share_one_gpu():
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 16
     assert len(out['per_rank']['ms_per_step']) == 2 and out['value'] > 0
     assert out['roofline'] is not None and out['cpu_baseline'] is None
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the form the driver uses at N = 1) must start two ranks itself and say so."""
+    env = dict(os.environ, WDNO_DIST_BACKEND='gloo', WDNO_DIST_SHARE_GPU='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-extras']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 16
+    assert out['config']['process_group']['ranks'] == 2 and out['config']['process_group']['backend'] == 'gloo'
+    assert len(out['per_rank']['ms_per_step']) == 2
+
+
+def test_bench_refuses_a_rank_count_mismatch():
+    """A process group whose size differs from --gpus must not print a line (CPU: the check sits before any GPU use... after the CUDA assert,
+    so here only the launcher-less N > 1 path is exercised: without GPUs every rank fails loudly and the exit code is non-zero)."""
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.is_available():
+        env.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')          # one-rank environment, --gpus 2 requested
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and 'refusing' in (r.stderr + r.stdout)
+    else:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and '{"metric"' not in r.stdout
