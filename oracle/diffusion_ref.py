@@ -146,43 +146,60 @@ def smoke_p_losses(model, buf, x0, t, noise, *, padded_shape, loss_layer_weight,
     return (loss * loss_layer_weight).mean()
 
 
-def smoke_model_predictions(model, buf, x, t, clip_x_start=False, rederive=False):
+def smoke_model_predictions(model, buf, x, t, clip_x_start=False, rederive=False, guidance=None):
+    """diffusion_2d.py:723-754. guidance = None or a dict(design_fn=..., kind='standard' | 'standard-alpha', standard_fixed_ratio=...,
+    coeff_ratio=..., low=, init=, init_u=): the callback's gradient at the (clipped) x_start is added to pred_noise -- scaled by
+    standard_fixed_ratio, or by coeff_ratio * betas.flip(0)[t] -- BEFORE x_start is derived (and clipped) a second time."""
     eps = model(x, t)
     xs = predict_start_from_noise(buf, x, t, eps)
     if clip_x_start:
         xs = xs.clamp(-1., 1.)
-        if rederive:
-            eps = predict_noise_from_start(buf, x, t, xs)
+    if guidance is not None:
+        with torch.enable_grad():
+            xc = xs.clone().detach().requires_grad_()
+            g = guidance['design_fn'](xc, low=guidance.get('low'), init=guidance.get('init'), init_u=guidance.get('init_u'))
+        g = g.detach()
+        if guidance['kind'] == 'standard':
+            eps = eps + guidance['standard_fixed_ratio'] * g
+        elif guidance['kind'] == 'standard-alpha':
+            eps = eps + _ex(guidance['coeff_ratio'] * buf['betas'].flip(0), t, x) * g
+        else:
+            raise ValueError(guidance['kind'])
+        xs = predict_start_from_noise(buf, x, t, eps)
+        if clip_x_start:
+            xs = xs.clamp(-1., 1.)
+    if clip_x_start and rederive:
+        eps = predict_noise_from_start(buf, x, t, xs)
     return eps, xs
 
 
-def smoke_p_sample(model, buf, x, t_int, noise):
-    """diffusion_2d.py:757-785 (clip_denoised=True, no guidance) -> (x_{t-1}, x_start)."""
+def smoke_p_sample(model, buf, x, t_int, noise, guidance=None):
+    """diffusion_2d.py:757-785 (clip_denoised=True) -> (x_{t-1}, x_start)."""
     t = torch.full((x.shape[0],), t_int, dtype=torch.long)
-    _, xs = smoke_model_predictions(model, buf, x, t)
+    _, xs = smoke_model_predictions(model, buf, x, t, guidance=guidance)
     xs = xs.clamp(-1., 1.)
     return posterior_step(buf, x, t_int, xs, noise), xs
 
 
-def smoke_p_sample_loop(model, buf, noise_seq, T, *, padded_shape, init, control=None, **kw):
+def smoke_p_sample_loop(model, buf, noise_seq, T, *, padded_shape, init, control=None, guidance=None, **kw):
     """diffusion_2d.py:788-849. noise_seq[0] is the initial draw, then one per step with t>0."""
     it = iter(noise_seq)
     x = next(it).clone()
     smoke_apply_conditions(x, padded_shape, init=init, control=control, **kw)
     for t_int in reversed(range(T)):
-        x, _ = smoke_p_sample(model, buf, x, t_int, next(it) if t_int > 0 else None)
+        x, _ = smoke_p_sample(model, buf, x, t_int, next(it) if t_int > 0 else None, guidance)
         smoke_apply_conditions(x, padded_shape, init=init, control=control, **kw)
     return x
 
 
-def smoke_ddim_sample(model, buf, noise_seq, T, S, eta, *, padded_shape, init, control=None, **kw):
+def smoke_ddim_sample(model, buf, noise_seq, T, S, eta, *, padded_shape, init, control=None, guidance=None, **kw):
     """diffusion_2d.py:851-933."""
     it = iter(noise_seq)
     x = next(it).clone()
     smoke_apply_conditions(x, padded_shape, init=init, control=control, **kw)
     for time, time_next in ddim_times(T, S):
         t = torch.full((x.shape[0],), time, dtype=torch.long)
-        eps, xs = smoke_model_predictions(model, buf, x, t, clip_x_start=True, rederive=True)
+        eps, xs = smoke_model_predictions(model, buf, x, t, clip_x_start=True, rederive=True, guidance=guidance)
         if time_next < 0:
             x = xs
             continue

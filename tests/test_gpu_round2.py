@@ -5,7 +5,8 @@ tests/golden/make_ref_round2_golden.py from the imported reference). GPU box onl
   * D6   : sample(..., design_fn=...) / sample(..., nablaJ=..., J_scheduler=...) through model_predictions' guidance hook
            (diffusion_2d.py:723-754, diffusion_1d.py:205-227, model_utils.py:35-50)
   * 8f-3 : the super-resolution cascade of smoke/inference_2d.py:155-215, stage by stage and end to end, finished by the IDWT
-Unguided chains are compared at 1e-5; the guided smoke DDIM chain and the 3-step cascade from t = 999 at the bounds stated where they are asserted;
+Unguided chains are compared at 1e-5; chains that start at t = 999 (ill conditioned: the reference's own fp32 result is 2e-5 .. 6e-5 from the
+exact chain) are gated against the fp64 oracle as arbiter -- no further from exact than 1.5 x the reference is (tests/arbiter.py);
 index / packing stages are bit-exact."""
 import json
 import os
@@ -70,18 +71,19 @@ def test_smoke_three_optimizer_steps_vs_reference(trees):
     dif.load_state_dict(W(gz, 'w0::'), strict=True)
     dif = dif.to(DEV)
     ts = TrainStep(dif, lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=multistep_lr, use_ema=False)
+    from tests import arbiter as A
+    le, ge, exact = A.smoke_train3(torch.float64)          # the same three steps by the oracle in fp64: the arbiter
+    rel = lambda a, b: abs(a - b) / abs(b)
     for step in range(3):
         x0, t, noise = (torch.from_numpy(gz[f's{step}_{k}']).to(DEV) for k in ('x0', 't', 'noise'))
         loss, gn = ts.step_with(x0, t, noise)
-        assert abs(loss.item() - float(gz[f's{step}_loss'])) < 5e-5 * abs(float(gz[f's{step}_loss'])), step
-        assert abs(gn.item() - float(gz[f's{step}_gnorm'])) < 2e-4 * float(gz[f's{step}_gnorm']), step
-    ref, w0, sd = W(gz, 'w3::'), W(gz, 'w0::'), dif.state_dict()
-    worst = 0.0
-    for k, v in ref.items():
-        if v.is_floating_point() and (v - w0[k]).abs().max() > 0:
-            worst = max(worst, rel_l2(sd[k].cpu() - w0[k], v - w0[k]))
-    print('T2 worst parameter-update rel-L2 after 3 steps:', worst)
-    assert worst < 2e-3
+        # loss and gradient norm: the north-star bar (1e-5) against the exact value, or no further from it than the reference's own fp32 run
+        assert A.gate_or_bar(rel(loss.item(), le[step]), rel(float(gz[f's{step}_loss']), le[step])), (step, loss.item(), le[step])
+        assert A.gate_or_bar(rel(gn.item(), ge[step]), rel(float(gz[f's{step}_gnorm']), ge[step])), (step, gn.item(), ge[step])
+    w0 = {k[len('model.'):]: v for k, v in W(gz, 'w0::').items() if k.startswith('model.')}
+    ref = {k[len('model.'):]: v for k, v in W(gz, 'w3::').items() if k.startswith('model.')}
+    ours = {k[len('model.'):]: v.cpu() for k, v in dif.state_dict().items() if k.startswith('model.')}
+    A.check_updates('T2 smoke', w0, ours, ref, exact)
 
 
 def test_smoke_guided_sampling_vs_reference(trees):
@@ -116,11 +118,17 @@ def test_smoke_guided_sampling_vs_reference(trees):
     dif6.sample_noise = lambda shape, device: next(seq6)
     out6 = dif6.sample(batch_size=2, design_fn=design_fn, design_guidance='standard-alpha', init=init, init_u=init_u)
     e2 = rel_l2(out6, gz['ddpm6_out'])
-    print('smoke guided chains vs reference: ddim4', e1, 'ddpm6', e2)
-    # e1 (measured 2.2e-5; 7.7e-5 before the DDIM coefficients were made host independent): at t = 999 the guidance term enters pred_noise
-    # BEFORE x_start = c1 x - c2 eps (c2 = 1.8e3) is clipped, so the few entries that stay inside (-1, 1) carry 1.8e3 x the last-bit
-    # differences between the GPU's and the CPU's evaluation of the callback's autograd graph; the unguided chain of the same model is at 4e-6
-    assert len(calls) == 1 + 4 + 6 and e1 < 5e-5 and e2 < 1e-5
+    from tests import arbiter as A
+    ex = A.smoke_guided(torch.float64)                      # the same two guided chains by the oracle in fp64
+    h1, r1 = rel_l2(out, ex['ddim']), rel_l2(gz['ddim_out'], ex['ddim'])
+    h2, r2 = rel_l2(out6, ex['ddpm6']), rel_l2(gz['ddpm6_out'], ex['ddpm6'])
+    print('smoke guided chains: ddim4 hip vs reference', e1, 'hip vs exact', h1, 'reference vs exact', r1, '| ddpm6', e2, h2, r2)
+    # DDIM-4 from t = 999: the guidance term enters pred_noise BEFORE x_start = c1 x - c2 eps (c2 = 1.8e3) is clipped, so the few entries that
+    # stay inside (-1, 1) carry 1.8e3 x the last-bit differences of whoever evaluates the chain -- the reference's own fp32 result is 2.1e-5 from
+    # the exact chain. Gate: HIP no further from exact than 1.5 x that (and from the reference no further than the two distances together).
+    assert len(calls) == 1 + 4 + 6
+    assert A.gate(h1, r1) and e1 <= h1 + r1 + 1e-6, (e1, h1, r1)
+    assert e2 < 1e-5 and A.gate_or_bar(h2, r2), (e2, h2, r2)
 
 
 def test_burgers_guided_sampling_vs_reference(trees):
@@ -220,17 +228,26 @@ def test_smoke_super_resolution_cascade_vs_reference(trees):
         o64 = chain({k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}, {k: v.double() for k, v in buf32.items()}, torch.float64)
     ref_exact, hip_exact, host_ref = rel_l2(gz['wave0'], o64), rel_l2(w0, o64), rel_l2(o32, gz['wave0'])
     print('   base chain: reference vs exact', ref_exact, 'hip vs exact', hip_exact, "this host's fp32 oracle vs reference", host_ref)
-    assert hip_exact < 1.5 * ref_exact + 2e-6 and e_base < hip_exact + ref_exact + 1e-6
-    # SR stage from the reference's own low-resolution input: 1e-5. End to end: the base deviation above (arbiter-gated) carried through
-    # the SR chain, whose own t = 999 step amplifies differences of its conditioning input ~3x (measured 1.0e-4)
-    assert e_sr < 1e-5 and e_chain < 2e-4
-    # --- reconstruction: our waverec3 of the unpacked coefficients vs the oracle's IDWT of the reference's coefficients
+    assert hip_exact < 1.5 * ref_exact + 1e-6 and e_base < hip_exact + ref_exact + 1e-6
+    # SR stage from the reference's own low-resolution input: 1e-5. End to end (base deviation carried through the SR chain, whose own t = 999
+    # step amplifies differences of its conditioning input ~3x): arbiter = the whole cascade by the oracle in fp64 (tests/arbiter.py); the
+    # reference's own fp32 cascade is 6.4e-5 from it.
+    from tests import arbiter as A
+    ex = A.smoke_cascade(torch.float64)
+    h_chain, r_chain = rel_l2(w1, ex['wave1']), rel_l2(gz['wave1'], ex['wave1'])
+    print('   cascade end to end: hip vs exact', h_chain, 'reference vs exact', r_chain)
+    assert e_sr < 1e-5
+    assert A.gate(h_chain, r_chain) and e_chain <= h_chain + r_chain + 1e-6, (e_chain, h_chain, r_chain)
+    # --- reconstruction: our waverec3 of the unpacked coefficients; arbiter = the exact cascade's IDWT (fp64), yardstick = the oracle's IDWT of the
+    # reference's coefficients
     c_ours, _ = pack(w1, shape[1], 'space')
     rec = ptwt.waverec3([c_ours[0].contiguous(), {k: v.contiguous() for k, v in c_ours[1].items()}], pywt.Wavelet('bior1.3'))
     yh = gz['coef1_yh']
     rec_ref = R.idwt3(gz['coef1_yl'].astype(np.float64), {k: yh[:, i].astype(np.float64) for i, k in enumerate(R_BANDS)}, 'bior1.3')
-    assert rec.shape == rec_ref.shape
-    assert rel_l2(rec, rec_ref) < 3e-4
+    assert rec.shape == rec_ref.shape == tuple(ex['rec'].shape)
+    h_rec, r_rec = rel_l2(rec, ex['rec']), rel_l2(rec_ref, ex['rec'])
+    print('   reconstruction: hip vs exact', h_rec, 'reference vs exact', r_rec)
+    assert A.gate(h_rec, r_rec), (h_rec, r_rec)
     rec2 = ptwt.waverec3([coef1[0].contiguous(), {k: v.contiguous() for k, v in coef1[1].items()}], pywt.Wavelet('bior1.3'))
     assert rel_l2(rec2, rec_ref) < 1e-6           # same coefficients in: the transform itself
 
