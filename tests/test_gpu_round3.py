@@ -226,14 +226,27 @@ def test_weight_gradients_land_in_the_flat_buffer(trees):
             res.append(ts.opt.buf.flat_param.clone())
             if flag:
                 buf = ts.opt.buf
+                # a backward that is NOT the trainer's (no ops.flat_wgrad_scope): the flat buffer is left alone
                 buf.zero_grad()
+                before = buf.flat_grad.clone()
                 torch.manual_seed(12)
                 dif(x).backward()
+                assert not any(p.grad is not None and p.grad.data_ptr() == vp for p, vp in zip(buf.params, buf._view_ptrs))
+                assert torch.equal(buf.flat_grad, before)
+                unarmed = [p.grad.clone() for p in buf.params]
+                # the trainer's backward: armed explicitly; the split convolutions' weight gradients ARE the flat views
+                buf.zero_grad()
+                torch.manual_seed(12)
+                with ops.flat_wgrad_scope():
+                    dif(x).backward()
                 alias = [p.grad is not None and p.grad.data_ptr() == vp for p, vp in zip(buf.params, buf._view_ptrs)]
                 assert sum(alias) >= 8, sum(alias)
                 g1 = [p.grad.clone() for p in buf.params]
+                for a, b in zip(g1, unarmed):
+                    assert torch.equal(a, b)
                 torch.manual_seed(12)
-                dif(x).backward()                                    # accumulation: no zero_grad in between
+                with ops.flat_wgrad_scope():
+                    dif(x).backward()                                # accumulation: no zero_grad in between
                 for p, a in zip(buf.params, g1):
                     assert torch.allclose(p.grad, 2 * a, rtol=1e-6, atol=1e-9)
     finally:

@@ -241,6 +241,7 @@ class _StepGraph:
         self.graph = torch.cuda.CUDAGraph()
         with ops.graph_capture(self.graph):
             self._body(mod, guided)
+        self._keep = ops.cache_snapshot()         # the operand caches evict on their own terms; the graph replays raw pointers into them
 
     def load_static(self, static):
         for k, v in (static or {}).items():

@@ -555,7 +555,8 @@ def _refresh_weight_plans(epoch_used):
     dev = _wplans[keys[0]].wd.device
     tabs = _wtables.get(keys)
     if tabs is None:
-        _wtables.clear()
+        while len(_wtables) >= 8:          # bounded, oldest first; a captured graph that replays an evicted entry holds its own reference (cache_snapshot)
+            _wtables.pop(next(iter(_wtables)))
         wptrs = []
         for k in keys:
             pl = _wplans[k]
@@ -594,6 +595,28 @@ def _refresh_weight_plans(epoch_used):
     for k in keys:
         pl = _wplans[k]
         pl.ver = (pl.w._version, WEIGHT_EPOCH)
+
+
+def cache_snapshot():
+    """Strong references to everything the operand caches hold right now -- packed / split weight planes, the device tables of the
+    multi-tensor refresh and of the grouped linear layers, rotary / frequency / pixel tables. A captured HIP graph replays raw device
+    pointers into these tensors; the caches themselves evict (size bounds, a changed key set, drop_weight_caches), so whoever owns a
+    graph keeps the snapshot for as long as the graph may be replayed (trainer.CapturedStep, diffusion_core._StepGraph)."""
+    return [dict(_pack_cache), dict(_wplans), dict(_wtables), dict(_lin_tables), dict(_rot_cache), dict(_pixel_tables), dict(_freq_cache),
+            {k: v[0] for k, v in _amax_pool.items()}]
+
+
+def captured_plans():
+    """The split weight operands alive right now (a graph owner passes them to touch_plans after every replay)."""
+    return list(_wplans.values())
+
+
+def touch_plans(plans):
+    """Replays do not run Python: mark the operands a replayed step used as used in the current weight epoch, so that an eager step that
+    follows (a batch of another shape, sampling between steps) refreshes all of them in the usual two launches instead of one by one."""
+    e = WEIGHT_EPOCH
+    for pl in plans:
+        pl.used = e
 
 
 def prepare_graph_refresh():
@@ -727,6 +750,20 @@ def _wgrad_h3_kernel_name(k, run, window=False):
 
 
 FLAT_WGRAD = True         # weight gradients of split convolutions land in the trainer's flat gradient buffer (no gather copy for them)
+_FLAT_ARMED = False       # ... only inside flat_wgrad_scope(): the trainers wrap THEIR backward in it
+
+
+@contextlib.contextmanager
+def flat_wgrad_scope():
+    """Arms the direct write of weight gradients into the trainer's flat gradient buffer for the backward pass run inside this scope
+    (TrainStep / TrainerCore / CapturedStep). Any other backward over a FlatBuffers-registered model -- torch.autograd.grad for a
+    guidance term, a user's own loss.backward() -- allocates its gradients as usual and leaves the flat buffer alone."""
+    global _FLAT_ARMED
+    prev, _FLAT_ARMED = _FLAT_ARMED, True
+    try:
+        yield
+    finally:
+        _FLAT_ARMED = prev
 
 
 def _flat_grad_out(w, shape):
@@ -735,7 +772,7 @@ def _flat_grad_out(w, shape):
     None and no other node of this backward has claimed the span), so autograd will STORE the returned tensor -- which then already is
     the flat view gather_grads() would have copied into. None otherwise (the caller allocates)."""
     v = getattr(w, '_wdno_flat_grad', None)
-    if v is None or not FLAT_WGRAD or w.grad is not None or getattr(w, '_wdno_flat_busy', True) or v.numel() != math.prod(shape) or v.device != w.device:
+    if v is None or not FLAT_WGRAD or not _FLAT_ARMED or w.grad is not None or getattr(w, '_wdno_flat_busy', True) or v.numel() != math.prod(shape) or v.device != w.device:
         return None
     w._wdno_flat_busy = True
     return v.view(shape)

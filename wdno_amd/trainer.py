@@ -120,7 +120,7 @@ class FlatBuffers:
         n = len(self.params)
         host = torch.empty((n, 3), dtype=torch.int64).pin_memory()
         table = torch.empty((n, 3), dtype=torch.int64, device=self.flat_grad.device)
-        self._capture_tables = getattr(self, '_capture_tables', []) + [(host, table)]
+        self._capture_tables = [(host, table)]        # the CapturedStep that uses it takes its own reference (discarded captures free theirs)
 
     def gather_grads(self, capture=False):
         """After backward: every p.grad -> its span of flat_grad (zeros where backward produced none), then p.grad becomes the
@@ -422,9 +422,13 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with ops.graph_capture(self.graph, stream=side):
             loss = diffusion.p_losses(self.x, self.t, noise=self.noise)
-            loss.backward()
+            with ops.flat_wgrad_scope():
+                loss.backward()
             buf.gather_grads(capture=True)
         self.loss, self.shape = loss.detach(), tuple(ex.shape)
+        # the graph replays raw pointers into the operand caches of wdno_amd.ops, which evict on their own terms: hold what it reads
+        self._keep, self._plans = ops.cache_snapshot(), ops.captured_plans()
+        self._capture_table = buf._capture_tables[-1]
         buf.params_changed()          # the capture only RECORDED the refresh of the packed weight operands: nothing may pass for fresh
 
     def draw(self, batch):
@@ -440,6 +444,7 @@ class CapturedStep:
         self.x.copy_(x); self.t.copy_(t); self.noise.copy_(noise)
         self.graph.replay()
         self.buf._gathered = True                      # the replay left every gradient in the flat buffer
+        ops.touch_plans(self._plans)
         return self.loss.clone()
 
 
@@ -476,11 +481,13 @@ class TrainStep:
     def _backward_and_exchange(self, loss):
         if self.overlap is not None:
             self.overlap.begin()
-            loss.backward()
+            with ops.flat_wgrad_scope():
+                loss.backward()
             self.overlap.finish()
             self.opt.buf.gather_grads()
             return
-        loss.backward()
+        with ops.flat_wgrad_scope():
+            loss.backward()
         self.opt.buf.gather_grads()
         if self.exchange:
             if self.time_comm:                    # bench.py: the exposed part of the exchange (backward has finished), HIP events
@@ -743,8 +750,9 @@ class TrainerCore:
         total = None
         if self.use_graph and self.gradient_accumulate_every == 1:
             batch = next_batch()
-            cap = getattr(self, '_cap', None)
-            if cap is not None and cap.shape == tuple(batch.shape):
+            caps = self.__dict__.setdefault('_caps', {})                 # one captured step per batch shape (the loader's last batch of an epoch is short)
+            cap = caps.get(tuple(batch.shape))
+            if cap is not None:
                 total = float(cap.run(batch))
             else:
                 next_batch = lambda _b=batch: _b            # this step runs launch by launch (it is the warm-up), the capture follows it
@@ -753,7 +761,8 @@ class TrainerCore:
             total = 0.0
             for _ in range(self.gradient_accumulate_every):
                 loss = self.model(next_batch()) / self.gradient_accumulate_every
-                loss.backward()
+                with ops.flat_wgrad_scope():
+                    loss.backward()
                 total += float(loss.detach())
             del loss
             self.opt.buf.gather_grads()
@@ -761,9 +770,16 @@ class TrainerCore:
             allreduce_sum_(self.opt.buf.flat_grad, self.world)
         self.last_grad_norm = self.opt.step(lr=self.lr_schedule(self.train_lr, self.step), grad_scale=1.0 / self.world)
         self.total_loss = total
-        if self.use_graph and self.gradient_accumulate_every == 1 and (getattr(self, '_cap', None) is None or self._cap.shape != tuple(batch.shape)):
-            self._cap = CapturedStep(self.model, self.opt.buf, batch)
+        if self.use_graph and self.gradient_accumulate_every == 1 and tuple(batch.shape) not in self._caps:
+            if len(self._caps) >= 3:                         # a capture pins one step's activations: keep the full batch, the short one and one more
+                self._caps.pop(next(iter(self._caps)))
+            self._caps[tuple(batch.shape)] = CapturedStep(self.model, self.opt.buf, batch)
         return total
+
+    @property
+    def _cap(self):                   # the most recent capture (tests / diagnostics)
+        caps = self.__dict__.get('_caps') or {}
+        return next(reversed(caps.values()), None) if caps else None
 
     # ------------------------------------------------------------------ checkpoints (T3)
     def checkpoint_dict(self):
