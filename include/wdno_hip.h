@@ -311,6 +311,22 @@ int wdno_linattn_bwd_planes(const float* qkv, const float* dout, const float* ks
 int wdno_linattn_fwd_planes(const float* qkv, void* out_hi, void* out_lo, float* out_scale, float* kstats, float* ctx,
                             const float* rec_qkv, int64_t units, int n_tok, int heads, float scale, wdno_stream_t s);
 
+/* The whole temporal-attention block of the smoke U-Net's first level as ONE launch (csrc/attn_fused.hip): replaces
+ * Residual(PreNorm(dim, EinopsToAndFrom('b c f h w', 'b (h w) f c', Attention(dim, heads, 32, rotary_emb)))) --
+ * smoke/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py:165-174 (LayerNorm), :277-353 (Attention.forward: to_qkv, scale,
+ * rotary, + pos_bias, softmax, to_out), :176-183 / :259-275 (PreNorm, the einops wrapper), Residual's add.
+ *   x, y: CL [n_batch, n_tok, hw, C] fp32 (frames before pixels; y = x + to_out(attention(LayerNorm(x)))); gamma [C];
+ *   wq_* / wo_*: the packed forward operands (fp16 hi / lo planes + scale) of to_qkv [3*heads*32][C] and to_out [C][heads*32] as
+ *   wdno_pack_split_weight writes them; rot_cos / rot_sin [n_tok][32] or NULL; bias [heads][n_tok][n_tok] or NULL;
+ *   amax_rec: optional amax record of y; qkv_out: optional [rows][3*heads*32] raw projections for a backward pass that wants them.
+ * wdno_tattn_fused_takes: 1 for the shapes the kernel is built for (C = 64, 24 tokens, 4 heads), else 0 (callers then run the block
+ * layer by layer). */
+int wdno_tattn_fused_takes(int C, int n_tok, int heads);
+int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
+                         const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,
+                         const float* bias, float* y, float* amax_rec, float* qkv_out, int64_t n_batch, int n_tok, int64_t hw, int C,
+                         int heads, float scale, wdno_stream_t s);
+
 /* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]
  * (nn.Embedding weight) and bucket [n, n] int64 (host-built integer table); and dW from d(bias). One launch each. */
 int wdno_relpos_bias_fwd(const float* w, const int64_t* bucket, float* out, int n, int heads, wdno_stream_t s);

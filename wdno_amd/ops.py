@@ -1674,6 +1674,40 @@ def linear_attention(qkv, units, n_tok, heads, scale, out_planes=False):
     return _LinAttn.apply(qkv, units, n_tok, heads, scale, out_planes)
 
 
+FUSED_TATTN = True        # the level-0 temporal attention block as one launch where the kernel takes the shape (test knob: layer by layer otherwise)
+
+
+def tattn_fused_takes(x, heads, weights):
+    """Does csrc/attn_fused.hip run Residual(PreNorm(temporal attention)) on this CL tensor [B, F, H, W, C] in one launch? Forward only
+    for now: the block is fused when nothing in it needs a gradient (sampling); a training step runs it layer by layer."""
+    if not (FUSED_TATTN and CONV_MATH == 'f16x3' and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)):
+        return False
+    b, f, h, w, c = x.shape
+    return bool(_lib_().wdno_tattn_fused_takes(c, f, heads)) and b * h * w >= 64
+
+
+def temporal_attention_fused(x, gamma, eps, w_qkv, w_out, rot, bias, heads, scale):
+    """y = x + to_out(attention_over_frames(LayerNorm(x))) for CL x [B, F, H, W, 64] in ONE launch (csrc/attn_fused.hip); the projections
+    read the same packed split weight operands as the layer-by-layer path (split_weight: refreshed with all others after an optimiser step)."""
+    x = _chk(x, 'x')
+    b, f, h, w, c = x.shape
+    hd = heads * 32
+    wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)
+    woh, wol, wos = split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
+    rc, rs = (None, None) if rot is None else rot
+    bc = None if bias is None else _chk(bias, 'bias')
+    y = torch.empty_like(x)
+    rec = _new_amax_record(x.device)
+    flops = 2.0 * b * f * h * w * (c * 3 * hd + hd * c) + 4.0 * b * h * w * heads * f * f * 32
+    with _timed('tattn_fused_fwd_kernel', flops):
+        _lib.check(_lib_().wdno_tattn_fused_fwd(_p(x), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
+                                                _p(rc), _p(rs), _p(bc), _p(y), _p(rec), None, b, f, h * w, c, heads, float(scale), _stream()),
+                   'tattn_fused_fwd')
+    return _leave_amax(y, rec)
+
+
 class _RelPosBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bucket):
