@@ -35,6 +35,7 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 #define TF_VST 36     /* floats per row of the V tile */
 #define TF_YST 68     /* floats per row of a partial output tile */
 #define TF_RST 18     /* float2 per row of the rotary table (16 pairs + pad: the two lane halves start 2 pairs apart) */
+#define TF_BST 28     /* floats per query row of the bias table (24 keys + pad: conflict-free 16-byte reads down a column of rows) */
 
 struct TFusedP {
   const float* x; const float* gamma; float eps;
@@ -48,11 +49,38 @@ struct TFusedP {
 
 __device__ __forceinline__ int tf_key(int m, int hh) { return 8 * (m >> 2) + 4 * hh + (m & 3); }
 
+// Reductions without the LDS crossbar (a __shfl_xor is a ds_bpermute: ~100 cycles of latency each, and the LayerNorm of a row is a chain of
+// eight of them): DPP operands inside a row of 16 lanes -- quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- leave the
+// sum / maximum of the row in all of its lanes; v_permlane32_swap joins the two halves of the wave.
+template <int CTRL>
+__device__ __forceinline__ float tf_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float tf_row16_sum(float v) {
+  v += tf_dpp<0xB1>(v); v += tf_dpp<0x4E>(v); v += tf_dpp<0x141>(v); v += tf_dpp<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float tf_row16_max(float v) {
+  v = fmaxf(v, tf_dpp<0xB1>(v)); v = fmaxf(v, tf_dpp<0x4E>(v)); v = fmaxf(v, tf_dpp<0x141>(v)); v = fmaxf(v, tf_dpp<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float tf_wave_max(float v) {      // uniform result
+  v = tf_row16_max(v);
+  const unsigned u = __float_as_uint(v);
+  const float a = __uint_as_float(__builtin_amdgcn_readlane(u, 0)), b = __uint_as_float(__builtin_amdgcn_readlane(u, 16));
+  const float c = __uint_as_float(__builtin_amdgcn_readlane(u, 32)), d = __uint_as_float(__builtin_amdgcn_readlane(u, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ void tf_halves(float v, float& lo, float& hi) {      // the value of lane (l & 31) and of lane (l & 31) + 32, in every lane
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ void tf_ln_row(float4 xv, float4 g, float eps, float ps, _Float16* __restrict__ Ah, _Float16* __restrict__ Al, int row, int c4) {
-  // arithmetic of norm.hip's layernorm_kernel (two-pass mean / variance over the 16 lanes of the row)
-  const float mean = group_sum<16>((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / TF_C);
+  // norm.hip's layernorm_kernel (two-pass mean / variance over the 16 lanes of the row), the lane sums taken in DPP order
+  const float mean = tf_row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / TF_C);
   xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
-  const float var = group_sum<16>((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / TF_C);
+  const float var = tf_row16_sum((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / TF_C);
   const float rstd = 1.0f / sqrtf(var + eps);
   const float o[4] = {xv.x * rstd * g.x, xv.y * rstd * g.y, xv.z * rstd * g.z, xv.w * rstd * g.w};
   half4v h, l;
@@ -72,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
   __shared__ __attribute__((aligned(16))) float Vt[TF_HEADS][32 * TF_VST];
   __shared__ __attribute__((aligned(16))) float Yp[TF_HEADS][TF_NT * TF_YST];
   __shared__ __attribute__((aligned(16))) float2 Rt[32 * TF_RST];
+  __shared__ __attribute__((aligned(16))) float Bs[TF_HEADS][32 * TF_BST];
   const int tid = threadIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, li = lane & 31, hh = lane >> 5;
@@ -108,28 +137,39 @@ __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
     if (p.rcos && t < TF_NT) v = make_float2(p.rcos[t * 32 + 2 * j], p.rsin[t * 32 + 2 * j]);
     Rt[t * TF_RST + j] = v;
   }
+  // relative-position bias [head][query][key] (zeros where absent / beyond the 24 tokens)
+  for (int i = tid; i < TF_HEADS * 32 * TF_BST; i += 256) {
+    const int hd = i / (32 * TF_BST), r = i - hd * (32 * TF_BST), q = r / TF_BST, k = r - q * TF_BST;
+    Bs[hd][r] = (p.bias && q < TF_NT && k < TF_NT) ? p.bias[(hd * TF_NT + q) * TF_NT + k] : 0.f;
+  }
   const float4 g4 = reinterpret_cast<const float4*>(p.gamma)[lc4];
   const float ps = scale_from_amax(8.0f * group_max<16>(amax4(0.f, g4)));        // |LayerNorm(x)| <= sqrt(64) max|g|
   const float inv_qkv = 1.0f / (ps * p.wq_scale[0]);
   const float sw_o = p.wo_scale[0];
-  const float* brow = p.bias ? p.bias + ((int64_t)h * TF_NT + (tok ? li : 0)) * TF_NT : nullptr;
   const int64_t fstride = (int64_t)p.HW * TF_C;
   float am = 0.f;
 
+  // rows of the first sequence; afterwards the rows of sequence n + 1 are requested while sequence n is in the matrix pipes
+  float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int64_t r0) {
+    const float* xr = p.x + r0 * TF_C;
+    nx0 = *reinterpret_cast<const float4*>(xr + lrow * fstride + 4 * lc4);
+    if (lrow < 8) nx1 = *reinterpret_cast<const float4*>(xr + (16 + lrow) * fstride + 4 * lc4);
+  };
+  // sequence -> (sample b, pixel): advanced incrementally (a 64-bit division per sequence is ~200 instructions of every wave)
+  int nb = (int)(blockIdx.x / (unsigned)p.HW), npix = (int)(blockIdx.x - (unsigned)nb * (unsigned)p.HW);
+  const int gstep_b = (int)(gridDim.x / (unsigned)p.HW), gstep_p = (int)(gridDim.x - (unsigned)gstep_b * (unsigned)p.HW);
+  if ((int64_t)blockIdx.x < p.nseq) fetch((int64_t)nb * TF_NT * p.HW + npix);
   for (int64_t seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
-    const int64_t b = seq / p.HW;
-    const int pix = (int)(seq - b * p.HW);
-    const int64_t row0 = b * TF_NT * p.HW + pix;                  // row of frame 0; frame f at + f * HW
+    const int64_t row0 = (int64_t)nb * TF_NT * p.HW + npix;      // row of frame 0; frame f at + f * HW
     const float* xb = p.x + row0 * TF_C;
+    nb += gstep_b; npix += gstep_p;
+    if (npix >= p.HW) { npix -= p.HW; ++nb; }
     // ---- rows -> LayerNorm -> planes (rows 24..31: zeros in, zeros out)
-    {
-      const float4 x0 = *reinterpret_cast<const float4*>(xb + lrow * fstride + 4 * lc4);
-      float4 x1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lrow < 8) x1 = *reinterpret_cast<const float4*>(xb + (16 + lrow) * fstride + 4 * lc4);
-      tf_ln_row(x0, g4, p.eps, ps, Ah, Al, lrow, lc4);
-      tf_ln_row(x1, g4, p.eps, ps, Ah, Al, 16 + lrow, lc4);
-    }
+    tf_ln_row(nx0, g4, p.eps, ps, Ah, Al, lrow, lc4);
+    tf_ln_row(nx1, g4, p.eps, ps, Ah, Al, 16 + lrow, lc4);
     __syncthreads();
+    if (seq + gridDim.x < p.nseq) fetch((int64_t)nb * TF_NT * p.HW + npix);
     // ---- (q | k | v)^T of this head: [feature][token]
     f32x16 aq, ak, av;
 #pragma unroll
@@ -168,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
       amv = amax4(amv, v4);
       *reinterpret_cast<float4*>(vt + li * TF_VST + 8 * c + 4 * hh) = v4;
     }
-    amv = wave_max(amv);
+    amv = tf_wave_max(amv);
     // q * scale, rotary on q and k (pairs (2i, 2i + 1) = accumulator registers (2 j, 2 j + 1))
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -195,22 +235,24 @@ __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
     {
       float mx = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int j = tf_key(e, hh);
-        float v = sT[e];
-        if (brow && tok && j < TF_NT) v += brow[j];
-        v = j < TF_NT ? v : -INFINITY;
-        sT[e] = v;
-        mx = fmaxf(mx, v);
+      for (int c = 0; c < 3; ++c) {                     // keys 8 c + 4 hh + (0..3) < 24
+        const float4 b4 = *reinterpret_cast<const float4*>(Bs[h] + li * TF_BST + 8 * c + 4 * hh);
+        sT[4 * c] += b4.x; sT[4 * c + 1] += b4.y; sT[4 * c + 2] += b4.z; sT[4 * c + 3] += b4.w;
+        mx = fmaxf(fmaxf(mx, fmaxf(sT[4 * c], sT[4 * c + 1])), fmaxf(sT[4 * c + 2], sT[4 * c + 3]));
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float m0, m1;
+      tf_halves(mx, m0, m1);
+      mx = fmaxf(m0, m1);
       float l = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { sT[e] = expf(sT[e] - mx); l += sT[e]; }
-      l += __shfl_xor(l, 32);
-      const float il = 1.0f / l;
+      for (int e = 0; e < 12; ++e) { sT[e] = expf(sT[e] - mx); l += sT[e]; }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sT[e] *= il;
+      for (int e = 12; e < 16; ++e) sT[e] = 0.f;            // keys 24 .. 31 do not exist
+      float l0, l1;
+      tf_halves(l, l0, l1);
+      const float il = 1.0f / (l0 + l1);
+#pragma unroll
+      for (int e = 0; e < 12; ++e) sT[e] *= il;
     }
     // ---- O^T = V^T P^T
     __builtin_amdgcn_wave_barrier();
