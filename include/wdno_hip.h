@@ -326,6 +326,19 @@ int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const vo
                          const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,
                          const float* bias, float* y, float* amax_rec, float* qkv_out, int64_t n_batch, int n_tok, int64_t hw, int C,
                          int heads, float scale, wdno_stream_t s);
+/* Backward of the same block as ONE launch + an ordered reduction (csrc/attn_fused_bwd.hip): the backward of conv3d.py:165-174 and
+ * :277-353 through autograd in the reference. Only x is needed from the forward: LayerNorm, projections, scores and attention output
+ * are recomputed per sequence.
+ *   dy: gradient of y, CL like x; dx: gradient of x (the residual path included), amax_rec: optional amax record of dx;
+ *   grads: wdno_tattn_fused_bwd_grads() floats = [ dW_qkv [3*heads*32][C] | dW_out [C][heads*32] | dgamma [C] | dbias [heads][n_tok][n_tok] ],
+ *   each the sum over the launch's blocks of per-block partials in `ws` (wdno_tattn_fused_bwd_ws_bytes() bytes) taken in block order:
+ *   two launches on the same inputs return the same bits. */
+size_t wdno_tattn_fused_bwd_ws_bytes(void);
+int wdno_tattn_fused_bwd_grads(void);
+int wdno_tattn_fused_bwd(const float* x, const float* dy, const float* gamma, float eps, const void* wq_hi, const void* wq_lo,
+                         const float* wq_scale, const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos,
+                         const float* rot_sin, const float* bias, float* dx, float* amax_rec, float* grads, void* ws, size_t ws_bytes,
+                         int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s);
 
 /* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]
  * (nn.Embedding weight) and bucket [n, n] int64 (host-built integer table); and dW from d(bias). One launch each. */

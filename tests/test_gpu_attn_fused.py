@@ -1,6 +1,7 @@
-"""csrc/attn_fused.hip: Residual(PreNorm(temporal attention)) of the smoke U-Net's first level (conv3d.py:165-174, 277-353) as one launch.
-Checked against the oracle's restatement of the block in fp64 (the arbiter), against the layer-by-layer HIP path, and inside the whole
-U-Net forward (sampling is where the fused block runs)."""
+"""csrc/attn_fused.hip + csrc/attn_fused_bwd.hip: Residual(PreNorm(temporal attention)) of the smoke U-Net's first level (conv3d.py:165-174,
+277-353) as one launch forward and one launch backward. Checked against the oracle's restatement of the block in fp64 (the arbiter; its
+autograd gives the exact gradients), against the layer-by-layer HIP path, and inside the whole U-Net (forward when sampling, all
+gradients of a training step)."""
 import sys
 
 import pytest
@@ -123,7 +124,133 @@ def test_unet_forward_uses_the_fused_block_when_sampling(mods):
     print(f'U-Net forward: fused vs exact {e_f:.2e}, layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
     assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
     ops.PROFILE = {}
-    out_g = net(x.to(DEV), t.to(DEV))               # parameters require gradients here
-    assert 'tattn_fused_fwd_kernel' not in ops.PROFILE
+    out_g = net(x.to(DEV), t.to(DEV))               # parameters require gradients here: still fused (the backward is one launch too)
+    assert len(ops.PROFILE.get('tattn_fused_fwd_kernel', [])) == 4
     ops.PROFILE = None
+    assert torch.equal(out_g.detach(), out)
+    ops.FUSED_TATTN_BWD = False
+    try:
+        ops.PROFILE = {}
+        out_g = net(x.to(DEV), t.to(DEV))           # test knob: a step with gradients runs the block layer by layer
+        assert 'tattn_fused_fwd_kernel' not in ops.PROFILE
+        ops.PROFILE = None
+    finally:
+        ops.FUSED_TATTN_BWD = True
     assert torch.equal(out_g.detach(), out_layers)
+
+
+def _grads_of(blk, rpb, x, gy, dev):
+    """(y, dx, {parameter: gradient}) of the block on `dev` tensors through the product path."""
+    xr = x.detach().clone().to(dev).requires_grad_(True)
+    for p_ in list(blk.parameters()) + list(rpb.parameters()):
+        p_.grad = None
+    y = blk(xr, pos_bias=rpb(24, device=dev))
+    y.backward(gy.to(dev))
+    g = {'gamma': blk.fn.norm.gamma.grad, 'to_qkv': blk.fn.fn.fn.to_qkv.weight.grad, 'to_out': blk.fn.fn.fn.to_out.weight.grad,
+         'rel_pos': rpb.relative_attention_bias.weight.grad}
+    return y.detach(), xr.grad.clone(), {k: v.clone() for k, v in g.items()}
+
+
+@pytest.mark.parametrize('b,h,w', [(1, 8, 8), (3, 7, 11), (2, 40, 40)])
+def test_fused_block_backward_vs_oracle_and_layers(mods, b, h, w):
+    """dx, dgamma, dW_qkv, dW_out and the gradient of the relative-position embedding from ONE backward launch: against the fp64 oracle's
+    autograd (exact), with the layer-by-layer HIP path and the fp32 oracle as the yardsticks; two launches give the same bits."""
+    ops, V = mods
+    blk, att, rpb = _block(V, 7)
+    torch.manual_seed(11)
+    x = torch.randn(b, 24, h, w, 64) * 1.5 + 0.2
+    gy = torch.randn(b, 24, h, w, 64) * (0.5 + torch.rand(b, 1, h, w, 1) * 4.0)        # pixels with very different gradient sizes
+
+    def oracle(dt):
+        prm = {'gamma': blk.fn.norm.gamma, 'to_qkv': att.to_qkv.weight, 'to_out': att.to_out.weight, 'rel_pos': rpb.relative_attention_bias.weight}
+        leaf = {k: v.detach().to(dt).requires_grad_(True) for k, v in prm.items()}
+        xe = x.detach().clone().to(dt).requires_grad_(True)
+        from oracle import unet_ref as U
+        xc = xe.permute(0, 4, 1, 2, 3)
+        bias = U.time_rel_pos_bias(leaf['rel_pos'], 24)
+        y = U.channel_layernorm(xc, leaf['gamma'])
+        bb, c, f, hh_, ww_ = y.shape
+        y = y.permute(0, 3, 4, 2, 1).reshape(bb, hh_ * ww_, f, c)
+        y = U.token_attention(y, leaf['to_qkv'], leaf['to_out'], 4, 32, freqs=att.rotary_emb.freqs.detach().to(dt), pos_bias=bias)
+        y = (y.reshape(bb, hh_, ww_, f, c).permute(0, 4, 3, 1, 2) + xc).permute(0, 2, 3, 4, 1)
+        y.backward(gy.to(dt))
+        return xe.grad, {k: v.grad for k, v in leaf.items()}
+
+    dx_e, g_e = oracle(torch.float64)
+    dx_r, g_r = oracle(torch.float32)
+    blk, rpb = blk.to(DEV), rpb.to(DEV)
+    ops.PROFILE = {}
+    y_f, dx_f, g_f = _grads_of(blk, rpb, x, gy, DEV)
+    used = set(ops.PROFILE)
+    ops.PROFILE = None
+    assert 'tattn_fused_bwd_kernel' in used and not any('conv' in k or 'attn_bwd' in k or 'layernorm' in k for k in used), used
+    _, dx_f2, g_f2 = _grads_of(blk, rpb, x, gy, DEV)
+    assert torch.equal(dx_f, dx_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)          # no atomics: bit-reproducible
+    ops.FUSED_TATTN_BWD = False
+    try:
+        y_l, dx_l, g_l = _grads_of(blk, rpb, x, gy, DEV)
+    finally:
+        ops.FUSED_TATTN_BWD = True
+    rec = ops._known_amax(dx_f)
+    print(f'fused backward [{b},24,{h},{w},64]:')
+    worst = 0.0
+    for name, f_, l_, r_, e_ in [('dx', dx_f, dx_l, dx_r, dx_e)] + [(k, g_f[k], g_l[k], g_r[k], g_e[k]) for k in g_f]:
+        e_f, e_l, e_r = rel_l2(f_, e_), rel_l2(l_, e_), rel_l2(r_, e_)
+        print(f'  {name:8s} fused vs exact {e_f:.2e}   layer by layer vs exact {e_l:.2e}   fp32 oracle vs exact {e_r:.2e}')
+        worst = max(worst, e_f / (1.5 * max(e_l, e_r) + 2e-7), e_f / 5e-6)
+    assert worst <= 1.0, worst
+    # the attention branch of dx alone (dx - dy), where the residual path does not mask the error
+    assert rel_l2(dx_f.cpu().double() - gy.double(), dx_e - gy.double()) < 1e-5
+
+
+def test_fused_backward_leaves_the_amax_of_dx(mods):
+    ops, V = mods
+    blk, att, rpb = _block(V, 8)
+    blk, rpb = blk.to(DEV), rpb.to(DEV)
+    x = (torch.randn(2, 24, 9, 5, 64, device=DEV) * 2).requires_grad_(True)
+    seen = {}
+    y = blk(x, pos_bias=rpb(24, device=DEV))
+    x.register_hook(lambda g: seen.__setitem__('rec', ops._known_amax(g)))
+    y.backward(torch.randn_like(y))
+    assert seen.get('rec') is not None and abs(seen['rec'].max().item() - x.grad.abs().max().item()) == 0.0
+
+
+def test_unet_training_gradients_with_the_fused_block(mods):
+    """All parameter gradients of the denoiser with the four 64-channel temporal attention blocks fused (forward + backward launches) against
+    the fp64 oracle, the layer-by-layer path as the yardstick."""
+    ops, V = mods
+    from oracle import unet_ref as U
+    torch.manual_seed(3)
+    net = V.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x, t = torch.randn(1, 24, 42, 16, 16) * 0.7, torch.tensor([321])
+    gy = torch.randn(1, 24, 42, 16, 16)
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() and not k.endswith('freqs') else v) for k, v in sd.items()}
+    U.unet3d_forward(sd64, x.double(), t, dim=64, dim_mults=(1, 2, 4), groups=8).backward(gy.double())
+    net = net.to(DEV)
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        ops.PROFILE = {}
+        out = net(x.to(DEV), t.to(DEV))
+        out.backward(gy.to(DEV))
+        prof = ops.PROFILE
+        ops.PROFILE = None
+        return {k: p_.grad.clone() for k, p_ in net.named_parameters() if p_.grad is not None}, prof
+
+    g_f, prof = run()
+    assert len(prof.get('tattn_fused_fwd_kernel', [])) == 4 and len(prof.get('tattn_fused_bwd_kernel', [])) == 4
+    ops.FUSED_TATTN_BWD = False
+    try:
+        g_l, prof_l = run()
+    finally:
+        ops.FUSED_TATTN_BWD = True
+    assert 'tattn_fused_bwd_kernel' not in prof_l
+    assert set(g_f) == set(g_l)
+    worst = (0.0, None)
+    for k in g_f:
+        e_f, e_l = rel_l2(g_f[k], sd64[k].grad), rel_l2(g_l[k], sd64[k].grad)
+        assert e_f <= 1.5 * e_l + 3e-6, (k, e_f, e_l)
+        if e_f > worst[0]:
+            worst = (e_f, k, e_l)
+    print(f'U-Net gradients with fused blocks: worst vs exact {worst[0]:.2e} ({worst[1]}; layer by layer {worst[2]:.2e})')

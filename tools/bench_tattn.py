@@ -44,3 +44,34 @@ with torch.no_grad():
 mb = 2 * x.numel() * 4 / 1e6
 print(f'[{b},24,{side},{side},64]: fused {t_f:.1f} us ({mb / t_f * 1e-3 * 1e3:.2f} GB/s-equivalent: {mb:.0f} MB in+out -> {mb / t_f:.3f} TB/s), '
       f'layer by layer {t_l:.1f} us, max |diff| {(y_f - y_l).abs().max().item():.2e}')
+
+
+# forward + backward (a training step's use of the block): one launch each way vs the layer-by-layer path
+def timed_train(n=10):
+    xr = x.clone().requires_grad_(True)
+    gy = torch.randn(x.shape, device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    fw = bw = 0.0
+    for it in range(n + 3):
+        for p_ in list(blk.parameters()) + list(rpb.parameters()):
+            p_.grad = None
+        xr.grad = None
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        y = blk(xr, pos_bias=rpb(24, device='cuda'))
+        e1.record()
+        y.backward(gy)
+        e2.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            fw += e0.elapsed_time(e1) * 1e3 / n
+            bw += e1.elapsed_time(e2) * 1e3 / n
+    return fw, bw, xr.grad.clone(), blk.fn.fn.fn.to_qkv.weight.grad.clone()
+
+
+f_f, b_f, dx_f, dw_f = timed_train()
+ops.FUSED_TATTN_BWD = False
+f_l, b_l, dx_l, dw_l = timed_train()
+ops.FUSED_TATTN_BWD = True
+print(f'with gradients: fused forward {f_f:.1f} us + backward {b_f:.1f} us (3 x {x.numel() * 4 / 1e6:.0f} MB in+out -> {3 * x.numel() * 4 / 1e6 / b_f:.3f} TB/s); '
+      f'layer by layer forward {f_l:.1f} us + backward {b_l:.1f} us; max |d dx| {(dx_f - dx_l).abs().max().item():.2e} of {dx_l.abs().max().item():.2e}, '
+      f'max |d dW_qkv| {(dw_f - dw_l).abs().max().item():.2e} of {dw_l.abs().max().item():.2e}')

@@ -1,0 +1,46 @@
+// attn_fused.h -- helpers shared by the fused temporal-attention kernels (attn_fused.hip forward, attn_fused_bwd.hip backward).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+#define TF_C 64
+#define TF_NT 24
+#define TF_HEADS 4
+#define TF_HD 128
+#define TF_AST 72     /* halves per token row of an A plane (144 B) */
+#define TF_VST 36     /* floats per row of the V tile */
+#define TF_YST 68     /* floats per row of a partial output tile */
+#define TF_RST 18     /* float2 per row of the rotary table (16 pairs + pad: the two lane halves start 2 pairs apart) */
+#define TF_BST 28     /* floats per query row of the bias table (24 keys + pad: conflict-free 16-byte reads down a column of rows) */
+
+__device__ __forceinline__ int tf_key(int m, int hh) { return 8 * (m >> 2) + 4 * hh + (m & 3); }
+
+// Reductions without the LDS crossbar (a __shfl_xor is a ds_bpermute: ~100 cycles of latency each, and the LayerNorm of a row is a chain of
+// eight of them): DPP operands inside a row of 16 lanes -- quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- leave the
+// sum / maximum of the row in all of its lanes; v_permlane32_swap joins the two halves of the wave.
+template <int CTRL>
+__device__ __forceinline__ float tf_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float tf_row16_sum(float v) {
+  v += tf_dpp<0xB1>(v); v += tf_dpp<0x4E>(v); v += tf_dpp<0x141>(v); v += tf_dpp<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float tf_row16_max(float v) {
+  v = fmaxf(v, tf_dpp<0xB1>(v)); v = fmaxf(v, tf_dpp<0x4E>(v)); v = fmaxf(v, tf_dpp<0x141>(v)); v = fmaxf(v, tf_dpp<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float tf_wave_max(float v) {      // uniform result
+  v = tf_row16_max(v);
+  const unsigned u = __float_as_uint(v);
+  const float a = __uint_as_float(__builtin_amdgcn_readlane(u, 0)), b = __uint_as_float(__builtin_amdgcn_readlane(u, 16));
+  const float c = __uint_as_float(__builtin_amdgcn_readlane(u, 32)), d = __uint_as_float(__builtin_amdgcn_readlane(u, 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ void tf_halves(float v, float& lo, float& hi) {      // the value of lane (l & 31) and of lane (l & 31) + 32, in every lane
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+}

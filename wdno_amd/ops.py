@@ -1675,37 +1675,78 @@ def linear_attention(qkv, units, n_tok, heads, scale, out_planes=False):
 
 
 FUSED_TATTN = True        # the level-0 temporal attention block as one launch where the kernel takes the shape (test knob: layer by layer otherwise)
+FUSED_TATTN_BWD = True    # ... with gradients too: forward + ONE backward launch (csrc/attn_fused_bwd.hip); False: a training step runs the block layer by layer
 
 
 def tattn_fused_takes(x, heads, weights):
-    """Does csrc/attn_fused.hip run Residual(PreNorm(temporal attention)) on this CL tensor [B, F, H, W, C] in one launch? Forward only
-    for now: the block is fused when nothing in it needs a gradient (sampling); a training step runs it layer by layer."""
+    """Does csrc/attn_fused.hip run Residual(PreNorm(temporal attention)) on this CL tensor [B, F, H, W, C] in one launch (and, when something
+    in it needs a gradient, csrc/attn_fused_bwd.hip its backward in one more)?"""
     if not (FUSED_TATTN and CONV_MATH == 'f16x3' and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
         return False
-    if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)):
+    if not FUSED_TATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)):
         return False
     b, f, h, w, c = x.shape
     return bool(_lib_().wdno_tattn_fused_takes(c, f, heads)) and b * h * w >= 64
 
 
+def _tattn_operands(w_qkv, w_out, c, hd):
+    return split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd) + split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
+
+
+class _TAttnFused(torch.autograd.Function):
+    """y = x + to_out(attention_over_frames(LayerNorm(x))): one launch forward, one launch (+ the ordered sum of the per-block weight-gradient
+    partials) backward. Nothing but x and the parameters is kept for the backward -- it recomputes the block per sequence."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, w_qkv, w_out, bias, rc, rs, eps, heads, scale):
+        x = _chk(x, 'x')
+        b, f, h, w, c = x.shape
+        hd = heads * 32
+        wqh, wql, wqs, woh, wol, wos = _tattn_operands(w_qkv, w_out, c, hd)
+        bc = None if bias is None else _chk(bias, 'bias')
+        y = torch.empty_like(x)
+        rec = _new_amax_record(x.device)
+        flops = 2.0 * b * f * h * w * (c * 3 * hd + hd * c) + 4.0 * b * h * w * heads * f * f * 32
+        with _timed('tattn_fused_fwd_kernel', flops):
+            _lib.check(_lib_().wdno_tattn_fused_fwd(_p(x), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
+                                                    _p(rc), _p(rs), _p(bc), _p(y), _p(rec), None, b, f, h * w, c, heads, float(scale), _stream()),
+                       'tattn_fused_fwd')
+        ctx.save_for_backward(x, gamma, w_qkv, w_out, bc, rc, rs)
+        ctx.meta = (eps, heads, scale)
+        return _leave_amax(y, rec)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, w_qkv, w_out, bias, rc, rs = ctx.saved_tensors
+        eps, heads, scale = ctx.meta
+        gy = _chk(gy, 'grad')
+        b, f, h, w, c = x.shape
+        hd = heads * 32
+        lib = _lib_()
+        wqh, wql, wqs, woh, wol, wos = _tattn_operands(w_qkv, w_out, c, hd)       # the forward's operands (cached per weight epoch)
+        nb = lib.wdno_tattn_fused_bwd_ws_bytes()
+        ws = _ws(nb, x.device)
+        dx = torch.empty_like(x)
+        grads = torch.empty((lib.wdno_tattn_fused_bwd_grads(),), device=x.device, dtype=torch.float32)
+        rec = _new_amax_record(x.device)
+        flops = 3.0 * (2.0 * b * f * h * w * (c * 3 * hd + hd * c)) + 12.0 * b * h * w * heads * f * f * 32
+        with _timed('tattn_fused_bwd_kernel', flops):
+            _lib.check(lib.wdno_tattn_fused_bwd(_p(x), _p(gy), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
+                                                _p(rc), _p(rs), _p(bias), _p(dx), _p(rec), _p(grads), _p(ws), nb, b, f, h * w, c, heads, float(scale),
+                                                _stream()), 'tattn_fused_bwd')
+        n_q, n_o = 3 * hd * c, c * hd
+        dwq = grads[:n_q].view(3 * hd, c)
+        dwo = grads[n_q:n_q + n_o].view(c, hd)
+        dg = grads[n_q + n_o:n_q + n_o + c].view(gamma.shape)
+        dbias = None if bias is None else grads[n_q + n_o + c:].view(heads, f, f)
+        return _leave_amax(dx, rec), dg, dwq, dwo, dbias, None, None, None, None, None
+
+
 def temporal_attention_fused(x, gamma, eps, w_qkv, w_out, rot, bias, heads, scale):
     """y = x + to_out(attention_over_frames(LayerNorm(x))) for CL x [B, F, H, W, 64] in ONE launch (csrc/attn_fused.hip); the projections
     read the same packed split weight operands as the layer-by-layer path (split_weight: refreshed with all others after an optimiser step)."""
-    x = _chk(x, 'x')
-    b, f, h, w, c = x.shape
-    hd = heads * 32
-    wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)
-    woh, wol, wos = split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
     rc, rs = (None, None) if rot is None else rot
-    bc = None if bias is None else _chk(bias, 'bias')
-    y = torch.empty_like(x)
-    rec = _new_amax_record(x.device)
-    flops = 2.0 * b * f * h * w * (c * 3 * hd + hd * c) + 4.0 * b * h * w * heads * f * f * 32
-    with _timed('tattn_fused_fwd_kernel', flops):
-        _lib.check(_lib_().wdno_tattn_fused_fwd(_p(x), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
-                                                _p(rc), _p(rs), _p(bc), _p(y), _p(rec), None, b, f, h * w, c, heads, float(scale), _stream()),
-                   'tattn_fused_fwd')
-    return _leave_amax(y, rec)
+    return _TAttnFused.apply(x, gamma, w_qkv, w_out, bias, rc, rs, eps, heads, scale)
 
 
 class _RelPosBias(torch.autograd.Function):
