@@ -318,18 +318,20 @@ int wdno_linattn_fwd_planes(const float* qkv, void* out_hi, void* out_lo, float*
  *   x, y: CL [n_batch, n_tok, hw, C] fp32 (frames before pixels; y = x + to_out(attention(LayerNorm(x)))); gamma [C];
  *   wq_* / wo_*: the packed forward operands (fp16 hi / lo planes + scale) of to_qkv [3*heads*32][C] and to_out [C][heads*32] as
  *   wdno_pack_split_weight writes them; rot_cos / rot_sin [n_tok][32] or NULL; bias [heads][n_tok][n_tok] or NULL;
- *   amax_rec: optional amax record of y; qkv_out: optional [rows][3*heads*32] raw projections for a backward pass that wants them.
+ *   amax_rec: optional amax record of y; qkv_out: optional [rows][3*heads*32] raw projections for a backward pass that wants them;
+ *   rec_v: optional zeroed amax record that receives max|v| (wdno_tattn_fused_bwd: the plane scale of the attention output).
  * wdno_tattn_fused_takes: 1 for the shapes the kernel is built for (C = 64, 24 tokens, 4 heads), else 0 (callers then run the block
  * layer by layer). */
 int wdno_tattn_fused_takes(int C, int n_tok, int heads);
 int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                          const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,
-                         const float* bias, float* y, float* amax_rec, float* qkv_out, int64_t n_batch, int n_tok, int64_t hw, int C,
-                         int heads, float scale, wdno_stream_t s);
+                         const float* bias, float* y, float* amax_rec, float* qkv_out, float* rec_v,
+                         int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s);
 /* Backward of the same block as ONE launch + an ordered reduction (csrc/attn_fused_bwd.hip): the backward of conv3d.py:165-174 and
  * :277-353 through autograd in the reference. Only x is needed from the forward: LayerNorm, projections, scores and attention output
  * are recomputed per sequence.
- *   dy: gradient of y, CL like x; dx: gradient of x (the residual path included), amax_rec: optional amax record of dx;
+ *   dy: gradient of y, CL like x; rec_dy: its amax record; rec_v: the record the forward launch filled;
+ *   dx: gradient of x (the residual path included), amax_rec: optional amax record of dx;
  *   grads: wdno_tattn_fused_bwd_grads() floats = [ dW_qkv [3*heads*32][C] | dW_out [C][heads*32] | dgamma [C] | dbias [heads][n_tok][n_tok] ],
  *   each the sum over the launch's blocks of per-block partials in `ws` (wdno_tattn_fused_bwd_ws_bytes() bytes) taken in block order:
  *   two launches on the same inputs return the same bits. */
@@ -337,7 +339,8 @@ size_t wdno_tattn_fused_bwd_ws_bytes(void);
 int wdno_tattn_fused_bwd_grads(void);
 int wdno_tattn_fused_bwd(const float* x, const float* dy, const float* gamma, float eps, const void* wq_hi, const void* wq_lo,
                          const float* wq_scale, const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos,
-                         const float* rot_sin, const float* bias, float* dx, float* amax_rec, float* grads, void* ws, size_t ws_bytes,
+                         const float* rot_sin, const float* bias, const float* rec_dy, const float* rec_v, float* dx, float* amax_rec,
+                         float* grads, void* ws, size_t ws_bytes,
                          int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s);
 
 /* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]

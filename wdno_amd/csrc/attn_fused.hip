@@ -30,6 +30,7 @@ struct TFusedP {
   const float* rcos; const float* rsin; const float* bias;                  // [24][32], [24][32], [4][24][24] (any may be null)
   float* y; float* amax_rec;
   float* qkv_out;                                                           // optional: raw projections [rows][384] (the un-fused backward reads them)
+  float* rec_v;                                                             // optional amax record of v (attn_fused_bwd.hip: the plane scale of the attention output)
   int HW; float scale; int64_t nseq;
 };
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
   const float inv_qkv = 1.0f / (ps * p.wq_scale[0]);
   const float sw_o = p.wo_scale[0];
   const int64_t fstride = (int64_t)p.HW * TF_C;
-  float am = 0.f;
+  float am = 0.f, stv = 0.f;
 
   // rows of the first sequence; afterwards the rows of sequence n + 1 are requested while sequence n is in the matrix pipes
   float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
       amv = amax4(amv, v4);
       *reinterpret_cast<float4*>(vt + li * TF_VST + 8 * c + 4 * hh) = v4;
     }
+    stv = fmaxf(stv, amv);
     amv = tf_wave_max(amv);
     // q * scale, rotary on q and k (pairs (2i, 2i + 1) = accumulator registers (2 j, 2 j + 1))
 #pragma unroll
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
     }
   }
   if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * TF_HEADS + h);
+  if (p.rec_v) wave_amax_emit(stv, p.rec_v, (int)blockIdx.x * TF_HEADS + h);
 }
 
 static int tf_num_cus() {
@@ -298,8 +301,8 @@ extern "C" int wdno_tattn_fused_takes(int C, int n_tok, int heads) { return C ==
 
 extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                                     const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,
-                                    const float* bias, float* y, float* amax_rec, float* qkv_out, int64_t n_batch, int n_tok, int64_t hw, int C,
-                                    int heads, float scale, wdno_stream_t s) {
+                                    const float* bias, float* y, float* amax_rec, float* qkv_out, float* rec_v,
+                                    int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s) {
   WDNO_REQUIRE(x && gamma && wq_hi && wq_lo && wq_scale && wo_hi && wo_lo && wo_scale && y && n_batch > 0 && hw > 0);
   WDNO_REQUIRE((rot_cos == nullptr) == (rot_sin == nullptr));
   if (!wdno_tattn_fused_takes(C, n_tok, heads) || hw > 0x7fffffff / (TF_C * TF_NT)) return WDNO_EUNSUPPORTED;
@@ -309,6 +312,7 @@ extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float ep
   p.wo_hi = (const _Float16*)wo_hi; p.wo_lo = (const _Float16*)wo_lo; p.wo_scale = wo_scale;
   p.rcos = rot_cos; p.rsin = rot_sin; p.bias = bias;
   p.y = y; p.amax_rec = amax_rec; p.qkv_out = qkv_out;
+  p.rec_v = rec_v;
   p.HW = (int)hw; p.scale = scale; p.nseq = n_batch * hw;
   int64_t grid = 2 * (int64_t)tf_num_cus();
   if (grid > p.nseq) grid = p.nseq;

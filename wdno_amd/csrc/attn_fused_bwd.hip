@@ -19,15 +19,22 @@
 //   * Weight gradients contract over the tokens of BOTH operands: the gradient tile (dq, dk, dv, O) is written as fp16 planes [token][32]
 //     into the head's second tile and both operands come back through transpose reads ([token][channel] images, no transposed copies).
 //     dW_qkv (96 registers per lane) and dW_out (32) are MFMA accumulators over all sequences of the block, never touched by the VALU (they
-//     live in the AGPR half of the register file): the planes of dy, O and dq / dk / dv are written at a RUNNING power-of-two scale -- the
-//     scale of the largest tile seen so far, i.e. what one scale per tensor (the layer-by-layer path) gives -- and when a larger tile
-//     arrives the accumulators are multiplied by the ratio of the scales (exact, a power of two; a handful of times per launch).
+//     live in the AGPR half of the register file), so the planes of a tensor carry ONE power-of-two scale at a time: dy and O the scale
+//     of their exact maxima (the amax record of dy; max|v| recorded by the forward launch: rows of P sum to 1), dq / dk / dv a RUNNING
+//     scale per wave -- the scale of the largest tile seen so far, i.e. what one scale per tensor (the layer-by-layer path) gives; when a
+//     larger tile arrives the two accumulator tiles of that tensor are multiplied by the ratio of the scales (exact, a power of two; a
+//     handful of times per launch). (Scales from upper BOUNDS of dq / dk / dv -- 2^14 .. 2^18 above the true maxima -- cost 2e-6 of
+//     accuracy: the lo plane falls into fp16's subnormal range. Measured, dropped.)
+//   * Order inside a head: the operands of a product are requested (LDS) before the matrix instructions of the PREVIOUS product are issued,
+//     so one wave per SIMD keeps its matrix pipe busy across the LDS round trips (three tiles per head: column operand, transposed
+//     operand, planes).
 //   * Every block writes ONE partial [dW_qkv | dW_out | dgamma | dbias]; tattn_fused_reduce_kernel adds the partials in block order
 //     (bit-reproducible: no atomics anywhere).
+#include <stdlib.h>
 #include "attn_fused.h"
 
 #define TB_TS 36                      /* floats per row of an fp32 tile */
-#define TB_PS 36                      /* halves per row of a per-head plane tile (same bytes as half an fp32 tile) */
+#define TB_PS 36                      /* halves per row of a per-head plane tile */
 #define TB_N_WQ (3 * TF_HD * TF_C)    /* 24576 */
 #define TB_N_WO (TF_C * TF_HD)        /* 8192 */
 #define TB_OFF_WO TB_N_WQ
@@ -35,17 +42,20 @@
 #define TB_OFF_DB (TB_OFF_DG + TF_C)
 #define TB_E (TB_OFF_DB + TF_HEADS * TF_NT * TF_NT)      /* 35136 floats per partial */
 
-// LDS map (bytes)
+// LDS map (bytes). Images hold the 24 token rows only: a lane whose token / reduction rows would be 24 .. 31 reads the zero block instead.
+#define TB_IMG (TF_NT * TF_AST * 2)          /* 3456: one plane of xn / dy */
+#define TB_TILE (TF_NT * TB_TS * 4)          /* 3456: an fp32 tile; also the two planes [24][36] of a head's plane tile */
 #define TB_L_WH 0
 #define TB_L_WL 49152
 #define TB_L_XH 98304
-#define TB_L_XL (TB_L_XH + 4608)
-#define TB_L_GH (TB_L_XL + 4608)
-#define TB_L_GL (TB_L_GH + 4608)
-#define TB_L_T (TB_L_GL + 4608)              /* 116736: per head 2 x 4608 */
-#define TB_L_RT (TB_L_T + TF_HEADS * 9216)   /* 153600 */
-#define TB_L_WM (TB_L_RT + 4608)             /* 158208 */
-#define TB_LDS_BYTES (TB_L_WM + 16)
+#define TB_L_XL (TB_L_XH + TB_IMG)
+#define TB_L_GH (TB_L_XL + TB_IMG)
+#define TB_L_GL (TB_L_GH + TB_IMG)
+#define TB_L_T (TB_L_GL + TB_IMG)                    /* per head: T0, T1, PL */
+#define TB_HEAD_LDS (3 * TB_TILE)
+#define TB_L_RT (TB_L_T + TF_HEADS * TB_HEAD_LDS)
+#define TB_L_ZB (TB_L_RT + 4608)                     /* 256 bytes of zeros */
+#define TB_LDS_BYTES (TB_L_ZB + 256)
 
 #define TB_FENCE() asm volatile("" ::: "memory")
 
@@ -54,6 +64,7 @@ struct TFusedBwdP {
   const _Float16* wq_hi; const _Float16* wq_lo; const float* wq_scale;      // packed forward operand of to_qkv: [384][64]
   const _Float16* wo_hi; const _Float16* wo_lo; const float* wo_scale;      // ... of to_out: [64][128]
   const float* rcos; const float* rsin; const float* bias;                  // [24][32], [24][32], [4][24][24] (any may be null)
+  const float* rec_dy; const float* rec_v;                                  // amax records: dy; v of the forward launch
   float* dx; float* amax_rec; float* part;
   int HW; float scale; int64_t nseq;
 };
@@ -68,12 +79,16 @@ __device__ __forceinline__ half8 tb_tr2(const _Float16* p0, const _Float16* p1) 
   const tb_short8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(half8, c);
 }
-// operand fragment from a [token][channel] image: lane (li, hh) receives channel ch0 + li of tokens tok0 + 8 hh + (0..7)
-// (conv_h3.hip: tr_frag; inside a 16-lane group lanes 4 j .. 4 j + 3 point at the four 8-byte pieces of row j)
-__device__ __forceinline__ half8 tb_trf(const _Float16* tile, int stride, int tok0, int ch0, int lane) {
+// operand fragment from a [token][channel] image of 24 rows: lane (li, hh) receives channel ch0 + li of tokens 16 s + 8 hh + (0..7)
+// (conv_h3.hip: tr_frag; inside a 16-lane group lanes 4 j .. 4 j + 3 point at the four 8-byte pieces of row j). Tokens 24 .. 31 -- the
+// upper lane half of step s = 1 -- come from the zero block.
+template <int S>
+__device__ __forceinline__ half8 tb_trf(const _Float16* tile, int stride, int ch0, int lane, const _Float16* zb) {
   const int g = lane >> 4, xl = lane & 15;
-  const _Float16* p0 = tile + (tok0 + 8 * (g >> 1) + (xl >> 2)) * stride + ch0 + 16 * (g & 1) + 4 * (xl & 3);
-  return tb_tr2(p0, p0 + 4 * stride);
+  const _Float16* p0 = tile + (16 * S + 8 * (g >> 1) + (xl >> 2)) * stride + ch0 + 16 * (g & 1) + 4 * (xl & 3);
+  const _Float16* p1 = p0 + 4 * stride;
+  if (S == 1 && (g >> 1)) { p0 = zb; p1 = zb; }
+  return tb_tr2(p0, p1);
 }
 // halves offset of the 16-byte chunk `chunk` of row f in a swizzled W plane
 __device__ __forceinline__ int tb_woff(int f, int chunk) { return f * TF_C + ((chunk ^ ((f >> 1) & 7)) << 3); }
@@ -96,49 +111,38 @@ __device__ __forceinline__ f32x16 tb_mfma3(half8 ah, half8 al, half8 bh, half8 b
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
 }
-__device__ __forceinline__ float tb_absmax16(const f32x16& v) {
-  float m = 0.f;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(v[e]));
-  return m;
-}
-// accumulator tile X^T[feature e][token li] -> fp32 tile [token][32]
+// accumulator tile X^T[feature e][token li] -> fp32 tile [token][32] (tokens < 24)
 __device__ __forceinline__ void tb_acc_to_tile(float* __restrict__ T, const f32x16& v, int li, int hh) {
+  if (li < TF_NT) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-    *reinterpret_cast<float4*>(T + li * TB_TS + 8 * c + 4 * hh) = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<float4*>(T + li * TB_TS + 8 * c + 4 * hh) = make_float4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+  }
 }
-// accumulator tile S^T[key e][query li] -> fp32 tile [key][query] (the lane roles swap when a lane reads ITS row)
+// accumulator tile S^T[key e][query li] -> fp32 tile [key < 24][query] (the lane roles swap when a lane reads ITS row)
 __device__ __forceinline__ void tb_acc_to_tile_t(float* __restrict__ T, const f32x16& v, int li, int hh) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e) T[tf_key(e, hh) * TB_TS + li] = v[e];
+  for (int e = 0; e < 12; ++e) T[tf_key(e, hh) * TB_TS + li] = v[e];
 }
-// D^T[d][j] = sum_{token t < 24} T[t][d] b[t][j]: T columns (lane = d), b = an accumulator tile in place (register m <-> token tf_key(m, hh))
-__device__ __forceinline__ f32x16 tb_col_product(const float* __restrict__ T, const f32x16& b, int li, int hh) {
-  f32x16 acc = tb_zero();
+// the 12 values of column li a lane feeds to a product over the tokens (step m <-> token tf_key(m, hh))
+__device__ __forceinline__ void tb_cols(const float* __restrict__ T, int li, int hh, float (&c)[12]) {
+#pragma unroll
+  for (int m = 0; m < 12; ++m) c[m] = T[tf_key(m, hh) * TB_TS + li];
+}
+// ... and of row `row` of a transposed tile
+__device__ __forceinline__ void tb_rows(const float* __restrict__ T, int row, int hh, float (&r)[12]) {
 #pragma unroll
   for (int g4 = 0; g4 < 3; ++g4) {
-    float a[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = T[(8 * g4 + 4 * hh + q) * TB_TS + li];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[4 * g4 + q], acc, 0, 0, 0);
+    const float4 b4 = *reinterpret_cast<const float4*>(T + row * TB_TS + 8 * g4 + 4 * hh);
+    r[4 * g4] = b4.x; r[4 * g4 + 1] = b4.y; r[4 * g4 + 2] = b4.z; r[4 * g4 + 3] = b4.w;
   }
-  return acc;
 }
-// D^T[d][j] = sum_{token t < 24} Ta[t][d] Tb[j][t]: Ta columns (lane = d), Tb rows (lane = j)
-__device__ __forceinline__ f32x16 tb_row_product(const float* __restrict__ Ta, const float* __restrict__ Tb, int li, int hh) {
+// D^T[d][j] = sum_{token t < 24} a[t][d] b[t][j] on the exact-fp32 matrix instruction
+template <typename B>
+__device__ __forceinline__ f32x16 tb_product12(const float (&a)[12], const B& b) {
   f32x16 acc = tb_zero();
 #pragma unroll
-  for (int g4 = 0; g4 < 3; ++g4) {
-    float a[4];
-    const float4 b4 = *reinterpret_cast<const float4*>(Tb + li * TB_TS + 8 * g4 + 4 * hh);
-    const float b[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = Ta[(8 * g4 + 4 * hh + q) * TB_TS + li];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
-  }
+  for (int m = 0; m < 12; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[m], acc, 0, 0, 0);
   return acc;
 }
 // the 16 accumulator values of a lane as (hi, lo) halves at scale s: k-step s' of a product that contracts over the features takes
@@ -152,50 +156,17 @@ __device__ __forceinline__ void tb_split16(const f32x16& v, float s, half8 (&h)[
     h[e >> 3][e & 7] = th;
     l[e >> 3][e & 7] = (_Float16)(t - (float)th);
   }
+  if (li < TF_NT) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    half4v a, b;
+    for (int c = 0; c < 4; ++c) {
+      half4v a, b;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = h[c >> 1][4 * (c & 1) + j]; b[j] = l[c >> 1][4 * (c & 1) + j]; }
-    *reinterpret_cast<half4v*>(Ph + li * TB_PS + 8 * c + 4 * hh) = a;
-    *reinterpret_cast<half4v*>(Pl + li * TB_PS + 8 * c + 4 * hh) = b;
-  }
-}
-// two weight-gradient tiles  acc[ct][feature][c] += inv * sum_tok P[tok][feature] X[tok][32 ct + c]   (P: the head's plane tile, X: a shared image)
-__device__ __forceinline__ void tb_dw_pair(f32x16& acc0, f32x16& acc1, const _Float16* Ph, const _Float16* Pl, const _Float16* Xh, const _Float16* Xl,
-                                           int lane) {
-  half8 ah[2], al[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) { ah[s] = tb_trf(Ph, TB_PS, 16 * s, 0, lane); al[s] = tb_trf(Pl, TB_PS, 16 * s, 0, lane); }
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    f32x16& acc = ct ? acc1 : acc0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const half8 bh = tb_trf(Xh, TF_AST, 16 * s, 32 * ct, lane), bl = tb_trf(Xl, TF_AST, 16 * s, 32 * ct, lane);
-      acc = tb_mfma3(ah[s], al[s], bh, bl, acc);
+      for (int j = 0; j < 4; ++j) { a[j] = h[c >> 1][4 * (c & 1) + j]; b[j] = l[c >> 1][4 * (c & 1) + j]; }
+      *reinterpret_cast<half4v*>(Ph + li * TB_PS + 8 * c + 4 * hh) = a;
+      *reinterpret_cast<half4v*>(Pl + li * TB_PS + 8 * c + 4 * hh) = b;
     }
   }
 }
-// dxn^T[c][tok] += inv * sum_f W[fbase + f][c] d[tok][f] over the head's 32 features of one of q / k / v
-__device__ __forceinline__ void tb_dxn(f32x16& d0, f32x16& d1, const _Float16* WH, const _Float16* WL, int fbase, const half8 (&h)[2], const half8 (&l)[2],
-                                       int lane) {
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    f32x16& acc = ct ? d1 : d0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const half8 wh = tb_wtr(WH, fbase + 16 * s, ct, lane), wl = tb_wtr(WL, fbase + 16 * s, ct, lane);
-      acc = tb_mfma3(wh, wl, h[s], l[s], acc);
-    }
-  }
-}
-__device__ __forceinline__ void tb_rescale(f32x16& a, float r) {
-#pragma unroll
-  for (int e = 0; e < 16; ++e) a[e] *= r;
-}
-// power-of-two plane scale for a tile of maximum `amax`, never above 2^100 (a denormal maximum must not turn into an infinite scale)
-__device__ __forceinline__ float tb_scale(float amax) { return fminf(scale_from_amax(amax), 0x1p100f); }
 // LayerNorm of one row by its 16 lanes (norm.hip: layernorm_kernel), planes written, mean and 1/std returned
 __device__ __forceinline__ void tb_ln_row(float4 xv, float4 g, float eps, float ps, _Float16* __restrict__ Ah, _Float16* __restrict__ Al, int row, int c4,
                                           float& mean, float& rstd) {
@@ -241,7 +212,39 @@ __device__ __forceinline__ void tb_unrotate(f32x16& v, const float2* __restrict_
     }
   }
 }
+// power-of-two plane scale for a tensor bounded by `bound`, kept inside [2^-100, 2^100]
+__device__ __forceinline__ float tb_scale(float bound) { return fminf(fmaxf(scale_from_amax(bound), 0x1p-100f), 0x1p100f); }
 
+// w *= r without a VALU instruction touching the accumulator (a value the VALU multiplies has to live in the architectural half of the
+// register file for its whole life -- 128 such registers spill) and IN PLACE (a fresh result tile merged back at the end of a rare branch
+// costs the allocator ~100 registers): sixteen accumulating steps of the exact-fp32 matrix instruction, step e adding (r - 1) * (the two
+// rows accumulator register e holds) -- row operand (r - 1) * unit vector, column operand the accumulator register itself. One rounding
+// per entry (r is a power of two, (r - 1) w is not exactly representable): 2^-24 relative, a handful of times per launch.
+__device__ __forceinline__ void tb_rescale(f32x16& w, float r, int li, int hh) {
+  const float r1 = r - 1.0f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) w = __builtin_amdgcn_mfma_f32_32x32x2f32(li == tf_key(e, hh) ? r1 : 0.f, w[e], w, 0, 0, 0);
+}
+// a gradient tile larger than every one before it: the tensor's two weight-gradient tiles move to the new scale (exact: a power of two)
+__device__ __forceinline__ void tb_fit(float& sc, float amax, f32x16& w0, f32x16& w1, int li, int hh) {
+  const float need = tb_scale(amax);
+  if (need < sc) {
+    const float r = need / sc;
+    tb_rescale(w0, r, li, hh);
+    tb_rescale(w1, r, li, hh);
+    sc = need;
+  }
+}
+__device__ __forceinline__ float tb_absmax16(const f32x16& v) {
+  float m = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(v[e]));
+  return m;
+}
+
+// ABL: timing ablations (tools/tattn_ablate.sh, WDNO_TB_ABLATE): 1 = no weight-gradient / dxn products, 2 = no score-sized fp32 products,
+// 3 = no block barriers (results are wrong in all three)
+template <int ABL>
 __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tb_smem[];
   _Float16* WH = reinterpret_cast<_Float16*>(tb_smem + TB_L_WH);
@@ -251,25 +254,26 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
   _Float16* GH = reinterpret_cast<_Float16*>(tb_smem + TB_L_GH);
   _Float16* GL = reinterpret_cast<_Float16*>(tb_smem + TB_L_GL);
   float2* Rt = reinterpret_cast<float2*>(tb_smem + TB_L_RT);
-  float* WM = reinterpret_cast<float*>(tb_smem + TB_L_WM);
+  const _Float16* ZB = reinterpret_cast<const _Float16*>(tb_smem + TB_L_ZB);
   const int tid = threadIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, li = lane & 31, hh = lane >> 5;
   const int lrow = tid >> 4, lc4 = tid & 15;
-  float* T0 = reinterpret_cast<float*>(tb_smem + TB_L_T + h * 9216);
-  float* T1 = T0 + 32 * TB_TS;
-  _Float16* PH = reinterpret_cast<_Float16*>(T1);
-  _Float16* PL = PH + 32 * TB_PS;
-  float* Yp = T0;                                          // [24][TF_YST] partial dxn of this head (6528 B of the head's 9216)
+  float* T0 = reinterpret_cast<float*>(tb_smem + TB_L_T + h * TB_HEAD_LDS);
+  float* T1 = T0 + TF_NT * TB_TS;
+  _Float16* PH = reinterpret_cast<_Float16*>(T1 + TF_NT * TB_TS);
+  _Float16* PL = PH + TF_NT * TB_PS;
+  float* Yp = T0;                                          // [24][TF_YST] partial dxn of this head (6528 B of T0 + T1's 6912)
 
-  // ---- once per kernel: W_qkv planes -> LDS, zeroed images, rotary table, W_out^T fragments, bias rows, LayerNorm gain
+  // ---- once per kernel: W_qkv planes -> LDS, zeroed images, rotary table, W_out^T fragments, LayerNorm gain, plane scales
   for (int q = tid; q < 3 * TF_HD * 8; q += 256) {
     const int f = q >> 3, ch = q & 7;
     const int dst = tb_woff(f, ch);
     *reinterpret_cast<uint4*>(WH + dst) = *reinterpret_cast<const uint4*>(p.wq_hi + f * TF_C + ch * 8);
     *reinterpret_cast<uint4*>(WL + dst) = *reinterpret_cast<const uint4*>(p.wq_lo + f * TF_C + ch * 8);
   }
-  for (int i = tid; i < (TB_L_RT - TB_L_XH) / 16; i += 256) reinterpret_cast<uint4*>(tb_smem + TB_L_XH)[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < (TB_LDS_BYTES - TB_L_XH) / 16; i += 256) reinterpret_cast<uint4*>(tb_smem + TB_L_XH)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
   for (int i = tid; i < 32 * 16; i += 256) {
     const int t = i >> 4, j = i & 15;
     float2 v = make_float2(1.f, 0.f);
@@ -286,14 +290,20 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
       woth[s][t] = p.wo_hi[off];
       wotl[s][t] = p.wo_lo[off];
     }
-  float bs[12];
-#pragma unroll
-  for (int e = 0; e < 12; ++e) bs[e] = (p.bias && li < TF_NT) ? p.bias[(h * TF_NT + li) * TF_NT + tf_key(e, hh)] : 0.f;
   const float4 g4 = reinterpret_cast<const float4*>(p.gamma)[lc4];
   const float ps = scale_from_amax(8.0f * group_max<16>(amax4(0.f, g4)));        // |LayerNorm(x)| <= sqrt(64) max|g|
   const float wq_s = p.wq_scale[0], wo_s = p.wo_scale[0];
   const float inv_qkv = 1.0f / (ps * wq_s);
+  // plane scales: dy and O fixed for the launch (exact maxima), dq / dk / dv running (powers of two, only ever decreasing)
+  const float sc_g = tb_scale(amax_record_read(p.rec_dy)), sc_o = tb_scale(amax_record_read(p.rec_v));
+  float sc_q = 0x1p100f, sc_k = 0x1p100f, sc_v = 0x1p100f;
+  const float inv_do = 1.0f / (sc_g * wo_s);
   const int64_t fstride = (int64_t)p.HW * TF_C;
+  // LDS addresses of this lane's operand rows (lanes of tokens 24 .. 31 read zeros)
+  const _Float16* xrow = li < TF_NT ? XH + li * TF_AST + 8 * hh : ZB + 8 * hh;           // + 16 s; XL = + TB_IMG bytes
+  const _Float16* grow = li < TF_NT ? GH + li * TF_AST + 8 * hh : ZB + 8 * hh;
+  const int xl_off = li < TF_NT ? TB_IMG / 2 : 0;                                          // halves from the hi to the lo plane
+  const int trow = li < TF_NT ? li : li - 8;                                               // row of a transposed tile this lane reads
 
   f32x16 dwq[3][2], dwo[2];
 #pragma unroll
@@ -304,8 +314,6 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
   for (int e = 0; e < 12; ++e) dbacc[e] = 0.f;
   float4 dgacc = make_float4(0.f, 0.f, 0.f, 0.f);
   float am = 0.f;
-  // running plane scales (powers of two, only ever decreasing): dy (block-uniform), O and dq / dk / dv (per wave)
-  float sc_g = 0x1p100f, sc_o = 0x1p100f, sc_d = 0x1p100f;
   __syncthreads();
 
   float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, ng0 = nx0, ng1 = nx0;
@@ -326,47 +334,44 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     const int64_t row0 = (int64_t)nb * TF_NT * p.HW + npix;
     nb += gstep_b; npix += gstep_p;
     if (npix >= p.HW) { npix -= p.HW; ++nb; }
-    // ---- rows -> LayerNorm -> planes of xn; max|dy| of the sequence. Only (mean, 1/std) of the two rows stay in registers: x and dy are
-    // read again (L2) for the last phase, together with the rows of the next sequence.
-    float mean0, mean1, rs0, rs1;
+    // ---- rows -> LayerNorm -> planes of xn; planes of dy. Only (mean, 1/std) of the two rows stay in registers: x and dy are read again
+    // (L2) for the last phase, together with the rows of the next sequence.
+    float mean0, mean1 = 0.f, rs0, rs1 = 0.f;
     tb_ln_row(nx0, g4, p.eps, ps, XH, XL, lrow, lc4, mean0, rs0);
-    tb_ln_row(nx1, g4, p.eps, ps, XH, XL, 16 + lrow, lc4, mean1, rs1);
-    {
-      const float gm = tf_wave_max(amax4(amax4(0.f, ng0), ng1));
-      if (lane == 0) WM[h] = gm;
-    }
-    __syncthreads();                                                          // B1: xn planes, wave maxima
-    {
-      const float need = tb_scale(fmaxf(fmaxf(WM[0], WM[1]), fmaxf(WM[2], WM[3])));
-      if (need < sc_g) {
-        const float r = need / sc_g;
-        tb_rescale(dwo[0], r); tb_rescale(dwo[1], r);
-        sc_g = need;
-      }
-    }
     tb_plane_row(ng0, sc_g, GH, GL, lrow, lc4);
-    tb_plane_row(ng1, sc_g, GH, GL, 16 + lrow, lc4);
-    // ---- (q | k | v)^T of this head
-    f32x16 aq = tb_zero(), ak = tb_zero(), av = tb_zero();
+    if (lrow < 8) {
+      tb_ln_row(nx1, g4, p.eps, ps, XH, XL, 16 + lrow, lc4, mean1, rs1);
+      tb_plane_row(ng1, sc_g, GH, GL, 16 + lrow, lc4);
+    }
+    // the bias rows of this lane's query (L1 / L2: 96 bytes per lane), wanted after the first score product
+    float bs[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias && li < TF_NT) b4 = *reinterpret_cast<const float4*>(p.bias + (h * TF_NT + li) * TF_NT + 8 * c + 4 * hh);
+      bs[4 * c] = b4.x; bs[4 * c + 1] = b4.y; bs[4 * c + 2] = b4.z; bs[4 * c + 3] = b4.w;
+    }
+    if (ABL != 3) __syncthreads();                                            // B1: planes of xn and dy
+    // ---- (q | k | v)^T of this head, dO^T = W_out^T dy^T (this head's 32 columns)
+    f32x16 aq = tb_zero(), ak = tb_zero(), av = tb_zero(), dOT = tb_zero();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const half8 bh = *reinterpret_cast<const half8*>(XH + li * TF_AST + 16 * s + 8 * hh);
-      const half8 bl = *reinterpret_cast<const half8*>(XL + li * TF_AST + 16 * s + 8 * hh);
+      const half8 bh = *reinterpret_cast<const half8*>(xrow + 16 * s);
+      const half8 bl = *reinterpret_cast<const half8*>(xrow + xl_off + 16 * s);
       const int o0 = tb_woff(h * 32 + li, 2 * s + hh);                       // rows + 128, + 256: same swizzle term ((f >> 1) & 7 has period 16)
       aq = tb_mfma3(*reinterpret_cast<const half8*>(WH + o0), *reinterpret_cast<const half8*>(WL + o0), bh, bl, aq);
       ak = tb_mfma3(*reinterpret_cast<const half8*>(WH + o0 + TF_HD * TF_C), *reinterpret_cast<const half8*>(WL + o0 + TF_HD * TF_C), bh, bl, ak);
       av = tb_mfma3(*reinterpret_cast<const half8*>(WH + o0 + 2 * TF_HD * TF_C), *reinterpret_cast<const half8*>(WL + o0 + 2 * TF_HD * TF_C), bh, bl, av);
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { aq[e] *= inv_qkv; ak[e] *= inv_qkv; av[e] *= inv_qkv; }
-    {
-      const float need = tb_scale(tf_wave_max(tb_absmax16(av)));              // rows of P sum to 1: |O| <= max|v|
-      if (need < sc_o) {
-        const float r = need / sc_o;
-        tb_rescale(dwo[0], r); tb_rescale(dwo[1], r);
-        sc_o = need;
-      }
+    for (int s = 0; s < 4; ++s) {
+      const half8 bh = *reinterpret_cast<const half8*>(grow + 16 * s);
+      const half8 bl = *reinterpret_cast<const half8*>(grow + xl_off + 16 * s);
+      dOT = tb_mfma3(woth[s], wotl[s], bh, bl, dOT);
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { aq[e] *= inv_qkv; ak[e] *= inv_qkv; av[e] *= inv_qkv; dOT[e] *= inv_do; }
+    tb_acc_to_tile(T0, av, li, hh);                                           // T0 = v
     // q * scale, rotary on q and k
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -383,25 +388,17 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
         ak[2 * j + 1] = ky * cs2[q] + kx * sn2[q];
       }
     }
-    __syncthreads();                                                          // B2: dy planes
-    // ---- dO^T = W_out^T dy^T (this head's 32 columns)
-    f32x16 dOT = tb_zero();
+    TB_FENCE();
+    // ---- S^T = K Q^T and dP^T = V dO^T (exact fp32, operands in place); under them: the columns of v, then T0 = k
+    f32x16 sT = tb_zero(), dsT = tb_zero();
+    float cv[12];
+    tb_cols(T0, li, hh, cv);
+    TB_FENCE();
+    tb_acc_to_tile(T0, ak, li, hh);                                           // T0 = k'
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const half8 bh = *reinterpret_cast<const half8*>(GH + li * TF_AST + 16 * s + 8 * hh);
-      const half8 bl = *reinterpret_cast<const half8*>(GL + li * TF_AST + 16 * s + 8 * hh);
-      dOT = tb_mfma3(woth[s], wotl[s], bh, bl, dOT);
-    }
-    {
-      const float inv_do = 1.0f / (sc_g * wo_s);
+    for (int e = 0; e < 16; ++e) if (ABL != 2) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[e], aq[e], sT, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dOT[e] *= inv_do;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- P^T = softmax(S^T), S^T = K Q^T (exact fp32)
-    f32x16 sT = tb_zero();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[e], aq[e], sT, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) if (ABL != 2) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], dOT[e], dsT, 0, 0, 0);
     {
       float mx = -INFINITY;
 #pragma unroll
@@ -420,10 +417,13 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
 #pragma unroll
       for (int e = 0; e < 12; ++e) sT[e] *= il;
     }
-    // ---- dP^T = V dO^T, dS^T = P^T (dP^T - delta), delta_i = sum_j P_ij dP_ij
-    f32x16 dsT = tb_zero();
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], dOT[e], dsT, 0, 0, 0);
+    TB_FENCE();
+    float ck[12];
+    tb_cols(T0, li, hh, ck);
+    TB_FENCE();
+    tb_acc_to_tile(T0, aq, li, hh);                                           // T0 = q'
+    // ---- O^T = V^T P^T; under it: dS^T = P^T (dP^T - delta), delta_i = sum_j P_ij dP_ij
+    f32x16 oT = ABL == 2 ? sT : tb_product12(cv, sT);
     {
       float delta = 0.f;
 #pragma unroll
@@ -433,110 +433,104 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
       delta = d0 + d1;
 #pragma unroll
       for (int e = 0; e < 12; ++e) { dsT[e] = sT[e] * (dsT[e] - delta); dbacc[e] += dsT[e]; }
-#pragma unroll
-      for (int e = 12; e < 16; ++e) dsT[e] = 0.f;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 dx0 = tb_zero(), dx1 = tb_zero();                                  // dxn^T of this head at scale sc_d * wq_s: channels 0..31, 32..63
-    half8 dh[2], dl[2];
-    // a gradient tile larger than every one before: the accumulators that carry sc_d move to the new scale
-    auto fit_d = [&](float amax) {
-      const float need = tb_scale(amax);
-      if (need < sc_d) {
-        const float r = need / sc_d;
+    tb_acc_to_tile_t(T1, dsT, li, hh);                                        // T1 = dS (lane roles swapped)
+    TB_FENCE();
+    float cq[12], rS[12];
+    tb_cols(T0, li, hh, cq);
+    tb_rows(T1, trow, hh, rS);
+    TB_FENCE();
+    tb_acc_to_tile(T0, dOT, li, hh);                                          // T0 = dO
+    tb_acc_to_tile_t(T1, sT, li, hh);                                         // T1 = P (lane roles swapped)
+    // ---- dQ'^T = K'^T dS^T; under it: the planes of O
+    f32x16 dq = ABL == 2 ? dsT : tb_product12(ck, dsT);
+    half8 oh[2], ol[2];
+    tb_split16(oT, sc_o, oh, ol, PH, PL, li, hh);
+    TB_FENCE();
+    half8 bo_h[2], bo_l[2];
+    bo_h[0] = tb_trf<0>(PH, TB_PS, 0, lane, ZB); bo_l[0] = tb_trf<0>(PL, TB_PS, 0, lane, ZB);
+    bo_h[1] = tb_trf<1>(PH, TB_PS, 0, lane, ZB); bo_l[1] = tb_trf<1>(PL, TB_PS, 0, lane, ZB);
+    float cdo[12], rP[12];
+    tb_cols(T0, li, hh, cdo);
+    tb_rows(T1, trow, hh, rP);
+    TB_FENCE();
+    // ---- dK'^T = Q'^T dS; under it: dq un-rotated, its planes
+    f32x16 dk = ABL == 2 ? dsT : tb_product12(cq, rS);
+    tb_unrotate(dq, Rt, li, hh, p.scale);
+    tb_fit(sc_q, tf_wave_max(tb_absmax16(dq)), dwq[0][0], dwq[0][1], li, hh);
+    half8 qh[2], ql[2];
+    tb_split16(dq, sc_q, qh, ql, PH, PL, li, hh);                              // (after the reads of O's planes: LDS keeps a wave's order)
+    TB_FENCE();
+    // ---- dW_out[c][32 h + d] += sum_tok dy[tok][c] O[tok][d]: rows = channels (A = dy image), columns = d (B = the O planes)
+    if (ABL != 1) {
 #pragma unroll
-        for (int ti = 0; ti < 3; ++ti) { tb_rescale(dwq[ti][0], r); tb_rescale(dwq[ti][1], r); }
-        tb_rescale(dx0, r); tb_rescale(dx1, r);
-        sc_d = need;
+      for (int ct = 0; ct < 2; ++ct) {
+        dwo[ct] = tb_mfma3(tb_trf<0>(GH, TF_AST, 32 * ct, lane, ZB), tb_trf<0>(GL, TF_AST, 32 * ct, lane, ZB), bo_h[0], bo_l[0], dwo[ct]);
+        dwo[ct] = tb_mfma3(tb_trf<1>(GH, TF_AST, 32 * ct, lane, ZB), tb_trf<1>(GL, TF_AST, 32 * ct, lane, ZB), bo_h[1], bo_l[1], dwo[ct]);
       }
-    };
-    // ---- O^T = V^T P^T -> dW_out
-    tb_acc_to_tile(T0, av, li, hh);
-    TB_FENCE();
-    {
-      const f32x16 oT = tb_col_product(T0, sT, li, hh);
-      tb_split16(oT, sc_o, dh, dl, PH, PL, li, hh);
-      TB_FENCE();
-      // dW_out[c][32 h + d] += sum_tok dy[tok][c] O[tok][d]: rows = channels (A = dy image), columns = d (B = the O planes)
-      half8 bh[2], bl[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) { bh[s] = tb_trf(PH, TB_PS, 16 * s, 0, lane); bl[s] = tb_trf(PL, TB_PS, 16 * s, 0, lane); }
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const half8 ah = tb_trf(GH, TF_AST, 16 * s, 32 * ct, lane), al = tb_trf(GL, TF_AST, 16 * s, 32 * ct, lane);
-          dwo[ct] = tb_mfma3(ah, al, bh[s], bl[s], dwo[ct]);
-        }
     }
-    TB_FENCE();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- dQ'^T = K'^T dS^T -> dq -> dW_q, dxn
-    tb_acc_to_tile(T0, ak, li, hh);
-    TB_FENCE();
-    {
-      f32x16 dq = tb_col_product(T0, dsT, li, hh);
-      tb_unrotate(dq, Rt, li, hh, p.scale);
-      fit_d(tf_wave_max(tb_absmax16(dq)));
-      tb_split16(dq, sc_d, dh, dl, PH, PL, li, hh);
-      TB_FENCE();
-      tb_dw_pair(dwq[0][0], dwq[0][1], PH, PL, XH, XL, lane);
-      tb_dxn(dx0, dx1, WH, WL, h * 32, dh, dl, lane);
-    }
-    TB_FENCE();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- dK'^T = Q'^T dS -> dk
-    tb_acc_to_tile(T0, aq, li, hh);
-    tb_acc_to_tile_t(T1, dsT, li, hh);
-    TB_FENCE();
-    {
-      f32x16 dk = tb_row_product(T0, T1, li, hh);
-      tb_unrotate(dk, Rt, li, hh, 1.0f);
-      fit_d(tf_wave_max(tb_absmax16(dk)));
-      TB_FENCE();
-      tb_split16(dk, sc_d, dh, dl, PH, PL, li, hh);
-      TB_FENCE();
-      tb_dw_pair(dwq[1][0], dwq[1][1], PH, PL, XH, XL, lane);
-      tb_dxn(dx0, dx1, WH, WL, TF_HD + h * 32, dh, dl, lane);
-    }
-    TB_FENCE();
-    __builtin_amdgcn_sched_barrier(0);
-    // the rows of this sequence again (for the LayerNorm backward and the residual gradient) and those of the next one: in flight under dV
+    // the rows of this sequence again (for the LayerNorm backward and the residual gradient) and those of the next one: in flight from here
     float4 cx0 = make_float4(0.f, 0.f, 0.f, 0.f), cx1 = cx0, cg0 = cx0, cg1 = cx0;
     fetch(row0, cx0, cx1, cg0, cg1);
     if (seq + gridDim.x < p.nseq) fetch((int64_t)nb * TF_NT * p.HW + npix, nx0, nx1, ng0, ng1);
-    // ---- dV^T = dO^T P -> dv
-    tb_acc_to_tile(T0, dOT, li, hh);
-    tb_acc_to_tile_t(T1, sT, li, hh);
+    // ---- dV^T = dO^T P; under it: the operands of dW_q / dxn_q
+    f32x16 dv = ABL == 2 ? sT : tb_product12(cdo, rP);
+    f32x16 xq0 = tb_zero(), xq1 = tb_zero(), xk0 = tb_zero(), xk1 = tb_zero(), xv0 = tb_zero(), xv1 = tb_zero();
+    // weight-gradient tiles  dW[feature][32 ct + c] += sum_tok P[tok][feature] xn[tok][c]  and  dxn^T[c][tok] += sum_f W[f][c] d[tok][f]
+    auto grad_products = [&](f32x16& w0, f32x16& w1, f32x16& d0, f32x16& d1, int fbase, const half8 (&dh)[2], const half8 (&dl)[2]) {
+      if (ABL == 1) return;
+      const half8 a0h = tb_trf<0>(PH, TB_PS, 0, lane, ZB), a0l = tb_trf<0>(PL, TB_PS, 0, lane, ZB);
+      const half8 a1h = tb_trf<1>(PH, TB_PS, 0, lane, ZB), a1l = tb_trf<1>(PL, TB_PS, 0, lane, ZB);
+      w0 = tb_mfma3(a0h, a0l, tb_trf<0>(XH, TF_AST, 0, lane, ZB), tb_trf<0>(XL, TF_AST, 0, lane, ZB), w0);
+      w0 = tb_mfma3(a1h, a1l, tb_trf<1>(XH, TF_AST, 0, lane, ZB), tb_trf<1>(XL, TF_AST, 0, lane, ZB), w0);
+      w1 = tb_mfma3(a0h, a0l, tb_trf<0>(XH, TF_AST, 32, lane, ZB), tb_trf<0>(XL, TF_AST, 32, lane, ZB), w1);
+      w1 = tb_mfma3(a1h, a1l, tb_trf<1>(XH, TF_AST, 32, lane, ZB), tb_trf<1>(XL, TF_AST, 32, lane, ZB), w1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        d0 = tb_mfma3(tb_wtr(WH, fbase + 16 * s, 0, lane), tb_wtr(WL, fbase + 16 * s, 0, lane), dh[s], dl[s], d0);
+        d1 = tb_mfma3(tb_wtr(WH, fbase + 16 * s, 1, lane), tb_wtr(WL, fbase + 16 * s, 1, lane), dh[s], dl[s], d1);
+      }
+    };
+    grad_products(dwq[0][0], dwq[0][1], xq0, xq1, h * 32, qh, ql);
     TB_FENCE();
-    {
-      const f32x16 dv = tb_row_product(T0, T1, li, hh);
-      fit_d(tf_wave_max(tb_absmax16(dv)));
-      TB_FENCE();
-      tb_split16(dv, sc_d, dh, dl, PH, PL, li, hh);
-      TB_FENCE();
-      tb_dw_pair(dwq[2][0], dwq[2][1], PH, PL, XH, XL, lane);
-      tb_dxn(dx0, dx1, WH, WL, 2 * TF_HD + h * 32, dh, dl, lane);
-    }
+    tb_unrotate(dk, Rt, li, hh, 1.0f);
+    tb_fit(sc_k, tf_wave_max(tb_absmax16(dk)), dwq[1][0], dwq[1][1], li, hh);
+    tb_split16(dk, sc_k, qh, ql, PH, PL, li, hh);
+    TB_FENCE();
+    grad_products(dwq[1][0], dwq[1][1], xk0, xk1, TF_HD + h * 32, qh, ql);
+    TB_FENCE();
+    tb_fit(sc_v, tf_wave_max(tb_absmax16(dv)), dwq[2][0], dwq[2][1], li, hh);
+    tb_split16(dv, sc_v, qh, ql, PH, PL, li, hh);
+    TB_FENCE();
+    grad_products(dwq[2][0], dwq[2][1], xv0, xv1, 2 * TF_HD + h * 32, qh, ql);
     TB_FENCE();
     // ---- the head's part of dxn as [token][channel]
     if (li < TF_NT) {
-      const float inv = 1.0f / (sc_d * wq_s);
+      const float inv_xq = 1.0f / (sc_q * wq_s), inv_xk = 1.0f / (sc_k * wq_s), inv_xv = 1.0f / (sc_v * wq_s);
       float* yp = Yp + li * TF_YST + 4 * hh;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        *reinterpret_cast<float4*>(yp + 8 * c) = make_float4(dx0[4 * c] * inv, dx0[4 * c + 1] * inv, dx0[4 * c + 2] * inv, dx0[4 * c + 3] * inv);
-        *reinterpret_cast<float4*>(yp + 32 + 8 * c) = make_float4(dx1[4 * c] * inv, dx1[4 * c + 1] * inv, dx1[4 * c + 2] * inv, dx1[4 * c + 3] * inv);
+        float4 a, b;
+        a.x = xq0[4 * c] * inv_xq + (xk0[4 * c] * inv_xk + xv0[4 * c] * inv_xv);
+        a.y = xq0[4 * c + 1] * inv_xq + (xk0[4 * c + 1] * inv_xk + xv0[4 * c + 1] * inv_xv);
+        a.z = xq0[4 * c + 2] * inv_xq + (xk0[4 * c + 2] * inv_xk + xv0[4 * c + 2] * inv_xv);
+        a.w = xq0[4 * c + 3] * inv_xq + (xk0[4 * c + 3] * inv_xk + xv0[4 * c + 3] * inv_xv);
+        b.x = xq1[4 * c] * inv_xq + (xk1[4 * c] * inv_xk + xv1[4 * c] * inv_xv);
+        b.y = xq1[4 * c + 1] * inv_xq + (xk1[4 * c + 1] * inv_xk + xv1[4 * c + 1] * inv_xv);
+        b.z = xq1[4 * c + 2] * inv_xq + (xk1[4 * c + 2] * inv_xk + xv1[4 * c + 2] * inv_xv);
+        b.w = xq1[4 * c + 3] * inv_xq + (xk1[4 * c + 3] * inv_xk + xv1[4 * c + 3] * inv_xv);
+        *reinterpret_cast<float4*>(yp + 8 * c) = a;
+        *reinterpret_cast<float4*>(yp + 32 + 8 * c) = b;
       }
     }
-    __syncthreads();                                                          // B3
+    if (ABL != 3) __syncthreads();                                            // B2
     // ---- heads summed, LayerNorm backward, residual gradient added, rows stored (the lanes that loaded a row finish it)
     float* db = p.dx + row0 * TF_C;
     const float* Y0 = reinterpret_cast<const float*>(tb_smem + TB_L_T);
     auto finish = [&](int row, const float4& xr, float mean, float rstd, const float4& gy) {
       const int o = row * TF_YST + 4 * lc4;
-      const float4 a = *reinterpret_cast<const float4*>(Y0 + o), b2 = *reinterpret_cast<const float4*>(Y0 + 2304 + o);
-      const float4 c = *reinterpret_cast<const float4*>(Y0 + 4608 + o), d = *reinterpret_cast<const float4*>(Y0 + 6912 + o);
+      const float4 a = *reinterpret_cast<const float4*>(Y0 + o), b2 = *reinterpret_cast<const float4*>(Y0 + TB_HEAD_LDS / 4 + o);
+      const float4 c = *reinterpret_cast<const float4*>(Y0 + 2 * (TB_HEAD_LDS / 4) + o), d = *reinterpret_cast<const float4*>(Y0 + 3 * (TB_HEAD_LDS / 4) + o);
       const float4 xh = make_float4((xr.x - mean) * rstd, (xr.y - mean) * rstd, (xr.z - mean) * rstd, (xr.w - mean) * rstd);
       float4 dn;                                                              // dxn of this row
       dn.x = (a.x + b2.x) + (c.x + d.x); dn.y = (a.y + b2.y) + (c.y + d.y);
@@ -553,20 +547,24 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     };
     finish(lrow, cx0, mean0, rs0, cg0);
     if (lrow < 8) finish(16 + lrow, cx1, mean1, rs1, cg1);
+    if (ABL != 3) __syncthreads();                                            // B3: the partial tiles (= T0, T1 of the next sequence) are free
   }
   // ---- this block's partial sums
   float* part = p.part + (size_t)blockIdx.x * TB_E;
-  const float inv_wq = 1.0f / (sc_d * ps), inv_wo = 1.0f / (sc_g * sc_o);
+  {
+    const float inv_w[3] = {1.0f / (sc_q * ps), 1.0f / (sc_k * ps), 1.0f / (sc_v * ps)};
+    const float inv_wo = 1.0f / (sc_g * sc_o);
 #pragma unroll
-  for (int ti = 0; ti < 3; ++ti)
+    for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[(ti * TF_HD + h * 32 + tf_key(e, hh)) * TF_C + 32 * ct + li] = dwq[ti][ct][e] * inv_w[ti];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) part[(ti * TF_HD + h * 32 + tf_key(e, hh)) * TF_C + 32 * ct + li] = dwq[ti][ct][e] * inv_wq;
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) part[TB_OFF_WO + (32 * ct + tf_key(e, hh)) * TF_HD + h * 32 + li] = dwo[ct][e] * inv_wo;
+      for (int e = 0; e < 16; ++e) part[TB_OFF_WO + (32 * ct + tf_key(e, hh)) * TF_HD + h * 32 + li] = dwo[ct][e] * inv_wo;
+  }
   if (li < TF_NT) {
 #pragma unroll
     for (int e = 0; e < 12; ++e) part[TB_OFF_DB + (h * TF_NT + li) * TF_NT + tf_key(e, hh)] = dbacc[e];
@@ -624,9 +622,11 @@ extern "C" int wdno_tattn_fused_bwd_grads(void) { return TB_E; }
 
 extern "C" int wdno_tattn_fused_bwd(const float* x, const float* dy, const float* gamma, float eps, const void* wq_hi, const void* wq_lo,
                                     const float* wq_scale, const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos,
-                                    const float* rot_sin, const float* bias, float* dx, float* amax_rec, float* grads, void* ws, size_t ws_bytes,
+                                    const float* rot_sin, const float* bias, const float* rec_dy, const float* rec_v, float* dx, float* amax_rec,
+                                    float* grads, void* ws, size_t ws_bytes,
                                     int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s) {
   WDNO_REQUIRE(x && dy && gamma && wq_hi && wq_lo && wq_scale && wo_hi && wo_lo && wo_scale && dx && grads && ws && n_batch > 0 && hw > 0);
+  WDNO_REQUIRE(rec_dy && rec_v);
   WDNO_REQUIRE((rot_cos == nullptr) == (rot_sin == nullptr));
   if (!wdno_tattn_fused_takes(C, n_tok, heads) || hw > 0x7fffffff / (TF_C * TF_NT)) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_tattn_fused_bwd_ws_bytes()) return WDNO_EWORKSPACE;
@@ -635,16 +635,21 @@ extern "C" int wdno_tattn_fused_bwd(const float* x, const float* dy, const float
   p.wq_hi = (const _Float16*)wq_hi; p.wq_lo = (const _Float16*)wq_lo; p.wq_scale = wq_scale;
   p.wo_hi = (const _Float16*)wo_hi; p.wo_lo = (const _Float16*)wo_lo; p.wo_scale = wo_scale;
   p.rcos = rot_cos; p.rsin = rot_sin; p.bias = bias;
+  p.rec_dy = rec_dy; p.rec_v = rec_v;
   p.dx = dx; p.amax_rec = amax_rec; p.part = (float*)ws;
   p.HW = (int)hw; p.scale = scale; p.nseq = n_batch * hw;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)tattn_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES) != hipSuccess) return WDNO_ELAUNCH;
-    attr_done = true;
+  static int abl = -1;
+  typedef void (*kern_t)(TFusedBwdP);
+  static kern_t kern = nullptr;
+  if (abl < 0) {
+    const char* e = getenv("WDNO_TB_ABLATE");
+    abl = e ? atoi(e) : 0;
+    kern = abl == 1 ? tattn_fused_bwd_kernel<1> : abl == 2 ? tattn_fused_bwd_kernel<2> : abl == 3 ? tattn_fused_bwd_kernel<3> : tattn_fused_bwd_kernel<0>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES) != hipSuccess) return WDNO_ELAUNCH;
   }
   int64_t grid = tb_num_cus();
   if (grid > p.nseq) grid = p.nseq;
-  tattn_fused_bwd_kernel<<<(int)grid, 256, TB_LDS_BYTES, as_stream(s)>>>(p);
+  kern<<<(int)grid, 256, TB_LDS_BYTES, as_stream(s)>>>(p);
   int rc = wdno_check_launch();
   if (rc) return rc;
   tattn_fused_reduce_kernel<<<(TB_E + 31) / 32, 256, 0, as_stream(s)>>>((const float*)ws, (int)grid, grads, TB_E);

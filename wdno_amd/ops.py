@@ -1706,20 +1706,26 @@ class _TAttnFused(torch.autograd.Function):
         bc = None if bias is None else _chk(bias, 'bias')
         y = torch.empty_like(x)
         rec = _new_amax_record(x.device)
+        # a backward will follow: the launch also records max|v| (the backward's plane scale of the attention output)
+        vrec = _amax_slot(x.device) if any(ctx.needs_input_grad) else None
         flops = 2.0 * b * f * h * w * (c * 3 * hd + hd * c) + 4.0 * b * h * w * heads * f * f * 32
         with _timed('tattn_fused_fwd_kernel', flops):
             _lib.check(_lib_().wdno_tattn_fused_fwd(_p(x), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
-                                                    _p(rc), _p(rs), _p(bc), _p(y), _p(rec), None, b, f, h * w, c, heads, float(scale), _stream()),
-                       'tattn_fused_fwd')
+                                                    _p(rc), _p(rs), _p(bc), _p(y), _p(rec), None, _p(vrec),
+                                                    b, f, h * w, c, heads, float(scale), _stream()), 'tattn_fused_fwd')
         ctx.save_for_backward(x, gamma, w_qkv, w_out, bc, rc, rs)
         ctx.meta = (eps, heads, scale)
+        ctx.vrec = vrec
         return _leave_amax(y, rec)
 
     @staticmethod
     def backward(ctx, gy):
         x, gamma, w_qkv, w_out, bias, rc, rs = ctx.saved_tensors
         eps, heads, scale = ctx.meta
+        grec = _known_amax(gy)
         gy = _chk(gy, 'grad')
+        if grec is None:                     # a gradient autograd summed itself: one sweep for its maximum
+            grec = tensor_amax(gy)
         b, f, h, w, c = x.shape
         hd = heads * 32
         lib = _lib_()
@@ -1732,8 +1738,8 @@ class _TAttnFused(torch.autograd.Function):
         flops = 3.0 * (2.0 * b * f * h * w * (c * 3 * hd + hd * c)) + 12.0 * b * h * w * heads * f * f * 32
         with _timed('tattn_fused_bwd_kernel', flops):
             _lib.check(lib.wdno_tattn_fused_bwd(_p(x), _p(gy), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
-                                                _p(rc), _p(rs), _p(bias), _p(dx), _p(rec), _p(grads), _p(ws), nb, b, f, h * w, c, heads, float(scale),
-                                                _stream()), 'tattn_fused_bwd')
+                                                _p(rc), _p(rs), _p(bias), _p(grec), _p(ctx.vrec), _p(dx), _p(rec),
+                                                _p(grads), _p(ws), nb, b, f, h * w, c, heads, float(scale), _stream()), 'tattn_fused_bwd')
         n_q, n_o = 3 * hd * c, c * hd
         dwq = grads[:n_q].view(3 * hd, c)
         dwo = grads[n_q:n_q + n_o].view(c, hd)
