@@ -330,7 +330,9 @@ int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const vo
 /* Backward of the same block as ONE launch + an ordered reduction (csrc/attn_fused_bwd.hip): the backward of conv3d.py:165-174 and
  * :277-353 through autograd in the reference. Only x is needed from the forward: LayerNorm, projections, scores and attention output
  * are recomputed per sequence.
- *   dy: gradient of y, CL like x; rec_dy: its amax record; rec_v: the record the forward launch filled;
+ *   wq_*: the packed FORWARD operand of to_qkv (as in the forward), wo_*: the packed DATA-GRADIENT operand of to_out (W_out^T
+ *   [heads*32][C], wdno_pack_split_weight mode 1); dy: gradient of y, CL like x; rec_dy: its amax record; rec_v: the record the forward
+ *   launch filled;
  *   dx: gradient of x (the residual path included), amax_rec: optional amax record of dx;
  *   grads: wdno_tattn_fused_bwd_grads() floats = [ dW_qkv [3*heads*32][C] | dW_out [C][heads*32] | dgamma [C] | dbias [heads][n_tok][n_tok] ],
  *   each the sum over the launch's blocks of per-block partials in `ws` (wdno_tattn_fused_bwd_ws_bytes() bytes) taken in block order:

@@ -62,7 +62,7 @@
 struct TFusedBwdP {
   const float* x; const float* dy; const float* gamma; float eps;
   const _Float16* wq_hi; const _Float16* wq_lo; const float* wq_scale;      // packed forward operand of to_qkv: [384][64]
-  const _Float16* wo_hi; const _Float16* wo_lo; const float* wo_scale;      // ... of to_out: [64][128]
+  const _Float16* wo_hi; const _Float16* wo_lo; const float* wo_scale;      // packed DATA-GRADIENT operand of to_out: W_out^T [128][64]
   const float* rcos; const float* rsin; const float* bias;                  // [24][32], [24][32], [4][24][24] (any may be null)
   const float* rec_dy; const float* rec_v;                                  // amax records: dy; v of the forward launch
   float* dx; float* amax_rec; float* part;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void tb_fit(float& sc, float amax, f32x16& w0, f32x16
     const float r = need / sc;
     tb_rescale(w0, r, li, hh);
     tb_rescale(w1, r, li, hh);
-    sc = need;
+    sc = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(need)));
   }
 }
 __device__ __forceinline__ float tb_absmax16(const f32x16& v) {
@@ -280,16 +280,10 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     if (p.rcos && t < TF_NT) v = make_float2(p.rcos[t * 32 + 2 * j], p.rsin[t * 32 + 2 * j]);
     Rt[t * TF_RST + j] = v;
   }
-  // dO^T[d][tok] = sum_c W_out[c][32 h + d] dy[tok][c]: A fragment of k-step s = channels 16 s + 8 hh + (0..7) of column 32 h + li
-  half8 woth[4], wotl[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int off = (16 * s + 8 * hh + t) * TF_HD + 32 * h + li;
-      woth[s][t] = p.wo_hi[off];
-      wotl[s][t] = p.wo_lo[off];
-    }
+  // dO^T[d][tok] = sum_c W_out[c][32 h + d] dy[tok][c]: the A fragment of k-step s = channels 16 s + 8 hh + (0..7) of row 32 h + li of
+  // W_out^T, 16 bytes of the packed data-gradient operand; fetched per sequence (L1 / L2) -- 32 registers held for the whole kernel spill
+  const _Float16* wot_h = p.wo_hi + (32 * h + li) * TF_C + 8 * hh;
+  const _Float16* wot_l = p.wo_lo + (32 * h + li) * TF_C + 8 * hh;
   const float4 g4 = reinterpret_cast<const float4*>(p.gamma)[lc4];
   const float ps = scale_from_amax(8.0f * group_max<16>(amax4(0.f, g4)));        // |LayerNorm(x)| <= sqrt(64) max|g|
   const float wq_s = p.wq_scale[0], wo_s = p.wo_scale[0];
@@ -350,6 +344,12 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
       float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p.bias && li < TF_NT) b4 = *reinterpret_cast<const float4*>(p.bias + (h * TF_NT + li) * TF_NT + 8 * c + 4 * hh);
       bs[4 * c] = b4.x; bs[4 * c + 1] = b4.y; bs[4 * c + 2] = b4.z; bs[4 * c + 3] = b4.w;
+    }
+    half8 woth[4], wotl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      woth[s] = *reinterpret_cast<const half8*>(wot_h + 16 * s);
+      wotl[s] = *reinterpret_cast<const half8*>(wot_l + 16 * s);
     }
     if (ABL != 3) __syncthreads();                                            // B1: planes of xn and dy
     // ---- (q | k | v)^T of this head, dO^T = W_out^T dy^T (this head's 32 columns)
@@ -475,10 +475,11 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     if (seq + gridDim.x < p.nseq) fetch((int64_t)nb * TF_NT * p.HW + npix, nx0, nx1, ng0, ng1);
     // ---- dV^T = dO^T P; under it: the operands of dW_q / dxn_q
     f32x16 dv = ABL == 2 ? sT : tb_product12(cdo, rP);
-    f32x16 xq0 = tb_zero(), xq1 = tb_zero(), xk0 = tb_zero(), xk1 = tb_zero(), xv0 = tb_zero(), xv1 = tb_zero();
+    f32x16 dxs0 = tb_zero(), dxs1 = tb_zero();                                // dxn^T of this head, channels 0..31 / 32..63 (fp32 sum of the three tensors' parts)
     // weight-gradient tiles  dW[feature][32 ct + c] += sum_tok P[tok][feature] xn[tok][c]  and  dxn^T[c][tok] += sum_f W[f][c] d[tok][f]
-    auto grad_products = [&](f32x16& w0, f32x16& w1, f32x16& d0, f32x16& d1, int fbase, const half8 (&dh)[2], const half8 (&dl)[2]) {
+    auto grad_products = [&](f32x16& w0, f32x16& w1, float sc, int fbase, const half8 (&dh)[2], const half8 (&dl)[2]) {
       if (ABL == 1) return;
+      f32x16 d0 = tb_zero(), d1 = tb_zero();
       const half8 a0h = tb_trf<0>(PH, TB_PS, 0, lane, ZB), a0l = tb_trf<0>(PL, TB_PS, 0, lane, ZB);
       const half8 a1h = tb_trf<1>(PH, TB_PS, 0, lane, ZB), a1l = tb_trf<1>(PL, TB_PS, 0, lane, ZB);
       w0 = tb_mfma3(a0h, a0l, tb_trf<0>(XH, TF_AST, 0, lane, ZB), tb_trf<0>(XL, TF_AST, 0, lane, ZB), w0);
@@ -490,37 +491,30 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
         d0 = tb_mfma3(tb_wtr(WH, fbase + 16 * s, 0, lane), tb_wtr(WL, fbase + 16 * s, 0, lane), dh[s], dl[s], d0);
         d1 = tb_mfma3(tb_wtr(WH, fbase + 16 * s, 1, lane), tb_wtr(WL, fbase + 16 * s, 1, lane), dh[s], dl[s], d1);
       }
+      const float inv = 1.0f / (sc * wq_s);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dxs0[e] = fmaf(d0[e], inv, dxs0[e]); dxs1[e] = fmaf(d1[e], inv, dxs1[e]); }
     };
-    grad_products(dwq[0][0], dwq[0][1], xq0, xq1, h * 32, qh, ql);
+    grad_products(dwq[0][0], dwq[0][1], sc_q, h * 32, qh, ql);
     TB_FENCE();
     tb_unrotate(dk, Rt, li, hh, 1.0f);
     tb_fit(sc_k, tf_wave_max(tb_absmax16(dk)), dwq[1][0], dwq[1][1], li, hh);
     tb_split16(dk, sc_k, qh, ql, PH, PL, li, hh);
     TB_FENCE();
-    grad_products(dwq[1][0], dwq[1][1], xk0, xk1, TF_HD + h * 32, qh, ql);
+    grad_products(dwq[1][0], dwq[1][1], sc_k, TF_HD + h * 32, qh, ql);
     TB_FENCE();
     tb_fit(sc_v, tf_wave_max(tb_absmax16(dv)), dwq[2][0], dwq[2][1], li, hh);
     tb_split16(dv, sc_v, qh, ql, PH, PL, li, hh);
     TB_FENCE();
-    grad_products(dwq[2][0], dwq[2][1], xv0, xv1, 2 * TF_HD + h * 32, qh, ql);
+    grad_products(dwq[2][0], dwq[2][1], sc_v, 2 * TF_HD + h * 32, qh, ql);
     TB_FENCE();
     // ---- the head's part of dxn as [token][channel]
     if (li < TF_NT) {
-      const float inv_xq = 1.0f / (sc_q * wq_s), inv_xk = 1.0f / (sc_k * wq_s), inv_xv = 1.0f / (sc_v * wq_s);
       float* yp = Yp + li * TF_YST + 4 * hh;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        float4 a, b;
-        a.x = xq0[4 * c] * inv_xq + (xk0[4 * c] * inv_xk + xv0[4 * c] * inv_xv);
-        a.y = xq0[4 * c + 1] * inv_xq + (xk0[4 * c + 1] * inv_xk + xv0[4 * c + 1] * inv_xv);
-        a.z = xq0[4 * c + 2] * inv_xq + (xk0[4 * c + 2] * inv_xk + xv0[4 * c + 2] * inv_xv);
-        a.w = xq0[4 * c + 3] * inv_xq + (xk0[4 * c + 3] * inv_xk + xv0[4 * c + 3] * inv_xv);
-        b.x = xq1[4 * c] * inv_xq + (xk1[4 * c] * inv_xk + xv1[4 * c] * inv_xv);
-        b.y = xq1[4 * c + 1] * inv_xq + (xk1[4 * c + 1] * inv_xk + xv1[4 * c + 1] * inv_xv);
-        b.z = xq1[4 * c + 2] * inv_xq + (xk1[4 * c + 2] * inv_xk + xv1[4 * c + 2] * inv_xv);
-        b.w = xq1[4 * c + 3] * inv_xq + (xk1[4 * c + 3] * inv_xk + xv1[4 * c + 3] * inv_xv);
-        *reinterpret_cast<float4*>(yp + 8 * c) = a;
-        *reinterpret_cast<float4*>(yp + 32 + 8 * c) = b;
+        *reinterpret_cast<float4*>(yp + 8 * c) = make_float4(dxs0[4 * c], dxs0[4 * c + 1], dxs0[4 * c + 2], dxs0[4 * c + 3]);
+        *reinterpret_cast<float4*>(yp + 32 + 8 * c) = make_float4(dxs1[4 * c], dxs1[4 * c + 1], dxs1[4 * c + 2], dxs1[4 * c + 3]);
       }
     }
     if (ABL != 3) __syncthreads();                                            // B2
@@ -644,7 +638,11 @@ extern "C" int wdno_tattn_fused_bwd(const float* x, const float* dy, const float
   if (abl < 0) {
     const char* e = getenv("WDNO_TB_ABLATE");
     abl = e ? atoi(e) : 0;
+#ifdef WDNO_TB_ABLATIONS        /* hipcc -DWDNO_TB_ABLATIONS: tools/tattn_ablate.sh */
     kern = abl == 1 ? tattn_fused_bwd_kernel<1> : abl == 2 ? tattn_fused_bwd_kernel<2> : abl == 3 ? tattn_fused_bwd_kernel<3> : tattn_fused_bwd_kernel<0>;
+#else
+    kern = tattn_fused_bwd_kernel<0>;
+#endif
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS_BYTES) != hipSuccess) return WDNO_ELAUNCH;
   }
   int64_t grid = tb_num_cus();

@@ -1729,7 +1729,8 @@ class _TAttnFused(torch.autograd.Function):
         b, f, h, w, c = x.shape
         hd = heads * 32
         lib = _lib_()
-        wqh, wql, wqs, woh, wol, wos = _tattn_operands(w_qkv, w_out, c, hd)       # the forward's operands (cached per weight epoch)
+        wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)         # the forward's operand (cached per weight epoch)
+        woh, wol, wos = split_weight(w_out, 'd', pad8(c), hd, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_))      # W_out^T [hd][c]
         nb = lib.wdno_tattn_fused_bwd_ws_bytes()
         ws = _ws(nb, x.device)
         dx = torch.empty_like(x)
