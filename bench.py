@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16 / _bf16, dense (the 3 x fp16-split kernels spend 3 MFMA flop per algorithmic flop)
 PEAK_HBM_TBS = 8.0
-PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
 
 
 def _trees():
@@ -288,8 +288,40 @@ def sampling_leg(dif, device, batch, steps):
             torch.cuda.synchronize()
             graph = steps / (time.perf_counter() - t0)
         out[f'batch{b}'] = {'eager_steps_per_sec': round(eager, 2), 'graph_steps_per_sec': round(graph, 2)}
+        if b == batch:
+            out['roofline'] = sampling_roofline(dif, shape, x, src, desc, graph)
         K._graph_cache.pop(dif, None)
     return out
+
+
+def sampling_roofline(dif, shape, x, src, desc, steps_per_sec):
+    """The sampling half of the metric against the rooflines (SURVEY 8d counting rule: one p_sample step = one U-Net forward, 326.3 GFLOP and
+    2.02 GB of un-fused leaf-op traffic per sample, + 5 streams of the state): the kernel with the largest total time in one eager step
+    (HIP events around every profiled launch, on the launch stream) and the whole graph-replayed step."""
+    from wdno_amd import ops, diffusion_core as K
+    with torch.no_grad():
+        ops.PROFILE = {}
+        y, _ = dif.p_sample(shape, x, 321)
+        K.apply_cond(y, src, desc)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+    agg = {k: (sum(e0.elapsed_time(e1) for e0, e1, _ in v), sum(f for _, _, f in v), len(v)) for k, v in prof.items()}
+    dom = max(agg, key=lambda k: agg[k][0])
+    ms, fl, n = agg[dom]
+    b = shape[0]
+    gf, gb = 326.3, 2.02 + 5 * 4 * 24 * 42 * 40 * 40 / 1e9
+    tfl = b * gf / 1e3 * steps_per_sec
+    gbs = b * gb * steps_per_sec
+    split = 'h3' in dom or 'tattn' in dom
+    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    return {'bound': 'mfma', 'kernel': dom, 'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(fl / (ms * 1e-3) / 1e12 / peak, 4), 'frac_of_fp32_equivalent_ceiling': round(fl / (ms * 1e-3) / 1e12 / (peak / 3), 4) if split else None,
+            'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4), 'gflop_per_launch': round(fl / n / 1e9, 3),
+            'step': {'tflops_algorithmic': round(tfl, 1), 'frac_mfma': round(tfl / PEAK_F16_MFMA_TFLOPS, 4),
+                     'frac_mfma_of_fp32_equivalent_ceiling': round(tfl / (PEAK_F16_MFMA_TFLOPS / 3), 4),
+                     'hbm_GBps_unfused': round(gbs, 1), 'frac_hbm': round(gbs / (PEAK_HBM_TBS * 1e3), 4), 'gflop_per_sample': gf,
+                     'GB_per_sample_unfused': round(gb, 3)},
+            'kernel_ms_per_step': {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}}
 
 
 def sr_leg(device, batch=2, steps=10):
@@ -388,7 +420,7 @@ def burgers_leg(device, batch, steps, lowp=None, grid=(64, 64)):
         ops.CONV_MATH = prev
 
 
-def train_graph_leg(ts, x, steps):
+def train_graph_leg(ts, x, steps, cap=None):
     """The same training step with loss -> backward -> gradient gather replayed from ONE captured HIP graph (TrainStep.capture; draws,
     clip + Adam and EMA stay outside): host time to enqueue a step and steps/s, eager vs graph. Same kernels either way -- at batch 8
     the GPU is the bound, so the rate barely moves; what changes is the host side (18 ms of Python per step -> a graph launch)."""
@@ -405,11 +437,16 @@ def train_graph_leg(ts, x, steps):
             ts.step(x)
         torch.cuda.synchronize()
         return round(_median(enq), 2), round((time.perf_counter() - t0) / steps * 1e3, 3)
+    ts._cap = None
     e_enq, e_ms = measure()
-    ts.capture(x, warmup=1)
+    if cap is not None:
+        ts._cap = cap
+    else:
+        ts.capture(x, warmup=1)
     for _ in range(2):
         ts.step(x)
     g_enq, g_ms = measure()
+    ts._cap = None
     return {'eager': {'host_enqueue_ms_per_step': e_enq, 'ms_per_step': e_ms}, 'graph': {'host_enqueue_ms_per_step': g_enq, 'ms_per_step': g_ms}}
 
 
@@ -476,7 +513,7 @@ def conv_roofline(ts_step, ops):
         fam, dims = dom.split('<')
         dims = dims.rstrip('>').split(',')
         sym = fam + 'I' + ''.join(f'Li{d}E' for d in dims) if all(d.isdigit() for d in dims) else None
-        path = next((q for q in (PROFILE_JSON, os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'), os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json'))
+        path = next((q for q in (PROFILE_JSON, os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'), os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'))
                      if os.path.exists(q)), PROFILE_JSON)
         with open(path) as f:
             recs = json.load(f)['kernels']
@@ -526,6 +563,7 @@ def main():
     ap.add_argument('--workload', default='smoke', choices=['smoke', 'burgers', 'burgers-bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the sampling / DWT / Burgers side legs')
+    ap.add_argument('--eager', action='store_true', help='timed steps launch by launch instead of replaying the captured HIP graph')
     ap.add_argument('--sample-steps', type=int, default=20)
     ap.add_argument('--burgers-grid', default='64x64', help="tensor size of the Burgers workloads: 64x64 (reference-native) or 80x64 (north-star synthetic: fields [B,2,160,128] through the HIP DWT)")
     args = ap.parse_args()
@@ -575,6 +613,13 @@ def main():
     losses = []
     for _ in range(args.warmup):
         loss, _ = ts.step(x)
+    # The timed steps replay ONE captured HIP graph (loss -> backward -> gradient gather; the draws, the RCCL exchange, clip + Adam and EMA are
+    # launched around it, wdno_amd.trainer.CapturedStep): the drop-in Trainers' default. Same kernels in the same order as the eager step
+    # (bit-identical, tests/test_gpu_graph.py); not with the overlapped bucket exchange (Python hooks during backward). --eager: launch by launch.
+    graphed = ts.overlap is None and not args.eager
+    if graphed:
+        ts.capture(x, warmup=1)
+        ts.step(x)
     barrier()
     ts.comm_events = []
     t0 = time.perf_counter()
@@ -597,6 +642,7 @@ def main():
 
     extras = {}
     roofline = cpu = None
+    cap, ts._cap = getattr(ts, '_cap', None), None          # the profiled extra step runs launch by launch (HIP events around every convolution)
     if rank != 0 and world > 1:
         ts.step(x)              # rank 0's profiled extra step below contains the gradient all-reduce: every rank has to take part in it
     if rank == 0:
@@ -606,7 +652,7 @@ def main():
                 if smoke:
                     extras['sampling'] = sampling_leg(dif, device, batch, args.sample_steps)
                     extras['fields_pipeline'] = smoke_pipeline_leg(ts, device, batch, 10)
-                    extras['train_step_graph'] = train_graph_leg(ts, x, 20)
+                    extras['train_step_graph'] = train_graph_leg(ts, x, 20, cap)
                 extras['dwt'] = dwt_leg(device)
                 if smoke:
                     del ts, dif
@@ -663,6 +709,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0,
+                       'step_launch': 'hip_graph_replay (loss + backward + gradient gather captured; draws, exchange, clip + Adam, EMA around it)' if graphed else 'launch by launch',
                        'process_group': ({'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                           'rccl_version': _rccl_version() if dist.get_backend() == 'nccl' else None,
                                           'devices_visible': torch.cuda.device_count()} if world > 1 else None)},
@@ -672,6 +719,7 @@ def main():
         }
         if 'sampling' in extras:
             out['ddpm_sample_steps_per_sec'] = extras['sampling'][f'batch{batch}']['graph_steps_per_sec']
+            out['sampling_roofline'] = extras['sampling'].pop('roofline', None)
         out['per_rank'] = per_rank
         out.update(extras)
         print(json.dumps(out))

@@ -741,9 +741,10 @@ class TrainerCore:
                           num_workers=num_workers, drop_last=False)
 
     # ------------------------------------------------------------------ one optimisation step (T1 / T2)
-    use_graph = False           # True: the step (loss -> backward -> gradient gather) is replayed from one captured HIP graph per batch shape
-                                # (CapturedStep; gradient_accumulate_every == 1 only). A class attribute like num_workers: the constructors keep the
-                                # reference's parameter lists. Bit-identical to the launch-by-launch step (tests/test_gpu_trainer.py).
+    use_graph = True            # the step (loss -> backward -> gradient gather) is replayed from one captured HIP graph per batch shape
+                                # (CapturedStep; gradient_accumulate_every == 1 only; the first step of a shape runs launch by launch, the capture
+                                # follows it). A class attribute like num_workers: the constructors keep the reference's parameter lists.
+                                # Bit-identical to the launch-by-launch step (tests/test_gpu_trainer.py); False: every step launch by launch.
 
     def optimisation_step(self, next_batch):
         """next_batch() -> device tensor. Returns the python float loss of this rank (the reference logs it per rank)."""
