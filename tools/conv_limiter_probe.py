@@ -6,7 +6,7 @@ Runs pure loops of one kernel for a few seconds each and samples, for the GPU th
     "gfx clock below host limit" accumulators split by cause (power / thermal)   (amd-smi metric --violation)
 Loops: idle; level-0 3x3x3 64->64 forward (tap-resident split kernel) on random operands and on ALL-ZERO operands (same instruction
 stream, no data toggling); its weight gradient; an HBM-bound kernel (fp16 split pass) for contrast.
-    python tools/conv_limiter_probe.py [seconds_per_phase] > profiles/r03_conv_limiter.md"""
+    python tools/conv_limiter_probe.py [seconds_per_phase] > profiles/r04_conv_limiter.md"""
 import glob
 import json
 import os
@@ -107,6 +107,25 @@ flops = 2.0 * x.numel() // 64 * 64 * 64 * 27
 res = []
 res.append(phase('idle', None))
 res.append(phase('conv fwd 64->64 level 0 (random operands)', lambda: ops.conv_fwd_h3(xpl, xs[:4], w, ops.pack_fwd, 'f', None, None, ks, st, pd, 64)))
+# round 4: the 128 x 64 accumulator tile per compute wave (512 x 64 block tiles on 16-channel stages, debug 45: 12 fragment reads per
+# 24 matrix instructions instead of 8 per 12) -- at batch 8 (600 tiles: 2.34 rounds of 256 CUs against 4.69 of the 256 x 64 tiles) and at
+# batch 10 (750 / 1500 tiles: both 97.7 % of their last round)
+lib = ops._lib_()
+def with_debug(mode, fn):
+    def g():
+        lib.wdno_set_debug(mode)
+        fn()
+        lib.wdno_set_debug(0)
+    return g
+res.append(phase('conv fwd 64->64 level 0, 128 x 64 accumulator tile per wave (512 x 64 blocks, debug 45)',
+                 with_debug(45, lambda: ops.conv_fwd_h3(xpl, xs[:4], w, ops.pack_fwd, 'f', None, None, ks, st, pd, 64))))
+xs10 = (10, 24, 40, 40, 64)
+x10 = torch.randn(*xs10, device=dev)
+xpl10 = ops.split_f16(x10.reshape(-1, 64))
+F10 = 10.0 / 8.0
+res.append(phase('batch 10: 64 x 64 per wave (1500 tiles of 256 x 64) [TFLOP/s column: x 1.25]', lambda: ops.conv_fwd_h3(xpl10, xs10[:4], w, ops.pack_fwd, 'f', None, None, ks, st, pd, 64)))
+res.append(phase('batch 10: 128 x 64 per wave (750 tiles of 512 x 64, debug 45) [TFLOP/s column: x 1.25]',
+                 with_debug(45, lambda: ops.conv_fwd_h3(xpl10, xs10[:4], w, ops.pack_fwd, 'f', None, None, ks, st, pd, 64))))
 res.append(phase('conv fwd 64->64 level 0 (all-zero operands)', lambda: ops.conv_fwd_h3(zpl, xs[:4], wz, ops.pack_fwd, 'f', None, None, ks, st, pd, 64)))
 res.append(phase('conv wgrad 64->64 level 0', lambda: ops.conv_wgrad_h3(xpl, xs[:4], ypl, tuple(y.shape[1:4]), ks, st, pd)))
 res.append(phase('fp16 split pass (HBM-bound, 79 MB in / 79 MB out)', lambda: ops.split_f16(x.reshape(-1, 64))))

@@ -242,8 +242,8 @@ __device__ __forceinline__ float tb_absmax16(const f32x16& v) {
   return m;
 }
 
-// ABL: timing ablations (tools/tattn_ablate.sh, WDNO_TB_ABLATE): 1 = no weight-gradient / dxn products, 2 = no score-sized fp32 products,
-// 3 = no block barriers (results are wrong in all three)
+// ABL: timing ablations (tools/tattn_ablate.sh, WDNO_TB_ABLATE, built with -DWDNO_TB_ABLATIONS): 1 = no weight-gradient / dxn products, 2 = no
+// score-sized fp32 products, 3 = no block barriers, 4 = 1 + 2, 5 = 4 without the projections (results are wrong in all of them)
 template <int ABL>
 __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tb_smem[];
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     // ---- (q | k | v)^T of this head, dO^T = W_out^T dy^T (this head's 32 columns)
     f32x16 aq = tb_zero(), ak = tb_zero(), av = tb_zero(), dOT = tb_zero();
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < (ABL == 5 ? 0 : 4); ++s) {
       const half8 bh = *reinterpret_cast<const half8*>(xrow + 16 * s);
       const half8 bl = *reinterpret_cast<const half8*>(xrow + xl_off + 16 * s);
       const int o0 = tb_woff(h * 32 + li, 2 * s + hh);                       // rows + 128, + 256: same swizzle term ((f >> 1) & 7 has period 16)
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
       av = tb_mfma3(*reinterpret_cast<const half8*>(WH + o0 + 2 * TF_HD * TF_C), *reinterpret_cast<const half8*>(WL + o0 + 2 * TF_HD * TF_C), bh, bl, av);
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < (ABL == 5 ? 0 : 4); ++s) {
       const half8 bh = *reinterpret_cast<const half8*>(grow + 16 * s);
       const half8 bl = *reinterpret_cast<const half8*>(grow + xl_off + 16 * s);
       dOT = tb_mfma3(woth[s], wotl[s], bh, bl, dOT);
@@ -396,9 +396,9 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     TB_FENCE();
     tb_acc_to_tile(T0, ak, li, hh);                                           // T0 = k'
 #pragma unroll
-    for (int e = 0; e < 16; ++e) if (ABL != 2) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[e], aq[e], sT, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) if (!(ABL == 2 || ABL >= 4)) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[e], aq[e], sT, 0, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) if (ABL != 2) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], dOT[e], dsT, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) if (!(ABL == 2 || ABL >= 4)) dsT = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], dOT[e], dsT, 0, 0, 0);
     {
       float mx = -INFINITY;
 #pragma unroll
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     TB_FENCE();
     tb_acc_to_tile(T0, aq, li, hh);                                           // T0 = q'
     // ---- O^T = V^T P^T; under it: dS^T = P^T (dP^T - delta), delta_i = sum_j P_ij dP_ij
-    f32x16 oT = ABL == 2 ? sT : tb_product12(cv, sT);
+    f32x16 oT = (ABL == 2 || ABL >= 4) ? sT : tb_product12(cv, sT);
     {
       float delta = 0.f;
 #pragma unroll
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     tb_acc_to_tile(T0, dOT, li, hh);                                          // T0 = dO
     tb_acc_to_tile_t(T1, sT, li, hh);                                         // T1 = P (lane roles swapped)
     // ---- dQ'^T = K'^T dS^T; under it: the planes of O
-    f32x16 dq = ABL == 2 ? dsT : tb_product12(ck, dsT);
+    f32x16 dq = (ABL == 2 || ABL >= 4) ? dsT : tb_product12(ck, dsT);
     half8 oh[2], ol[2];
     tb_split16(oT, sc_o, oh, ol, PH, PL, li, hh);
     TB_FENCE();
@@ -455,14 +455,14 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     tb_rows(T1, trow, hh, rP);
     TB_FENCE();
     // ---- dK'^T = Q'^T dS; under it: dq un-rotated, its planes
-    f32x16 dk = ABL == 2 ? dsT : tb_product12(cq, rS);
+    f32x16 dk = (ABL == 2 || ABL >= 4) ? dsT : tb_product12(cq, rS);
     tb_unrotate(dq, Rt, li, hh, p.scale);
     tb_fit(sc_q, tf_wave_max(tb_absmax16(dq)), dwq[0][0], dwq[0][1], li, hh);
     half8 qh[2], ql[2];
     tb_split16(dq, sc_q, qh, ql, PH, PL, li, hh);                              // (after the reads of O's planes: LDS keeps a wave's order)
     TB_FENCE();
     // ---- dW_out[c][32 h + d] += sum_tok dy[tok][c] O[tok][d]: rows = channels (A = dy image), columns = d (B = the O planes)
-    if (ABL != 1) {
+    if (ABL != 1 && ABL < 4) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         dwo[ct] = tb_mfma3(tb_trf<0>(GH, TF_AST, 32 * ct, lane, ZB), tb_trf<0>(GL, TF_AST, 32 * ct, lane, ZB), bo_h[0], bo_l[0], dwo[ct]);
@@ -474,11 +474,11 @@ __global__ __launch_bounds__(256, 1) void tattn_fused_bwd_kernel(TFusedBwdP p) {
     fetch(row0, cx0, cx1, cg0, cg1);
     if (seq + gridDim.x < p.nseq) fetch((int64_t)nb * TF_NT * p.HW + npix, nx0, nx1, ng0, ng1);
     // ---- dV^T = dO^T P; under it: the operands of dW_q / dxn_q
-    f32x16 dv = ABL == 2 ? sT : tb_product12(cdo, rP);
+    f32x16 dv = (ABL == 2 || ABL >= 4) ? sT : tb_product12(cdo, rP);
     f32x16 dxs0 = tb_zero(), dxs1 = tb_zero();                                // dxn^T of this head, channels 0..31 / 32..63 (fp32 sum of the three tensors' parts)
     // weight-gradient tiles  dW[feature][32 ct + c] += sum_tok P[tok][feature] xn[tok][c]  and  dxn^T[c][tok] += sum_f W[f][c] d[tok][f]
     auto grad_products = [&](f32x16& w0, f32x16& w1, float sc, int fbase, const half8 (&dh)[2], const half8 (&dl)[2]) {
-      if (ABL == 1) return;
+      if (ABL == 1 || ABL >= 4) return;
       f32x16 d0 = tb_zero(), d1 = tb_zero();
       const half8 a0h = tb_trf<0>(PH, TB_PS, 0, lane, ZB), a0l = tb_trf<0>(PL, TB_PS, 0, lane, ZB);
       const half8 a1h = tb_trf<1>(PH, TB_PS, 0, lane, ZB), a1l = tb_trf<1>(PL, TB_PS, 0, lane, ZB);
@@ -639,7 +639,8 @@ extern "C" int wdno_tattn_fused_bwd(const float* x, const float* dy, const float
     const char* e = getenv("WDNO_TB_ABLATE");
     abl = e ? atoi(e) : 0;
 #ifdef WDNO_TB_ABLATIONS        /* hipcc -DWDNO_TB_ABLATIONS: tools/tattn_ablate.sh */
-    kern = abl == 1 ? tattn_fused_bwd_kernel<1> : abl == 2 ? tattn_fused_bwd_kernel<2> : abl == 3 ? tattn_fused_bwd_kernel<3> : tattn_fused_bwd_kernel<0>;
+    kern = abl == 1 ? tattn_fused_bwd_kernel<1> : abl == 2 ? tattn_fused_bwd_kernel<2> : abl == 3 ? tattn_fused_bwd_kernel<3> : abl == 4 ? tattn_fused_bwd_kernel<4> :
+           abl == 5 ? tattn_fused_bwd_kernel<5> : tattn_fused_bwd_kernel<0>;
 #else
     kern = tattn_fused_bwd_kernel<0>;
 #endif

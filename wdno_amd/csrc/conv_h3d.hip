@@ -394,6 +394,7 @@ static int fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void
       if (wdno_debug_mode == 55) best = 7;
       if (wdno_debug_mode == 30) best = narrow_only ? 5 : 4;     // tests: the new shapes on small cases
       if (wdno_debug_mode == 31) best = 5;
+      if (wdno_debug_mode == 45 && best == 2 && (g.C % 16) == 0) best = 8;      // experiment: 128 x 64 accumulator tile per wave (conv_h3t.hip)
     }
     return wdno_conv_fwd_h3_tap(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
   }

@@ -392,6 +392,9 @@ static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, co
   if (shape == 5) return launch_h3t<320, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 6) return launch_h3t<64, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);      // few pixels x many channels (Burgers 8 x 8 level)
   if (shape == 7) return launch_h3t<128, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
+  // experiment (debug 45, tools/bench_conv.py): 128 x 64 accumulator tile per compute wave -- 512 x 64 block tiles on 16-channel stages (rows
+  // of 32 B: two stages of 32-channel blocks would need 180 KB), 12 fragment reads per 24 matrix instructions instead of 8 per 12
+  if (shape == 8) return launch_h3t<512, 64, 4, 1, 3, 16, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   return launch_h3t<256, 64, 4, 1, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
 }
 int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
