@@ -124,8 +124,12 @@ def test_bf16_transposed_conv(ops):
     assert torch.isfinite(wd.grad).all()
 
 
-def test_bf16_burgers_train_step_documented_tolerance(ops):
-    """Full-width Unet2D(dim=128) training step [4, 9, 64, 64]: bf16 path against the fp32 oracle on the host."""
+def test_bf16_burgers_train_step_vs_autocast_arbiter(ops):
+    """Full-width Unet2D(dim=128) training step [4, 9, 64, 64] on the single-product bf16 path (BASELINE configs[1]). The reference's
+    semantics for that configuration are accelerate's mixed precision (train_diffusion.py:62, 71-74): fp32 master weights, the forward under
+    torch.autocast(bfloat16). Three evaluations of the same step on the same weights and inputs: HIP bf16, the oracle under CPU
+    autocast(bfloat16) (= what the reference computes), the oracle in fp64 (the arbiter). Gate: the HIP path is no further from exact than
+    1.5 x the autocast reference -- loss, median and worst parameter gradient."""
     from wdno_amd import tree_path
     for t in ('third_party', 'smoke', 'burgers'):
         p = tree_path(t)
@@ -142,11 +146,18 @@ def test_bf16_burgers_train_step_documented_tolerance(ops):
     noise = torch.randn(4, 9, 64, 64, generator=gen)
     t = torch.tensor([77, 805, 310, 999])
     lw = torch.ones(1, 9, 1, 1)
-    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
-    model = lambda x, tt: U.unet2d_forward(sd, x, tt, dim=128, dim_mults=(1, 2, 4, 8), groups=1)
-    ref = D.burgers_p_losses(model, D.make_buffers('cosine', 1000), x0, t, noise, padded_shape=[41, 60], loss_layer_weight=lw,
-                             flags=dict(pad=True, u0=True, uT=False, f=True))
-    ref.backward()
+
+    def oracle(dt, autocast):
+        sd = {k: (v.clone().to(dt).requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        model = lambda x, tt: U.unet2d_forward(sd, x, tt, dim=128, dim_mults=(1, 2, 4, 8), groups=1)
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
+            loss = D.burgers_p_losses(model, D.make_buffers('cosine', 1000), x0.to(dt), t, noise.to(dt), padded_shape=[41, 60],
+                                      loss_layer_weight=lw.to(dt), flags=dict(pad=True, u0=True, uT=False, f=True))
+        loss.float().backward() if autocast else loss.backward()
+        return float(loss.detach()), {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+
+    l_e, g_e = oracle(torch.float64, False)
+    l_a, g_a = oracle(torch.float32, True)
     dif = GaussianDiffusion(net, seq_length=(64, 64), padded_shape=[41, 60], ori_shape=[81, 120], loss_layer_weight=lw,
                             is_condition_pad=True, is_condition_u0=True, is_condition_f=True).to(DEV)
     ops.PROFILE = {}
@@ -155,11 +166,17 @@ def test_bf16_burgers_train_step_documented_tolerance(ops):
     torch.cuda.synchronize()
     used, ops.PROFILE = set(ops.PROFILE), None
     assert any('h3d' in k or 'h3t' in k for k in used)
-    errs = sorted(rel_l2(p.grad, sd[k].grad) for k, p in net.named_parameters())
-    rel_loss = abs(loss.item() - ref.item()) / abs(ref.item())
-    print(f'bf16 Burgers step: loss rel {rel_loss:.3e}; gradient rel-L2 median {errs[len(errs) // 2]:.3e}, worst {errs[-1]:.3e}')
-    assert rel_loss < 2e-2
-    assert errs[len(errs) // 2] < 5e-2 and errs[-1] < 2.5e-1
+    names = [k for k, _ in net.named_parameters()]
+    e_h = sorted(rel_l2(p.grad, g_e[k]) for k, p in net.named_parameters())
+    e_a = sorted(rel_l2(g_a[k], g_e[k]) for k in names)
+    rl_h, rl_a = abs(loss.item() - l_e) / abs(l_e), abs(l_a - l_e) / abs(l_e)
+    mid = len(names) // 2
+    print(f'bf16 Burgers step vs exact: loss rel HIP {rl_h:.3e} / autocast oracle {rl_a:.3e}; gradient rel-L2 median HIP {e_h[mid]:.3e} / autocast {e_a[mid]:.3e}, '
+          f'worst HIP {e_h[-1]:.3e} / autocast {e_a[-1]:.3e}')
+    # (the loss is ONE number: its error is a draw from the bf16 noise, which the gradients measure 276 times -- the autocast oracle's own draw
+    # can be 30 x below its typical size, so the loss is held to the typical size)
+    assert rl_h <= 1.5 * max(rl_a, e_a[mid])
+    assert e_h[mid] <= 1.5 * e_a[mid] and e_h[-1] <= 1.5 * e_a[-1]
 
 
 def test_bf16_training_reduces_the_loss(ops):
