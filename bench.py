@@ -617,9 +617,15 @@ def main():
     # launched around it, wdno_amd.trainer.CapturedStep): the drop-in Trainers' default. Same kernels in the same order as the eager step
     # (bit-identical, tests/test_gpu_graph.py); not with the overlapped bucket exchange (Python hooks during backward). --eager: launch by launch.
     graphed = ts.overlap is None and not args.eager
+    capture_error = None
     if graphed:
-        ts.capture(x, warmup=1)
-        ts.step(x)
+        try:
+            ts.capture(x, warmup=1)
+            ts.step(x)
+        except Exception as e:          # a failed capture must not cost the measurement: the same step launch by launch, and the line says so
+            capture_error, graphed, ts._cap = repr(e)[:200], False, None
+            torch.cuda.synchronize()
+            ts.step(x)
     barrier()
     ts.comm_events = []
     t0 = time.perf_counter()
@@ -709,7 +715,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0,
-                       'step_launch': 'hip_graph_replay (loss + backward + gradient gather captured; draws, exchange, clip + Adam, EMA around it)' if graphed else 'launch by launch',
+                       'step_launch': 'hip_graph_replay (loss + backward + gradient gather captured; draws, exchange, clip + Adam, EMA around it)' if graphed else ('launch by launch' + (f' (capture failed: {capture_error})' if capture_error else '')),
                        'process_group': ({'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                           'rccl_version': _rccl_version() if dist.get_backend() == 'nccl' else None,
                                           'devices_visible': torch.cuda.device_count()} if world > 1 else None)},

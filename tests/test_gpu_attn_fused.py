@@ -203,6 +203,34 @@ def test_fused_block_backward_vs_oracle_and_layers(mods, b, h, w):
     assert rel_l2(dx_f.cpu().double() - gy.double(), dx_e - gy.double()) < 1e-5
 
 
+def test_fused_backward_without_rotary_and_bias(mods):
+    """The block without rotary embedding and position bias (Attention(rotary_emb=None), pos_bias=None): one backward launch against the
+    fp64 oracle's autograd."""
+    ops, V = mods
+    torch.manual_seed(21)
+    att = V.EinopsToAndFrom('b c f h w', 'b (h w) f c', V.Attention(64, heads=4, dim_head=32, rotary_emb=None))
+    blk = V.Residual(V.PreNorm(64, att))
+    x = torch.randn(2, 24, 6, 7, 64)
+    gy = torch.randn(2, 24, 6, 7, 64)
+    from oracle import unet_ref as U
+    leaf = {k: v.detach().double().requires_grad_(True) for k, v in (('g', blk.fn.norm.gamma), ('q', att.fn.to_qkv.weight), ('o', att.fn.to_out.weight))}
+    xe = x.double().requires_grad_(True)
+    xc = xe.permute(0, 4, 1, 2, 3)
+    y = U.channel_layernorm(xc, leaf['g'])
+    bb, c, f, hh_, ww_ = y.shape
+    y = U.token_attention(y.permute(0, 3, 4, 2, 1).reshape(bb, hh_ * ww_, f, c), leaf['q'], leaf['o'], 4, 32)
+    ((y.reshape(bb, hh_, ww_, f, c).permute(0, 4, 3, 1, 2) + xc).permute(0, 2, 3, 4, 1)).backward(gy.double())
+    blk = blk.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    ops.PROFILE = {}
+    blk(xd).backward(gy.to(DEV))
+    used, ops.PROFILE = set(ops.PROFILE), None
+    assert 'tattn_fused_bwd_kernel' in used
+    for name, got, want in (('dx', xd.grad, xe.grad), ('gamma', blk.fn.norm.gamma.grad, leaf['g'].grad), ('to_qkv', att.fn.to_qkv.weight.grad, leaf['q'].grad),
+                            ('to_out', att.fn.to_out.weight.grad, leaf['o'].grad)):
+        assert rel_l2(got, want) < 2e-6, (name, rel_l2(got, want))
+
+
 def test_fused_backward_leaves_the_amax_of_dx(mods):
     ops, V = mods
     blk, att, rpb = _block(V, 8)

@@ -1362,6 +1362,7 @@ class _GroupNormAct(torch.autograd.Function):
                                                          n, s, c, groups, float(eps), int(act_silu), _p(wsp), nbp, _stream()), 'groupnorm_fwd_planes')
             ctx.save_for_backward(x, gamma, beta, ssc, stats)
             ctx.meta = (n, s, c, groups, int(act_silu))
+            ctx.epoch = WEIGHT_EPOCH
             ctx.grad_planes = GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False)
             return _planes_only(y, (hi, lo, scale))
         rec = _new_amax_record(x.device)
@@ -1369,6 +1370,7 @@ class _GroupNormAct(torch.autograd.Function):
                                                    float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (n, s, c, groups, int(act_silu))
+        ctx.epoch = WEIGHT_EPOCH
         # the convolution that produced x takes its dy as fp16 planes (conv_cl(..., grad_planes=True)): deliver dx in that form
         c8 = c // 8
         ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0
@@ -1379,6 +1381,12 @@ class _GroupNormAct(torch.autograd.Function):
     def backward(ctx, gy):
         x, gamma, beta, ss, stats = ctx.saved_tensors
         n, s, c, groups, act_silu = ctx.meta
+        # The backward kernels read the affine tables the FORWARD left in `stats` (and park their two group means beside them): gamma, beta
+        # and scale_shift must be what the forward saw. Autograd's version counters guard in-place changes of the saved tensors; a write
+        # through the trainers' flat parameter buffer does not bump them, the weight epoch does. (One backward of a node at a time: the
+        # parked means are not safe under two concurrent backward passes of the same graph on different streams.)
+        if getattr(ctx, 'epoch', WEIGHT_EPOCH) != WEIGHT_EPOCH:
+            raise RuntimeError('wdno_amd GroupNorm backward: the parameters were updated (optimiser step / checkpoint load) between this forward and its backward')
         gy = _chk(gy, 'grad')
         lib = _lib_()
         dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
@@ -1434,6 +1442,7 @@ class _GroupNormActAdd(torch.autograd.Function):
                    'groupnorm_add_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (n, s, c, groups, int(act_silu))
+        ctx.epoch = WEIGHT_EPOCH
         c8 = c // 8
         ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0
                            and c8 <= 256 and (c8 & (c8 - 1)) == 0)
