@@ -1,6 +1,6 @@
 """Debugging aid (GPU box): follow one multi-seed smoke DDIM-4 chain (tests/golden/ref_round3.npz) step by step in three evaluations --
 hip (product path), cpu32 (oracle fp32) and exact (oracle fp64), each on its OWN state -- and print where hip leaves cpu32.
-    python tests/debug/chain_trace.py [seed]"""
+    python tools/diagnostics/chain_trace.py [seed]"""
 import json
 import os
 import sys
