@@ -522,7 +522,13 @@ class TrainStep:
     def _step_graph(self, batch):
         loss = self._cap.run(batch)
         if self.exchange:
+            if self.time_comm:                    # bench.py: the exposed exchange (the replayed backward has been enqueued in full), HIP events
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             allreduce_sum_(self.opt.buf.flat_grad, self.world, self.group, force=True)
+            if self.time_comm:
+                e1.record()
+                self.comm_events.append((e0, e1))
         lr = self.lr_schedule(self.base_lr, self.step_idx)
         gnorm = self.opt.step(lr=lr, grad_scale=1.0 / self.world)
         self.step_idx += 1
