@@ -872,14 +872,17 @@ __global__ __launch_bounds__(64 * AM_WAVES, ATT_BWD_BLOCKS_PER_CU) void attn_bwd
       for (int e = 0; e < 16; ++e) dk[e] = 0.f;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        float qa[4], sb[4];
+        float qa[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = 4 * g4 + q;
           const unsigned i = (unsigned)(8 * (m >> 2) + (m & 3)) + hz;
           qa[q] = Ta[i * AM_TS + (unsigned)li];
-          sb[q] = St[li * AM_TS + i];
         }
+        // this lane's row of dS, four consecutive queries as ONE 16-byte read (four ds_read_b32 at a row stride of 36 floats were 2-way
+        // bank-conflicted: 36 li mod 64 takes 16 values for 32 lanes)
+        const float4 sb4 = *reinterpret_cast<const float4*>(St + li * AM_TS + 8 * g4 + hz);
+        const float sb[4] = {sb4.x, sb4.y, sb4.z, sb4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q], sb[q], dk, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -909,14 +912,15 @@ __global__ __launch_bounds__(64 * AM_WAVES, ATT_BWD_BLOCKS_PER_CU) void attn_bwd
       for (int e = 0; e < 16; ++e) dv[e] = 0.f;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        float ga[4], pb[4];
+        float ga[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = 4 * g4 + q;
           const unsigned i = (unsigned)(8 * (m >> 2) + (m & 3)) + hz;
           ga[q] = i < (unsigned)n ? gb[i * gstride + (unsigned)li] : 0.f;
-          pb[q] = Pt[li * AM_TS + i];
         }
+        const float4 pb4 = *reinterpret_cast<const float4*>(Pt + li * AM_TS + 8 * g4 + hz);
+        const float pb[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) dv = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[q], pb[q], dv, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
