@@ -345,6 +345,19 @@ int wdno_tattn_fused_bwd(const float* x, const float* dy, const float* gamma, fl
                          float* grads, void* ws, size_t ws_bytes,
                          int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s);
 
+/* The SpatialLinearAttention block of the 64-channel levels FORWARD, for passes that need no gradient (csrc/linattn_fused.hip): replaces
+ * Residual(PreNorm(dim, SpatialLinearAttention(dim, heads))) -- smoke/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py:165-174
+ * (LayerNorm), :232-258 (to_qkv, softmax over features / tokens, context, to_out) and Residual's add -- by two passes over the tokens and a
+ * merge; the [rows][384] projections are never written.
+ *   x, y: CL [units][n_tok][C] fp32 (units = batch * frames, n_tok = H * W); gamma [C]; wq_* / wo_*: packed forward operands of to_qkv
+ *   [3*heads*32][C] and to_out [C][heads*32]; bias_out [C] or NULL; amax_rec: optional amax record of y; ws: wdno_lattn_fused_ws_bytes bytes.
+ * wdno_lattn_fused_takes: 1 for C = 64, 4 heads, n_tok >= 32. */
+int wdno_lattn_fused_takes(int C, int heads, int n_tok);
+size_t wdno_lattn_fused_ws_bytes(int64_t units, int n_tok);
+int wdno_lattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
+                         const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* bias_out, float* y, float* amax_rec,
+                         void* ws, size_t ws_bytes, int64_t units, int n_tok, int C, int heads, float scale, wdno_stream_t s);
+
 /* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]
  * (nn.Embedding weight) and bucket [n, n] int64 (host-built integer table); and dW from d(bias). One launch each. */
 int wdno_relpos_bias_fwd(const float* w, const int64_t* bucket, float* out, int n, int heads, wdno_stream_t s);

@@ -1,0 +1,107 @@
+"""csrc/linattn_fused.hip: Residual(PreNorm(SpatialLinearAttention)) of the smoke U-Net's 64-channel levels (conv3d.py:165-174, 232-258) as two
+passes over the tokens + a merge, without the [pixels x 384] projections -- the form sampling runs. Checked against the oracle's restatement
+of the block in fp64 (the arbiter), with the layer-by-layer HIP path and the fp32 oracle as yardsticks, and inside the whole U-Net forward."""
+import sys
+
+import pytest
+import torch
+
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def mods():
+    from wdno_amd import ops, tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from video_diffusion_pytorch import video_diffusion_pytorch_conv3d as V
+    return ops, V
+
+
+def _block(V, seed):
+    torch.manual_seed(seed)
+    blk = V.Residual(V.PreNorm(64, V.SpatialLinearAttention(64, heads=4)))
+    with torch.no_grad():
+        blk.fn.norm.gamma.add_(0.3 * torch.randn_like(blk.fn.norm.gamma))
+        blk.fn.fn.to_qkv.weight.mul_(3.0)            # wider logits: the softmax over 1 600 tokens is not flat
+    return blk
+
+
+def _oracle(blk, x_cl, dt):
+    from oracle import unet_ref as U
+    att = blk.fn.fn
+    x = x_cl.to(dt).permute(0, 4, 1, 2, 3)                                   # b c f h w
+    y = U.channel_layernorm(x, blk.fn.norm.gamma.detach().to(dt))
+    b, c, f, hh, ww = y.shape
+    y = y.permute(0, 2, 1, 3, 4).reshape(b * f, c, hh, ww)
+    y = U.linear_attention_2d(y, att.to_qkv.weight.detach().to(dt), att.to_out.weight.detach().to(dt), att.to_out.bias.detach().to(dt), 4, 32)
+    return (y.reshape(b, f, c, hh, ww).permute(0, 2, 1, 3, 4) + x).permute(0, 2, 3, 4, 1)
+
+
+@pytest.mark.parametrize('b,f,h,w', [(1, 2, 8, 8), (2, 3, 7, 11), (1, 5, 20, 20), (2, 24, 40, 40)])
+def test_fused_linear_attention_block_vs_oracle_and_layers(mods, b, f, h, w):
+    ops, V = mods
+    blk = _block(V, 5)
+    x = torch.randn(b, f, h, w, 64) * 1.5 + 0.2
+    exact = _oracle(blk, x, torch.float64)
+    ref32 = _oracle(blk, x, torch.float32)
+    blk = blk.to(DEV)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        assert ops.lattn_fused_takes(xd, 4, (blk.fn.norm.gamma,))
+        ops.PROFILE = {}
+        y = blk(xd)
+        used = set(ops.PROFILE)
+        ops.PROFILE = None
+        assert 'lattn_fused_fwd_kernels' in used and not any('conv' in k or 'linattn' in k for k in used), used
+        assert ops._known_amax(y) is not None and abs(ops._known_amax(y).max().item() - y.abs().max().item()) == 0.0
+        ops.FUSED_LATTN = False
+        try:
+            y_layers = blk(xd)
+        finally:
+            ops.FUSED_LATTN = True
+    e_f, e_l, e_r = rel_l2(y, exact), rel_l2(y_layers, exact), rel_l2(ref32, exact)
+    # the attention branch alone (y - x), where the residual does not mask the error
+    b_f = rel_l2(y.cpu().double() - x.double(), exact - x.double())
+    b_l = rel_l2(y_layers.cpu().double() - x.double(), exact - x.double())
+    print(f'fused linear attention [{b},{f},{h},{w},64]: fused vs exact {e_f:.2e} (branch {b_f:.2e}), layer by layer {e_l:.2e} (branch {b_l:.2e}), fp32 oracle {e_r:.2e}')
+    assert e_f < 1e-6 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    assert b_f < 5e-6 and b_f <= 1.5 * b_l + 5e-7
+
+
+def test_unet_forward_uses_the_fused_linear_attention_when_sampling(mods):
+    """The whole denoiser under no_grad: the three 64-channel SpatialLinearAttention blocks (downs[0], ups[1], ups[2]) run fused; result vs
+    the oracle and vs the layer-by-layer path; with gradients enabled they run layer by layer."""
+    ops, V = mods
+    from oracle import unet_ref as U
+    torch.manual_seed(4)
+    net = V.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x, t = torch.randn(1, 24, 42, 16, 16) * 0.7, torch.tensor([611])
+    with torch.no_grad():
+        ref = U.unet3d_forward(sd, x, t, dim=64, dim_mults=(1, 2, 4), groups=8)
+        ref64 = U.unet3d_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double(), t, dim=64, dim_mults=(1, 2, 4), groups=8)
+    net = net.to(DEV)
+    with torch.no_grad():
+        ops.PROFILE = {}
+        out = net(x.to(DEV), t.to(DEV))
+        n_fused = len(ops.PROFILE.get('lattn_fused_fwd_kernels', []))
+        ops.PROFILE = None
+        ops.FUSED_LATTN = False
+        try:
+            out_layers = net(x.to(DEV), t.to(DEV))
+        finally:
+            ops.FUSED_LATTN = True
+    assert n_fused == 3, n_fused
+    e_f, e_l, e_r = rel_l2(out, ref64), rel_l2(out_layers, ref64), rel_l2(ref, ref64)
+    print(f'U-Net forward: fused linear attention vs exact {e_f:.2e}, layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
+    assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    ops.PROFILE = {}
+    net(x.to(DEV), t.to(DEV))               # parameters require gradients here: layer by layer
+    assert 'lattn_fused_fwd_kernels' not in ops.PROFILE
+    ops.PROFILE = None

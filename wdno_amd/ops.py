@@ -1765,6 +1765,41 @@ def temporal_attention_fused(x, gamma, eps, w_qkv, w_out, rot, bias, heads, scal
     return _TAttnFused.apply(x, gamma, w_qkv, w_out, bias, rc, rs, eps, heads, scale)
 
 
+FUSED_LATTN = True        # the 64-channel SpatialLinearAttention block as two passes + a merge when nothing in it needs a gradient (test knob)
+
+
+def lattn_fused_takes(x, heads, weights):
+    """Does csrc/linattn_fused.hip run Residual(PreNorm(SpatialLinearAttention)) on this CL tensor [B, F, H, W, C]? Forward only: the block is
+    fused when nothing in it needs a gradient (sampling); a training step runs it layer by layer (its backward reads the projections)."""
+    if not (FUSED_LATTN and CONV_MATH == 'f16x3' and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights)):
+        return False
+    b, f, h, w, c = x.shape
+    return bool(_lib_().wdno_lattn_fused_takes(c, heads, h * w))
+
+
+def linear_attention_fused(x, gamma, eps, w_qkv, w_out, b_out, heads, scale):
+    """y = x + to_out(linear_attention(LayerNorm(x))) for CL x [B, F, H, W, 64] (csrc/linattn_fused.hip: context pass, merge, output pass)."""
+    x = _chk(x, 'x')
+    b, f, h, w, c = x.shape
+    hd = heads * 32
+    lib = _lib_()
+    wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)
+    woh, wol, wos = split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
+    units, n = b * f, h * w
+    nb = lib.wdno_lattn_fused_ws_bytes(units, n)
+    ws = _ws(nb, x.device)
+    y = torch.empty_like(x)
+    rec = _new_amax_record(x.device)
+    flops = 2.0 * units * n * (c * 3 * hd + hd * c) + 4.0 * units * n * heads * 32 * 32
+    with _timed('lattn_fused_fwd_kernels', flops):
+        _lib.check(lib.wdno_lattn_fused_fwd(_p(x), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
+                                            _p(None if b_out is None else _chk(b_out, 'bias')), _p(y), _p(rec), _p(ws), nb, units, n, c, heads,
+                                            float(scale), _stream()), 'lattn_fused_fwd')
+    return _leave_amax(y, rec)
+
+
 class _RelPosBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bucket):

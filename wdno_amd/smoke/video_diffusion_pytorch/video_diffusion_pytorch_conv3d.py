@@ -108,6 +108,11 @@ class PreNorm(nn.Module):
             rot = ops.rotary_tables(att.rotary_emb.freqs, x.shape[1]) if exists(att.rotary_emb) else None
             return ops.temporal_attention_fused(x, self.norm.gamma, self.norm.eps, att.to_qkv.weight, att.to_out.weight, rot,
                                                 kwargs.get('pos_bias'), att.heads, att.scale)
+        if (residual is True and isinstance(self.fn, SpatialLinearAttention)
+                and ops.lattn_fused_takes(x, att.heads, (self.norm.gamma, att.to_qkv.weight, att.to_out.weight, att.to_out.bias))):
+            # norm -> to_qkv -> linear attention -> to_out -> + x without the [pixels x 384] projections (csrc/linattn_fused.hip; no gradient)
+            return ops.linear_attention_fused(x, self.norm.gamma, self.norm.eps, att.to_qkv.weight, att.to_out.weight, att.to_out.bias,
+                                              att.heads, att.scale)
         planes = hasattr(att, 'to_qkv') and ops.conv_reads_planes(x.numel() // x.shape[-1], att.to_qkv.weight)
         if residual is True:
             y, xs = ops.layernorm_cl_skip(x, self.norm.gamma, self.norm.eps, planes)
