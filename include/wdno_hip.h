@@ -350,13 +350,26 @@ int wdno_tattn_fused_bwd(const float* x, const float* dy, const float* gamma, fl
  * (LayerNorm), :232-258 (to_qkv, softmax over features / tokens, context, to_out) and Residual's add -- by two passes over the tokens and a
  * merge; the [rows][384] projections are never written.
  *   x, y: CL [units][n_tok][C] fp32 (units = batch * frames, n_tok = H * W); gamma [C]; wq_* / wo_*: packed forward operands of to_qkv
- *   [3*heads*32][C] and to_out [C][heads*32]; bias_out [C] or NULL; amax_rec: optional amax record of y; ws: wdno_lattn_fused_ws_bytes bytes.
+ *   [3*heads*32][C] and to_out [C][heads*32]; bias_out [C] or NULL; amax_rec: optional amax record of y; ws: wdno_lattn_fused_ws_bytes bytes;
+ *   ctx_out [units][heads][32][32] / kstat_out [units][heads][2][32] (max over the tokens of k, 1 / Z): optional, what the backward call reads.
  * wdno_lattn_fused_takes: 1 for C = 64, 4 heads, n_tok >= 32. */
 int wdno_lattn_fused_takes(int C, int heads, int n_tok);
 size_t wdno_lattn_fused_ws_bytes(int64_t units, int n_tok);
 int wdno_lattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                          const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* bias_out, float* y, float* amax_rec,
-                         void* ws, size_t ws_bytes, int64_t units, int n_tok, int C, int heads, float scale, wdno_stream_t s);
+                         float* ctx_out, float* kstat_out, void* ws, size_t ws_bytes, int64_t units, int n_tok, int C, int heads, float scale,
+                         wdno_stream_t s);
+
+/* Backward of the same block (csrc/linattn_fused_bwd.hip): one reduction pass over the tokens (dctx), a merge, one pass that recomputes the
+ * projections per token tile and writes dx, and the ordered sum of the per-block weight-gradient partials. Needs x, the ctx / kstat tensors the
+ * forward call left, dy with its amax record, the packed forward operand of to_qkv and the packed DATA-GRADIENT operand of to_out (W_out^T).
+ *   grads: wdno_lattn_fused_bwd_grads() floats = [ dW_qkv [3*heads*32][C] | dW_out [C][heads*32] | dgamma [C] | db_out [C] ]. */
+int wdno_lattn_fused_bwd_grads(void);
+size_t wdno_lattn_fused_bwd_ws_bytes(int64_t units, int n_tok);
+int wdno_lattn_fused_bwd(const float* x, const float* dy, const float* gamma, float eps, const void* wq_hi, const void* wq_lo,
+                         const float* wq_scale, const void* wot_hi, const void* wot_lo, const float* wot_scale, const float* ctx,
+                         const float* kstat, const float* rec_dy, float* dx, float* amax_rec, float* grads, void* ws, size_t ws_bytes,
+                         int64_t units, int n_tok, int C, int heads, float scale, wdno_stream_t s);
 
 /* relative-position bias of the temporal attention (conv3d.py:74-112): bias[h][i][j] = W[bucket[i][j]][h] with W [num_buckets, heads]
  * (nn.Embedding weight) and bucket [n, n] int64 (host-built integer table); and dW from d(bias). One launch each. */

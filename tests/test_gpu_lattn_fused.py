@@ -102,6 +102,77 @@ def test_unet_forward_uses_the_fused_linear_attention_when_sampling(mods):
     print(f'U-Net forward: fused linear attention vs exact {e_f:.2e}, layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
     assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
     ops.PROFILE = {}
-    net(x.to(DEV), t.to(DEV))               # parameters require gradients here: layer by layer
-    assert 'lattn_fused_fwd_kernels' not in ops.PROFILE
+    out_g = net(x.to(DEV), t.to(DEV))       # parameters require gradients here: still fused (the backward is fused too)
+    assert len(ops.PROFILE.get('lattn_fused_fwd_kernels', [])) == 3
     ops.PROFILE = None
+    assert torch.equal(out_g.detach(), out)
+    ops.FUSED_LATTN_BWD = False
+    try:
+        ops.PROFILE = {}
+        net(x.to(DEV), t.to(DEV))           # test knob: a step with gradients runs the block layer by layer
+        assert 'lattn_fused_fwd_kernels' not in ops.PROFILE
+        ops.PROFILE = None
+    finally:
+        ops.FUSED_LATTN_BWD = True
+
+
+def _grads_of(blk, x, gy, dev):
+    xr = x.detach().clone().to(dev).requires_grad_(True)
+    for p_ in blk.parameters():
+        p_.grad = None
+    y = blk(xr)
+    y.backward(gy.to(dev))
+    att = blk.fn.fn
+    g = {'gamma': blk.fn.norm.gamma.grad, 'to_qkv': att.to_qkv.weight.grad, 'to_out': att.to_out.weight.grad, 'b_out': att.to_out.bias.grad}
+    return y.detach(), xr.grad.clone(), {k: v.clone() for k, v in g.items()}
+
+
+@pytest.mark.parametrize('b,f,h,w', [(1, 2, 8, 8), (2, 3, 7, 11), (1, 5, 20, 20), (2, 24, 40, 40)])
+def test_fused_linear_attention_backward_vs_oracle_and_layers(mods, b, f, h, w):
+    """dx, dgamma, dW_qkv, dW_out, db_out of the fused block against the fp64 oracle's autograd (exact), the layer-by-layer HIP path and the
+    fp32 oracle as yardsticks; two evaluations give the same bits."""
+    ops, V = mods
+    blk = _block(V, 9)
+    torch.manual_seed(13)
+    x = torch.randn(b, f, h, w, 64) * 1.5 + 0.2
+    gy = torch.randn(b, f, h, w, 64) * (0.5 + torch.rand(b, f, 1, 1, 1) * 4.0)
+
+    def oracle(dt):
+        from oracle import unet_ref as U
+        att = blk.fn.fn
+        prm = {'gamma': blk.fn.norm.gamma, 'to_qkv': att.to_qkv.weight, 'to_out': att.to_out.weight, 'b_out': att.to_out.bias}
+        leaf = {k: v.detach().to(dt).requires_grad_(True) for k, v in prm.items()}
+        xe = x.detach().clone().to(dt).requires_grad_(True)
+        xc = xe.permute(0, 4, 1, 2, 3)
+        y = U.channel_layernorm(xc, leaf['gamma'])
+        bb, c, ff, hh_, ww_ = y.shape
+        y = y.permute(0, 2, 1, 3, 4).reshape(bb * ff, c, hh_, ww_)
+        y = U.linear_attention_2d(y, leaf['to_qkv'], leaf['to_out'], leaf['b_out'], 4, 32)
+        y = (y.reshape(bb, ff, c, hh_, ww_).permute(0, 2, 1, 3, 4) + xc).permute(0, 2, 3, 4, 1)
+        y.backward(gy.to(dt))
+        return xe.grad, {k: v.grad for k, v in leaf.items()}
+
+    dx_e, g_e = oracle(torch.float64)
+    dx_r, g_r = oracle(torch.float32)
+    blk = blk.to(DEV)
+    ops.PROFILE = {}
+    y_f, dx_f, g_f = _grads_of(blk, x, gy, DEV)
+    used = set(ops.PROFILE)
+    ops.PROFILE = None
+    assert 'lattn_fused_bwd_kernels' in used and not any('conv' in k or 'linattn' in k or 'layernorm' in k for k in used), used
+    _, dx_f2, g_f2 = _grads_of(blk, x, gy, DEV)
+    assert torch.equal(dx_f, dx_f2) and all(torch.equal(g_f[k], g_f2[k]) for k in g_f)          # no atomics: bit-reproducible
+    ops.FUSED_LATTN_BWD = False
+    try:
+        y_l, dx_l, g_l = _grads_of(blk, x, gy, DEV)
+    finally:
+        ops.FUSED_LATTN_BWD = True
+    print(f'fused linear attention backward [{b},{f},{h},{w},64]:')
+    worst = 0.0
+    rows = [('dx-dy', dx_f.cpu().double() - gy.double(), dx_l.cpu().double() - gy.double(), dx_r.double() - gy.double(), dx_e - gy.double())]
+    rows += [(k, g_f[k], g_l[k], g_r[k], g_e[k]) for k in g_f]
+    for name, f_, l_, r_, e_ in rows:
+        e_f, e_l, e_r = rel_l2(f_, e_), rel_l2(l_, e_), rel_l2(r_, e_)
+        print(f'  {name:8s} fused vs exact {e_f:.2e}   layer by layer vs exact {e_l:.2e}   fp32 oracle vs exact {e_r:.2e}')
+        worst = max(worst, e_f / (1.5 * max(e_l, e_r) + 3e-7), e_f / 1e-5)
+    assert worst <= 1.0, worst

@@ -113,7 +113,10 @@ PROTOTYPES = {
     'wdno_tattn_fused_fwd': (I, [P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, L, I, L, I, I, F, P]),
     'wdno_lattn_fused_takes': (I, [I, I, I]),
     'wdno_lattn_fused_ws_bytes': (Z, [L, I]),
-    'wdno_lattn_fused_fwd': (I, [P, P, F, P, P, P, P, P, P, P, P, P, P, Z, L, I, I, I, F, P]),
+    'wdno_lattn_fused_fwd': (I, [P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, Z, L, I, I, I, F, P]),
+    'wdno_lattn_fused_bwd_grads': (I, []),
+    'wdno_lattn_fused_bwd_ws_bytes': (Z, [L, I]),
+    'wdno_lattn_fused_bwd': (I, [P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, Z, L, I, I, I, F, P]),
     'wdno_tattn_fused_bwd_ws_bytes': (Z, []),
     'wdno_tattn_fused_bwd_grads': (I, []),
     'wdno_tattn_fused_bwd': (I, [P, P, P, F, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, Z, L, I, L, I, I, F, P]),

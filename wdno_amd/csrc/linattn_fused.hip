@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void lattn_fused_ctx_kernel(LFusedP p) {
 }
 
 // chunks of a frame merged in chunk order: ctx[d][e] = sum_c ctx_c[d][e] exp(m_c - M) / sum_c Z_c exp(m_c - M)
-__global__ __launch_bounds__(256) void lattn_fused_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, int chunks) {
+__global__ __launch_bounds__(256) void lattn_fused_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, int chunks,
+                                                                  float* __restrict__ kstat /* optional [units][heads][2][32]: max_n k, 1 / Z */) {
   const int64_t unit = blockIdx.x / TF_HEADS;
   const int h = (int)(blockIdx.x - unit * TF_HEADS);
   const float* p0 = part + ((unit * chunks) * TF_HEADS + h) * (int64_t)LF_PART;
@@ -169,6 +170,10 @@ __global__ __launch_bounds__(256) void lattn_fused_merge_kernel(const float* __r
       v += p0[c * cstride + 64 + o] * wgt;
     }
     co[o] = v / Z;
+    if (kstat && (o & 31) == 0) {
+      kstat[(int64_t)blockIdx.x * 64 + d] = M;
+      kstat[(int64_t)blockIdx.x * 64 + 32 + d] = 1.0f / Z;
+    }
   }
 }
 
@@ -333,7 +338,8 @@ extern "C" size_t wdno_lattn_fused_ws_bytes(int64_t units, int n_tok) {
 }
 extern "C" int wdno_lattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                                     const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* bias_out, float* y, float* amax_rec,
-                                    void* ws, size_t ws_bytes, int64_t units, int n_tok, int C, int heads, float scale, wdno_stream_t s) {
+                                    float* ctx_out, float* kstat_out, void* ws, size_t ws_bytes, int64_t units, int n_tok, int C, int heads,
+                                    float scale, wdno_stream_t s) {
   WDNO_REQUIRE(x && gamma && wq_hi && wq_lo && wq_scale && wo_hi && wo_lo && wo_scale && y && ws && units > 0 && n_tok > 0);
   if (!wdno_lattn_fused_takes(C, heads, n_tok) || units * (int64_t)n_tok * TF_C > 0x7fffffff0ll) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_lattn_fused_ws_bytes(units, n_tok)) return WDNO_EWORKSPACE;
@@ -347,12 +353,12 @@ extern "C" int wdno_lattn_fused_fwd(const float* x, const float* gamma, float ep
   p.tiles_per_chunk = (ntiles + p.chunks - 1) / p.chunks;
   p.scale = scale;
   p.part = (float*)ws;
-  float* ctx = (float*)ws + (size_t)units * p.chunks * TF_HEADS * LF_PART;
+  float* ctx = ctx_out ? ctx_out : (float*)ws + (size_t)units * p.chunks * TF_HEADS * LF_PART;
   p.ctx = ctx; p.y = y; p.amax_rec = amax_rec;
   if (units * p.chunks > 0x7fffffff) return WDNO_EUNSUPPORTED;
   hipStream_t st = as_stream(s);
   lattn_fused_ctx_kernel<<<(unsigned)(units * p.chunks), 256, 0, st>>>(p);
-  lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 256, 0, st>>>(p.part, ctx, p.chunks);
+  lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 256, 0, st>>>(p.part, ctx, p.chunks, kstat_out);
   lattn_fused_out_kernel<<<(unsigned)(units * p.chunks), 256, 0, st>>>(p);
   return wdno_check_launch();
 }

@@ -1765,39 +1765,87 @@ def temporal_attention_fused(x, gamma, eps, w_qkv, w_out, rot, bias, heads, scal
     return _TAttnFused.apply(x, gamma, w_qkv, w_out, bias, rc, rs, eps, heads, scale)
 
 
-FUSED_LATTN = True        # the 64-channel SpatialLinearAttention block as two passes + a merge when nothing in it needs a gradient (test knob)
+FUSED_LATTN = True        # the 64-channel SpatialLinearAttention block as two passes + a merge (test knob: layer by layer otherwise)
+FUSED_LATTN_BWD = True    # ... with gradients too (csrc/linattn_fused_bwd.hip); False: a training step runs the block layer by layer
 
 
 def lattn_fused_takes(x, heads, weights):
-    """Does csrc/linattn_fused.hip run Residual(PreNorm(SpatialLinearAttention)) on this CL tensor [B, F, H, W, C]? Forward only: the block is
-    fused when nothing in it needs a gradient (sampling); a training step runs it layer by layer (its backward reads the projections)."""
+    """Does csrc/linattn_fused.hip run Residual(PreNorm(SpatialLinearAttention)) on this CL tensor [B, F, H, W, C] (and, when something in it
+    needs a gradient, csrc/linattn_fused_bwd.hip its backward)?"""
     if not (FUSED_LATTN and CONV_MATH == 'f16x3' and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
         return False
-    if torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights)):
+    if not FUSED_LATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights)):
         return False
     b, f, h, w, c = x.shape
     return bool(_lib_().wdno_lattn_fused_takes(c, heads, h * w))
 
 
+class _LAttnFused(torch.autograd.Function):
+    """y = x + to_out(linear_attention(LayerNorm(x))) without the [pixels x 384] projections: two passes + a merge forward, a reduction
+    pass + a merge + one pass (+ the ordered sum of the weight-gradient partials) backward. Kept for the backward: x, the parameters and a
+    few KB per frame (the context and the softmax statistics of k)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, w_qkv, w_out, b_out, eps, heads, scale):
+        x = _chk(x, 'x')
+        b, f, h, w, c = x.shape
+        hd = heads * 32
+        lib = _lib_()
+        wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)
+        woh, wol, wos = split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
+        units, n = b * f, h * w
+        nb = lib.wdno_lattn_fused_ws_bytes(units, n)
+        ws = _ws(nb, x.device)
+        y = torch.empty_like(x)
+        rec = _new_amax_record(x.device)
+        need = any(ctx.needs_input_grad)
+        cx = torch.empty((units, heads, 32, 32), device=x.device, dtype=torch.float32) if need else None
+        kst = torch.empty((units, heads, 2, 32), device=x.device, dtype=torch.float32) if need else None
+        bo = None if b_out is None else _chk(b_out, 'bias')
+        flops = 2.0 * units * n * (c * 3 * hd + hd * c) + 4.0 * units * n * heads * 32 * 32
+        with _timed('lattn_fused_fwd_kernels', flops):
+            _lib.check(lib.wdno_lattn_fused_fwd(_p(x), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
+                                                _p(bo), _p(y), _p(rec), _p(cx), _p(kst), _p(ws), nb, units, n, c, heads, float(scale), _stream()),
+                       'lattn_fused_fwd')
+        ctx.save_for_backward(x, gamma, w_qkv, w_out, cx, kst)
+        ctx.meta = (eps, heads, scale, b_out is not None)
+        return _leave_amax(y, rec)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, w_qkv, w_out, cx, kst = ctx.saved_tensors
+        eps, heads, scale, has_bias = ctx.meta
+        grec = _known_amax(gy)
+        gy = _chk(gy, 'grad')
+        if grec is None:                     # a gradient autograd summed itself: one sweep for its maximum
+            grec = tensor_amax(gy)
+        b, f, h, w, c = x.shape
+        hd = heads * 32
+        lib = _lib_()
+        wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)
+        woh, wol, wos = split_weight(w_out, 'd', pad8(c), hd, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_))      # W_out^T [hd][c]
+        units, n = b * f, h * w
+        nb = lib.wdno_lattn_fused_bwd_ws_bytes(units, n)
+        ws = _ws(nb, x.device)
+        dx = torch.empty_like(x)
+        grads = torch.empty((lib.wdno_lattn_fused_bwd_grads(),), device=x.device, dtype=torch.float32)
+        rec = _new_amax_record(x.device)
+        flops = 3.0 * (2.0 * units * n * (c * 3 * hd + hd * c)) + 20.0 * units * n * heads * 32 * 32
+        with _timed('lattn_fused_bwd_kernels', flops):
+            _lib.check(lib.wdno_lattn_fused_bwd(_p(x), _p(gy), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
+                                                _p(cx), _p(kst), _p(grec), _p(dx), _p(rec), _p(grads), _p(ws), nb, units, n, c, heads, float(scale),
+                                                _stream()), 'lattn_fused_bwd')
+        n_q, n_o = 3 * hd * c, c * hd
+        dwq = grads[:n_q].view(w_qkv.shape)
+        dwo = grads[n_q:n_q + n_o].view(w_out.shape)
+        dg = grads[n_q + n_o:n_q + n_o + c].view(gamma.shape)
+        dbo = grads[n_q + n_o + c:n_q + n_o + 2 * c] if has_bias else None
+        return _leave_amax(dx, rec), dg, dwq, dwo, dbo, None, None, None
+
+
 def linear_attention_fused(x, gamma, eps, w_qkv, w_out, b_out, heads, scale):
-    """y = x + to_out(linear_attention(LayerNorm(x))) for CL x [B, F, H, W, 64] (csrc/linattn_fused.hip: context pass, merge, output pass)."""
-    x = _chk(x, 'x')
-    b, f, h, w, c = x.shape
-    hd = heads * 32
-    lib = _lib_()
-    wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)
-    woh, wol, wos = split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
-    units, n = b * f, h * w
-    nb = lib.wdno_lattn_fused_ws_bytes(units, n)
-    ws = _ws(nb, x.device)
-    y = torch.empty_like(x)
-    rec = _new_amax_record(x.device)
-    flops = 2.0 * units * n * (c * 3 * hd + hd * c) + 4.0 * units * n * heads * 32 * 32
-    with _timed('lattn_fused_fwd_kernels', flops):
-        _lib.check(lib.wdno_lattn_fused_fwd(_p(x), _p(gamma.reshape(-1)), float(eps), _p(wqh), _p(wql), _p(wqs), _p(woh), _p(wol), _p(wos),
-                                            _p(None if b_out is None else _chk(b_out, 'bias')), _p(y), _p(rec), _p(ws), nb, units, n, c, heads,
-                                            float(scale), _stream()), 'lattn_fused_fwd')
-    return _leave_amax(y, rec)
+    """y = x + to_out(linear_attention(LayerNorm(x))) for CL x [B, F, H, W, 64] (csrc/linattn_fused.hip, csrc/linattn_fused_bwd.hip)."""
+    return _LAttnFused.apply(x, gamma, w_qkv, w_out, b_out, eps, heads, scale)
 
 
 class _RelPosBias(torch.autograd.Function):
