@@ -1,11 +1,13 @@
 # same-box A/B of the round-4 changes (ms per smoke training step): default (fused temporal attention forward + backward, graph replay),
-# launch by launch, and the level-0 temporal attention layer by layer in training steps (ops.FUSED_TATTN_BWD = False)
+# the 64-channel linear attention blocks layer by layer in training steps (ops.FUSED_LATTN_BWD = False), the temporal ones (ops.FUSED_TATTN_BWD = False), both
 cd $GRAFT_REPO_ROOT
 run () { python - "$@" <<'P'
 import json, runpy, sys, io, contextlib
 knob, args = sys.argv[1], sys.argv[2:]
 import wdno_amd.ops as o
 if knob == 'layers': o.FUSED_TATTN_BWD = False
+if knob == 'lattn_layers': o.FUSED_LATTN_BWD = False
+if knob == 'all_layers': o.FUSED_TATTN_BWD = o.FUSED_LATTN_BWD = False
 sys.argv = ['bench.py', '--steps', '40', '--warmup', '5', '--no-cpu-baseline', '--no-extras'] + args
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
@@ -20,7 +22,7 @@ P
 }
 for rep in 1 2; do
 run default
-run default --eager
+run lattn_layers
 run layers
-run layers --eager
+run all_layers
 done

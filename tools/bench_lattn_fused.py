@@ -41,6 +41,39 @@ mb = 3 * x.numel() * 4 / 1e6
 print(f'[{b},24,{side},{side},64]: fused {t_f:.1f} us ({mb:.0f} MB read twice + written once -> {mb / t_f:.3f} TB/s), layer by layer {t_l:.1f} us, '
       f'max |diff| {(y_f - y_l).abs().max().item():.2e}')
 
+
+
+# forward + backward (a training step's use of the block)
+def timed_train(n=10):
+    xr = x.clone().requires_grad_(True)
+    gy = torch.randn(x.shape, device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    fw = bw = 0.0
+    for it in range(n + 3):
+        for p_ in blk.parameters():
+            p_.grad = None
+        xr.grad = None
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        y = blk(xr)
+        e1.record()
+        y.backward(gy)
+        e2.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            fw += e0.elapsed_time(e1) * 1e3 / n
+            bw += e1.elapsed_time(e2) * 1e3 / n
+    return fw, bw, xr.grad.clone(), blk.fn.fn.to_qkv.weight.grad.clone()
+
+
+f_f, b_f, dx_f, dw_f = timed_train()
+ops.FUSED_LATTN_BWD = False
+f_l, b_l, dx_l, dw_l = timed_train()
+ops.FUSED_LATTN_BWD = True
+print(f'with gradients: fused forward {f_f:.1f} us + backward {b_f:.1f} us; layer by layer forward {f_l:.1f} us + backward {b_l:.1f} us; '
+      f'max |d dx| {(dx_f - dx_l).abs().max().item():.2e} of {dx_l.abs().max().item():.2e}, max |d dW_qkv| {(dw_f - dw_l).abs().max().item():.2e} of {dw_l.abs().max().item():.2e}')
+if '--block-only' in sys.argv:
+    sys.exit(0)
+
 import bench  # noqa: E402
 from wdno_amd import diffusion_core as K  # noqa: E402
 dif = bench.build_model('cuda', b)

@@ -340,17 +340,20 @@ __global__ __launch_bounds__(256, 1) void lattn_fused_bwd_kernel(LBwdP p) {
     const int tile1 = min(ntiles, tile0 + p.tiles_per_chunk);
     if (tile0 >= tile1) continue;                                  // (block-uniform)
     // ---- tables of this (frame, head): ctx and dctx in both orientations (row operands of the feature-contracting products), k statistics, T
-    float ctxf[16], ctxT[16], dcf[16], dcT[16];
-    {
-      const float* cu = p.ctx + (unit * TF_HEADS + h) * 1024;
-      const float* du = p.dctx + (unit * TF_HEADS + h) * 1024;
-      float amc = 0.f;
+    // (the column orientation stays in registers for the item; the row orientation -- this lane's row of the table, 64 bytes per lane half --
+    // is fetched per tile, L1 / L2: 64 more registers held for the whole item spilled)
+    float ctxf[16], dcf[16];
+    const float* cu = p.ctx + (unit * TF_HEADS + h) * 1024;
+    const float* du = p.dctx + (unit * TF_HEADS + h) * 1024;
+    auto table_row = [&](const float* tab, float (&t)[16]) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float4 a = *reinterpret_cast<const float4*>(cu + li * 32 + 8 * c + 4 * hh), b = *reinterpret_cast<const float4*>(du + li * 32 + 8 * c + 4 * hh);
-        ctxT[4 * c] = a.x; ctxT[4 * c + 1] = a.y; ctxT[4 * c + 2] = a.z; ctxT[4 * c + 3] = a.w;
-        dcT[4 * c] = b.x; dcT[4 * c + 1] = b.y; dcT[4 * c + 2] = b.z; dcT[4 * c + 3] = b.w;
+        const float4 a = *reinterpret_cast<const float4*>(tab + li * 32 + 8 * c + 4 * hh);
+        t[4 * c] = a.x; t[4 * c + 1] = a.y; t[4 * c + 2] = a.z; t[4 * c + 3] = a.w;
       }
+    };
+    {
+      float amc = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         ctxf[r] = cu[tf_key(r, hh) * 32 + li];
@@ -453,6 +456,8 @@ __global__ __launch_bounds__(256, 1) void lattn_fused_bwd_kernel(LBwdP p) {
       LB_FENCE();
       // ---- dq = qs (dqs - sum_d qs dqs / scale),  dqs^T = ctx dout^T
       {
+        float ctxT[16];
+        table_row(cu, ctxT);
         f32x16 dq = lb_product16(ctxT, dOT);
         float sm = 0.f;
 #pragma unroll
@@ -470,6 +475,8 @@ __global__ __launch_bounds__(256, 1) void lattn_fused_bwd_kernel(LBwdP p) {
       LB_FENCE();
       // ---- dk = ks (dks - T),  dks^T = dctx v^T
       {
+        float dcT[16];
+        table_row(du, dcT);
         f32x16 dk = lb_product16(dcT, av);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
