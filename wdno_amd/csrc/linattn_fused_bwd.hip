@@ -52,6 +52,7 @@ struct LBwdP {
   float* dctx; float* tvec;  // [units][heads][1024], [units][heads][32]
   float* dx; float* amax_rec; float* part2;
   int n_tok, chunks, tiles_per_chunk; int64_t units; float scale;
+  int chunks2, tiles_per_chunk2;          // pass 2 (persistent grid): its own cut of the frames, chosen for equal tiles per block
 };
 
 typedef short lb_short4 __attribute__((ext_vector_type(4)));
@@ -332,12 +333,14 @@ __global__ __launch_bounds__(256, 1) void lattn_fused_bwd_kernel(LBwdP p) {
   __syncthreads();
 
   const int ntiles = (p.n_tok + 31) >> 5;
-  const int64_t nitems = p.units * p.chunks;
+  const int64_t nitems = p.units * p.chunks2;
   for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int64_t unit = item / p.chunks;
-    const int chunk = (int)(item - unit * p.chunks);
-    const int tile0 = chunk * p.tiles_per_chunk;
-    const int tile1 = min(ntiles, tile0 + p.tiles_per_chunk);
+    // chunk-major item order: the items a block takes (item, item + grid, ...) come from different chunk indices, so the short last chunk of a
+    // frame is spread over the blocks instead of landing on the same ones
+    const int chunk = (int)(item / p.units);
+    const int64_t unit = item - (int64_t)chunk * p.units;
+    const int tile0 = chunk * p.tiles_per_chunk2;
+    const int tile1 = min(ntiles, tile0 + p.tiles_per_chunk2);
     if (tile0 >= tile1) continue;                                  // (block-uniform)
     // ---- tables of this (frame, head): ctx and dctx in both orientations (row operands of the feature-contracting products), k statistics, T
     // (the column orientation stays in registers for the item; the row orientation -- this lane's row of the table, 64 bytes per lane half --
@@ -614,6 +617,19 @@ static int lb_chunks(int64_t units, int n_tok) {          // as linattn_fused.hi
   return (int)c;
 }
 
+// pass 2 runs one block per CU over (frame, chunk) items: the cut that minimises the tiles of the busiest block -- 192 frames of 50 tiles on
+// 256 CUs: 3 chunks = 576 items = 2.25 per block (a quarter of the blocks take three: 51 tiles against 37.5 on average), 4 chunks = exactly three
+// items of 11 .. 13 tiles per block (39)
+static int lb_chunks2(int64_t units, int n_tok, int64_t grid) {
+  const int ntiles = (n_tok + 31) / 32;
+  int best = 1;
+  int64_t best_cost = -1;
+  for (int c = 1; c <= 16 && c <= ntiles; ++c) {
+    const int64_t cost = ((units * c + grid - 1) / grid) * ((ntiles + c - 1) / c);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
 extern "C" int wdno_lattn_fused_bwd_grads(void) { return LB_E; }
 extern "C" size_t wdno_lattn_fused_bwd_ws_bytes(int64_t units, int n_tok) {
   return ((size_t)units * lb_chunks(units, n_tok) * TF_HEADS * 1024 + (size_t)units * TF_HEADS * (1024 + 32) + (size_t)lb_num_cus() * LB_E) * sizeof(float);
@@ -642,6 +658,9 @@ extern "C" int wdno_lattn_fused_bwd(const float* x, const float* dy, const float
   p.dx = dx; p.amax_rec = amax_rec;
   const int64_t nitems = units * p.chunks;
   if (nitems > 0x7fffffff) return WDNO_EUNSUPPORTED;
+  p.chunks2 = lb_chunks2(units, n_tok, lb_num_cus());
+  p.tiles_per_chunk2 = (ntiles + p.chunks2 - 1) / p.chunks2;
+  const int64_t nitems2 = units * p.chunks2;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)lattn_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LB_LDS_BYTES) != hipSuccess) return WDNO_ELAUNCH;
@@ -651,7 +670,7 @@ extern "C" int wdno_lattn_fused_bwd(const float* x, const float* dy, const float
   lattn_fused_dctx_kernel<<<(unsigned)nitems, 256, 0, st>>>(p);
   lattn_fused_dctx_merge_kernel<<<(unsigned)(units * TF_HEADS), 256, 0, st>>>(p.part1, ctx, p.dctx, p.tvec, p.chunks);
   int64_t grid = lb_num_cus();
-  if (grid > nitems) grid = nitems;
+  if (grid > nitems2) grid = nitems2;
   lattn_fused_bwd_kernel<<<(unsigned)grid, 256, LB_LDS_BYTES, st>>>(p);
   lattn_fused_reduce_kernel<<<(LB_E + 31) / 32, 256, 0, st>>>(p.part2, (int)grid, grads, LB_E);
   return wdno_check_launch();
