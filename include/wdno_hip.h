@@ -147,6 +147,13 @@ int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const v
 int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                              const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
                              wdno_stream_t s);
+/* the same with a caller-lent workspace: layers of few pixels x many channels (the 8 x 8 / 16 x 16 levels of the Burgers U-Net, unet.py:150-181)
+   cut the reduction of a tile into four runs of stages, one block each; the runs' partial sums go through `ws` and are added in a fixed order.
+   wdno_conv_fwd_split_ws_bytes(g): bytes such a geometry wants (0 = it never splits; ws may then be NULL). */
+int wdno_conv_fwd_f16x3_ws(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                           const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
+                           void* ws, size_t ws_bytes, wdno_stream_t s);
+size_t wdno_conv_fwd_split_ws_bytes(const wdno_conv_geom* g);
 /* weight gradient on the same split planes (g->C = C8 of x, g->K = K8 of dy); dwp [kd][kh][K8][kw*C8] fp32 */
 size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g);
 /* pixel_table: [N*OD*OH*OW] 16-byte records from wdno_conv_pixel_table (depends on the geometry only; callers cache it) */

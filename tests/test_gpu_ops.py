@@ -270,6 +270,40 @@ def test_conv_f16x3_tap_five_row_tiles(ops, name, xs, ws, stride, padding, mode)
         lib.wdno_set_debug(0)
 
 
+# few pixels x many channels with a long reduction (the deep levels of the Burgers U-Net): 128 x 128 tiles, reduction cut into runs of stages
+CONV_CASES_SPLIT = [
+    ('split_2d_512', (16, 512, 8, 8), (512, 512, 3, 3), 1, 1, '/4'),       # 32 tiles x 4 runs of 12 stages
+    ('split_2d_ragged', (17, 512, 8, 8), (520, 512, 3, 3), 1, 1, '/4'),    # 1088 pixels (half a tile at the end), ragged last column of tiles
+    ('split_3d_256', (4, 256, 4, 8, 8), (256, 256, 3, 3, 3), 1, 1, '/4'),  # 72 stages in 4 runs of 18
+]
+
+
+@pytest.mark.parametrize('residual', [False, True], ids=['plain', 'residual'])
+@pytest.mark.parametrize('name,xs,ws,stride,padding,tag', CONV_CASES_SPLIT, ids=[c[0] for c in CONV_CASES_SPLIT])
+def test_conv_f16x3_split_reduction(ops, name, xs, ws, stride, padding, tag, residual):
+    """csrc/conv_h3t.hip with p.tsplit > 1: the runs' partial sums go through the caller's workspace and are added in a fixed order (forward
+    and data gradient both pass here); same tolerance as every other kernel, the split must have been taken, and two runs agree bit for bit."""
+    n_launch = {}
+    ops.PROFILE = n_launch
+    try:
+        conv_case(ops, xs, ws, stride, padding, seed=sum(name.encode()) % 1000, residual=residual)
+    finally:
+        ops.PROFILE = None
+    assert any(k.endswith(tag) for k in n_launch), f'split reduction was not used: {list(n_launch)}'
+    x = dev(to_cl(g(xs, 5)).float().contiguous())
+    w = dev(g(ws, 6, 0.02).float())
+    y0 = ops.conv_cl(x, w, None, padding=padding)
+    y1 = ops.conv_cl(x, w, None, padding=padding)
+    assert torch.equal(y0, y1)
+    lib = ops._lib_()
+    lib.wdno_set_debug(56)                           # the unsplit kernels on the same operands
+    try:
+        y2 = ops.conv_cl(x, w, None, padding=padding)
+    finally:
+        lib.wdno_set_debug(0)
+    assert rel_l2(y0.double().cpu(), y2.double().cpu()) < TOL       # two fp32 accumulation orders of a 4608-term sum
+
+
 def test_conv_f16x3_wide_dynamic_range(ops):
     """Gradient-like magnitudes (1e-7) and large activations (1e3) must survive the per-tensor scaling."""
     for scale in (1e-7, 1.0, 1e3):

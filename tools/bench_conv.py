@@ -21,6 +21,9 @@ CASES = [  # name, x [N,D,H,W,C], weight [K,C,kd,kh,kw], stride, pad
     ('burgers l1 3x3 256->256', (16, 1, 32, 32, 256), (256, 256, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('burgers l2 3x3 512->512', (16, 1, 16, 16, 512), (512, 512, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
     ('burgers l3 3x3 1024->1024', (16, 1, 8, 8, 1024), (1024, 1024, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('burgers d2 3x3 256->256 @16', (16, 1, 16, 16, 256), (256, 256, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('burgers d3 3x3 512->512 @8', (16, 1, 8, 8, 512), (512, 512, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ('burgers u3 3x3 1536->1024 @8', (16, 1, 8, 8, 1536), (1024, 1536, 1, 3, 3), (1, 1, 1), (0, 1, 1)),
 ]
 only = [a for a in sys.argv[1:] if not a.startswith('-')]
 fp32_too = '--fp32' in sys.argv

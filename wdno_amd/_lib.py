@@ -71,6 +71,8 @@ PROTOTYPES = {
     'wdno_pack_split_weight_multi': (I, [P, I, I, P]),
     'wdno_conv_fwd_f16x3': (I, [P, P, P, P, P, P, P, P, P, PG, P]),
     'wdno_conv_fwd_f16x3_amax': (I, [P, P, P, P, P, P, P, P, P, P, PG, P]),
+    'wdno_conv_fwd_f16x3_ws': (I, [P, P, P, P, P, P, P, P, P, P, PG, P, Z, P]),
+    'wdno_conv_fwd_split_ws_bytes': (Z, [PG]),
     'wdno_conv_wgrad_f16x3_ws_bytes': (Z, [PG]),
     'wdno_conv_pixel_table': (I, [P, PG, P]),
     'wdno_conv_wgrad_f16x3': (I, [P, P, P, P, P, P, P, P, P, Z, PG, P]),

@@ -19,6 +19,11 @@ struct ConvP {
   int ntiles;
   int ksplit;     // register-staged split kernels: tap rows dealt to blockIdx.y = 0 .. ksplit-1, partial sums added with atomics (1 = off)
   float* amax_rec; // optional amax record of the output (common.h), filled by the epilogue; nullptr = not wanted
+  // tap-resident kernel (conv_h3t.hip): the reduction of a tile cut into tsplit runs of stages, one block each; run s writes its raw partial
+  // sums to split_ws[s][P][K] and conv_split_reduce_kernel adds them in order (1 = off). split_ws / split_ws_bytes: what the caller lent.
+  int tsplit;
+  float* split_ws;
+  size_t split_ws_bytes;
 };
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -57,6 +62,7 @@ int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const v
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st, int stages);
 // conv_h3t.hip: tap-resident variant for stride-1 convolutions on equal grids (called by conv_h3d.hip with the tile shape it chose)
 bool wdno_conv_h3t_takes(const wdno_conv_geom& g);
+int wdno_conv_h3t_split(const wdno_conv_geom& g, int64_t P, int cus);
 int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st);
 #ifdef __HIPCC__
@@ -73,6 +79,9 @@ static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.g = *g;
   p.amax_rec = nullptr;
   p.ksplit = 1;
+  p.tsplit = 1;
+  p.split_ws = nullptr;
+  p.split_ws_bytes = 0;
   p.debug = wdno_debug_mode;
   p.R = g->kw * g->C;
   p.nchunk = cdiv(p.R, BK);

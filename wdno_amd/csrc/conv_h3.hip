@@ -537,13 +537,16 @@ extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* 
 }
 template <bool LP>
 static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
-                       const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g, wdno_stream_t s) {
+                       const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g, wdno_stream_t s,
+                       float* split_ws = nullptr, size_t split_ws_bytes = 0) {
   int rc = check_geom(g);
   if (rc) return rc;
   if (g->C & 7) return WDNO_EUNSUPPORTED;       // 16-bit rows must be 16-byte multiples
   ConvP p;
   fill_params(p, g);
   p.amax_rec = amax_rec;
+  p.split_ws = split_ws;
+  p.split_ws_bytes = split_ws_bytes;
   p.nchunk = cdiv(p.R, HBK);
   p.nsteps = g->kd * g->kh * p.nchunk;
   hipStream_t st = as_stream(s);
@@ -580,6 +583,24 @@ extern "C" int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const fl
                                         const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
                                         wdno_stream_t s) {
   return conv_fwd_16<false>(xh, xl, sx, wph, wpl, sw, bias, residual, y, amax_rec, g, s);
+}
+// ... with a workspace for the partial sums of a split reduction (conv_h3t.hip): wdno_conv_fwd_split_ws_bytes() bytes, 0 = this geometry
+// never splits. Same results contract; the partial sums are added in a fixed order.
+extern "C" int wdno_conv_fwd_f16x3_ws(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                                      const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
+                                      void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return conv_fwd_16<false>(xh, xl, sx, wph, wpl, sw, bias, residual, y, amax_rec, g, s, (float*)ws, ws ? ws_bytes : 0);
+}
+extern "C" size_t wdno_conv_fwd_split_ws_bytes(const wdno_conv_geom* g) {
+  if (!g || check_geom(g) || (g->C & 7)) return 0;
+  ConvP p;
+  fill_params(p, g);
+  if (!p.identity_out || !wdno_conv_h3t_takes(*g)) return 0;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int runs = wdno_conv_h3t_split(*g, p.P, cus & ~7);
+  return runs > 1 ? (size_t)runs * p.P * g->K * sizeof(float) : 0;
 }
 extern "C" int wdno_conv_fwd_bf16(const void* x16, const void* wp16, const float* bias, const float* residual, float* y, float* amax_rec,
                                   const wdno_conv_geom* g, wdno_stream_t s) {

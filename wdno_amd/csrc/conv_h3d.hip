@@ -395,6 +395,13 @@ static int fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void
       if (wdno_debug_mode == 30) best = narrow_only ? 5 : 4;     // tests: the new shapes on small cases
       if (wdno_debug_mode == 31) best = 5;
       if (wdno_debug_mode == 45 && best == 2 && (g.C % 16) == 0) best = 8;      // experiment: 128 x 64 accumulator tile per wave (conv_h3t.hip)
+      // ... but where those small tiles were chosen for a LONG reduction (8 x 8 x 16 samples x 1024 channels: 256 tiles of 64 x 64 with 96 stages
+      // each, every stage a 33 KB delivery for 18 matrix instructions per wave -- delivery-bound, 89 vs 46 us with the DMA issue off), 128 x 128
+      // tiles whose reduction is cut into four runs fill the chip too, with 66 KB per 72 matrix instructions: 89 -> 61 us (debug 56: not).
+      // (Not where 128 x 64 tiles were chosen -- 16 x 16 x 16 samples x 512 channels: 61 us unsplit, 63 us as two runs.) Needs the caller's
+      // workspace for the partial sums (wdno_conv_fwd_split_ws_bytes).
+      const int split = wdno_conv_h3t_split(g, p.P, cus);
+      if (best == 6 && split > 1 && p.split_ws && (size_t)split * p.P * g.K * sizeof(float) <= p.split_ws_bytes) { best = 0; p.tsplit = split; }
     }
     return wdno_conv_fwd_h3_tap(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
   }

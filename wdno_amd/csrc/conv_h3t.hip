@@ -84,13 +84,18 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
   const wdno_conv_geom& g = p.g;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // Split reduction (p.tsplit > 1: few pixels x many channels with hundreds of stages per tile -- the 8 x 8 and 16 x 16 levels of the Burgers U-Net
+  // at batch 16): a block's unit of work is (run of stages, tile), run-major -- the blocks of an XCD share one run's slice of the weights --
+  // and its epilogue writes raw partial sums to p.split_ws[run]; conv_split_reduce_kernel adds the runs in order.
+  const int nruns = p.tsplit;
+  const int nvt = p.ntiles * nruns;
+  const int my_tiles = (nvt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int ncb = (g.C + CB - 1) / CB;                             // channel blocks (the last one may be ragged: CB == 16 only)
   // stages per tile. With an odd number of sub-steps per stage (7-wide taps on 16-channel blocks) the fragment set a stage starts on
   // alternates, so stages run in pairs: an odd count gets one all-zero stage at the end (every piece out of bounds; 1 / 148 more MFMA work
   // on the smoke stem) rather than a second copy of the loop tail for the other parity (which cost 21 spilled registers)
-  const bool padded = (NSUB & 1) && ((g.kd * g.kh * ncb) & 1);
-  const int nstages = g.kd * g.kh * ncb + (padded ? 1 : 0);
+  const bool padded = (NSUB & 1) && ((g.kd * g.kh * ncb) & 1);   // (launch_h3t: no split reduction there)
+  const int nstages = g.kd * g.kh * ncb / nruns + (padded ? 1 : 0);
 
   if (wave >= WM * WN) {
     // ================================================================== producer waves
@@ -109,9 +114,19 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
       int lo = c0 < 0 ? -c0 : 0, hi = n - c0 < k ? n - c0 : k;
       return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
     };
+    int c_tile = 0, s_dz = 0, s_dy = 0, s_cb = 0, s_rem = 0;      // issue cursor: (tap row, channel block) of the next stage, stages left in the unit
+    int x_uni = 0, w_uni = 0;
     // piece i of this wave is piece pq + 4 i of the plane; its lane covers LDS row 16 (pq + 4 i) + prow
     auto setup_tile = [&](int t) {
-      const int tile = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, p.ntiles);
+      const int vt = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, nvt);
+      const int run = vt / p.ntiles, tile = vt - run * p.ntiles;
+      const int g0 = run * (nstages - (padded ? 1 : 0));            // first stage of the run: (dz, dy, cb) in that order
+      s_cb = g0 % ncb;
+      s_dy = (g0 / ncb) % g.kh;
+      s_dz = g0 / (ncb * g.kh);
+      s_rem = nstages;
+      x_uni = ((s_dz * g.H + s_dy) * g.W * g.C + s_cb * CB) * 2;
+      w_uni = ((s_dz * g.kh + s_dy) * g.K * p.R + s_cb * CB) * 2;
       const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
       const int64_t p0 = (int64_t)tile_m * BM;
 #pragma unroll
@@ -134,8 +149,6 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
         b_off[i] = (k * p.R + dx * g.C + c8) * 2;
       }
     };
-    int c_tile = 0, s_dz = 0, s_dy = 0, s_cb = 0;                  // issue cursor
-    int x_uni = 0, w_uni = 0;
     if (my_tiles > 0) setup_tile(0);
     const bool no_dma = p.debug == 21 || p.debug >= 100;                             // ablation (tools/bench_conv.py): compute waves alone
     auto issue_stage = [&](int buf) {
@@ -159,16 +172,13 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
         if (!LP) t_piece(rwl, off, dst + B_LO + i * 4096);
       }
       x_uni += ROWB; w_uni += ROWB;
-      if (pad || ++s_cb == ncb) {
+      if (!pad && ++s_cb == ncb) {
         s_cb = 0;
-        if (!pad && ++s_dy == g.kh) { s_dy = 0; ++s_dz; }
-        if (s_dz == g.kd && (pad || !padded)) {          // tile finished: move the cursor to the next one
-          s_dz = 0;
-          if (++c_tile < my_tiles) setup_tile(c_tile);
-        }
+        if (++s_dy == g.kh) { s_dy = 0; ++s_dz; }
         x_uni = (s_dz * g.H + s_dy) * g.W * g.C * 2;
         w_uni = (s_dz * g.kh + s_dy) * g.K * p.R * 2;
       }
+      if (--s_rem == 0 && ++c_tile < my_tiles) setup_tile(c_tile);   // unit finished: move the cursor to the next one
     };
     const int total = my_tiles * nstages;
     if (total > 0) issue_stage(0);
@@ -232,7 +242,8 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
   uint64_t c_epi = 0;
   int boff = 0;                                                   // byte offset of the stage being read
   for (int t = 0; t < my_tiles; ++t) {
-    const int tile = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, p.ntiles);
+    const int vt = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, nvt);
+    const int run = vt / p.ntiles, tile = vt - run * p.ntiles;
     const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -312,6 +323,18 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
       const int64_t pm = m0 + m_base + a * 32 + li;
       if (pm >= p.P) continue;
       const int64_t yr = pm;                                      // identity output placement only (conv_h3d.hip checks it before coming here)
+      if (nruns > 1) {                                            // raw partial sums of this run; scale, bias, residual and amax in the reduce pass
+        float* wrow = p.split_ws + ((int64_t)run * p.P + pm) * g.K;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int kc = n0 + n_base + b * 32 + 8 * e4 + 4 * hh;
+            if (kc < g.K) *reinterpret_cast<float4*>(wrow + kc) = make_float4(acc[a][b][4 * e4], acc[a][b][4 * e4 + 1], acc[a][b][4 * e4 + 2], acc[a][b][4 * e4 + 3]);
+          }
+        }
+        continue;
+      }
       float* yrow = y + yr * g.K;
       const float* rrow = res ? res + yr * g.K : nullptr;
 #pragma unroll
@@ -333,6 +356,24 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
   }
   if (stamps) am = sdbg == 23 ? (float)(__builtin_amdgcn_s_memtime() - c_begin) : sdbg == 24 ? (float)c_epi : (float)(__builtin_amdgcn_s_memrealtime() - r_begin);
   if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * (WM * WN) + wave);
+}
+
+// y = (run 0 + run 1 + ... in this order) / (sx sw) + bias + residual of a split reduction, and the amax record of y
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float4* __restrict__ ws, int nruns, int64_t n4, int K4, const float* __restrict__ sx,
+                                                                 const float* __restrict__ sw, const float4* __restrict__ bias, const float4* res,
+                                                                 float4* y, float* __restrict__ amax_rec) {
+  const float inv = sx ? 1.0f / (sx[0] * sw[0]) : 1.0f;
+  float am = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 v = ws[i];
+    for (int r = 1; r < nruns; ++r) { const float4 u = ws[(int64_t)r * n4 + i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+    if (bias) { const float4 tb = bias[(int)(i % K4)]; v.x += tb.x; v.y += tb.y; v.z += tb.z; v.w += tb.w; }
+    if (res) { const float4 tr = res[i]; v.x += tr.x; v.y += tr.y; v.z += tr.z; v.w += tr.w; }
+    y[i] = v;
+    am = amax4(am, v);
+  }
+  if (amax_rec) wave_amax_emit(am, amax_rec, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
 
 static int t_num_cus() {
@@ -361,13 +402,22 @@ static int launch_h3t(const void* xh, const void* xl, const void* wh, const void
   const int64_t x_elems = (int64_t)g.N * g.D * g.H * g.W * g.C;
   const int64_t w_elems = (int64_t)g.kd * g.kh * g.K * p.R;
   if (x_elems * 2 >= T_OOB || w_elems * 2 >= T_OOB || p.P >= 0x7fffffff - BM) return WDNO_EUNSUPPORTED;
+  if (p.tsplit > 1) {                             // (conv_h3d.hip asks for it on whole 32-channel blocks and 3-wide taps only)
+    const int nst = g.kd * g.kh * ((g.C + CB - 1) / CB);
+    if (((CB / 16) * KW & 1) || nst % p.tsplit || !p.split_ws || (size_t)p.tsplit * p.P * g.K * sizeof(float) > p.split_ws_bytes || (g.K & 3)) p.tsplit = 1;
+  }
   int grid = t_num_cus() & ~7;
   if (grid < 8) grid = 8;
-  if (p.ntiles < grid) grid = p.ntiles;
+  if ((int64_t)p.ntiles * p.tsplit < grid) grid = p.ntiles * p.tsplit;
   static bool done = false;
   if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
   conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
                                                                     sx, sw, bias, residual, y, p, (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
+  if (p.tsplit > 1) {
+    const int64_t n4 = p.P * g.K / 4;
+    conv_split_reduce_kernel<<<(unsigned)std::min<int64_t>((n4 + 255) / 256, 2048), 256, 0, st>>>(
+        (const float4*)p.split_ws, p.tsplit, n4, g.K / 4, LP ? nullptr : sx, sw, (const float4*)bias, (const float4*)residual, (float4*)y, p.amax_rec);
+  }
   return WDNO_OK;
 }
 
@@ -381,6 +431,15 @@ static bool t_stem(const wdno_conv_geom& g) { return g.kw == 7 && (g.C % 16) == 
 bool wdno_conv_h3t_takes(const wdno_conv_geom& g) {
   return g.sd == 1 && g.sh == 1 && g.sw == 1 && g.OD == g.D && g.OH == g.H && g.OW == g.W && ((g.kw == 3 && (g.C % 32) == 0) || t_stem(g)) &&
          g.kd <= 8 && g.kh <= 8 && wdno_debug_mode != 8;
+}
+// Runs the reduction of a 128 x 128-tiled layer is cut into (conv_h3d.hip; 1 = no split): four where that still is one round of the persistent
+// grid, of whole stages, at least 8 per run. (Two runs were measured too: 256 -> 256 channels at 16 x 16 x 16 samples 26 -> 32 us, the
+// 1024 -> 1536 data gradient at 8 x 8 116 -> 118 us -- no gain; four: 1024 -> 1024 93 -> 64, 512 -> 512 40 -> 32, 1536 -> 1024 132 -> 84 us.)
+int wdno_conv_h3t_split(const wdno_conv_geom& g, int64_t P, int cus) {
+  if (wdno_debug_mode == 56 || g.kw != 3 || (g.C % 32) || g.K < 128 || (g.K & 3)) return 1;
+  const int64_t t128 = cdiv64(P, 128) * cdiv(g.K, 128);
+  const int nst = g.kd * g.kh * (g.C / 32);
+  return t128 * 4 <= cus && nst % 4 == 0 && nst / 4 >= 8 ? 4 : 1;
 }
 template <bool LP>
 static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,

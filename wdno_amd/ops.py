@@ -695,19 +695,34 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
     flops = 2.0 * n * osp[0] * osp[1] * osp[2] * kp * ks[0] * ks[1] * ks[2] * cp8
     tap = (out is None and tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and max(ks) <= 8 and      # csrc/conv_h3t.hip: wdno_conv_h3t_takes
            ((ks[2] == 3 and cp8 % 32 == 0) or (ks[2] == 7 and cp8 % 16 == 0 and kp <= 64)))
-    with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks, tap), flops):
+    with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks, tap, cp8 if xl is not None else None), flops):
         if xl is None:       # single bf16 plane per operand
             _lib.check(_lib_().wdno_conv_fwd_bf16(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_bf16')
+            return y
+        # layers of few pixels x many channels lend the library a workspace for the partial sums of a split reduction (csrc/conv_h3t.hip)
+        key = (n, d, h, ww, cp8, kp, tuple(ks), tuple(osp)) if tap and ks[2] == 3 else None
+        wsb = 0
+        if key is not None:
+            wsb = _split_ws_bytes.get(key)
+            if wsb is None:
+                wsb = _split_ws_bytes[key] = int(_lib_().wdno_conv_fwd_split_ws_bytes(C.byref(g)))
+        if wsb:
+            ws = torch.empty(wsb // 4, device=xh.device, dtype=torch.float32)
+            _lib.check(_lib_().wdno_conv_fwd_f16x3_ws(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
+                                                      _p(amax_rec), C.byref(g), _p(ws), wsb, _stream()), 'conv_fwd_f16x3_ws')
             return y
         _lib.check(_lib_().wdno_conv_fwd_f16x3_amax(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
                                                     _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_f16x3')
     return y
 
 
+_split_ws_bytes = {}
+
+
 _pixel_tables = {}
 
 
-def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
+def _fwd_h3_kernel_name(pixels, k, ks, tap=False, c=None):
     """Kernel family wdno_conv_fwd_f16x3 picks (mirrors the dispatch in csrc/conv_h3.hip; used as the profiling key)."""
     cdiv = lambda a, b: -(-a // b)
     tiles = cdiv(pixels, 128) * cdiv(k, 128) if k > 64 else cdiv(pixels, 256)
@@ -730,6 +745,11 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False):
                 best, c_best = (128, 64, 1.15), cost(128, 64, 1.15)
             if cost(64, 64, 1.35) < c_best:
                 best = (64, 64, 1.35)
+            # csrc/conv_h3t.hip wdno_conv_h3t_split: a long reduction on 64 x 64 tiles -> 128 x 128 tiles, the reduction cut into 4 runs
+            if best[:2] == (64, 64) and c is not None and c % 32 == 0 and k >= 128:
+                t128, nst = cdiv(pixels, 128) * cdiv(k, 128), ks[0] * ks[1] * (c // 32)
+                if t128 * 4 <= cus and nst % 4 == 0 and nst // 4 >= 8:
+                    return 'conv_fwd_h3t_kernel<128,128>/4'
         if tap and _lp() and k > 64 and cdiv(pixels, 256) * cdiv(k, 128) >= 2 * cus:
             best = (256, 128)                        # csrc/conv_h3t.hip: the wide tiles of the single-plane mode
         if tap and ks[2] == 7:
