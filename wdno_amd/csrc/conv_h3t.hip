@@ -46,6 +46,7 @@ __device__ __forceinline__ int4v t_rsrc(const void* ptr, unsigned bytes) {
   return r;
 }
 __device__ __forceinline__ void t_piece(int4v rsrc, int off, unsigned lds_dst) {
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);      // (wave-uniform by construction; with nine pieces per wave the compiler kept it in a vector register)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(off), "s"(lds_dst), "s"(rsrc) : "memory");
 }
 
@@ -64,7 +65,7 @@ struct TapShape {
   static constexpr int B_PLANE = BPIECES * 1024;
 };
 
-template <int BM, int BN, int WM, int WN, int KW, int CB, bool LP>
+template <int BM, int BN, int WM, int WN, int KW, int CB, bool LP, bool SP = false>
 __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                             const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
                                                             const float* __restrict__ sx, const float* __restrict__ sw,
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
   // Split reduction (p.tsplit > 1: few pixels x many channels with hundreds of stages per tile -- the 8 x 8 and 16 x 16 levels of the Burgers U-Net
   // at batch 16): a block's unit of work is (run of stages, tile), run-major -- the blocks of an XCD share one run's slice of the weights --
   // and its epilogue writes raw partial sums to p.split_ws[run]; conv_split_reduce_kernel adds the runs in order.
-  const int nruns = p.tsplit;
+  // (SP: its own instantiation -- the cursor of the unsplit kernels stays as it was)
+  const int nruns = SP ? p.tsplit : 1;
   const int nvt = p.ntiles * nruns;
   const int my_tiles = (nvt - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int ncb = (g.C + CB - 1) / CB;                             // channel blocks (the last one may be ragged: CB == 16 only)
@@ -119,14 +121,16 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
     // piece i of this wave is piece pq + 4 i of the plane; its lane covers LDS row 16 (pq + 4 i) + prow
     auto setup_tile = [&](int t) {
       const int vt = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, nvt);
-      const int run = vt / p.ntiles, tile = vt - run * p.ntiles;
-      const int g0 = run * (nstages - (padded ? 1 : 0));            // first stage of the run: (dz, dy, cb) in that order
-      s_cb = g0 % ncb;
-      s_dy = (g0 / ncb) % g.kh;
-      s_dz = g0 / (ncb * g.kh);
-      s_rem = nstages;
-      x_uni = ((s_dz * g.H + s_dy) * g.W * g.C + s_cb * CB) * 2;
-      w_uni = ((s_dz * g.kh + s_dy) * g.K * p.R + s_cb * CB) * 2;
+      const int run = SP ? vt / p.ntiles : 0, tile = vt - run * p.ntiles;
+      if constexpr (SP) {
+        const int g0 = run * nstages;                                // first stage of the run: (dz, dy, cb) in that order
+        s_cb = g0 % ncb;
+        s_dy = (g0 / ncb) % g.kh;
+        s_dz = g0 / (ncb * g.kh);
+        s_rem = nstages;
+        x_uni = ((s_dz * g.H + s_dy) * g.W * g.C + s_cb * CB) * 2;
+        w_uni = ((s_dz * g.kh + s_dy) * g.K * p.R + s_cb * CB) * 2;
+      }
       const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
       const int64_t p0 = (int64_t)tile_m * BM;
 #pragma unroll
@@ -172,13 +176,24 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
         if (!LP) t_piece(rwl, off, dst + B_LO + i * 4096);
       }
       x_uni += ROWB; w_uni += ROWB;
-      if (!pad && ++s_cb == ncb) {
+      if constexpr (SP) {
+        if (++s_cb == ncb) {
+          s_cb = 0;
+          if (++s_dy == g.kh) { s_dy = 0; ++s_dz; }
+          x_uni = (s_dz * g.H + s_dy) * g.W * g.C * 2;
+          w_uni = (s_dz * g.kh + s_dy) * g.K * p.R * 2;
+        }
+        if (--s_rem == 0 && ++c_tile < my_tiles) setup_tile(c_tile);   // unit finished: move the cursor to the next one
+      } else if (pad || ++s_cb == ncb) {
         s_cb = 0;
-        if (++s_dy == g.kh) { s_dy = 0; ++s_dz; }
+        if (!pad && ++s_dy == g.kh) { s_dy = 0; ++s_dz; }
+        if (s_dz == g.kd && (pad || !padded)) {          // tile finished: move the cursor to the next one
+          s_dz = 0;
+          if (++c_tile < my_tiles) setup_tile(c_tile);
+        }
         x_uni = (s_dz * g.H + s_dy) * g.W * g.C * 2;
         w_uni = (s_dz * g.kh + s_dy) * g.K * p.R * 2;
       }
-      if (--s_rem == 0 && ++c_tile < my_tiles) setup_tile(c_tile);   // unit finished: move the cursor to the next one
     };
     const int total = my_tiles * nstages;
     if (total > 0) issue_stage(0);
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
   int boff = 0;                                                   // byte offset of the stage being read
   for (int t = 0; t < my_tiles; ++t) {
     const int vt = xcd_swizzle((int)blockIdx.x + t * (int)gridDim.x, nvt);
-    const int run = vt / p.ntiles, tile = vt - run * p.ntiles;
+    const int run = SP ? vt / p.ntiles : 0, tile = vt - run * p.ntiles;
     const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
       const int64_t pm = m0 + m_base + a * 32 + li;
       if (pm >= p.P) continue;
       const int64_t yr = pm;                                      // identity output placement only (conv_h3d.hip checks it before coming here)
-      if (nruns > 1) {                                            // raw partial sums of this run; scale, bias, residual and amax in the reduce pass
+      if constexpr (SP) {                                         // raw partial sums of this run; scale, bias, residual and amax in the reduce pass
         float* wrow = p.split_ws + ((int64_t)run * p.P + pm) * g.K;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -387,7 +402,7 @@ static int t_num_cus() {
   return n;
 }
 
-template <int BM, int BN, int WM, int WN, int KW, int CB, bool LP>
+template <int BM, int BN, int WM, int WN, int KW, int CB, bool LP, bool SP = false>
 static int launch_h3t(const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                       const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
   using S = TapShape<BM, BN, KW, CB>;
@@ -402,16 +417,17 @@ static int launch_h3t(const void* xh, const void* xl, const void* wh, const void
   const int64_t x_elems = (int64_t)g.N * g.D * g.H * g.W * g.C;
   const int64_t w_elems = (int64_t)g.kd * g.kh * g.K * p.R;
   if (x_elems * 2 >= T_OOB || w_elems * 2 >= T_OOB || p.P >= 0x7fffffff - BM) return WDNO_EUNSUPPORTED;
-  if (p.tsplit > 1) {                             // (conv_h3d.hip asks for it on whole 32-channel blocks and 3-wide taps only)
+  if (SP) {                                       // (conv_h3d.hip asks for it on whole 32-channel blocks and 3-wide taps only)
     const int nst = g.kd * g.kh * ((g.C + CB - 1) / CB);
-    if (((CB / 16) * KW & 1) || nst % p.tsplit || !p.split_ws || (size_t)p.tsplit * p.P * g.K * sizeof(float) > p.split_ws_bytes || (g.K & 3)) p.tsplit = 1;
-  }
+    if (p.tsplit < 2 || ((CB / 16) * KW & 1) || nst % p.tsplit || !p.split_ws || (size_t)p.tsplit * p.P * g.K * sizeof(float) > p.split_ws_bytes || (g.K & 3))
+      return WDNO_EINVAL;
+  } else p.tsplit = 1;
   int grid = t_num_cus() & ~7;
   if (grid < 8) grid = 8;
   if ((int64_t)p.ntiles * p.tsplit < grid) grid = p.ntiles * p.tsplit;
   static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
-  conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
+  if (!done) { (void)hipFuncSetAttribute((const void*)conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
+  conv_fwd_h3t_kernel<BM, BN, WM, WN, KW, CB, LP, SP><<<grid, 512, lds, st>>>((const _Float16*)xh, (const _Float16*)xl, (const _Float16*)wh, (const _Float16*)wl,
                                                                     sx, sw, bias, residual, y, p, (unsigned)(x_elems * 2), (unsigned)(w_elems * 2));
   if (p.tsplit > 1) {
     const int64_t n4 = p.P * g.K / 4;
@@ -444,6 +460,7 @@ int wdno_conv_h3t_split(const wdno_conv_geom& g, int64_t P, int cus) {
 template <bool LP>
 static int fwd_h3t(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                    const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st) {
+  if (shape == 0 && p.tsplit > 1 && !LP) return launch_h3t<128, 128, 2, 2, 3, 32, false, true>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 0) return launch_h3t<128, 128, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 1) return launch_h3t<192, 128, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   if (shape == 3) return launch_h3t<192, 64, 2, 2, 3, 32, LP>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
