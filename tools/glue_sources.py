@@ -1,4 +1,4 @@
-"""Which Python lines launch the torch-side kernels of one smoke training step (copies, fills, adds): a TorchDispatchMode over one step
+"""Which Python lines launch the torch-side kernels of one smoke (or, with the argument `burgers`, Burgers batch-16) training step (copies, fills, adds): a TorchDispatchMode over one step
 with the autograd engine on the calling thread, every aten op that launches a kernel grouped by its innermost wdno_amd frames
 (run on the GPU box)."""
 import collections, os, sys, traceback
@@ -11,9 +11,10 @@ from wdno_amd import _lib
 from wdno_amd.trainer import TrainStep, multistep_lr
 _lib.load()
 dev = torch.device('cuda', 0)
-dif = bench.build_model(dev, 8)
+burgers = 'burgers' in sys.argv[1:]
+dif = bench.build_burgers(dev) if burgers else bench.build_model(dev, 8)
 ts = TrainStep(dif, lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=multistep_lr, use_ema=True)
-batch = (torch.randn(8, 24, 42, 40, 40) * 0.5).to(dev)
+batch = (torch.randn(16, 9, 64, 64) * 0.5).to(dev) if burgers else (torch.randn(8, 24, 42, 40, 40) * 0.5).to(dev)
 for _ in range(3):
     ts.step(batch)
 torch.cuda.synchronize()
