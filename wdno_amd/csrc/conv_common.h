@@ -63,10 +63,6 @@ int wdno_conv_fwd_h3_dma(const void* xh, const void* xl, const void* wh, const v
 // conv_h3t.hip: tap-resident variant for stride-1 convolutions on equal grids (called by conv_h3d.hip with the tile shape it chose)
 bool wdno_conv_h3t_takes(const wdno_conv_geom& g);
 int wdno_conv_h3t_split(const wdno_conv_geom& g, int64_t P, int cus);
-// conv_h3p.hip: plane-resident variant (3 x 3 taps in (H, W), rows of <= 64 pixels): one stage serves all nine (dy, dx) of a 16-channel block
-bool wdno_conv_h3p_takes(const wdno_conv_geom& g);
-int wdno_conv_fwd_h3_plane(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
-                           const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st);
 int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* wh, const void* wl, const float* sx, const float* sw,
                          const float* bias, const float* residual, float* y, ConvP& p, hipStream_t st);
 #ifdef __HIPCC__

@@ -403,7 +403,6 @@ static int fwd_h3_dma(const void* xh, const void* xl, const void* wh, const void
       const int split = wdno_conv_h3t_split(g, p.P, cus);
       if (best == 6 && split > 1 && p.split_ws && (size_t)split * p.P * g.K * sizeof(float) <= p.split_ws_bytes) { best = 0; p.tsplit = split; }
     }
-    if (best == 2 && wdno_debug_mode == 58 && wdno_conv_h3p_takes(g)) return wdno_conv_fwd_h3_plane(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
     return wdno_conv_fwd_h3_tap(best, xh, LP ? nullptr : xl, wh, wl, sx, sw, bias, residual, y, p, st);
   }
   // (deeper rings -- NS = 4 / 5 fill the 160 KB -- measured no faster: the 7 x 7 x 7 init convolution keeps its 3.1 M shader cycles)

@@ -21,6 +21,10 @@
 //     the next stage from them; the first fragments of the next stage are in flight during those MFMAs.
 //     (Tried and dropped: warming L2 for the next tile's leading source plane with plain loads from the producer waves --
 //     no change on cold inputs, 0.212 vs 0.193 ms with x resident in the memory-side cache, and none in the training step.)
+//     (Tried and dropped, round 4, commit 66bf75e: a "plane-resident" stage -- one dz and a 16-channel block, the BM + 2 W + 2 source pixels of
+//     all nine (dy, dx), 0.70 instead of 1.04 MB of DMA per 256 x 64 tile -- 185 -> 190 us on the level-0 64 -> 64 layer. With the tap-resident
+//     stage the DMA issue is worth 5 % of this kernel (0.181 vs 0.171 ms with it off); the compute waves' matrix pipe is busy for 82 % of their
+//     252 K cycles at a 1.41 GHz clock: what is left is the package power limit, see profiles/r04_conv_limiter.md.)
 // Arithmetic, operand formats, weight pack and epilogue are those of conv_h3d.hip; the fp32 accumulation order differs
 // (dz, dy, channel block, dx instead of dz, dy, dx, channel block), so the two agree to rounding, not bit for bit.
 #include "conv_common.h"
