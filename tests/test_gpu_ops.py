@@ -304,6 +304,35 @@ def test_conv_f16x3_split_reduction(ops, name, xs, ws, stride, padding, tag, res
     assert rel_l2(y0.double().cpu(), y2.double().cpu()) < TOL       # two fp32 accumulation orders of a 4608-term sum
 
 
+@pytest.mark.parametrize('xs,ws', [((4, 64, 32, 32), (128, 64, 2, 2)), ((6, 40, 1, 36, 20), (72, 40, 1, 2, 2))], ids=['2d', '3d_ragged'])
+def test_conv_patch2_dgrad_on_split_kernels(ops, xs, ws):
+    """Data gradient of the folded (1,2,2) / stride-2 Downsample (Burgers unet.py:64-68) as four 1x1 convolutions of the planes of dy, the
+    operand of tap (py, px) gathered from the weight by the pack kernel (kind 'q{py}{px}'): fp32 tolerance against float64 autograd, the
+    split kernels must have run, and the exact-fp32 path (the knob off) agrees."""
+    nd = len(ws) - 2
+    stride = 2 if nd == 2 else (1, 2, 2)
+    n_launch = {}
+    ops.PROFILE = n_launch
+    try:
+        conv_case(ops, xs, ws, stride, 0, seed=77)
+    finally:
+        ops.PROFILE = None
+    assert sum(len(v) for k, v in n_launch.items() if 'h3' in k) >= 5, list(n_launch)      # forward + four taps
+    x = dev(to_cl(g(xs, 5)), grad=True)
+    w = dev(g(ws, 6, 0.05))
+    go = dev(to_cl(g((xs[0], ws[0], *[v // 2 if i >= len(xs) - 4 else v for i, v in enumerate(xs[2:])]), 7)))
+    grads = []
+    for knob in (True, False):
+        ops.PATCH_DGRAD_H3 = knob
+        try:
+            x.grad = None
+            ops.conv_cl(x, w, None, stride=stride, padding=0).backward(go)
+            grads.append(x.grad.clone())
+        finally:
+            ops.PATCH_DGRAD_H3 = True
+    assert rel_l2(grads[0].double().cpu(), grads[1].double().cpu()) < TOL
+
+
 def test_conv_f16x3_wide_dynamic_range(ops):
     """Gradient-like magnitudes (1e-7) and large activations (1e3) must survive the per-tensor scaling."""
     for scale in (1e-7, 1.0, 1e3):

@@ -1135,8 +1135,12 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
   // modes 2 .. 5: forward operand of parity class (py, px) = ((mode - 2) >> 1, (mode - 2) & 1) of the (1,4,4) / stride (1,2,2) transposed
   // convolution, read straight from its weight w[in = C][out = K][1][4][4]:  W[k][c][0][dy][dx] = w[c][k][0][3 - py - 2 dy][3 - px - 2 dx]
   // (kd, kh, kw = 1, 2, 2). Only the gather below differs; everything after it is the forward layout.
-  const int parity = mode_in >= 2 ? mode_in - 2 : -1;
-  const int mode = mode_in == 1 ? 1 : 0;
+  // modes 6 .. 9: data-gradient operand of tap (py, px) = ((mode - 6) >> 1, (mode - 6) & 1) of a (1,2,2) / stride (1,2,2) convolution (the folded
+  // Downsample of the Burgers U-Net, unet.py:64-68), whose data gradient is four 1 x 1 convolutions of dy scattered to the four pixel parities:
+  // out[a = c][b = k] = w[k][c][0][py][px]  (told kd, kh, kw = 1, 1, 1; data-gradient layout, only the gather differs)
+  const int parity = mode_in >= 2 && mode_in < 6 ? mode_in - 2 : -1;
+  const int patch = mode_in >= 6 ? mode_in - 6 : -1;
+  const int mode = mode_in == 1 || patch >= 0 ? 1 : 0;
   const bool lp = lo == nullptr;                     // one bf16 plane, no scale (amax / scale_out may be NULL)
   const float s = lp ? 1.0f : scale_from_amax(amax[0]);
   if (!lp && block == 0 && threadIdx.x == 0) scale_out[0] = s;
@@ -1167,7 +1171,7 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
         const int kk = ps_div(idx, run, m_run), r = idx - kk * run;
         const int cl = ps_div(r, T, m_T), tap = r - cl * T;
         const bool ok = k0 + kk < K && cl < cvalid;
-        const int64_t off = !ok ? 0 : parity < 0 ? ((int64_t)(k0 + kk) * C + c0) * T + r
+        const int64_t off = !ok ? 0 : patch >= 0 ? (((int64_t)(k0 + kk) * C + c0 + cl) * 4 + patch) : parity < 0 ? ((int64_t)(k0 + kk) * C + c0) * T + r
                             : ((int64_t)(c0 + cl) * K + (k0 + kk)) * 16 + (3 - (parity >> 1) - 2 * (tap >> 1)) * 4 + (3 - (parity & 1) - 2 * (tap & 1));
         v[u] = w[off];
         if (!ok) v[u] = 0.f;
@@ -1258,12 +1262,13 @@ extern "C" int wdno_pack_split_weight_multi(const void* table, int n_items, int 
 }
 extern "C" int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh,
                                       int kw, int A, int B, int mode, wdno_stream_t s) {
-  WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && mode >= 0 && mode <= 5);
-  WDNO_REQUIRE(mode < 2 || (kd == 1 && kh == 2 && kw == 2));      // parity classes of the (1,4,4) transposed convolution
-  WDNO_REQUIRE(mode != 1 ? (A >= K && B >= C) : (A >= C && B >= K));
+  WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && mode >= 0 && mode <= 9);
+  WDNO_REQUIRE(mode < 2 || mode > 5 || (kd == 1 && kh == 2 && kw == 2));      // parity classes of the (1,4,4) transposed convolution
+  WDNO_REQUIRE(mode < 6 || (kd == 1 && kh == 1 && kw == 1));                  // taps of the (1,2,2) / stride 2 convolution
+  WDNO_REQUIRE(mode != 1 && mode < 6 ? (A >= K && B >= C) : (A >= C && B >= K));
   WDNO_REQUIRE(lo == nullptr || (amax != nullptr && scale_out != nullptr));      // lo == NULL: one bf16 plane in `hi`
   int64_t total = (int64_t)kd * kh * A * kw * (B / 8);
-  const PackTile ptile = pack_tile(kd * kh * kw, A, B, mode == 1 ? 1 : 0);
+  const PackTile ptile = pack_tile(kd * kh * kw, A, B, mode == 1 || mode >= 6 ? 1 : 0);
   if ((int64_t)kd * kh * kw * ptile.KT * ptile.CTp > PS_LDS_FLOATS + 16) return WDNO_EUNSUPPORTED;      // > 640 taps (every operand passes here first)
   (void)total;
   pack_split_weight_kernel<<<std::min(2048, ptile.tiles_k * ptile.tiles_c), 256, 0, as_stream(s)>>>(w, amax, (_Float16*)hi, (_Float16*)lo, scale_out, K, C, kd, kh, kw,

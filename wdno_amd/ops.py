@@ -370,6 +370,7 @@ LOWP_AVAILABLE = True
 def _lp():
     return CONV_MATH == 'bf16'
 H3_MIN_PIXELS = 1024
+PATCH_DGRAD_H3 = True     # data gradient of the folded (1,2,2)/s2 Downsample on the split-fp16 kernels (test knob; False = four exact-fp32 launches)
 H3_MIN_REDUCTION = 64
 
 
@@ -521,6 +522,8 @@ class _WPlan:
 
 def _wmode(kind):
     """pack mode of csrc/conv_h3.hip: 'f' forward operand, 'd' data-gradient operand, 'p{py}{px}' parity class of a transposed convolution."""
+    if kind[0] == 'q':              # tap (py, px) of a (1,2,2) / stride-2 convolution as the data-gradient operand of a 1x1 convolution
+        return 6 + 2 * int(kind[1]) + int(kind[2])
     return 0 if kind == 'f' else 1 if kind == 'd' else 2 + 2 * int(kind[1]) + int(kind[2])
 
 
@@ -529,6 +532,9 @@ def _wdims(kind, w5):
     if kind[0] == 'p':              # ConvTranspose weight [in, out, 1, 4, 4] read as the [out, in, 1, 2, 2] weight of one parity class
         assert tuple(w5.shape[2:]) == (1, 4, 4)
         return w5.shape[1], w5.shape[0], 1, 2, 2
+    if kind[0] == 'q':              # [K, C, 1, 2, 2]: one tap of it
+        assert tuple(w5.shape[2:]) == (1, 2, 2)
+        return w5.shape[0], w5.shape[1], 1, 1, 1
     return tuple(w5.shape)
 
 
@@ -1114,7 +1120,13 @@ class _Conv(torch.autograd.Function):
                     gx5 = conv_transpose_raw(gy5, wt, None, cp)
             elif ks == (1, 2, 2) and stride == (1, 2, 2) and padding == (0, 0, 0):
                 # non-overlapping patches (Burgers Downsample2d folded into a 2x2/s2 conv): each input pixel has one tap
-                gx5 = _patch2_dgrad(gy5, weight, cp, kp)
+                if ctx.h3 and _use_h3(n * d * gy5.shape[2] * gy5.shape[3], kp) and _as5(weight).is_contiguous() and PATCH_DGRAD_H3:
+                    if gyplanes is None:
+                        gyplanes = split_f16(gy5.reshape(-1, kp), grec)
+                    drec = _new_amax_record(gy5.device)
+                    gx5 = _leave_amax(_patch2_dgrad(gy5, weight, cp, kp, gyplanes, drec), drec)
+                else:
+                    gx5 = _patch2_dgrad(gy5, weight, cp, kp)
             else:
                 raise RuntimeError(f'wdno_amd: unsupported convolution geometry for dgrad {ks} {stride} {padding}')
             if gs5 is not None:
@@ -1138,12 +1150,19 @@ class _Conv(torch.autograd.Function):
         return gx, gw, gb, gr, None, None
 
 
-def _patch2_dgrad(gy5, weight, cp, kp):
-    """dgrad of a (1,2,2)/s(1,2,2)/p0 conv: four 1x1 convolutions scattered to the four pixel parities."""
+def _patch2_dgrad(gy5, weight, cp, kp, gyplanes=None, amax_rec=None):
+    """dgrad of a (1,2,2)/s(1,2,2)/p0 conv: four 1x1 convolutions scattered to the four pixel parities. With the planes of dy: on the
+    split-fp16 kernels, the operand of tap (py, px) gathered from the weight itself (kind 'q{py}{px}', refreshed with all other operands)."""
     n, d, oh, ow, _ = gy5.shape
     w5 = _as5(weight)
     gx = torch.empty((n, d, 2 * oh, 2 * ow, cp), device=gy5.device, dtype=torch.float32)
     lib = _lib_()
+    if gyplanes is not None:
+        for py in range(2):
+            for px in range(2):
+                conv_fwd_h3(gyplanes, (n, d, oh, ow), w5, None, f'q{py}{px}', None, None, (1, 1, 1), (1, 1, 1), (0, 0, 0), cp, out=gx,
+                            osp=(d, oh, ow), ostride=(1, 2, 2), ooff=(0, py, px), amax_rec=amax_rec)      # the 4 taps merge into one record
+        return gx
 
     def build():
         wz = _padded(w5.detach(), kp, cp)           # [Kp, Cp, 1, 2, 2]
