@@ -327,8 +327,9 @@ int wdno_linattn_fwd_planes(const float* qkv, void* out_hi, void* out_lo, float*
  *   wdno_pack_split_weight writes them; rot_cos / rot_sin [n_tok][32] or NULL; bias [heads][n_tok][n_tok] or NULL;
  *   amax_rec: optional amax record of y; qkv_out: optional [rows][3*heads*32] raw projections for a backward pass that wants them;
  *   rec_v: optional zeroed amax record that receives max|v| (wdno_tattn_fused_bwd: the plane scale of the attention output).
- * wdno_tattn_fused_takes: 1 for the shapes the kernel is built for (C = 64, 24 tokens, 4 heads), else 0 (callers then run the block
- * layer by layer). */
+ * wdno_tattn_fused_takes: 1 for the shapes the kernels are built for (C = 64, 4 heads, 24 frames -- the base-resolution model -- or 48 --
+ * the super-resolution model of inference_2d.py; 48 frames forward only: qkv_out must be NULL and wdno_tattn_fused_bwd refuses them), else 0
+ * (callers then run the block layer by layer). */
 int wdno_tattn_fused_takes(int C, int n_tok, int heads);
 int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                          const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,

@@ -79,6 +79,51 @@ def test_fused_block_vs_oracle_and_layers(mods, b, h, w):
     assert rel_l2(y.cpu().double() - x.double(), exact - x.double()) < 5e-6
 
 
+@pytest.mark.parametrize('b,h,w', [(1, 8, 8), (2, 7, 11), (2, 40, 20)])
+def test_fused_block_48_frames_forward(mods, b, h, w):
+    """csrc/attn_fused48.hip: the block on the 48 wavelet frames of the super-resolution model (two token tiles per head, eight waves per
+    sequence), forward only: against the fp64 oracle and the layer-by-layer HIP path; with gradients enabled the block is not fused."""
+    ops, V = mods
+    blk, att, rpb = _block(V, 7)
+    x = torch.randn(b, 48, h, w, 64) * 1.5 + 0.2
+    exact = _oracle(blk, att, rpb, x, torch.float64)
+    ref32 = _oracle(blk, att, rpb, x, torch.float32)
+    blk, rpb = blk.to(DEV), rpb.to(DEV)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        bias = rpb(48, device=DEV)
+        assert ops.tattn_fused_takes(xd, 4, (blk.fn.norm.gamma,))
+        ops.PROFILE = {}
+        y = blk(xd, pos_bias=bias)
+        used = set(ops.PROFILE)
+        ops.PROFILE = None
+        assert 'tattn_fused_fwd_kernel' in used and not any('conv' in k for k in used), used
+        assert ops._known_amax(y) is not None and abs(ops._known_amax(y).max().item() - y.abs().max().item()) == 0.0
+        y2 = blk(xd, pos_bias=bias)
+        assert torch.equal(y, y2)
+        ops.FUSED_TATTN = False
+        try:
+            y_layers = blk(xd, pos_bias=bias)
+        finally:
+            ops.FUSED_TATTN = True
+        # no rotary, no bias
+        y_plain = ops.temporal_attention_fused(xd, blk.fn.norm.gamma, blk.fn.norm.eps, att.to_qkv.weight, att.to_out.weight, None, None, 4, att.scale)
+    e_f, e_l, e_r = rel_l2(y, exact), rel_l2(y_layers, exact), rel_l2(ref32, exact)
+    print(f'fused block [{b},48,{h},{w},64]: fused vs exact {e_f:.2e}, layer by layer vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
+    assert e_f < 1e-6 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    assert rel_l2(y.cpu().double() - x.double(), exact - x.double()) < 5e-6
+    from oracle import unet_ref as U
+    xe = x.double().permute(0, 4, 1, 2, 3)
+    yn = U.channel_layernorm(xe, blk.fn.norm.gamma.detach().double().cpu())
+    bb, c, f, hh, ww = yn.shape
+    yn = yn.permute(0, 3, 4, 2, 1).reshape(bb, hh * ww, f, c)
+    yn = U.token_attention(yn, att.to_qkv.weight.detach().double().cpu(), att.to_out.weight.detach().double().cpu(), 4, 32)
+    plain = (yn.reshape(bb, hh, ww, f, c).permute(0, 4, 3, 1, 2) + xe).permute(0, 2, 3, 4, 1)
+    assert rel_l2(y_plain, plain) < 1e-6
+    xg = xd.clone().requires_grad_(True)
+    assert not ops.tattn_fused_takes(xg, 4, (blk.fn.norm.gamma,))
+
+
 def test_fused_block_without_rotary_and_bias(mods):
     ops, V = mods
     blk, att, rpb = _block(V, 6)

@@ -44,3 +44,34 @@ __device__ __forceinline__ void tf_halves(float v, float& lo, float& hi) {      
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
 }
+
+// one row of 64 channels, 16 lanes x float4: LayerNorm (gain g) -> fp16 (hi, lo) planes of an LDS token tile (pitch TF_AST halves)
+__device__ __forceinline__ void tf_ln_row(float4 xv, float4 g, float eps, float ps, _Float16* __restrict__ Ah, _Float16* __restrict__ Al, int row, int c4) {
+  // norm.hip's layernorm_kernel (two-pass mean / variance over the 16 lanes of the row), the lane sums taken in DPP order
+  const float mean = tf_row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / TF_C);
+  xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
+  const float var = tf_row16_sum((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / TF_C);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float o[4] = {xv.x * rstd * g.x, xv.y * rstd * g.y, xv.z * rstd * g.z, xv.w * rstd * g.w};
+  half4v h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float t = o[j] * ps;
+    h[j] = (_Float16)t;
+    l[j] = (_Float16)(t - (float)h[j]);
+  }
+  *reinterpret_cast<half4v*>(Ah + row * TF_AST + 4 * c4) = h;
+  *reinterpret_cast<half4v*>(Al + row * TF_AST + 4 * c4) = l;
+}
+
+// launch parameters of the forward kernels (attn_fused.hip: 24 frames; attn_fused48.hip: 48)
+struct TFusedP {
+  const float* x; const float* gamma; float eps;
+  const _Float16* wq_hi; const _Float16* wq_lo; const float* wq_scale;      // packed forward operand of to_qkv: [384][64]
+  const _Float16* wo_hi; const _Float16* wo_lo; const float* wo_scale;      // ... of to_out: [64][128]
+  const float* rcos; const float* rsin; const float* bias;                  // [24][32], [24][32], [4][24][24] (any may be null)
+  float* y; float* amax_rec;
+  float* qkv_out;                                                           // optional: raw projections [rows][384] (the un-fused backward reads them)
+  float* rec_v;                                                             // optional amax record of v (attn_fused_bwd.hip: the plane scale of the attention output)
+  int HW; float scale; int64_t nseq;
+};

@@ -23,34 +23,6 @@
 //     summed through LDS together with the residual x (kept in registers by the lanes that loaded it), one coalesced store per row.
 #include "attn_fused.h"
 
-struct TFusedP {
-  const float* x; const float* gamma; float eps;
-  const _Float16* wq_hi; const _Float16* wq_lo; const float* wq_scale;      // packed forward operand of to_qkv: [384][64]
-  const _Float16* wo_hi; const _Float16* wo_lo; const float* wo_scale;      // ... of to_out: [64][128]
-  const float* rcos; const float* rsin; const float* bias;                  // [24][32], [24][32], [4][24][24] (any may be null)
-  float* y; float* amax_rec;
-  float* qkv_out;                                                           // optional: raw projections [rows][384] (the un-fused backward reads them)
-  float* rec_v;                                                             // optional amax record of v (attn_fused_bwd.hip: the plane scale of the attention output)
-  int HW; float scale; int64_t nseq;
-};
-
-__device__ __forceinline__ void tf_ln_row(float4 xv, float4 g, float eps, float ps, _Float16* __restrict__ Ah, _Float16* __restrict__ Al, int row, int c4) {
-  // norm.hip's layernorm_kernel (two-pass mean / variance over the 16 lanes of the row), the lane sums taken in DPP order
-  const float mean = tf_row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / TF_C);
-  xv.x -= mean; xv.y -= mean; xv.z -= mean; xv.w -= mean;
-  const float var = tf_row16_sum((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / TF_C);
-  const float rstd = 1.0f / sqrtf(var + eps);
-  const float o[4] = {xv.x * rstd * g.x, xv.y * rstd * g.y, xv.z * rstd * g.z, xv.w * rstd * g.w};
-  half4v h, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float t = o[j] * ps;
-    h[j] = (_Float16)t;
-    l[j] = (_Float16)(t - (float)h[j]);
-  }
-  *reinterpret_cast<half4v*>(Ah + row * TF_AST + 4 * c4) = h;
-  *reinterpret_cast<half4v*>(Al + row * TF_AST + 4 * c4) = l;
-}
 
 __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[32 * TF_AST];
@@ -297,7 +269,9 @@ static int tf_num_cus() {
   return n;
 }
 
-extern "C" int wdno_tattn_fused_takes(int C, int n_tok, int heads) { return C == TF_C && n_tok == TF_NT && heads == TF_HEADS; }
+// 24 frames: this file (and attn_fused_bwd.hip for the gradients); 48 frames: attn_fused48.hip, forward only
+int wdno_tattn_fused_fwd48_launch(const TFusedP& p, hipStream_t st);
+extern "C" int wdno_tattn_fused_takes(int C, int n_tok, int heads) { return C == TF_C && (n_tok == TF_NT || n_tok == 48) && heads == TF_HEADS; }
 
 extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                                     const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,
@@ -305,7 +279,7 @@ extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float ep
                                     int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s) {
   WDNO_REQUIRE(x && gamma && wq_hi && wq_lo && wq_scale && wo_hi && wo_lo && wo_scale && y && n_batch > 0 && hw > 0);
   WDNO_REQUIRE((rot_cos == nullptr) == (rot_sin == nullptr));
-  if (!wdno_tattn_fused_takes(C, n_tok, heads) || hw > 0x7fffffff / (TF_C * TF_NT)) return WDNO_EUNSUPPORTED;
+  if (!wdno_tattn_fused_takes(C, n_tok, heads) || hw > 0x7fffffff / (TF_C * 48)) return WDNO_EUNSUPPORTED;
   TFusedP p;
   p.x = x; p.gamma = gamma; p.eps = eps;
   p.wq_hi = (const _Float16*)wq_hi; p.wq_lo = (const _Float16*)wq_lo; p.wq_scale = wq_scale;
@@ -314,6 +288,10 @@ extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float ep
   p.y = y; p.amax_rec = amax_rec; p.qkv_out = qkv_out;
   p.rec_v = rec_v;
   p.HW = (int)hw; p.scale = scale; p.nseq = n_batch * hw;
+  if (n_tok == 48) {
+    if (qkv_out) return WDNO_EUNSUPPORTED;          // (only the un-fused backward of the 24-frame block asks for the projections)
+    return wdno_tattn_fused_fwd48_launch(p, as_stream(s));
+  }
   int64_t grid = 2 * (int64_t)tf_num_cus();
   if (grid > p.nseq) grid = p.nseq;
   tattn_fused_fwd_kernel<<<(int)grid, 256, 0, as_stream(s)>>>(p);

@@ -622,7 +622,7 @@ extern "C" int wdno_tattn_fused_bwd(const float* x, const float* dy, const float
   WDNO_REQUIRE(x && dy && gamma && wq_hi && wq_lo && wq_scale && wo_hi && wo_lo && wo_scale && dx && grads && ws && n_batch > 0 && hw > 0);
   WDNO_REQUIRE(rec_dy && rec_v);
   WDNO_REQUIRE((rot_cos == nullptr) == (rot_sin == nullptr));
-  if (!wdno_tattn_fused_takes(C, n_tok, heads) || hw > 0x7fffffff / (TF_C * TF_NT)) return WDNO_EUNSUPPORTED;
+  if (!wdno_tattn_fused_takes(C, n_tok, heads) || n_tok != TF_NT || hw > 0x7fffffff / (TF_C * TF_NT)) return WDNO_EUNSUPPORTED;      // (48 frames: forward only)
   if (ws_bytes < wdno_tattn_fused_bwd_ws_bytes()) return WDNO_EWORKSPACE;
   TFusedBwdP p;
   p.x = x; p.dy = dy; p.gamma = gamma; p.eps = eps;

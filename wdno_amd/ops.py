@@ -1734,6 +1734,8 @@ def tattn_fused_takes(x, heads, weights):
     if not FUSED_TATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)):
         return False
     b, f, h, w, c = x.shape
+    if f != 24 and torch.is_grad_enabled() and (x.requires_grad or any(w_.requires_grad for w_ in weights)):
+        return False                             # 48 frames (the super-resolution model): forward only
     return bool(_lib_().wdno_tattn_fused_takes(c, f, heads)) and b * h * w >= 64
 
 
