@@ -184,6 +184,40 @@ def test_unet_forward_uses_the_fused_block_when_sampling(mods):
     assert torch.equal(out_g.detach(), out_layers)
 
 
+def test_unet_forward_with_48_frames_when_sampling(mods):
+    """The denoiser of the super-resolution model (48 wavelet frames, inference_2d.py) under no_grad: its 64-channel temporal attentions
+    run on csrc/attn_fused48.hip; result vs the fp64 oracle and the layer-by-layer path. With gradients the blocks run layer by layer."""
+    ops, V = mods
+    from oracle import unet_ref as U
+    torch.manual_seed(3)
+    net = V.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x, t = torch.randn(1, 48, 42, 16, 16) * 0.7, torch.tensor([211])
+    with torch.no_grad():
+        ref = U.unet3d_forward(sd, x, t, dim=64, dim_mults=(1, 2, 4), groups=8)
+        ref64 = U.unet3d_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double(), t, dim=64, dim_mults=(1, 2, 4), groups=8)
+    net = net.to(DEV)
+    with torch.no_grad():
+        ops.PROFILE = {}
+        out = net(x.to(DEV), t.to(DEV))
+        n_fused = len(ops.PROFILE.get('tattn_fused_fwd_kernel', []))
+        ops.PROFILE = None
+        ops.FUSED_TATTN = False
+        try:
+            out_layers = net(x.to(DEV), t.to(DEV))
+        finally:
+            ops.FUSED_TATTN = True
+    assert n_fused == 4, n_fused
+    e_f, e_l, e_r = rel_l2(out, ref64), rel_l2(out_layers, ref64), rel_l2(ref, ref64)
+    print(f'U-Net forward, 48 frames: fused vs exact {e_f:.2e}, layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
+    assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    ops.PROFILE = {}
+    out_g = net(x.to(DEV), t.to(DEV))               # parameters require gradients: the 48-frame block has no fused backward -> layer by layer
+    assert 'tattn_fused_fwd_kernel' not in ops.PROFILE
+    ops.PROFILE = None
+    assert torch.equal(out_g.detach(), out_layers)
+
+
 def _grads_of(blk, rpb, x, gy, dev):
     """(y, dx, {parameter: gradient}) of the block on `dev` tensors through the product path."""
     xr = x.detach().clone().to(dev).requires_grad_(True)
