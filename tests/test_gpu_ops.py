@@ -344,6 +344,23 @@ def test_conv_f16x3_wide_dynamic_range(ops):
         assert rel_l2(from_cl(y.cpu()), yr) < TOL, scale
 
 
+def test_amax_multi_unaligned_spans(ops):
+    """wdno_amax_multi over spans of a flat buffer that start at every 4-byte phase of a 16-byte line and have 0 .. 3 trailing elements
+    (the weights of a model live at such offsets of the trainer's flat parameter buffer): equals torch's abs().max() exactly."""
+    import ctypes as C
+    flat = (torch.randn(70000, generator=torch.Generator().manual_seed(3)) * 3).to(DEV)
+    spans = [(0, 1), (1, 2), (3, 3), (6, 5), (11, 4), (15, 1000), (1015, 4097), (5112, 7), (5119, 60001)]
+    out = torch.zeros(len(spans), device=DEV)
+    items = (ops._AmaxItem * len(spans))()
+    for i, (o, n) in enumerate(spans):
+        items[i] = ops._AmaxItem(flat.data_ptr() + 4 * o, n, out.data_ptr() + 4 * i)
+    tab = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(DEV)
+    from wdno_amd import _lib
+    _lib.check(ops._lib_().wdno_amax_multi(ops._p(tab), len(spans), 256, ops._stream()), 'amax_multi')
+    want = torch.stack([flat[o:o + n].abs().max() for o, n in spans])
+    assert torch.equal(out, want), (out, want)
+
+
 def test_split_f16_reconstruction(ops):
     x = g((300, 44), 92) * torch.logspace(-6, 2, 300, dtype=torch.float64)[:, None]
     hi, lo, s = ops.split_f16(dev(x))

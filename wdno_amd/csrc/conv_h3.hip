@@ -1230,13 +1230,24 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const wdno_amax_item* _
   const float* x = (const float*)it.x;
   const int64_t n = it.n;
   float m = 0.f;
+  // weights sit at 4-byte-aligned offsets of the flat parameter buffer: up to three leading and trailing elements by block 0, the 16-byte-aligned
+  // body as float4 with four loads in flight (4-byte loads: 180 us for the 563 MB of Burgers weights = 3.1 TB/s)
+  int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2);
+  if (head > n) head = n;
+  const int64_t n4 = (n - head) >> 2, tail0 = head + 4 * n4;
+  if (blockIdx.x == 0) {
+    if ((int64_t)threadIdx.x < head) m = fabsf(x[threadIdx.x]);
+    if (tail0 + (int64_t)threadIdx.x < n) m = fmaxf(m, fabsf(x[tail0 + threadIdx.x]));
+  }
+  const float4* x4 = reinterpret_cast<const float4*>(x + head);
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; k + 3 * stride < n; k += 4 * stride) {            // four loads in flight (weights sit at 4-byte-aligned offsets of the flat buffer: no float4)
-    const float a = x[k], b = x[k + stride], c = x[k + 2 * stride], d = x[k + 3 * stride];
-    m = fmaxf(fmaxf(m, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+  for (; k + 3 * stride < n4; k += 4 * stride) {
+    const float4 a = x4[k], b = x4[k + stride], c = x4[k + 2 * stride], d = x4[k + 3 * stride];
+    m = amax4(amax4(m, a), b);
+    m = amax4(amax4(m, c), d);
   }
-  for (; k < n; k += stride) m = fmaxf(m, fabsf(x[k]));
+  for (; k < n4; k += stride) m = amax4(m, x4[k]);
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();

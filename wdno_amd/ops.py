@@ -596,7 +596,7 @@ def _refresh_weight_plans(epoch_used):
     with torch.no_grad():
         if not lp:
             amax.zero_()
-            _lib.check(lib.wdno_amax_multi(_p(at), nw, 256, _stream()), 'amax_multi')
+            _lib.check(lib.wdno_amax_multi(_p(at), nw, 64, _stream()), 'amax_multi')      # 64 blocks per weight: 16-byte loads, four in flight per thread
         _lib.check(lib.wdno_pack_split_weight_multi(_p(stt), len(keys), 256, _stream()), 'pack_split_weight_multi')
     for k in keys:
         pl = _wplans[k]
