@@ -344,6 +344,48 @@ def test_conv_f16x3_wide_dynamic_range(ops):
         assert rel_l2(from_cl(y.cpu()), yr) < TOL, scale
 
 
+@pytest.mark.parametrize('k,c', [(128, 64), (72, 40), (256, 256)])
+def test_pack_split_weight_patch_taps(ops, k, c):
+    """Pack modes 6-9 (kind 'q{py}{px}'): tap (py, px) of a [K, C, 1, 2, 2] weight as the data-gradient operand [Cp][K8] of a 1x1
+    convolution -- hi + lo planes reconstruct w[k][c][0][py][px] to 2^-21 of max|w|, padding rows / columns are zero."""
+    w = dev(g((k, c, 1, 2, 2), 31, 0.3))
+    cp, k8 = ops.pad4(c), ops.pad8(k)
+    for py in range(2):
+        for px in range(2):
+            hi, lo, sc = ops.split_weight(w, f'q{py}{px}', k8, cp)
+            assert hi.shape == (cp, k8) and lo.shape == (cp, k8)
+            rec = (hi.double() + lo.double()) / float(sc)
+            want = torch.zeros(cp, k8, dtype=torch.float64, device=DEV)
+            want[:c, :k] = w[:, :, 0, py, px].double().t()
+            assert float((rec - want).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+            assert float(rec[c:].abs().max() if cp > c else 0.0) == 0.0 and float(rec[:, k:].abs().max() if k8 > k else 0.0) == 0.0
+
+
+def test_conv_split_reduction_without_workspace(ops):
+    """wdno_conv_fwd_f16x3_ws with no (or too small a) workspace computes the same convolution unsplit; with the workspace the runs'
+    partial sums are added in a fixed order -- the three results agree to the accumulation-order tolerance, the split one bit for bit with itself."""
+    import ctypes as C
+    from wdno_amd import _lib
+    x = dev(to_cl(g((16, 512, 8, 8), 41)).float().contiguous())
+    w = dev(g((512, 512, 3, 3), 42, 0.02).float())
+    planes = ops.split_f16(x.reshape(-1, 512))
+    wh, wl, sw = ops.split_weight(w, 'f', 512, 512)
+    geom = ops._geom((16, 1, 8, 8), 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 8, 8))
+    lib = ops._lib_()
+    need = int(lib.wdno_conv_fwd_split_ws_bytes(C.byref(geom)))
+    assert need == 4 * 1024 * 512 * 4
+    outs = []
+    for ws_bytes in (need, need, 0, need // 2):
+        y = torch.empty(16, 1, 8, 8, 512, device=DEV)
+        ws = torch.empty(max(ws_bytes, 4) // 4, device=DEV) if ws_bytes else None
+        _lib.check(lib.wdno_conv_fwd_f16x3_ws(ops._p(planes[0]), ops._p(planes[1]), ops._p(planes[2]), ops._p(wh), ops._p(wl), ops._p(sw), None, None,
+                                              ops._p(y), None, C.byref(geom), ops._p(ws), ws_bytes, ops._stream()), 'conv_fwd_f16x3_ws')
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[2], outs[3])                      # both unsplit
+    assert 0 < rel_l2(outs[0].double().cpu(), outs[2].double().cpu()) < TOL
+
+
 def test_amax_multi_unaligned_spans(ops):
     """wdno_amax_multi over spans of a flat buffer that start at every 4-byte phase of a 16-byte line and have 0 .. 3 trailing elements
     (the weights of a model live at such offsets of the trainer's flat parameter buffer): equals torch's abs().max() exactly."""
