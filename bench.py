@@ -252,11 +252,13 @@ def dwt_leg(device):
     return out
 
 
-def sampling_leg(dif, device, batch, steps):
-    """DDPM sampling steps/s: the step issued launch by launch vs replays of one captured HIP graph (same arithmetic, bit-equal)."""
+def sampling_leg(dif, device, batch, steps, barrier=None, roofline=True):
+    """DDPM sampling steps/s: the step issued launch by launch vs replays of one captured HIP graph (same arithmetic, bit-equal).
+    barrier (N > 1): every rank samples its own batch (no collective on this path, smoke/inference_2d.py:123-152); the timed loops start
+    together so that the per-rank rates are concurrent rates."""
     from wdno_amd import diffusion_core as K
     out = {}
-    for b in sorted({batch, 1}):
+    for b in sorted({batch, 1} if barrier is None else {batch}):
         shape = (b, 24, 42, 40, 40)
         x = torch.randn(shape, device=device)
         init = torch.randn(b, 24, 40, 40, device=device)
@@ -280,6 +282,8 @@ def sampling_leg(dif, device, batch, steps):
             for _ in range(2):
                 sg.graph.replay()
             torch.cuda.synchronize()
+            if barrier is not None:
+                barrier()
             t0 = time.perf_counter()
             for i in range(steps):
                 sg.t.fill_(500 - i)
@@ -288,7 +292,7 @@ def sampling_leg(dif, device, batch, steps):
             torch.cuda.synchronize()
             graph = steps / (time.perf_counter() - t0)
         out[f'batch{b}'] = {'eager_steps_per_sec': round(eager, 2), 'graph_steps_per_sec': round(graph, 2)}
-        if b == batch:
+        if b == batch and roofline:
             out['roofline'] = sampling_roofline(dif, shape, x, src, desc, graph)
         K._graph_cache.pop(dif, None)
     return out
@@ -324,7 +328,7 @@ def sampling_roofline(dif, shape, x, src, desc, steps_per_sec):
             'kernel_ms_per_step': {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}}
 
 
-def sr_leg(device, batch=2, steps=10):
+def sr_leg(device, batch=2, steps=10, barrier=None):
     """BASELINE.json configs[4] on one GPU (its batch shards over 8 GPUs with no communication): super-resolution DDIM sampling with
     the step replayed from one HIP graph, then the IDWT reconstruction -- the cascade step of smoke/inference_2d.py:155-232 on a
     tensor doubled in time AND space ([B, 48, 82, 80, 80]: the reference's 5-field channel layout, 82 = 2 * 40 + 2, rather than the
@@ -350,6 +354,8 @@ def sr_leg(device, batch=2, steps=10):
             dif.use_graph = ug
             res = dif.sample(batch_size=batch, N_upsample=1, init=init, control=control, low=low)       # warm-up (and capture)
             torch.cuda.synchronize()
+            if barrier is not None:         # N > 1: every rank samples its shard of the global batch; no collective (inference_2d.py:155-232)
+                barrier()
             t0 = time.perf_counter()
             res = dif.sample(batch_size=batch, N_upsample=1, init=init, control=control, low=low)
             torch.cuda.synchronize()
@@ -415,6 +421,64 @@ def burgers_leg(device, batch, steps, lowp=None, grid=(64, 64)):
         if pipe is not None:
             out['fields_to_step'] = {'fields': [batch, 2, 2 * gh, 2 * gw], 'ms_per_step': round(pipe * 1e3, 2), 'steps_per_sec': round(1 / pipe, 2),
                                      'note': 'HIP DWT + packing + condition channel + train step, fields resident in HBM'}
+        return out
+    finally:
+        ops.CONV_MATH = prev
+
+
+SMOKE_BF16_NOTE = ('convolutions (3x3x3, 7x7x7 stem, 1x1, strided, transposed; forward, data and weight gradients) on ONE bf16 plane per operand '
+                   '(v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 master weights / outputs / norms / softmax); the seven fused 64-channel attention blocks '
+                   'keep their fp32-equivalent 3 x fp16-split projections and exact-fp32 score products; the attention blocks of the 128- / 256-channel levels '
+                   'project on bf16 planes and attend in fp32')
+
+
+def smoke_bf16_leg(device, batch, steps):
+    """the smoke training step on the single-product kernels (accelerate-style mixed precision, the semantics of
+    burgers/ddpm_burgers/train_diffusion.py:61-62,71-74 applied to the smoke model) as a LABELLED side leg -- where the north-star's
+    ">= 40 % of the HBM roofline" lands once the matrix work is one product instead of three. Never the headline: it cannot meet 1e-5."""
+    from wdno_amd import ops
+    from wdno_amd.trainer import TrainStep, multistep_lr
+    prev = ops.CONV_MATH
+    ops.CONV_MATH = 'bf16'
+    try:
+        dif = build_model(device, batch)
+        ts = TrainStep(dif, lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=multistep_lr, use_ema=True)
+        x = (torch.randn(batch, 24, 42, 40, 40, generator=torch.Generator().manual_seed(77)) * 0.5).to(device)
+        for _ in range(3):
+            ts.step(x)
+        launch = 'hip_graph_replay'
+        try:
+            ts.capture(x, warmup=1)
+            ts.step(x)
+        except Exception as e:
+            launch, ts._cap = 'launch by launch (capture failed: ' + repr(e)[:120] + ')', None
+            torch.cuda.synchronize()
+            ts.step(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _ = ts.step(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ts._cap = None
+        ops.PROFILE = {}
+        ts.step(x)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        agg = {k: (sum(e0.elapsed_time(e1) for e0, e1, _ in v), sum(f for _, _, f in v), len(v)) for k, v in prof.items()}
+        dom = max(agg, key=lambda k: agg[k][0]) if agg else None
+        gf, gb, par_mb = 908.2, 6.06, 95.3
+        tfl = batch * gf / 1e3 / dt
+        gbs = (batch * gb + 8 * par_mb / 1e3) / dt
+        out = {'batch': batch, 'tensor': [batch, 24, 42, 40, 40], 'conv_math': 'bf16', 'ms_per_step': round(dt * 1e3, 3), 'steps_per_sec': round(1 / dt, 2),
+               'step_launch': launch, 'final_loss': float(loss), 'tflops_algorithmic': round(tfl, 1), 'frac_mfma': round(tfl / PEAK_F16_MFMA_TFLOPS, 4),
+               'mfma_peak_tflops': PEAK_F16_MFMA_TFLOPS, 'hbm_GBps_unfused': round(gbs, 1), 'frac_hbm': round(gbs / (PEAK_HBM_TBS * 1e3), 4),
+               'north_star_target_frac_hbm': 0.40, 'arithmetic': SMOKE_BF16_NOTE}
+        if dom is not None:
+            ms, fl, n = agg[dom]
+            out['dominant_kernel'] = {'kernel': dom, 'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4), 'achieved_tflops': round(fl / (ms * 1e-3) / 1e12, 1),
+                                      'frac_of_bf16_peak': round(fl / (ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)}
+            out['kernel_ms_per_step'] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:10]}
         return out
     finally:
         ops.CONV_MATH = prev
@@ -508,7 +572,7 @@ def conv_roofline(ts_step, ops):
     achieved = fl / (ms * 1e-3) / 1e12
     split = 'h3' in dom and ops.CONV_MATH == 'f16x3'
     peak = PEAK_F32_MFMA_TFLOPS if 'h3' not in dom else PEAK_F16_MFMA_TFLOPS
-    traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json)
+    traffic = path = None          # HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json)
     try:
         fam, dims = dom.split('<')
         dims = dims.rstrip('>').split(',')
@@ -523,7 +587,8 @@ def conv_roofline(ts_step, ops):
     except Exception:
         traffic = None
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(achieved / peak, 4), 'traffic': traffic, 'launches_per_step': n,
+            'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': (os.path.relpath(path, ROOT) + ' (committed rocprofv3 --pmc passes of this kernel; a lookup, not a counter read in this run)') if traffic is not None else None,
+            'launches_per_step': n,
             'frac_of_fp32_equivalent_ceiling': round(achieved / (peak / 3), 4) if split else None,
             'note': ('fp32-equivalent 3 x fp16-split MFMA: 3 matrix flop per algorithmic flop, so frac <= 0.333; the exact-fp32 MFMA peak is 157.3 TFLOP/s'
                      if split else ('single-product 16-bit MFMA' if 'h3' in dom else 'exact-fp32 MFMA')),
@@ -560,7 +625,7 @@ def main():
     ap.add_argument('--steps', type=int, default=150)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None, help='samples per GPU per step (default 8 smoke, 16 burgers, 256 burgers-bf16)')
-    ap.add_argument('--workload', default='smoke', choices=['smoke', 'burgers', 'burgers-bf16'])
+    ap.add_argument('--workload', default='smoke', choices=['smoke', 'smoke-bf16', 'burgers', 'burgers-bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the sampling / DWT / Burgers side legs')
     ap.add_argument('--eager', action='store_true', help='timed steps launch by launch instead of replaying the captured HIP graph')
@@ -586,8 +651,8 @@ def main():
     from wdno_amd import _lib, ops
     from wdno_amd.trainer import TrainStep, cosine_annealing_lr, multistep_lr
     _lib.load()
-    smoke = args.workload == 'smoke'
-    if args.workload == 'burgers-bf16':
+    smoke = args.workload in ('smoke', 'smoke-bf16')
+    if args.workload in ('burgers-bf16', 'smoke-bf16'):
         ops.CONV_MATH = 'bf16'
     batch = args.batch or (8 if smoke else (256 if args.workload == 'burgers-bf16' else 16))
     if smoke:
@@ -653,6 +718,39 @@ def main():
         ts.step(x)              # rank 0's profiled extra step below contains the gradient all-reduce: every rank has to take part in it
     if rank == 0:
         roofline = conv_roofline(lambda: ts.step(x), ops)
+    if world > 1 and smoke and not args.no_extras:
+        # The sampling half of the metric at N > 1 (BASELINE configs[3] / [4]): every rank samples its own batch -- the path shards with no
+        # collective (smoke/inference_2d.py:123-152, 155-232) -- from loops that start together (barrier); the global rate is what the slowest
+        # rank allows: world x min over ranks = samples of all ranks / max-over-ranks time.
+        try:
+            sl = sampling_leg(dif, device, batch, args.sample_steps, barrier=barrier, roofline=False)
+            del ts, dif
+            torch.cuda.empty_cache()
+            sr = sr_leg(device, batch=2, steps=10, barrier=barrier)
+            mine = [sl[f'batch{batch}']['eager_steps_per_sec'], sl[f'batch{batch}']['graph_steps_per_sec'],
+                    sr['eager_ddim_steps_per_sec'], sr['graph_ddim_steps_per_sec'], sr['idwt_reconstruction_ms'], 0.0]
+        except Exception as e:          # every rank still takes part in the gather below
+            import traceback
+            mine, sr = [0.0] * 5 + [1.0], {'error': repr(e) + ' | ' + traceback.format_exc()[-400:]}
+        tt = torch.tensor(mine, device=device, dtype=torch.float64)
+        allv = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allv, tt)
+        if rank == 0:
+            col = lambda i: [round(float(v[i]), 2) for v in allv]
+            if any(float(v[5]) for v in allv):
+                extras['sampling_error'] = sr.get('error', 'a rank other than 0 failed in its sampling legs')
+            else:
+                extras['sampling'] = {'batch_per_rank': batch, 'tensor_per_rank': [batch, 24, 42, 40, 40], 'ranks': world,
+                                      'graph_steps_per_sec_global': round(world * min(col(1)), 2), 'eager_steps_per_sec_global': round(world * min(col(0)), 2),
+                                      'per_rank': {'graph_steps_per_sec': col(1), 'eager_steps_per_sec': col(0)},
+                                      'note': 'rank-steps/s: every rank advances its own batch of 8 by one DDPM step; no collective on this path'}
+                extras['sr_sampling'] = {'batch_per_rank': 2, 'global_batch': 2 * world, 'tensor_per_rank': [2, 48, 82, 80, 80], 'ddim_steps': 10, 'ranks': world,
+                                         'graph_ddim_steps_per_sec_global': round(world * min(col(3)), 2), 'eager_ddim_steps_per_sec_global': round(world * min(col(2)), 2),
+                                         'samples_per_sec_global': round(2 * world * min(col(3)) / 10, 3),
+                                         'per_rank': {'graph_ddim_steps_per_sec': col(3), 'eager_ddim_steps_per_sec': col(2), 'idwt_reconstruction_ms': col(4)},
+                                         'fields': sr.get('fields'),
+                                         'note': 'BASELINE configs[4]: the global batch shards over the ranks, each replays its captured DDIM step and reconstructs its fields (IDWT); rank-steps/s'}
+    if rank == 0:
         if world == 1 and not args.no_extras:
             try:
                 if smoke:
@@ -665,6 +763,9 @@ def main():
                     torch.cuda.empty_cache()
                     extras['sr_sampling'] = sr_leg(device)
                     torch.cuda.empty_cache()
+                    if args.workload == 'smoke' and ops.LOWP_AVAILABLE:
+                        extras['smoke_bf16'] = smoke_bf16_leg(device, batch, 20)
+                        torch.cuda.empty_cache()
                     extras['burgers'] = {'fp32_equivalent_batch16': burgers_leg(device, 16, 20),
                                          'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16') if ops.LOWP_AVAILABLE else 'bf16 path not built',
                                          'north_star_80x64': {'fp32_equivalent_batch16': burgers_leg(device, 16, 20, grid=(80, 64)),
@@ -682,7 +783,12 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        if smoke:
+        if smoke and args.workload == 'smoke-bf16':
+            metric = 'diffusion train steps/sec, 2D smoke U-Net (8 samples per GPU per step), bf16 single-product convolutions'
+            wl = (f'smoke base-resolution DDPM train step in MIXED PRECISION (not the headline configuration): Unet3D_with_Conv3D(dim=64,(1,2,4),ch=42) on wavelet tensor '
+                  f'[{batch},24,42,40,40] per GPU, fp32 in/out; ' + SMOKE_BF16_NOTE + '; Adam+clip+EMA')
+            dtype = 'bf16'
+        elif smoke:
             metric = 'diffusion train steps/sec, 2D smoke U-Net (8 samples per GPU per step)'
             wl = (f'smoke base-resolution DDPM train step: Unet3D_with_Conv3D(dim=64,(1,2,4),ch=42) on wavelet tensor [{batch},24,42,40,40] per GPU, '
                   'fp32 in/out, convolutions on the fp32-equivalent 3 x fp16-split MFMA path (small ones exact-fp32 MFMA), Adam+clip+EMA')
@@ -724,7 +830,8 @@ def main():
             'roofline': roofline, 'step_roofline': step_roofline, 'cpu_baseline': cpu,
         }
         if 'sampling' in extras:
-            out['ddpm_sample_steps_per_sec'] = extras['sampling'][f'batch{batch}']['graph_steps_per_sec']
+            out['ddpm_sample_steps_per_sec'] = (extras['sampling']['graph_steps_per_sec_global'] if world > 1 else
+                                                extras['sampling'][f'batch{batch}']['graph_steps_per_sec'])
             out['sampling_roofline'] = extras['sampling'].pop('roofline', None)
         out['per_rank'] = per_rank
         out.update(extras)

@@ -48,3 +48,26 @@ def randomise(model, gen, scale=0.05):
             if name.endswith('freqs'):
                 continue
             p.add_(scale * torch.randn(p.shape, generator=gen))
+
+
+def _hash_values(n, seed):
+    """n reproducible values in [-0.5, 0.5) from an integer hash (exact in fp64 on every host: no random generator, no libm)."""
+    i = np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B1)
+    i = (i ^ (i >> np.uint64(15))) * np.uint64(0x2C1B3C6D) & np.uint64(0xFFFFFFFF)
+    i = (i ^ (i >> np.uint64(12))) * np.uint64(0x297A2D39) & np.uint64(0xFFFFFFFF)
+    i = i ^ (i >> np.uint64(15))
+    return i.astype(np.float64) / 4294967296.0 - 0.5
+
+
+def guidance_input(tshape, shape, ori, seed):
+    """Inputs of the smoke control objective (smoke/inference_2d.py:30-66) for tests/golden/ref_guidance.npz, regenerated identically by the
+    fixture generator and by the tests: the state x [B, F, 42, H, W] in network units (coefficients inside `shape`, zero padding outside, a
+    full smoke-out channel), RESCALER [1, 1, 42, 1, 1] and the initial density init_u [B, H_ori, W_ori] (not rescaled)."""
+    b, f, c, h, w = tshape
+    tc, hc, wc = shape
+    x = np.zeros(tshape, dtype=np.float64)
+    x[:, :tc, :, :hc, :wc] = 0.6 * _hash_values(b * tc * c * hc * wc, seed).reshape(b, tc, c, hc, wc)
+    x[:, :tc, -1] = 0.6 * _hash_values(b * tc * h * w, seed + 1).reshape(b, tc, h, w)
+    resc = np.linspace(1.0, 9.0, c).reshape(1, 1, c, 1, 1)
+    init_u = 2.0 * _hash_values(b * ori[1] * ori[2], seed + 2).reshape(b, ori[1], ori[2])
+    return torch.from_numpy(x).float(), torch.from_numpy(resc).float(), torch.from_numpy(init_u).float()

@@ -25,8 +25,8 @@ def _free_port():
 def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ, WDNO_DIST_BACKEND='gloo', WDNO_DIST_SHARE_GPU='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1']
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--sample-steps', '3']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]            # rank 0 only
@@ -34,6 +34,13 @@ def test_bench_two_ranks_share_one_gpu():
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 16
     assert len(out['per_rank']['ms_per_step']) == 2 and out['value'] > 0
     assert out['roofline'] is not None and out['cpu_baseline'] is None
+    # the sampling half of the metric and configs[4] at N > 1 -- every rank samples its own batch / shard, global rates + per-rank lists
+    assert 'sampling_error' not in out, out.get('sampling_error')
+    assert out['ddpm_sample_steps_per_sec'] == out['sampling']['graph_steps_per_sec_global'] > 0
+    assert out['sampling']['ranks'] == 2 and len(out['sampling']['per_rank']['graph_steps_per_sec']) == 2
+    sr = out['sr_sampling']
+    assert sr['ranks'] == 2 and sr['global_batch'] == 4 and len(sr['per_rank']['graph_ddim_steps_per_sec']) == 2 and sr['graph_ddim_steps_per_sec_global'] > 0
+    assert sr['fields'] == [2, 5, 64, 128, 128]
 
 
 @pytest.mark.gpu

@@ -179,6 +179,63 @@ def test_bf16_burgers_train_step_vs_autocast_arbiter(ops):
     assert e_h[mid] <= 1.5 * e_a[mid] and e_h[-1] <= 1.5 * e_a[-1]
 
 
+def test_bf16_smoke_train_step_vs_autocast_arbiter(ops):
+    """the smoke model at the bench's own tensor size, [2, 24, 42, 40, 40] through Unet3D_with_Conv3D(dim=64, (1,2,4), 42), on
+    the single-product bf16 kernels (bench.py leg `smoke_bf16` / --workload smoke-bf16). Same three evaluations as the Burgers test above: HIP
+    bf16, the oracle under CPU autocast(bfloat16) (accelerate mixed-precision semantics), the oracle in fp64 (arbiter). The seven 64-channel
+    attention blocks stay on their fused fp32-equivalent kernels (asserted: they ran), so the HIP step may only be closer to exact."""
+    import os
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion
+    from oracle import diffusion_ref as D, unet_ref as U
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.manual_seed(0)
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    lw = torch.linspace(1.0, 22.0, 42).reshape(1, 1, 42, 1, 1)
+    gen = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 24, 42, 40, 40, generator=gen) * 0.5
+    noise = torch.randn(2, 24, 42, 40, 40, generator=gen)
+    t = torch.tensor([37, 911])
+
+    def oracle(dt, autocast):
+        sd = {k: (v.to(dt).clone().requires_grad_(True) if v.is_floating_point() and not k.endswith('freqs') else (v.to(dt) if v.is_floating_point() else v))
+              for k, v in sd0.items()}
+        model = lambda x, tt: U.unet3d_forward(sd, x, tt, dim=64, dim_mults=(1, 2, 4), groups=8)
+        buf = {k: v.to(dt) for k, v in D.make_buffers('sigmoid', 1000).items()}
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=autocast):
+            loss = D.smoke_p_losses(model, buf, x0.to(dt), t, noise.to(dt), padded_shape=(18, 34, 34), loss_layer_weight=lw.to(dt))
+        loss.float().backward() if autocast else loss.backward()
+        return float(loss.detach()), {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+
+    l_e, g_e = oracle(torch.float64, False)
+    l_a, g_a = oracle(torch.float32, True)
+    dif = GaussianDiffusion(net, lw, True, True, True, False, 'bior1.3', 'zero', (18, 34, 34), (32, 64, 64), image_size=40, frames=24).to(DEV)
+    ops.PROFILE = {}
+    loss = dif.p_losses(x0.to(DEV), t.to(DEV), noise=noise.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    used, ops.PROFILE = set(ops.PROFILE), None
+    assert any('h3t' in k for k in used) and any('wgrad_h3' in k for k in used), used
+    assert 'tattn_fused_bwd_kernel' in used and 'lattn_fused_bwd_kernels' in used, used        # the blocks the leg's label says stayed fp32-equivalent
+    names = [k for k, p in net.named_parameters() if p.grad is not None and k in g_e]
+    assert len(names) == 228
+    grads = dict(net.named_parameters())
+    e_h = sorted(rel_l2(grads[k].grad, g_e[k]) for k in names)
+    e_a = sorted(rel_l2(g_a[k], g_e[k]) for k in names)
+    rl_h, rl_a = abs(loss.item() - l_e) / abs(l_e), abs(l_a - l_e) / abs(l_e)
+    mid = len(names) // 2
+    print(f'bf16 smoke step [2,24,42,40,40] vs exact: loss rel HIP {rl_h:.3e} / autocast oracle {rl_a:.3e}; gradient rel-L2 median HIP {e_h[mid]:.3e} / '
+          f'autocast {e_a[mid]:.3e}, worst HIP {e_h[-1]:.3e} / autocast {e_a[-1]:.3e}')
+    assert rl_h <= 1.5 * max(rl_a, e_a[mid])
+    assert e_h[mid] <= 1.5 * e_a[mid] and e_h[-1] <= 1.5 * e_a[-1]
+
+
 def test_bf16_training_reduces_the_loss(ops):
     """20 optimiser steps on one fixed batch with fp32 master weights: the loss must fall like it does on the fp32 path."""
     from wdno_amd import tree_path

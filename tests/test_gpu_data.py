@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import load_npz
+from tests.helpers import load_npz, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -92,9 +92,10 @@ def test_smoke_offline_transform_vs_oracle_and_dataset_roundtrip(trees, tmp_path
 
 def test_smoke_guidance_gradient_vs_oracle_finite_difference(trees):
     """dJ/dx of the control objective (inference_2d.py:30-66) through the HIP IDWT adjoints, checked against
-    central differences of the same objective evaluated with the numpy oracle in fp64 (J is quadratic: the difference is exact)."""
+    central differences of the same objective evaluated with the numpy oracle in fp64 (oracle/guidance_ref.py, pinned against a run of the
+    reference's guidance_fn by tests/test_oracle_dwt.py; J is quadratic: the difference is exact)."""
     from wdno_amd.smoke import guidance as Gd
-    from oracle import dwt_ref as R
+    from oracle import guidance_ref as G
     rng = np.random.default_rng(9)
     shape, ori = (18, 34, 34), (32, 64, 64)
     x = np.zeros((1, 24, 42, 40, 40))
@@ -103,23 +104,38 @@ def test_smoke_guidance_gradient_vs_oracle_finite_difference(trees):
     resc = np.linspace(1.0, 9.0, 42).reshape(1, 1, 42, 1, 1)
     init_u = rng.standard_normal((1, 64, 64))
     w_e, w_i = 0.7, 1.3
-
-    def J(xs):                       # xs = x * RESCALER, numpy fp64
-        lll, det = R.smoke_tensor_to_coef(np.transpose(xs[:, :, :-2], (0, 2, 1, 3, 4)), shape)
-        state = R.idwt3(lll, det, 'bior1.3')[:, :32, :64, :64].reshape(-1, 5, 32, 64, 64)
-        lo = xs[:, :18, -1, :20].mean((-2, -1))[:, None]
-        hi = xs[:, :18, -1, 20:].mean((-2, -1))[:, None]
-        so = R.idwt1d(lo, hi, 'bior1.3', 'zero')[:, 0]
-        return -so[:, 31].sum() + w_e * (state[:, 3:5] ** 2).mean((1, 2, 3, 4)).sum() + w_i * ((state[:, 0, 0] - init_u) ** 2).mean((-1, -2)).sum()
-
     g = Gd.guidance_fn(torch.from_numpy(x).float().to(DEV), shape, ori, torch.from_numpy(resc).float().to(DEV), w_energy=w_e, w_init=w_i,
                        init_u=torch.from_numpy(init_u).float().to(DEV)).double().cpu().numpy()
     xs = x * resc
     for seed in range(3):
         v = np.random.default_rng(100 + seed).standard_normal(xs.shape)
-        fd = (J(xs + 0.5 * v) - J(xs - 0.5 * v))
+        fd = G.directional_derivative(xs, v, shape, ori, init_u, w_e, w_i)
         assert abs((g * v).sum() - fd) < 2e-5 * max(1.0, abs(fd)), (seed, (g * v).sum(), fd)
     # conditioned on the control: only the initial-density term remains
     g2 = Gd.guidance_fn(torch.from_numpy(x).float().to(DEV), shape, ori, torch.from_numpy(resc).float().to(DEV), is_condition_control=True,
                         w_energy=w_e, w_init=w_i, init_u=torch.from_numpy(init_u).float().to(DEV))
     assert float(g2[:, :, 8:].abs().max()) == 0 and float(g2[:, :, :8].abs().max()) > 0
+
+
+@pytest.mark.parametrize('name', ['full', 'full_control', 'small_b2', 'small_no_weights'])
+def test_smoke_guidance_gradient_vs_reference_run(trees, name):
+    """wdno_amd/smoke/guidance.py against gradients the REFERENCE's own guidance_fn returned (tests/golden/ref_guidance.npz,
+    generated by tests/golden/make_ref_guidance_golden.py from smoke/inference_2d.py:30-66 on inputs tests/helpers.guidance_input regenerates):
+    the autograd form through the HIP transforms and the closed form the graph-captured guided sampler uses, 1e-5 rel-L2, and exactly zero
+    where the reference's gradient is zero (the padding)."""
+    from wdno_amd.smoke import guidance as Gd
+    from tests.test_oracle_dwt import guidance_case
+    x, resc, init_u, g_ref, kw = guidance_case(name)
+    shape, ori = kw.pop('shape'), kw.pop('ori_shape')
+    xd, rd, ud = x.to(DEV), resc.to(DEV), init_u.to(DEV)
+    tc, hc, wc = shape
+    for fn in (Gd.guidance_fn, Gd.guidance_fn_explicit):
+        g = fn(xd, shape, ori, rd, init_u=ud, **kw)
+        assert rel_l2(g, g_ref) < 1e-5, (name, fn.__name__, rel_l2(g, g_ref))
+        rest = g.clone()
+        rest[:, :tc, :40, :hc, :wc] = 0
+        rest[:, :tc, -1] = 0
+        assert float(rest.abs().max()) == 0.0, (name, fn.__name__)
+    # through the callable the sampler receives (design_fn(x, low=, init=, init_u=), inference_2d.py:81-93)
+    dfn = Gd.GuidanceFn(shape, ori, rd, **kw)
+    assert rel_l2(dfn(xd, low=None, init=None, init_u=ud), g_ref) < 1e-5

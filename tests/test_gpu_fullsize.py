@@ -67,7 +67,8 @@ def test_smoke_ddim_chain_full_size_ab(R):
         # arbiter gate: no further from the exact chain than 1.5 x the reference arithmetic (fp32 oracle on this host) is; the distance to
         # that fp32 evaluation is then bounded by the two distances together
         assert h <= 1.5 * ref + 1e-6, (mode, res)
-        assert res[mode]['hip_vs_cpu32'] <= h + ref + 1e-6, (mode, res)
+        # measured ceiling (not a triangle bound, which cannot fail): 1.27e-5 / 9.7e-6 in round 4 -> 2 x the larger
+        assert res[mode]['hip_vs_cpu32'] < 2.6e-5, (mode, res)
 
 
 def test_golden_chains_against_exact_evaluation(R):
@@ -101,7 +102,7 @@ def test_ddim_chains_from_t999_over_seeds(R):
       * medians over seeds: the same with factor 1.5; and the HIP result is within 1e-5 of the reference's fp32 output in the median
         (smoke: for every seed). Burgers seed 7's chain is ill conditioned (the reference itself is 3.6e-4 from exact, 3x the other
         seeds, and two fp32 evaluations of it differ by 6e-5): it is gated like every other seed on the arbiter ratio, and its distance to
-        the reference's fp32 output by the triangle bound."""
+        the reference's fp32 output by a measured ceiling (2 x 5.9e-5)."""
     res = R.chain_seeds(('f16x3',))
     print(json.dumps(res, indent=1))
     for tree in ('smoke', 'burgers'):
@@ -114,7 +115,8 @@ def test_ddim_chains_from_t999_over_seeds(R):
     assert res['smoke_summary']['f16x3']['max_hip_vs_ref'] < 1e-5
     for r in res['burgers']:          # every seed, no waiver: within 1e-5 of the reference's fp32 output, or -- where the chain is ill conditioned
         # (seed 7: the reference itself is 3.6e-4 from exact) -- no further from it than the two distances to the exact chain together
-        assert r['f16x3']['hip_vs_ref'] < 1e-5 or r['f16x3']['hip_vs_ref'] <= r['f16x3']['hip_vs_exact'] + r['ref_vs_exact'] + 1e-6, r
+        # a measured ceiling of 2 x its round-3/4 value (5.9e-5)
+        assert r['f16x3']['hip_vs_ref'] < 1e-5 or (r['seed'] == 7 and r['f16x3']['hip_vs_ref'] < 1.2e-4), r
 
 
 def test_burgers_train_step_north_star_shape_vs_oracle(R):

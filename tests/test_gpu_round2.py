@@ -127,7 +127,7 @@ def test_smoke_guided_sampling_vs_reference(trees):
     # stay inside (-1, 1) carry 1.8e3 x the last-bit differences of whoever evaluates the chain -- the reference's own fp32 result is 2.1e-5 from
     # the exact chain. Gate: HIP no further from exact than 1.5 x that (and from the reference no further than the two distances together).
     assert len(calls) == 1 + 4 + 6
-    assert A.gate(h1, r1) and e1 <= h1 + r1 + 1e-6, (e1, h1, r1)
+    assert A.gate(h1, r1) and e1 < 4.5e-5, (e1, h1, r1)             # measured 2.2e-5 (round 3/4): ceiling 2 x that
     assert e2 < 1e-5 and A.gate_or_bar(h2, r2), (e2, h2, r2)
 
 
@@ -228,7 +228,7 @@ def test_smoke_super_resolution_cascade_vs_reference(trees):
         o64 = chain({k: (v.double() if v.is_floating_point() else v) for k, v in sd32.items()}, {k: v.double() for k, v in buf32.items()}, torch.float64)
     ref_exact, hip_exact, host_ref = rel_l2(gz['wave0'], o64), rel_l2(w0, o64), rel_l2(o32, gz['wave0'])
     print('   base chain: reference vs exact', ref_exact, 'hip vs exact', hip_exact, "this host's fp32 oracle vs reference", host_ref)
-    assert hip_exact < 1.5 * ref_exact + 1e-6 and e_base < hip_exact + ref_exact + 1e-6
+    assert hip_exact < 1.5 * ref_exact + 1e-6 and e_base < 6.5e-5             # measured 3.2e-5: ceiling 2 x that
     # SR stage from the reference's own low-resolution input: 1e-5. End to end (base deviation carried through the SR chain, whose own t = 999
     # step amplifies differences of its conditioning input ~3x): arbiter = the whole cascade by the oracle in fp64 (tests/arbiter.py); the
     # reference's own fp32 cascade is 6.4e-5 from it.
@@ -237,7 +237,7 @@ def test_smoke_super_resolution_cascade_vs_reference(trees):
     h_chain, r_chain = rel_l2(w1, ex['wave1']), rel_l2(gz['wave1'], ex['wave1'])
     print('   cascade end to end: hip vs exact', h_chain, 'reference vs exact', r_chain)
     assert e_sr < 1e-5
-    assert A.gate(h_chain, r_chain) and e_chain <= h_chain + r_chain + 1e-6, (e_chain, h_chain, r_chain)
+    assert A.gate(h_chain, r_chain) and e_chain < 2e-4, (e_chain, h_chain, r_chain)      # the reference's own fp32 cascade is 6.4e-5 from exact
     # --- reconstruction: our waverec3 of the unpacked coefficients; arbiter = the exact cascade's IDWT (fp64), yardstick = the oracle's IDWT of the
     # reference's coefficients
     c_ours, _ = pack(w1, shape[1], 'space')

@@ -189,3 +189,64 @@ def test_trainer_with_graph_replay_is_bit_identical(trees, tmp_path, tree):
     assert le == lg
     assert torch.equal(te.opt.buf.flat_param, tg.opt.buf.flat_param)
     assert torch.equal(te.opt.exp_avg, tg.opt.exp_avg) and torch.equal(te.opt.exp_avg_sq, tg.opt.exp_avg_sq)
+
+
+def test_trainer_survives_a_failed_graph_capture(trees, tmp_path, monkeypatch):
+    """use_graph is the default; a capture that fails (an op illegal under stream capture, no memory for the private
+    pool) must not abort a run that works launch by launch. The capture is made to fail INSIDE the stream capture (after launches were
+    recorded); the trainer warns, switches itself to eager steps and ends with the weights of a run that never tried to capture."""
+    from wdno_amd import trainer as T
+
+    def run(break_capture, sub):
+        torch.manual_seed(7)
+        dif = _burgers(trees, 3)
+        data = torch.randn(4, 9, 8, 8, generator=torch.Generator().manual_seed(1)) * 0.5
+        tr = trees['TB'](dif, _Fixed(data), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=5, results_folder=str(tmp_path / sub))
+        nxt = lambda: next(tr.dl).to(tr.device)
+        tr.use_graph = break_capture
+        if break_capture:
+            real = dif.p_losses
+
+            def p_losses(*a, **k):
+                out = real(*a, **k)
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('injected failure inside the capture')
+                return out
+            monkeypatch.setattr(dif, 'p_losses', p_losses)
+        torch.manual_seed(11)
+        losses = []
+        for _ in range(5):
+            losses.append(tr.optimisation_step(nxt))
+            tr.step += 1
+        torch.cuda.synchronize()
+        return tr, losses
+    te, le = run(False, 'e')
+    with pytest.warns(UserWarning, match='capturing the training step in a HIP graph failed'):
+        tf, lf = run(True, 'f')
+    assert tf.use_graph is False and not tf._caps
+    assert le == lf and torch.equal(te.opt.buf.flat_param, tf.opt.buf.flat_param)
+
+
+def test_groupnorm_backward_guard_follows_its_own_buffer(trees):
+    """the GroupNorm backward re-reads tables its forward derived from gamma / beta, so an optimiser step between the two
+    must raise -- but only a step of the buffer that OWNS the parameters: another model's step, a dropped operand cache or a plan-cache
+    clear change nothing about them."""
+    from wdno_amd import ops
+    from wdno_amd.trainer import FlatBuffers
+    x = torch.randn(2, 4, 8, 8, 16, device='cuda', requires_grad=True)
+    gam, bet = torch.nn.Parameter(torch.rand(16, device='cuda') + 0.5), torch.nn.Parameter(torch.randn(16, device='cuda'))
+    other = torch.nn.Parameter(torch.randn(32, device='cuda'))
+    mine, theirs = FlatBuffers([gam, bet]), FlatBuffers([other])
+    y = ops.groupnorm_act(x, gam, bet, 4)
+    theirs.params_changed()                      # another model's optimiser step
+    ops.drop_weight_caches()                     # cache evictions
+    y.sum().backward()                           # ... are none of this norm's business
+    assert torch.isfinite(x.grad).all()
+    y = ops.groupnorm_act(x, gam, bet, 4)
+    mine.params_changed()                        # this model's optimiser step between forward and backward
+    with pytest.raises(RuntimeError, match='parameters were updated'):
+        y.sum().backward()
+    y = ops.groupnorm_act(x, gam, bet, 4)
+    ops.bump_weight_epoch()                      # a checkpoint load / EMA copy (global value epoch)
+    with pytest.raises(RuntimeError, match='parameters were updated'):
+        y.sum().backward()

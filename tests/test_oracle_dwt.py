@@ -129,3 +129,40 @@ def test_multilevel_packing_reference_sizes():
     assert np.array_equal(t[:, :, 1:4, :41], yh[0]) and np.array_equal(t[:, :, 1:4, 43], yh[0][:, :, :, 40])
     assert np.array_equal(t[:, :, 4:7, :42:2, ::2], yh[1]) and np.array_equal(t[:, :, 4:7, 43, 1::2], yh[1][:, :, :, 20])
     assert np.array_equal(t[:, :, 7:10, ::4, ::4], yh[2])
+
+
+# ----------------------------------------------------------------------------------------- the smoke control objective (8f rank 2)
+GUIDANCE_CASES = ('full', 'full_control', 'small_b2', 'small_no_weights')
+
+
+def guidance_case(name):
+    """(x, rescaler, init_u, reference gradient [B, F, 42, H, W] fp64, keyword arguments) of a case of tests/golden/ref_guidance.npz."""
+    from tests.helpers import guidance_input, load_npz
+    gz = load_npz('ref_guidance.npz')
+    meta = [int(v) for v in gz[f'{name}::meta']]
+    tshape, shape, ori, control = tuple(meta[:5]), tuple(meta[5:8]), tuple(meta[8:11]), bool(meta[11])
+    w_e, w_i = (float(v) for v in gz[f'{name}::weights'])
+    x, resc, init_u = guidance_input(tshape, shape, ori, seed=sum(name.encode()))
+    g = np.zeros(tshape)
+    tc, hc, wc = shape
+    g[:, :tc, :40, :hc, :wc] = gz[f'{name}::g_coef']
+    g[:, :tc, -1] = gz[f'{name}::g_smokeout']
+    assert float(gz[f'{name}::g_rest_absmax']) == 0.0          # the reference's gradient is zero in the padding
+    return x, resc, init_u, g, dict(shape=shape, ori_shape=ori, w_energy=w_e, w_init=w_i, is_condition_control=control)
+
+
+@pytest.mark.parametrize('name', GUIDANCE_CASES)
+def test_guidance_objective_vs_reference_run(name):
+    """oracle/guidance_ref.py against gradients the REFERENCE's guidance_fn returned (smoke/inference_2d.py:30-66 run by
+    tests/golden/make_ref_guidance_golden.py): J is at most quadratic, so <g_ref, v> must equal the central difference of the restated J."""
+    from oracle import guidance_ref as G
+    x, resc, init_u, g, kw = guidance_case(name)
+    xs = x.double().numpy() * resc.double().numpy()
+    gn = float(np.sqrt((g ** 2).sum()))
+    for seed in range(3):
+        v = np.random.default_rng(100 + seed).standard_normal(xs.shape)
+        if seed == 2:                   # a direction along the gradient itself: a missing term cannot hide in an orthogonal direction
+            v = g / gn * np.sqrt(v.size)
+        fd = G.directional_derivative(xs, v, kw['shape'], kw['ori_shape'], init_u.double().numpy(), kw['w_energy'], kw['w_init'], kw['is_condition_control'])
+        tol = 1e-6 * gn * np.sqrt(v.size) if seed == 2 else 1e-5 * gn          # 1e-6 of <g, v> along g; 1e-5 of its typical size otherwise (the fixture is fp32)
+        assert abs((g * v).sum() - fd) < tol, (name, seed, (g * v).sum(), fd)

@@ -41,9 +41,22 @@ class _timed:
         return False
 
 
-def bump_weight_epoch():
-    global WEIGHT_EPOCH
+PARAM_EPOCH = 0           # bumped only when parameter VALUES may have changed behind autograd's version counters (not by cache evictions)
+
+
+def bump_weight_epoch(params=True):
+    """params=False: only the operand caches were dropped / marked stale (the parameters themselves hold the same values)."""
+    global WEIGHT_EPOCH, PARAM_EPOCH
     WEIGHT_EPOCH += 1
+    if params:
+        PARAM_EPOCH += 1
+
+
+def _param_epoch(p):
+    """What a backward that re-reads tables derived from parameter p compares: the global value epoch (checkpoint loads, EMA copies) and
+    the epoch of the flat buffer that owns p (trainer.FlatBuffers.params_changed) -- another model's optimiser step does not count."""
+    cell = getattr(p, '_wdno_epoch_cell', None)
+    return (PARAM_EPOCH, -1 if cell is None else cell[0])
 
 
 def drop_weight_caches():
@@ -51,7 +64,7 @@ def drop_weight_caches():
     _pack_cache.clear()
     _wplans.clear()
     _wtables.clear()
-    bump_weight_epoch()
+    bump_weight_epoch(params=False)
 
 
 def _lib_():
@@ -318,7 +331,7 @@ def _cached(w, kind, cp, kp, build):
         packed = build().contiguous()
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
-        bump_weight_epoch()          # captured graphs replay pointers into the dropped operands: the epoch is part of their cache key
+        bump_weight_epoch(params=False)          # captured graphs replay pointers into the dropped operands: the epoch is part of their cache key
     _pack_cache[key] = (ver, packed, w.detach())
     return packed
 
@@ -369,6 +382,18 @@ LOWP_AVAILABLE = True
 
 def _lp():
     return CONV_MATH == 'bf16'
+
+
+@contextlib.contextmanager
+def _math(mode):
+    """Run a block of launches under another convolution arithmetic (the fused attention blocks keep their split-fp16 projections when
+    the convolutions around them run on single bf16 planes)."""
+    global CONV_MATH
+    prev, CONV_MATH = CONV_MATH, mode
+    try:
+        yield
+    finally:
+        CONV_MATH = prev
 H3_MIN_PIXELS = 1024
 PATCH_DGRAD_H3 = True     # data gradient of the folded (1,2,2)/s2 Downsample on the split-fp16 kernels (test knob; False = four exact-fp32 launches)
 H3_MIN_REDUCTION = 64
@@ -551,10 +576,12 @@ class _WsplitItem(C.Structure):
                 ('K', C.c_int), ('C', C.c_int), ('kd', C.c_int), ('kh', C.c_int), ('kw', C.c_int), ('A', C.c_int), ('B', C.c_int), ('mode', C.c_int)]
 
 
-def _refresh_weight_plans(epoch_used):
+def _refresh_weight_plans(epoch_used, lp=None):
     """Refresh every registered plan that was used in one of the last few weight epochs (they will all be needed again; an
-    EMA update also counts as an epoch)."""
-    lp = _lp()
+    EMA update also counts as an epoch). lp: which family of operands (single bf16 plane / split fp16 planes); default = the current
+    arithmetic. Both exist side by side in the bf16 mode, whose fused attention blocks keep their split-fp16 projections."""
+    if lp is None:
+        lp = _lp()
     keys = tuple(k for k, pl in _wplans.items() if pl.used >= epoch_used - 3 and pl.wd.is_contiguous() and pl.lp == lp)
     if len(keys) < 2:
         return
@@ -612,9 +639,11 @@ def cache_snapshot():
             {k: v[0] for k, v in _amax_pool.items()}]
 
 
-def captured_plans():
-    """The split weight operands alive right now (a graph owner passes them to touch_plans after every replay)."""
-    return list(_wplans.values())
+def captured_plans(since=None):
+    """The split weight operands a capture used (a graph owner passes them to touch_plans after every replay): those whose `used` epoch
+    is at least `since` (the weight epoch the capture started in); without `since`, every operand alive. Operands of other models (the EMA
+    copy, a super-resolution model sampled between steps) are not the captured step's and are not re-packed on its account."""
+    return [pl for pl in _wplans.values() if since is None or pl.used >= since]
 
 
 def touch_plans(plans):
@@ -631,11 +660,13 @@ def prepare_graph_refresh():
     captured step records the two refresh launches -- every replay then re-splits all weights before it uses them."""
     epoch = WEIGHT_EPOCH
     for pl in _wplans.values():
-        pl.used = epoch                       # every live operand belongs to the step that is about to be captured
-    bump_weight_epoch()
+        if pl.used >= epoch - 3:              # the operands of the step that has just run eagerly (its optimiser step and an EMA update lie in between)
+            pl.used = epoch                   # belong to the step that is about to be captured; another model's (EMA copy, SR model) do not
+    bump_weight_epoch(params=False)
     if _wplans:
-        _refresh_weight_plans(WEIGHT_EPOCH)   # eager: tables built (and operands refreshed) outside the capture
-    bump_weight_epoch()
+        for lp in {pl.lp for pl in _wplans.values()}:
+            _refresh_weight_plans(WEIGHT_EPOCH, lp)   # eager: tables built (and operands refreshed) outside the capture
+    bump_weight_epoch(params=False)
 
 
 def split_weight(w, kind, cp8, kp, pack=None):
@@ -671,7 +702,7 @@ def split_weight(w, kind, cp8, kp, pack=None):
             pl.sc = None if lp else torch.empty(1, device=w.device, dtype=torch.float32)
             if len(_wplans) > 4096:
                 _wplans.clear(); _wtables.clear()
-                bump_weight_epoch()
+                bump_weight_epoch(params=False)
                 ver = (w._version, WEIGHT_EPOCH)
             _wplans[key] = pl
         _lib.check(_lib_().wdno_pack_split_weight(_p(wc), _p(amax), _p(pl.hi), _p(pl.lo), _p(pl.sc), k, c, kd, kh, kw, kp, cp8,
@@ -1401,7 +1432,7 @@ class _GroupNormAct(torch.autograd.Function):
                                                          n, s, c, groups, float(eps), int(act_silu), _p(wsp), nbp, _stream()), 'groupnorm_fwd_planes')
             ctx.save_for_backward(x, gamma, beta, ssc, stats)
             ctx.meta = (n, s, c, groups, int(act_silu))
-            ctx.epoch = WEIGHT_EPOCH
+            ctx.epoch = _param_epoch(gamma)
             ctx.grad_planes = GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False)
             return _planes_only(y, (hi, lo, scale))
         rec = _new_amax_record(x.device)
@@ -1409,7 +1440,7 @@ class _GroupNormAct(torch.autograd.Function):
                                                    float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (n, s, c, groups, int(act_silu))
-        ctx.epoch = WEIGHT_EPOCH
+        ctx.epoch = _param_epoch(gamma)
         # the convolution that produced x takes its dy as fp16 planes (conv_cl(..., grad_planes=True)): deliver dx in that form
         c8 = c // 8
         ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0
@@ -1424,7 +1455,7 @@ class _GroupNormAct(torch.autograd.Function):
         # and scale_shift must be what the forward saw. Autograd's version counters guard in-place changes of the saved tensors; a write
         # through the trainers' flat parameter buffer does not bump them, the weight epoch does. (One backward of a node at a time: the
         # parked means are not safe under two concurrent backward passes of the same graph on different streams.)
-        if getattr(ctx, 'epoch', WEIGHT_EPOCH) != WEIGHT_EPOCH:
+        if getattr(ctx, 'epoch', None) not in (None, _param_epoch(gamma)):
             raise RuntimeError('wdno_amd GroupNorm backward: the parameters were updated (optimiser step / checkpoint load) between this forward and its backward')
         gy = _chk(gy, 'grad')
         lib = _lib_()
@@ -1481,7 +1512,7 @@ class _GroupNormActAdd(torch.autograd.Function):
                    'groupnorm_add_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (n, s, c, groups, int(act_silu))
-        ctx.epoch = WEIGHT_EPOCH
+        ctx.epoch = _param_epoch(gamma)
         c8 = c // 8
         ctx.grad_planes = (GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False) and CONV_MATH in ('f16x3', 'bf16') and c % 8 == 0
                            and c8 <= 256 and (c8 & (c8 - 1)) == 0)
@@ -1729,12 +1760,12 @@ FUSED_TATTN_BWD = True    # ... with gradients too: forward + ONE backward launc
 def tattn_fused_takes(x, heads, weights):
     """Does csrc/attn_fused.hip run Residual(PreNorm(temporal attention)) on this CL tensor [B, F, H, W, C] in one launch (and, when something
     in it needs a gradient, csrc/attn_fused_bwd.hip its backward in one more)?"""
-    if not (FUSED_TATTN and CONV_MATH == 'f16x3' and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
+    if not (FUSED_TATTN and CONV_MATH in ('f16x3', 'bf16') and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
         return False
-    if not FUSED_TATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in weights)):
+    if not FUSED_TATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights)):
         return False
     b, f, h, w, c = x.shape
-    if f != 24 and torch.is_grad_enabled() and (x.requires_grad or any(w_.requires_grad for w_ in weights)):
+    if f != 24 and torch.is_grad_enabled() and (x.requires_grad or any(w_ is not None and w_.requires_grad for w_ in weights)):
         return False                             # 48 frames (the super-resolution model): forward only
     return bool(_lib_().wdno_tattn_fused_takes(c, f, heads)) and b * h * w >= 64
 
@@ -1743,11 +1774,22 @@ def _tattn_operands(w_qkv, w_out, c, hd):
     return split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd) + split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
 
 
+def _in_f16x3(fn):
+    """The fused attention blocks compute on the split-fp16 planes whatever the arithmetic of the convolutions around them (bf16 mode)."""
+    def wrap(*a, **k):
+        if CONV_MATH == 'f16x3':
+            return fn(*a, **k)
+        with _math('f16x3'):
+            return fn(*a, **k)
+    return wrap
+
+
 class _TAttnFused(torch.autograd.Function):
     """y = x + to_out(attention_over_frames(LayerNorm(x))): one launch forward, one launch (+ the ordered sum of the per-block weight-gradient
     partials) backward. Nothing but x and the parameters is kept for the backward -- it recomputes the block per sequence."""
 
     @staticmethod
+    @_in_f16x3
     def forward(ctx, x, gamma, w_qkv, w_out, bias, rc, rs, eps, heads, scale):
         x = _chk(x, 'x')
         b, f, h, w, c = x.shape
@@ -1769,6 +1811,7 @@ class _TAttnFused(torch.autograd.Function):
         return _leave_amax(y, rec)
 
     @staticmethod
+    @_in_f16x3
     def backward(ctx, gy):
         x, gamma, w_qkv, w_out, bias, rc, rs = ctx.saved_tensors
         eps, heads, scale = ctx.meta
@@ -1813,7 +1856,7 @@ FUSED_LATTN_BWD = True    # ... with gradients too (csrc/linattn_fused_bwd.hip);
 def lattn_fused_takes(x, heads, weights):
     """Does csrc/linattn_fused.hip run Residual(PreNorm(SpatialLinearAttention)) on this CL tensor [B, F, H, W, C] (and, when something in it
     needs a gradient, csrc/linattn_fused_bwd.hip its backward)?"""
-    if not (FUSED_LATTN and CONV_MATH == 'f16x3' and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
+    if not (FUSED_LATTN and CONV_MATH in ('f16x3', 'bf16') and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
         return False
     if not FUSED_LATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights)):
         return False
@@ -1827,6 +1870,7 @@ class _LAttnFused(torch.autograd.Function):
     few KB per frame (the context and the softmax statistics of k)."""
 
     @staticmethod
+    @_in_f16x3
     def forward(ctx, x, gamma, w_qkv, w_out, b_out, eps, heads, scale):
         x = _chk(x, 'x')
         b, f, h, w, c = x.shape
@@ -1853,6 +1897,7 @@ class _LAttnFused(torch.autograd.Function):
         return _leave_amax(y, rec)
 
     @staticmethod
+    @_in_f16x3
     def backward(ctx, gy):
         x, gamma, w_qkv, w_out, cx, kst = ctx.saved_tensors
         eps, heads, scale, has_bias = ctx.meta

@@ -103,7 +103,7 @@ class PreNorm(nn.Module):
         # the normed tensor is read by fn's to_qkv projection only: where that one takes fp16 planes, the norm writes them
         att = self.fn if hasattr(self.fn, 'to_qkv') else getattr(self.fn, 'fn', None)
         if (residual is True and getattr(self.fn, 'token_axis', None) == 'frames' and kwargs.get('focus_present_mask') is None
-                and ops.tattn_fused_takes(x, att.heads, (self.norm.gamma, att.to_qkv.weight, att.to_out.weight))):
+                and ops.tattn_fused_takes(x, att.heads, (self.norm.gamma, att.to_qkv.weight, att.to_out.weight, kwargs.get('pos_bias')))):
             # norm -> to_qkv -> rotary / attention over the frames -> to_out -> + x as one launch (csrc/attn_fused.hip)
             rot = ops.rotary_tables(att.rotary_emb.freqs, x.shape[1]) if exists(att.rotary_emb) else None
             return ops.temporal_attention_fused(x, self.norm.gamma, self.norm.eps, att.to_qkv.weight, att.to_out.weight, rot,

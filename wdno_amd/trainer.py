@@ -55,14 +55,17 @@ class FlatBuffers:
         self._gather_srcs, self._gather_table, self._gathered = None, None, False
         self._views = [self.flat_grad[o:o + n].view(p.shape) for p, (o, n) in zip(self.params, self.span_list)]
         self._view_ptrs = [v.data_ptr() for v in self._views]
+        self.epoch_cell = [0]                             # ops._param_epoch: bumped by params_changed(), seen through every parameter of THIS buffer
         for prm, v in zip(self.params, self._views):      # ops._flat_grad_out: weight-gradient kernels write their span of flat_grad directly
             prm._wdno_flat_grad, prm._wdno_flat_busy = v, False
+            prm._wdno_epoch_cell = self.epoch_cell
 
     def params_changed(self):
         """Call after ANY write to flat_param (optimiser step, broadcast, checkpoint load, EMA copy): the packed / split weight
         operands the convolutions cache are keyed on this epoch, parameter version counters do not see writes through the flat
         buffer. Every writer in this module goes through here."""
-        ops.bump_weight_epoch()
+        self.epoch_cell[0] += 1
+        ops.bump_weight_epoch(params=False)
 
     def watch_gradient_coverage(self):
         """Arms a one-step check that every parameter receives a gradient. The flat optimiser keeps zero-filled gradients
@@ -420,6 +423,7 @@ class CapturedStep:
         torch.cuda.synchronize()
         buf.zero_grad()
         self.graph = torch.cuda.CUDAGraph()
+        epoch0 = ops.WEIGHT_EPOCH                      # operands the captured step touches carry used >= this
         with ops.graph_capture(self.graph, stream=side):
             loss = diffusion.p_losses(self.x, self.t, noise=self.noise)
             with ops.flat_wgrad_scope():
@@ -427,7 +431,7 @@ class CapturedStep:
             buf.gather_grads(capture=True)
         self.loss, self.shape = loss.detach(), tuple(ex.shape)
         # the graph replays raw pointers into the operand caches of wdno_amd.ops, which evict on their own terms: hold what it reads
-        self._keep, self._plans = ops.cache_snapshot(), ops.captured_plans()
+        self._keep, self._plans = ops.cache_snapshot(), ops.captured_plans(epoch0)
         self._capture_table = buf._capture_tables[-1]
         buf.params_changed()          # the capture only RECORDED the refresh of the packed weight operands: nothing may pass for fresh
 
@@ -760,6 +764,7 @@ class TrainerCore:
             caps = self.__dict__.setdefault('_caps', {})                 # one captured step per batch shape (the loader's last batch of an epoch is short)
             cap = caps.get(tuple(batch.shape))
             if cap is not None:
+                caps[tuple(batch.shape)] = caps.pop(tuple(batch.shape))        # most recently used last: eviction below takes the least recently used
                 total = float(cap.run(batch))
             else:
                 next_batch = lambda _b=batch: _b            # this step runs launch by launch (it is the warm-up), the capture follows it
@@ -778,10 +783,27 @@ class TrainerCore:
         self.last_grad_norm = self.opt.step(lr=self.lr_schedule(self.train_lr, self.step), grad_scale=1.0 / self.world)
         self.total_loss = total
         if self.use_graph and self.gradient_accumulate_every == 1 and tuple(batch.shape) not in self._caps:
-            if len(self._caps) >= 3:                         # a capture pins one step's activations: keep the full batch, the short one and one more
+            if len(self._caps) >= 3:                         # a capture pins one step's activations: at most three shapes, the least recently used goes
                 self._caps.pop(next(iter(self._caps)))
-            self._caps[tuple(batch.shape)] = CapturedStep(self.model, self.opt.buf, batch)
+            try:
+                self._caps[tuple(batch.shape)] = CapturedStep(self.model, self.opt.buf, batch)
+            except Exception as e:                           # an op that is illegal under capture, a host sync, no memory for the private pool:
+                self._capture_failed(e)                      # the run continues launch by launch, as it did before graphs were the default
         return total
+
+    def _capture_failed(self, err):
+        import gc
+        import warnings
+        warnings.warn(f'wdno_amd Trainer: capturing the training step in a HIP graph failed ({err!r:.300}); continuing launch by launch '
+                      '(use_graph = False for this trainer)')
+        self.use_graph = False
+        self._caps.clear()                                   # frees the private pools and operand snapshots of the captures made so far
+        ops._CAPTURE = None
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        self.opt.buf._gathered = False
+        self.opt.buf.params_changed()                        # whatever the aborted capture recorded as refreshed is not
 
     @property
     def _cap(self):                   # the most recent capture (tests / diagnostics)
