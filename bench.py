@@ -680,8 +680,8 @@ def main():
         loss, _ = ts.step(x)
     # The timed steps replay ONE captured HIP graph (loss -> backward -> gradient gather; the draws, the RCCL exchange, clip + Adam and EMA are
     # launched around it, wdno_amd.trainer.CapturedStep): the drop-in Trainers' default. Same kernels in the same order as the eager step
-    # (bit-identical, tests/test_gpu_graph.py); not with the overlapped bucket exchange (Python hooks during backward). --eager: launch by launch.
-    graphed = ts.overlap is None and not args.eager
+    # (bit-identical, tests/test_gpu_graph.py). --eager: launch by launch.
+    graphed = not args.eager                 # (with the overlapped bucket exchange the all-reduces are captured inside the graph, trainer.CapturedStep)
     capture_error = None
     if graphed:
         try:
@@ -821,7 +821,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0,
-                       'step_launch': 'hip_graph_replay (loss + backward + gradient gather captured; draws, exchange, clip + Adam, EMA around it)' if graphed else ('launch by launch' + (f' (capture failed: {capture_error})' if capture_error else '')),
+                       'step_launch': ('hip_graph_replay (loss + backward + gradient gather captured' + ('; the overlapped bucket all-reduces are nodes of the graph; draws, clip + Adam, EMA around it)' if getattr(cap, 'exchanged', False) else '; draws, exchange, clip + Adam, EMA around it)')) if graphed else ('launch by launch' + (f' (capture failed: {capture_error})' if capture_error else '')),
                        'process_group': ({'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                           'rccl_version': _rccl_version() if dist.get_backend() == 'nccl' else None,
                                           'devices_visible': torch.cuda.device_count()} if world > 1 else None)},

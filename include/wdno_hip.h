@@ -147,6 +147,17 @@ int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* sx, const v
 int wdno_conv_fwd_f16x3_amax(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                              const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
                              wdno_stream_t s);
+/* Structural zeros of the activation operand, stated by the caller: x[n][d][h][w][c] == 0 for every c < channels at every pixel with d >= d0
+ * or h >= h0 or w >= w0 (the zero padding of the wavelet-coefficient channels that p_losses / the sampler impose, smoke/ddpm/diffusion_2d.py:
+ * 1008-1033: 18 x 34 x 34 coefficients in a 24 x 40 x 40 tensor). A hint about DATA: results are those of the plain entry points bit for bit
+ * (a skipped term is an exact zero); a kernel that can use it -- the 7 x 7 x 7 stem of the smoke U-Net, video_diffusion_pytorch_conv3d.py:393 --
+ * does not run the reduction stages of whole 16-channel blocks below `channels` whose source plane or row is >= d0 / h0 for every pixel of a tile. */
+typedef struct { int channels, d0, h0, w0; } wdno_zero_box;
+int wdno_conv_fwd_f16x3_zbox(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                             const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
+                             const wdno_zero_box* zb, wdno_stream_t s);
+int wdno_conv_fwd_bf16_zbox(const void* x16, const void* wp16, const float* bias, const float* residual, float* y, float* amax_rec,
+                            const wdno_conv_geom* g, const wdno_zero_box* zb, wdno_stream_t s);
 /* the same with a caller-lent workspace: layers of few pixels x many channels (the 8 x 8 / 16 x 16 levels of the Burgers U-Net, unet.py:150-181)
    cut the reduction of a tile into four runs of stages, one block each; the runs' partial sums go through `ws` and are added in a fixed order.
    wdno_conv_fwd_split_ws_bytes(g): bytes such a geometry wants (0 = it never splits; ws may then be NULL). */

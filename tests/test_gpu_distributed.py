@@ -208,9 +208,11 @@ def _worker_rccl_one_rank(port, overlap, out, graph=False):
     torch.save(info, out)
 
 
-@pytest.mark.parametrize('overlap,graph', [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize('overlap,graph', [(False, False), (True, False), (False, True), (True, True)])
 def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overlap, graph):
-    """graph = True: the step replayed from a captured HIP graph with the RCCL all-reduce between the replay and clip + Adam."""
+    """graph = True: the step replayed from a captured HIP graph with the RCCL all-reduce between the replay and clip + Adam; overlap AND
+    graph: the four bucket all-reduces are started by the gradient hooks while the backward is being captured and become
+    nodes of the graph -- the replay carries the exchange."""
     out = str(tmp_path / 'rccl.pt')
     ctx = mp.get_context('spawn')
     p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), overlap, out, graph))

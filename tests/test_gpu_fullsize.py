@@ -57,16 +57,19 @@ def test_burgers_train_step_full_width_vs_oracle(R):
     _check_step(res, want_dma=True)
 
 
-def test_smoke_ddim_chain_full_size_ab(R):
-    """A 10-step DDIM chain (eta = 1, injected noise) at [1, 24, 42, 40, 40], default arithmetic vs WDNO_CONV_MATH=fp32."""
-    res = R.smoke_chain_full(steps=10, batch=1)
+@pytest.mark.parametrize('seed', [7, 8, 9])
+def test_smoke_ddim_chain_full_size_ab(R, seed):
+    """A 10-step DDIM chain (eta = 1, injected noise) at [1, 24, 42, 40, 40], default arithmetic vs WDNO_CONV_MATH=fp32, three seeds.
+    Round 4 passed seed 7 only on the gate's additive 1e-6 (ratio 1.53): tools/diagnostics/error_trace.py put the excess of the split path at
+    the 7 x 7 x 7 stem (one chain of 3 087 fp32 accumulations: 1.39e-6 there against 2.7e-7 for the exact-fp32 kernel's two-level sums), which
+    now sums per tap row (csrc/conv_h3t.hip). The gate has NO additive slack any more."""
+    res = R.smoke_chain_full(steps=10, batch=1, seed=seed)
     print(json.dumps(res, indent=1))
     ref = res['cpu32_vs_exact']
     for mode in ('f16x3', 'f32'):
         h = res[mode]['hip_vs_exact']
-        # arbiter gate: no further from the exact chain than 1.5 x the reference arithmetic (fp32 oracle on this host) is; the distance to
-        # that fp32 evaluation is then bounded by the two distances together
-        assert h <= 1.5 * ref + 1e-6, (mode, res)
+        # arbiter gate: no further from the exact chain than 1.5 x the reference arithmetic (fp32 oracle on this host) is
+        assert h <= 1.5 * ref, (mode, h / ref, res)
         # measured ceiling (not a triangle bound, which cannot fail): 1.27e-5 / 9.7e-6 in round 4 -> 2 x the larger
         assert res[mode]['hip_vs_cpu32'] < 2.6e-5, (mode, res)
 

@@ -63,8 +63,8 @@ def hip_trace():
     rec = []
     cl = lambda y, c: y.detach().double().cpu().permute(0, 4, 1, 2, 3)[:, :c]
     for m in net.modules():
-        if isinstance(m, V.LayerNorm):
-            m.register_forward_pre_hook(lambda mod, inp: rec.append(('ln_in', cl(inp[0], mod.gamma.shape[1]))))
+        if isinstance(m, V.PreNorm):         # (the fused attention blocks never call their LayerNorm module: hook the PreNorm around it)
+            m.register_forward_pre_hook(lambda mod, inp: rec.append(('ln_in', cl(inp[0], mod.norm.gamma.shape[1]))))
         if isinstance(m, V.ResnetBlock):
             m.register_forward_hook(lambda mod, inp, out: rec.append(('res_out', cl(out, mod.block2.proj.weight.shape[0]))))
     with torch.no_grad():
@@ -73,10 +73,33 @@ def hip_trace():
     return rec
 
 
-r64, r32, rh = oracle_trace(torch.float64), oracle_trace(torch.float32), hip_trace()
-assert len(r64) == len(rh) == len(r32), (len(r64), len(r32), len(rh))
-print(f'{"#":>3} {"point":8} {"shape":24} {"hip vs exact":>14} {"cpu32 vs exact":>15} {"ratio":>7}')
-for i, ((n64, a), (n32, b), (nh, c)) in enumerate(zip(r64, r32, rh)):
-    assert n64 == nh, (i, n64, nh)
-    eh, e32 = rel_l2(c, a), rel_l2(b, a)
-    print(f'{i:3d} {n64:8} {str(tuple(a.shape)):24} {eh:14.3e} {e32:15.3e} {eh / max(e32, 1e-30):7.2f}')
+def main():
+    """MODES=f16x3,fp32 (default both): the HIP trace under each convolution arithmetic, side by side."""
+    from wdno_amd import ops
+    modes = os.environ.get('MODES', 'f16x3,fp32').split(',')
+    r64, r32 = oracle_trace(torch.float64), oracle_trace(torch.float32)
+    traces = {}
+    for mode in modes:
+        ops.CONV_MATH = mode
+        ops.bump_weight_epoch()
+        traces[mode] = hip_trace()
+        assert len(r64) == len(traces[mode]) == len(r32), (len(r64), len(r32), len(traces[mode]))
+    ops.CONV_MATH = 'f16x3'
+    print(f'{"#":>3} {"point":8} {"shape":24} {"cpu32 vs exact":>15} ' + ' '.join(f'{"hip " + m + " vs exact":>20} {"ratio":>6}' for m in modes))
+    rows = []
+    for i, ((n64, a), (n32, b)) in enumerate(zip(r64, r32)):
+        e32 = rel_l2(b, a)
+        cells, row = [], {'i': i, 'point': n64, 'shape': list(a.shape), 'cpu32': e32}
+        for m in modes:
+            nh, c = traces[m][i]
+            assert n64 == nh, (i, n64, nh)
+            eh = rel_l2(c, a)
+            row[m] = eh
+            cells.append(f'{eh:20.3e} {eh / max(e32, 1e-30):6.2f}')
+        rows.append(row)
+        print(f'{i:3d} {n64:8} {str(tuple(a.shape)):24} {e32:15.3e} ' + ' '.join(cells))
+    return rows
+
+
+if __name__ == '__main__':
+    main()

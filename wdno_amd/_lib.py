@@ -80,6 +80,8 @@ PROTOTYPES = {
     'wdno_cast_bf16': (I, [P, P, L, I, I, P]),
     'wdno_cast_bf16_colsum': (I, [P, P, P, P, Z, L, I, I, P]),
     'wdno_conv_fwd_bf16': (I, [P, P, P, P, P, P, PG, P]),
+    'wdno_conv_fwd_f16x3_zbox': (I, [P, P, P, P, P, P, P, P, P, P, PG, P, P]),
+    'wdno_conv_fwd_bf16_zbox': (I, [P, P, P, P, P, P, PG, P, P]),
     'wdno_conv_wgrad_bf16_param': (I, [P, P, P, P, I, I, P, Z, PG, P]),
     'wdno_conv_wgrad_ws_bytes': (Z, [PG]),
     'wdno_conv_wgrad': (I, [P, P, P, P, Z, PG, P]),

@@ -24,6 +24,10 @@ struct ConvP {
   int tsplit;
   float* split_ws;
   size_t split_ws_bytes;
+  // structural zeros of x (include/wdno_hip.h: wdno_zero_box), used by the 7-wide tap-resident kernel: the first zb_blocks 16-channel blocks of
+  // x are zero wherever d >= zb_d or h >= zb_h, so their stages with such a source plane / row for every pixel of a tile are not run
+  // (0 blocks = off; stages whose source plane / row lies outside the grid for the whole tile are skipped for every block then, too)
+  int zb_blocks, zb_d, zb_h;
 };
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -82,6 +86,7 @@ static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.tsplit = 1;
   p.split_ws = nullptr;
   p.split_ws_bytes = 0;
+  p.zb_blocks = 0; p.zb_d = 0; p.zb_h = 0;
   p.debug = wdno_debug_mode;
   p.R = g->kw * g->C;
   p.nchunk = cdiv(p.R, BK);

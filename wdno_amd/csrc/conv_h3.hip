@@ -538,12 +538,16 @@ extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* 
 template <bool LP>
 static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                        const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g, wdno_stream_t s,
-                       float* split_ws = nullptr, size_t split_ws_bytes = 0) {
+                       float* split_ws = nullptr, size_t split_ws_bytes = 0, const wdno_zero_box* zb = nullptr) {
   int rc = check_geom(g);
   if (rc) return rc;
   if (g->C & 7) return WDNO_EUNSUPPORTED;       // 16-bit rows must be 16-byte multiples
   ConvP p;
   fill_params(p, g);
+  if (zb) {                                     // a statement about x, used where a kernel can (conv_h3t.hip, 7-wide taps): whole 16-channel blocks
+    if (zb->channels < 0 || zb->d0 < 0 || zb->h0 < 0 || zb->w0 < 0) return WDNO_EINVAL;
+    p.zb_blocks = zb->channels / 16; p.zb_d = zb->d0; p.zb_h = zb->h0;
+  }
   p.amax_rec = amax_rec;
   p.split_ws = split_ws;
   p.split_ws_bytes = split_ws_bytes;
@@ -590,6 +594,17 @@ extern "C" int wdno_conv_fwd_f16x3_ws(const void* xh, const void* xl, const floa
                                       const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
                                       void* ws, size_t ws_bytes, wdno_stream_t s) {
   return conv_fwd_16<false>(xh, xl, sx, wph, wpl, sw, bias, residual, y, amax_rec, g, s, (float*)ws, ws ? ws_bytes : 0);
+}
+// ... with a statement about structural zeros of x (wdno_zero_box, include/wdno_hip.h): same results bit for bit (up to the sign of a zero),
+// the 7 x 7 x 7 stem skips the reduction stages that only see such zeros
+extern "C" int wdno_conv_fwd_f16x3_zbox(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
+                                        const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
+                                        const wdno_zero_box* zb, wdno_stream_t s) {
+  return conv_fwd_16<false>(xh, xl, sx, wph, wpl, sw, bias, residual, y, amax_rec, g, s, nullptr, 0, zb);
+}
+extern "C" int wdno_conv_fwd_bf16_zbox(const void* x16, const void* wp16, const float* bias, const float* residual, float* y, float* amax_rec,
+                                       const wdno_conv_geom* g, const wdno_zero_box* zb, wdno_stream_t s) {
+  return conv_fwd_16<true>(x16, x16, nullptr, wp16, wp16, nullptr, bias, residual, y, amax_rec, g, s, nullptr, 0, zb);
 }
 extern "C" size_t wdno_conv_fwd_split_ws_bytes(const wdno_conv_geom* g) {
   if (!g || check_geom(g) || (g->C & 7)) return 0;

@@ -97,12 +97,27 @@ def q_sample_cond(x0, noise, t, sqrt_ac, sqrt_1mac, desc):
     target = torch.empty_like(x0)
     _lib.check(_lib_().wdno_q_sample_cond(_p(x0), _p(noise), _p(t), _p(sqrt_ac), _p(sqrt_1mac), _p(x), _p(target), C.byref(desc), _stream()),
                'q_sample_cond')
-    return x, target
+    return _note_zero_box(x, desc), target
+
+
+def zero_box_of_desc(desc):
+    """(channels, frame0, row0, col0) of the zeros the smoke pad condition writes (csrc/diffusion.hip: cond_code, diffusion_2d.py:1024-1032): every
+    channel below C - 2 (below 40 when the low-resolution channels 40 .. 79 are kept clean) is zero wherever frame >= cT or row >= cH or
+    column >= cW. None for descriptors without such a box."""
+    if desc.tree != 0 or not desc.cond_pad:
+        return None
+    return (40 if desc.cond_low else desc.C - 2, desc.cT, desc.cH, desc.cW)
+
+
+def _note_zero_box(x, desc):
+    from . import ops
+    box = zero_box_of_desc(desc)
+    return ops.set_zero_box(x, box) if box is not None else x
 
 
 def apply_cond(x, src, desc):
     _lib.check(_lib_().wdno_apply_cond(_p(x), _p(src), C.byref(desc), _stream()), 'apply_cond')
-    return x
+    return _note_zero_box(x, desc)
 
 
 class _WeightedMSE(torch.autograd.Function):
@@ -249,9 +264,14 @@ class _StepGraph:
                 self.static[k].copy_(v)
 
     def _body(self, mod, guided):
+        from . import ops
         x = self.x
         if self.cond_first:
             apply_cond(x, self.src, self.desc)
+        else:
+            # smoke order: the conditions were imposed on x by the end of the previous step -- and on the initial draw by sampling_loop itself
+            # (it re-imposes them on the static buffer before the first replay), so the structural zeros of the pad condition hold at every replay
+            _note_zero_box(x, self.desc)
         if guided is not None:
             xn = guided(x, self.t, self.noise, self.coef).contiguous()
             if not self.cond_first:
@@ -266,6 +286,7 @@ class _StepGraph:
         if not self.cond_first:
             apply_cond(xn, self.src, self.desc)
         x.copy_(xn)
+        ops.carry_zero_box(x, xn)                  # (the next replay's U-Net input)
         self.x_start = xs
 
 
@@ -323,6 +344,8 @@ def sampling_loop(mod, x, src, desc, *, ddim_pairs=None, eta=0.0, cond_first, us
         sg = _step_graph(mod, shape, desc, ddim, cond_first, dev)
         sg.src.copy_(src)
         sg.x.copy_(x)
+        if not cond_first:                        # the captured step relies on the conditions holding on its input (_StepGraph._body): make it so
+            apply_cond(sg.x, sg.src, desc)        # whatever the caller passed (bit-identical when it already imposed them, as the smoke samplers do)
         if ddim:
             table = torch.tensor([[co[2], co[1], co[0]] if co is not None else [0., 0., 0.] for _, co in steps], dtype=torch.float32).to(dev)
         x = sg.x
@@ -388,6 +411,7 @@ def guided_sampling_loop_smoke(mod, x, src, desc, design_fn, design_guidance, *,
         sg = _step_graph(mod, shape, desc, ddim, False, dev, guided_factory, gkey, static=dict(low=low, init=init, init_u=init_u), keep=design_fn)
         sg.src.copy_(src)
         sg.x.copy_(x)
+        apply_cond(sg.x, sg.src, desc)            # (as sampling_loop: the captured step relies on the conditions holding on its input)
         if ddim:
             table = torch.tensor([[co[2], co[1], co[0]] if co is not None else [0., 0., 0.] for _, co in steps], dtype=torch.float32).to(dev)
         x = sg.x

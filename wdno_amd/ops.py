@@ -712,8 +712,34 @@ def split_weight(w, kind, cp8, kp, pack=None):
     return pl.hi, pl.lo, pl.sc
 
 
+ZERO_BOX = True           # structural-zero hints reach the kernels that can use them (test knob: results are bit-identical without)
+
+
+class _ZeroBox(C.Structure):          # include/wdno_hip.h: wdno_zero_box
+    _fields_ = [('channels', C.c_int), ('d0', C.c_int), ('h0', C.c_int), ('w0', C.c_int)]
+
+
+def set_zero_box(t, box):
+    """The kernel that wrote t (diffusion_core.q_sample_cond / apply_cond: the pad condition of diffusion_2d.py:1008-1033) left zeros in every
+    channel < box[0] wherever frame >= box[1] or row >= box[2] or column >= box[3]: remembered on the tensor object with its version, like an
+    amax record -- any later in-place change through torch voids it."""
+    t._wdno_zero_box = (tuple(int(v) for v in box), t._version)
+    return t
+
+
+def zero_box_of(t):
+    h = getattr(t, '_wdno_zero_box', None)
+    return h[0] if h is not None and h[1] == t._version and ZERO_BOX else None
+
+
+def carry_zero_box(dst, src):
+    """dst holds the same values as src in another layout / storage (nc_to_cl, a copy into a static buffer)."""
+    box = zero_box_of(src)
+    return set_zero_box(dst, box) if box is not None else dst
+
+
 def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp, out=None, osp=None, ostride=(1, 1, 1), ooff=(0, 0, 0),
-                amax_rec=None):
+                amax_rec=None, zero_box=None):
     """planes = (hi, lo, scale) of a CL tensor with logical shape4 = (N, D, H, W) and C8 channels; w raw weight;
     pack = pack_fwd / pack_dgrad. Returns y [N, OD, OH, OW, kp] fp32. With `out` ([N, YD, YH, YW, kp]) the osp output
     pixels are placed at ooff + ostride * index (parity classes of the transposed convolution)."""
@@ -733,8 +759,19 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
     tap = (out is None and tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and max(ks) <= 8 and      # csrc/conv_h3t.hip: wdno_conv_h3t_takes
            ((ks[2] == 3 and cp8 % 32 == 0) or (ks[2] == 7 and cp8 % 16 == 0 and kp <= 64)))
     with _timed(_fwd_h3_kernel_name(n * osp[0] * osp[1] * osp[2], kp, ks, tap, cp8 if xl is not None else None), flops):
+        zb = None
+        if zero_box is not None and tap and ks[2] == 7:      # the 7-wide stem skips the reduction stages that only see the caller's zeros (csrc/conv_h3t.hip)
+            zb = _ZeroBox(*zero_box)
         if xl is None:       # single bf16 plane per operand
+            if zb is not None:
+                _lib.check(_lib_().wdno_conv_fwd_bf16_zbox(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), C.byref(zb), _stream()),
+                           'conv_fwd_bf16_zbox')
+                return y
             _lib.check(_lib_().wdno_conv_fwd_bf16(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_bf16')
+            return y
+        if zb is not None:
+            _lib.check(_lib_().wdno_conv_fwd_f16x3_zbox(_p(xh), _p(xl), _p(sx), _p(wh), _p(wl), _p(sw), _p(bias_p), _p(residual), _p(y),
+                                                        _p(amax_rec), C.byref(g), C.byref(zb), _stream()), 'conv_fwd_f16x3_zbox')
             return y
         # layers of few pixels x many channels lend the library a workspace for the partial sums of a split reduction (csrc/conv_h3t.hip)
         key = (n, d, h, ww, cp8, kp, tuple(ks), tuple(osp)) if tap and ks[2] == 3 else None
@@ -1072,7 +1109,7 @@ class _Conv(torch.autograd.Function):
             planes = split_f16_of(x_in, x5.reshape(-1, cp), xrec, c8w)
             yrec = _new_amax_record(x5.device)
             y = _leave_amax(conv_fwd_h3(planes, tuple(x5.shape[:4]), weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp,
-                                        amax_rec=yrec), yrec)
+                                        amax_rec=yrec, zero_box=zero_box_of(x_in) if x_in.dim() == 5 else None), yrec)
             ctx.save_for_backward(planes[0], planes[1], planes[2], weight)     # the split planes replace x for wgrad
         else:
             y = conv_fwd_raw(x5, pack_fwd(weight, cp, kp), bias_p, res5, ks, stride, padding, kp)

@@ -13,7 +13,10 @@ from wdno_amd import wavelets as W
 from wave_trans_2d import tensor_to_coef
 
 
-SMOKE_OUT_SPLIT_ROW = 20      # inference_2d.py:44-45 writes int(40/2) whatever the tensor size: the super-resolution tensors (80 x 80) split at row 20 too
+def _split_row(rows):
+    """inference_2d.py:44-45 writes int(40/2) whatever the tensor size: the super-resolution tensors (80 x 80) split at row 20 too. Tensors
+    of 20 rows or fewer (the reduced-size tests; the reference's second mean would be over nothing there: NaN) are halved instead."""
+    return 20 if rows > 20 else rows // 2
 
 
 def guidance_value(x, shape, ori_shape, rescaler, wave_type='bior1.3', pad_mode='zero', is_condition_control=False, w_energy=0.0, w_init=0.0,
@@ -23,7 +26,7 @@ def guidance_value(x, shape, ori_shape, rescaler, wave_type='bior1.3', pad_mode=
     coef = tensor_to_coef(xs[:, :, :-2].permute(0, 2, 1, 3, 4), shape)
     rec = W.waverec3([coef[0].contiguous(), {k: v.contiguous() for k, v in coef[1].items()}], wave_type, pad_mode)
     state = rec[:, :ori_shape[0], :ori_shape[1], :ori_shape[2]].reshape(-1, 5, ori_shape[0], ori_shape[1], ori_shape[2])
-    half = SMOKE_OUT_SPLIT_ROW
+    half = _split_row(xs.shape[-2])
     lo = xs[:, :shape[0], -1, :half].mean((-2, -1)).unsqueeze(1)
     hi = xs[:, :shape[0], -1, half:].mean((-2, -1)).unsqueeze(1)
     smoke_out = W.DWT1DInverse(mode=pad_mode, wave=wave_type)((lo.contiguous(), [hi.contiguous()]))[:, 0]
@@ -93,7 +96,7 @@ def guidance_fn_explicit(x, shape, ori_shape, rescaler, wave_type='bior1.3', pad
     g[:, :tc, :40, :hc, :wc] = dpacked.reshape(b, 5, 8, tc, hc, wc).permute(0, 3, 1, 2, 4, 5).reshape(b, tc, 40, hc, wc)
     if not is_condition_control:
         g_lo, g_hi = _success_gradient(tc, to, wave_type, pad_mode, xs.device)
-        half = SMOKE_OUT_SPLIT_ROW             # the reference halves the ROW axis of the smoke-out channel (x[:, :T', -1, :20])
+        half = _split_row(hh)                  # the reference halves the ROW axis of the smoke-out channel (x[:, :T', -1, :20])
         g[:, :tc, -1, :half, :] -= (g_lo / (half * ww)).reshape(1, tc, 1, 1)
         g[:, :tc, -1, half:, :] -= (g_hi / ((hh - half) * ww)).reshape(1, tc, 1, 1)
     return g

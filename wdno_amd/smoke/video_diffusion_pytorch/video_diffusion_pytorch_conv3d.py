@@ -338,7 +338,9 @@ class Unet3D_with_Conv3D(nn.Module):
             raise NotImplementedError('prob_focus_present is always 0 on the WDNO path')
         b, f, c, h, w = x.shape
         # [B*F, C, H, W] -> channels-last [B, F, H, W, Cp]
+        x_api = x
         x = ops.nc_to_cl(x.reshape(b * f, c, h, w)).reshape(b, f, h, w, -1)
+        ops.carry_zero_box(x, x_api)       # the sampler / p_losses left structural zeros (pad condition): the stem skips the stages that only see them
         pos_bias = self.time_rel_pos_bias(f, device=x.device)
 
         x = ops.conv_cl(x, self.init_conv.weight, self.init_conv.bias, padding=self.init_conv.padding)

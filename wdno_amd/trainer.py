@@ -406,9 +406,13 @@ class CapturedStep:
     autograd graph of an earlier step alive (AccumulateGrad nodes are bound to the stream they were created on); every packed weight
     operand marked stale so that the captured step starts with the two refresh launches."""
 
-    def __init__(self, diffusion, buf, example_batch):
+    def __init__(self, diffusion, buf, example_batch, overlap=None):
+        """overlap: an OverlappedAllReduce -- its bucket all-reduces are started from the gradient hooks DURING the captured backward, so they
+        become nodes of the graph (RCCL's stream forks from the capturing stream at each bucket and joins it again in finish()): replays then
+        carry the exchange, overlapped exactly as in the eager step, and the caller must not reduce the flat buffer again (self.exchanged)."""
         import gc
         self.model, self.buf = diffusion, buf
+        self.exchanged = overlap is not None
         gc.collect()                                   # drop autograd graphs of earlier steps that only the cycle collector frees
         ex = example_batch
         side = torch.cuda.Stream()
@@ -426,8 +430,12 @@ class CapturedStep:
         epoch0 = ops.WEIGHT_EPOCH                      # operands the captured step touches carry used >= this
         with ops.graph_capture(self.graph, stream=side):
             loss = diffusion.p_losses(self.x, self.t, noise=self.noise)
+            if overlap is not None:
+                overlap.begin()
             with ops.flat_wgrad_scope():
                 loss.backward()
+            if overlap is not None:
+                overlap.finish()
             buf.gather_grads(capture=True)
         self.loss, self.shape = loss.detach(), tuple(ex.shape)
         # the graph replays raw pointers into the operand caches of wdno_amd.ops, which evict on their own terms: hold what it reads
@@ -510,12 +518,18 @@ class TrainStep:
         tests/test_gpu_graph.py). Left outside the graph on purpose: the random draws (two launches, so that eager and graphed steps
         consume the generator identically), the gradient exchange (RCCL) and clip + Adam (two launches whose learning rate and step
         count are host scalars). Runs `warmup` eager optimisation steps on the example first: packed weight operands, pixel tables
-        and the gradient-coverage check have to exist before a capture. Not with the overlapped bucket exchange (Python hooks)."""
-        if self.overlap is not None:
-            raise RuntimeError('wdno_amd TrainStep.capture: the overlapped bucket exchange runs Python hooks during backward; use WDNO_DP_OVERLAP=0')
+        and the gradient-coverage check have to exist before a capture."""
+        if self.overlap is not None and os.environ.get('WDNO_DP_GRAPH_OVERLAP', '1') == '0':
+            raise RuntimeError('wdno_amd TrainStep.capture: WDNO_DP_GRAPH_OVERLAP=0 -- the overlapped bucket exchange is not to be captured; use WDNO_DP_OVERLAP=0')
+        if self.overlap is not None and dist.get_backend(self.group) != 'nccl':
+            raise RuntimeError('wdno_amd TrainStep.capture: only RCCL collectives can be recorded in a HIP graph (backend '
+                               f'{dist.get_backend(self.group)!r} synchronises with the host); the overlapped exchange stays launch by launch')
         for _ in range(max(1, warmup)):
             self.step(example_batch)
-        self._cap = CapturedStep(self.model, self.opt.buf, example_batch)
+        # With the overlapped bucket exchange the hooks run while the backward is being captured: the async all-reduces they start are recorded
+        # as graph nodes on RCCL's stream (forked from / joined to the capturing stream), so a replay overlaps them with the rest of the backward
+        # like the eager step does. A capture that RCCL refuses raises here; callers fall back to launch-by-launch steps (bench.py does).
+        self._cap = CapturedStep(self.model, self.opt.buf, example_batch, overlap=self.overlap)
         return self
 
     @property
@@ -525,7 +539,7 @@ class TrainStep:
 
     def _step_graph(self, batch):
         loss = self._cap.run(batch)
-        if self.exchange:
+        if self.exchange and not self._cap.exchanged:
             if self.time_comm:                    # bench.py: the exposed exchange (the replayed backward has been enqueued in full), HIP events
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
