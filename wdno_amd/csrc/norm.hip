@@ -7,6 +7,7 @@
 // Backward mirrors it: per-channel sums of dz and dz*xhat, a per-sample finalize producing the parameter
 // gradients and the two group means, then one elementwise pass for dx.
 #include "common.h"
+extern int wdno_debug_mode;      // 58 / 59: GroupNorm timing experiments -- the forward statistics pass / the backward reduction pass is launched TWICE (same results): the step-time difference is what the pass costs inside the step
 
 #define GN_MAXC 1024
 
@@ -559,7 +560,7 @@ extern "C" int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, c
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_) gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0);
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps);
   int gx = stream_grid(S * (C / 4), 256);
   if (gx > 512) gx = 512;
@@ -584,7 +585,7 @@ extern "C" int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, cons
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 59 ? 2 : 1); ++rep_) gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu);
   gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk);
   int gx = stream_grid(S * (C / 4), 256);
   if (gx > 512) gx = 512;
@@ -617,7 +618,7 @@ extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma,
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_) gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
@@ -643,7 +644,7 @@ extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* ga
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_) gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
@@ -694,7 +695,7 @@ extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, co
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 59 ? 2 : 1); ++rep_) gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
   gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, dx_lo ? bound_rec : nullptr);
   const int gx = gn_planes_grid(N, S, C);
   gn_bwd_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp,
