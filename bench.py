@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16 / _bf16, dense (the 3 x fp16-split kernels spend 3 MFMA flop per algorithmic flop)
 PEAK_HBM_TBS = 8.0
-PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
 
 
 def _trees():
@@ -577,7 +577,7 @@ def conv_roofline(ts_step, ops):
         fam, dims = dom.split('<')
         dims = dims.rstrip('>').split(',')
         sym = fam + 'I' + ''.join(f'Li{d}E' for d in dims) if all(d.isdigit() for d in dims) else None
-        path = next((q for q in (PROFILE_JSON, os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'), os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json'))
+        path = next((q for q in (PROFILE_JSON, os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json'), os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'))
                      if os.path.exists(q)), PROFILE_JSON)
         with open(path) as f:
             recs = json.load(f)['kernels']

@@ -156,8 +156,11 @@ typedef struct { int channels, d0, h0, w0; } wdno_zero_box;
 int wdno_conv_fwd_f16x3_zbox(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                              const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g,
                              const wdno_zero_box* zb, wdno_stream_t s);
-int wdno_conv_fwd_bf16_zbox(const void* x16, const void* wp16, const float* bias, const float* residual, float* y, float* amax_rec,
-                            const wdno_conv_geom* g, const wdno_zero_box* zb, wdno_stream_t s);
+/* single-product (bf16) form with both options: zb may be NULL; y_bf16 != 0: y is bf16 storage [rows][K] (round-to-nearest-even of the fp32
+ * result; residual must be NULL) -- mixed-precision activation storage between a convolution and the GroupNorm that is its only reader
+ * (burgers/ddpm_burgers/train_diffusion.py:61-62: accelerate mixed precision), read by the wdno_groupnorm_*_t entry points. */
+int wdno_conv_fwd_bf16_ex(const void* x16, const void* wp16, const float* bias, const float* residual, void* y, int y_bf16, float* amax_rec,
+                          const wdno_conv_geom* g, const wdno_zero_box* zb, wdno_stream_t s);
 /* the same with a caller-lent workspace: layers of few pixels x many channels (the 8 x 8 / 16 x 16 levels of the Burgers U-Net, unet.py:150-181)
    cut the reduction of a tile into four runs of stages, one block each; the runs' partial sums go through `ws` and are added in a fixed order.
    wdno_conv_fwd_split_ws_bytes(g): bytes such a geometry wants (0 = it never splits; ws may then be NULL). */
@@ -248,6 +251,22 @@ int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* 
                                   const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
                                   float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
                                   void* ws, size_t ws_bytes, wdno_stream_t s);
+/* The same four entry points for bf16-stored activations (single-product mode): x_bf16 / dy_bf16 != 0 say that x / dy is bf16 storage -- what
+ * wdno_conv_fwd_bf16_ex(y_bf16 = 1) wrote. Statistics, affine, activation and every output are computed exactly as above (fp32 / fp64). */
+int wdno_groupnorm_act_fwd_amax_t(const void* x, int x_bf16, const float* gamma, const float* beta, const float* ss, float* y,
+                                  float* stats, float* amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                  void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_groupnorm_act_fwd_planes_t(const void* x, int x_bf16, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
+                                    float* y_scale, float* stats, float* bound_rec, int64_t N, int64_t S, int C, int G, float eps,
+                                    int silu, void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_groupnorm_act_add_fwd_planes_t(const void* x, int x_bf16, const float* gamma, const float* beta, const float* ss, const float* residual,
+                                        const float* res_rec, float* y, void* y_hi, void* y_lo, float* y_scale, float* stats,
+                                        float* bound_rec, float* y_amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                        void* ws, size_t ws_bytes, wdno_stream_t s);
+int wdno_groupnorm_act_bwd_planes_t(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* gamma, const float* beta, const float* ss,
+                                    const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
+                                    float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
+                                    void* ws, size_t ws_bytes, wdno_stream_t s);
 /* dgb_sum (round 3, optional): [2 C] = the sum over the samples of dgb_partial [N][2][C] (d gamma | d beta), produced by the launch that
  * also finishes dx_colsum; NULL = the caller reduces dgb_partial itself. */
 /* Channel LayerNorm over C of CL rows [P, C], gain only (unet.py:55-65, conv3d.py:165-174) */

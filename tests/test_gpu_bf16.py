@@ -31,6 +31,7 @@ def ops():
     o.CONV_MATH = 'bf16'
     yield o
     o.CONV_MATH = prev
+    o.ACT16 = False
 
 
 def bf(t):
@@ -234,6 +235,120 @@ def test_bf16_smoke_train_step_vs_autocast_arbiter(ops):
           f'autocast {e_a[mid]:.3e}, worst HIP {e_h[-1]:.3e} / autocast {e_a[-1]:.3e}')
     assert rl_h <= 1.5 * max(rl_a, e_a[mid])
     assert e_h[mid] <= 1.5 * e_a[mid] and e_h[-1] <= 1.5 * e_a[-1]
+
+
+def test_act16_conv_output_is_the_rounded_fp32_output(ops):
+    """Single-product mode stores the output of a convolution whose only reader is a GroupNorm as bf16 (ops.ACT16, wdno_conv_fwd_bf16_ex): the
+    stored values are the round-to-nearest-even of what the fp32-output launch writes, on the tap-resident, the chunked and the register-staged
+    kernel; without the caller's to_norm statement nothing changes."""
+    for name, xs, ws, pad in (('tap', (2, 64, 8, 20, 20), (64, 64, 3, 3, 3), 1), ('chunked_1x1', (4, 256, 4, 16, 16), (128, 256, 1, 1, 1), 0),
+                              ('register_staged', (1, 32, 2, 8, 8), (64, 32, 3, 3, 3), 1), ('2d', (8, 128, 16, 16), (128, 128, 3, 3), 1)):
+        x, w, b = g(xs, 11).float(), (g(ws, 12) / math.sqrt(np.prod(ws[1:]))).float(), g((ws[0],), 13).float()
+        xd, wd, bd = to_cl(x).to(DEV), w.to(DEV), b.to(DEV)
+        ops.ACT16 = True
+        y16 = ops.conv_cl(xd, wd, bd, padding=pad, grad_planes=True, to_norm=True)
+        y_plain = ops.conv_cl(xd, wd, bd, padding=pad, grad_planes=True)
+        ops.ACT16 = False
+        y32 = ops.conv_cl(xd, wd, bd, padding=pad, grad_planes=True, to_norm=True)
+        ops.ACT16 = True
+        assert y32.dtype == torch.float32 and y_plain.dtype == torch.float32 and torch.equal(y32, y_plain), name
+        if y16.dtype == torch.bfloat16:
+            assert torch.equal(y16, y32.to(torch.bfloat16)), name
+        else:                             # (layers below the split-kernel thresholds keep fp32 storage)
+            assert name == 'register_staged' and torch.equal(y16, y32), name
+    ops.ACT16 = False
+
+
+@pytest.mark.parametrize('shape,groups', [((2, 6, 20, 20, 64), 8), ((3, 16, 16, 128), 1), ((2, 4, 8, 8, 24), 4)])
+def test_act16_groupnorm_reads_bf16_storage_exactly(ops, shape, groups):
+    """GroupNorm on a bf16-stored activation == GroupNorm on the same values stored as fp32, bit for bit, in every form the U-Nets use: fp32
+    output, planes output, + residual; and backward (dx planes, column sums, parameter gradients) with dy stored as fp32 and as bf16."""
+    gen = torch.Generator().manual_seed(sum(shape))
+    c = shape[-1]
+    x16 = (torch.randn(shape, generator=gen) * 2 + 0.3).to(torch.bfloat16).to(DEV)
+    gam, bet = (torch.rand(c, generator=gen) + 0.5).to(DEV), (torch.randn(c, generator=gen) * 0.1).to(DEV)
+    ss = (torch.randn(shape[0], 2 * c, generator=gen) * 0.2).to(DEV)
+    res = torch.randn(shape, generator=gen).to(DEV)
+    gy32 = torch.randn(shape, generator=gen).to(torch.bfloat16).float().to(DEV)
+
+    planes_ok = c % 8 == 0 and (c // 8) & (c // 8 - 1) == 0          # the channel counts whose backward hands dx over as planes (the only ones a
+                                                                      # convolution stores as bf16 in front of a norm)
+
+    def run(xin, gy):
+        out = {}
+        if not planes_ok:
+            with torch.no_grad():
+                out['y'] = ops.groupnorm_act(xin, gam, bet, groups, ss, act=True).clone()
+            return out
+        xin = xin.clone().requires_grad_(True)
+        xin._wdno_grad_planes = True                      # (what conv_cl(..., grad_planes=True) states about its output)
+        g_, b_, s_ = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True), ss.clone().requires_grad_(True)
+        got = []
+        xin.register_hook(lambda t: got.append(t))
+        y = ops.groupnorm_act(xin, g_, b_, groups, s_, act=True)
+        out['y'] = y.detach().clone()
+        y.backward(gy)
+        po = got[0]._wdno_planes_only
+        out['dx_hi'], out['dx_colsum'] = po[0][0].clone(), po[1].clone()
+        out['dg'], out['db'], out['dss'] = g_.grad.clone(), b_.grad.clone(), s_.grad.clone()
+        with torch.no_grad():
+            yp = ops.groupnorm_act(xin.detach(), gam, bet, groups, ss, act=True, out_planes=True)
+            out['y_planes'] = yp._wdno_planes[0][0].clone()
+            out['y_add'] = ops.groupnorm_act_add(xin.detach(), gam, bet, groups, res, ss).clone()
+        return out
+    a = run(x16, gy32)
+    b = run(x16.float(), gy32)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    if planes_ok:                                             # dy stored as bf16 as well (the data gradient of the convolution behind the norm)
+        d = run(x16, gy32.to(torch.bfloat16))
+        for k in ('dx_hi', 'dx_colsum', 'dg', 'db', 'dss'):
+            assert torch.equal(d[k], b[k]), k
+
+
+def test_act16_changes_a_training_step_only_by_bf16_rounding(ops):
+    """A Burgers training step (dim 32, grids 64 .. 8) with bf16-stored convolution outputs against the same step with fp32 storage: the loss
+    agrees to bf16 rounding and the bf16 tensors were really used (the convolution outputs in front of the norms are bfloat16)."""
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion
+    res = {}
+    seen = []
+    orig = ops.groupnorm_act
+
+    def spy(x, *a, **k):
+        seen.append(x.dtype)
+        return orig(x, *a, **k)
+    for flag in (True, False):
+        ops.ACT16 = flag
+        torch.manual_seed(3)
+        net = Unet2D(dim=32, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
+        dif = GaussianDiffusion(net, seq_length=(64, 64), padded_shape=[41, 60], ori_shape=[81, 120], loss_layer_weight=torch.ones(1, 9, 1, 1),
+                                is_condition_pad=True, is_condition_u0=True, is_condition_f=True).to(DEV)
+        gen = torch.Generator().manual_seed(4)
+        x0 = (torch.randn(8, 9, 64, 64, generator=gen) * 0.5).to(DEV)
+        t = torch.randint(0, 1000, (8,), generator=gen).to(DEV)
+        noise = torch.randn(8, 9, 64, 64, generator=gen).to(DEV)
+        seen.clear()
+        ops.groupnorm_act = spy
+        try:
+            loss = dif.p_losses(x0, t, noise=noise)
+            loss.backward()
+        finally:
+            ops.groupnorm_act = orig
+        torch.cuda.synchronize()
+        res[flag] = (float(loss), {k: p.grad.clone() for k, p in net.named_parameters()}, list(seen))
+    ops.ACT16 = False
+    assert torch.bfloat16 in res[True][2] and torch.bfloat16 not in res[False][2]
+    assert abs(res[True][0] - res[False][0]) < 2e-2 * abs(res[False][0])
+    errs = sorted(rel_l2(res[True][1][k], res[False][1][k]) for k in res[True][1])
+    print('ACT16 vs fp32 storage, gradient rel-L2: median', errs[len(errs) // 2], 'worst', errs[-1])
+    assert errs[len(errs) // 2] < 5e-2
 
 
 def test_bf16_training_reduces_the_loss(ops):

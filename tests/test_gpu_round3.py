@@ -109,9 +109,15 @@ def test_default_kernel_selection_of_both_models():
     with open(os.path.join(GOLDEN, 'kernel_selection.json')) as f:
         want = json.load(f)
     dev = torch.device('cuda', 0)
-    cases = (('smoke', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)), ('burgers', lambda: bench.build_burgers(dev), (16, 9, 64, 64)),
-             ('burgers80', lambda: bench.build_burgers(dev, (80, 64)), (16, 9, 80, 64)))
-    for name, build, shape in cases:
+    cases = (('smoke', 'f16x3', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)), ('burgers', 'f16x3', lambda: bench.build_burgers(dev), (16, 9, 64, 64)),
+             ('burgers80', 'f16x3', lambda: bench.build_burgers(dev, (80, 64)), (16, 9, 80, 64)),
+             # BASELINE configs[1] at its own batch of 256 (the 256 x 128 single-plane tiles) and the smoke step on the single-product kernels
+             ('burgers_bf16_b256', 'bf16', lambda: bench.build_burgers(dev), (256, 9, 64, 64)),
+             ('smoke_bf16', 'bf16', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)))
+    for name, math, build, shape in cases:
+        if name not in want:
+            continue
+        ops.CONV_MATH = math
         ts = TrainStep(build(), lr=1e-3, use_ema=False)
         x = torch.randn(shape, device=dev) * 0.5
         ts.step(x)
@@ -122,6 +128,7 @@ def test_default_kernel_selection_of_both_models():
             got = {k: len(v) for k, v in ops.PROFILE.items()}
         finally:
             ops.PROFILE = None
+            ops.CONV_MATH = 'f16x3'
         assert got == want[name], (name, got)
         del ts
         ops.drop_weight_caches()

@@ -1,11 +1,17 @@
 import sys, json, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from wdno_amd import ops
 from wdno_amd.trainer import TrainStep, multistep_lr, cosine_annealing_lr
 dev = torch.device('cuda', 0)
 out = {}
-for name, build, shape in (('smoke', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)), ('burgers', lambda: bench.build_burgers(dev), (16, 9, 64, 64)), ('burgers80', lambda: bench.build_burgers(dev, (80, 64)), (16, 9, 80, 64))):
+CASES = (('smoke', 'f16x3', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)), ('burgers', 'f16x3', lambda: bench.build_burgers(dev), (16, 9, 64, 64)),
+         ('burgers80', 'f16x3', lambda: bench.build_burgers(dev, (80, 64)), (16, 9, 80, 64)),
+         # BASELINE configs[1] at its own batch and the smoke step on the single-product kernels (bench leg smoke_bf16)
+         ('burgers_bf16_b256', 'bf16', lambda: bench.build_burgers(dev), (256, 9, 64, 64)), ('smoke_bf16', 'bf16', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)))
+for name, math, build, shape in CASES:
+    ops.CONV_MATH = math
     dif = build()
     ts = TrainStep(dif, lr=1e-3, use_ema=False)
     x = torch.randn(shape, device=dev) * 0.5
@@ -17,4 +23,5 @@ for name, build, shape in (('smoke', lambda: bench.build_model(dev, 8), (8, 24, 
     ops.PROFILE = None
     del ts, dif
     ops.drop_weight_caches()
+ops.CONV_MATH = 'f16x3'
 print(json.dumps(out, indent=1))

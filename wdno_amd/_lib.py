@@ -81,7 +81,7 @@ PROTOTYPES = {
     'wdno_cast_bf16_colsum': (I, [P, P, P, P, Z, L, I, I, P]),
     'wdno_conv_fwd_bf16': (I, [P, P, P, P, P, P, PG, P]),
     'wdno_conv_fwd_f16x3_zbox': (I, [P, P, P, P, P, P, P, P, P, P, PG, P, P]),
-    'wdno_conv_fwd_bf16_zbox': (I, [P, P, P, P, P, P, PG, P, P]),
+    'wdno_conv_fwd_bf16_ex': (I, [P, P, P, P, P, I, P, PG, P, P]),
     'wdno_conv_wgrad_bf16_param': (I, [P, P, P, P, I, I, P, Z, PG, P]),
     'wdno_conv_wgrad_ws_bytes': (Z, [PG]),
     'wdno_conv_wgrad': (I, [P, P, P, P, Z, PG, P]),
@@ -99,6 +99,10 @@ PROTOTYPES = {
     'wdno_groupnorm_act_add_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_layernorm_fwd_planes': (I, [P, P, P, P, P, L, I, F, P]),
     'wdno_groupnorm_act_bwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
+    'wdno_groupnorm_act_fwd_amax_t': (I, [P, I, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
+    'wdno_groupnorm_act_fwd_planes_t': (I, [P, I, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
+    'wdno_groupnorm_act_add_fwd_planes_t': (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
+    'wdno_groupnorm_act_bwd_planes_t': (I, [P, I, P, I, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_layernorm_fwd': (I, [P, P, P, L, I, F, P]),
     'wdno_layernorm_fwd_amax': (I, [P, P, P, P, L, I, F, P]),
     'wdno_layernorm_bwd_ws_bytes': (Z, [L, I]),

@@ -80,6 +80,10 @@ __device__ __forceinline__ unsigned short bf16_rne(float v) {      // round-to-n
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+// four fp32 values -> four bf16 (8 bytes)
+__device__ __forceinline__ uint2 bf16x4_pack(float4 v) {
+  return make_uint2((unsigned)bf16_rne(v.x) | ((unsigned)bf16_rne(v.y) << 16), (unsigned)bf16_rne(v.z) | ((unsigned)bf16_rne(v.w) << 16));
+}
 // one value of a plane pair: (hi, lo) fp16 of v * s, or -- lo == nullptr, the single-product mode -- one bf16 in the hi plane's storage
 __device__ __forceinline__ void plane_pack(float v, float s, bool lp, _Float16& h, _Float16& l) {
   if (lp) { const unsigned short b = bf16_rne(v); h = __builtin_bit_cast(_Float16, b); l = (_Float16)0.f; return; }

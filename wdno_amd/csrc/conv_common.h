@@ -28,6 +28,7 @@ struct ConvP {
   // x are zero wherever d >= zb_d or h >= zb_h, so their stages with such a source plane / row for every pixel of a tile are not run
   // (0 blocks = off; stages whose source plane / row lies outside the grid for the whole tile are skipped for every block then, too)
   int zb_blocks, zb_d, zb_h;
+  int out_bf16;   // single-product mode: y is bf16 storage [rows][K] (round-to-nearest-even of the fp32 result; no residual, no split reduction)
 };
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -74,6 +75,16 @@ int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* 
 // asm-only wait it still counts the scalar loads of the previous tile's epilogue as possibly outstanding at the head of the
 // step loop, and (scalar loads return out of order) protects the first MFMA of every step with lgkmcnt(0) -- a wait for the
 // LDS reads issued just before it.
+// bf16 storage of two accumulator runs (channels 8 e + 4 hh .. + 3 and 8 (e + 1) + 4 hh .. + 3 of one pixel, the two lane halves hh = 0 / 1
+// holding the two halves of each group of eight): the halves trade runs (v_permlane32_swap), so that the lower half ends up with the eight
+// channels of group e and the upper half with those of group e + 1 -- ONE 16-byte store per lane instead of two 8-byte ones (with the
+// 8-byte stores the 256 x 128 single-plane kernel of the Burgers U-Net lost 2.7 %: 356 vs 366 us per launch).
+__device__ __forceinline__ uint4 bf16x8_from_runs(float4 va, float4 vb) {
+  const uint2 A = bf16x4_pack(va), B = bf16x4_pack(vb);
+  const auto sx = __builtin_amdgcn_permlane32_swap(A.x, B.x, false, false);
+  const auto sy = __builtin_amdgcn_permlane32_swap(A.y, B.y, false, false);
+  return make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
 __device__ __forceinline__ void lgkm0_barrier() {
   __builtin_amdgcn_s_waitcnt(0xc07f);
   asm volatile("s_barrier" : : : "memory");
@@ -87,6 +98,7 @@ static inline void fill_params(ConvP& p, const wdno_conv_geom* g) {
   p.split_ws = nullptr;
   p.split_ws_bytes = 0;
   p.zb_blocks = 0; p.zb_d = 0; p.zb_h = 0;
+  p.out_bf16 = 0;
   p.debug = wdno_debug_mode;
   p.R = g->kw * g->C;
   p.nchunk = cdiv(p.R, BK);

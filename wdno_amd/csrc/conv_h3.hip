@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256) void conv_fwd_h3_kernel(const _Float16* __rest
           }
           if (bias) v += bias[kc];
           if (res) v += res[yr * g.K + kc];
-          y[yr * g.K + kc] = v;
+          if (LP && p.out_bf16) reinterpret_cast<unsigned short*>(y)[yr * g.K + kc] = bf16_rne(v);
+          else y[yr * g.K + kc] = v;
           am = fmaxf(am, fabsf(v));
         }
       }
@@ -538,12 +539,14 @@ extern "C" int wdno_conv_fwd_f16x3(const void* xh, const void* xl, const float* 
 template <bool LP>
 static int conv_fwd_16(const void* xh, const void* xl, const float* sx, const void* wph, const void* wpl, const float* sw,
                        const float* bias, const float* residual, float* y, float* amax_rec, const wdno_conv_geom* g, wdno_stream_t s,
-                       float* split_ws = nullptr, size_t split_ws_bytes = 0, const wdno_zero_box* zb = nullptr) {
+                       float* split_ws = nullptr, size_t split_ws_bytes = 0, const wdno_zero_box* zb = nullptr, int y_bf16 = 0) {
   int rc = check_geom(g);
   if (rc) return rc;
   if (g->C & 7) return WDNO_EUNSUPPORTED;       // 16-bit rows must be 16-byte multiples
+  if (y_bf16 && (!LP || residual)) return WDNO_EUNSUPPORTED;      // bf16 output: single-product mode, no residual (its reader is a GroupNorm)
   ConvP p;
   fill_params(p, g);
+  p.out_bf16 = y_bf16 ? 1 : 0;
   if (zb) {                                     // a statement about x, used where a kernel can (conv_h3t.hip, 7-wide taps): whole 16-channel blocks
     if (zb->channels < 0 || zb->d0 < 0 || zb->h0 < 0 || zb->w0 < 0) return WDNO_EINVAL;
     p.zb_blocks = zb->channels / 16; p.zb_d = zb->d0; p.zb_h = zb->h0;
@@ -602,9 +605,11 @@ extern "C" int wdno_conv_fwd_f16x3_zbox(const void* xh, const void* xl, const fl
                                         const wdno_zero_box* zb, wdno_stream_t s) {
   return conv_fwd_16<false>(xh, xl, sx, wph, wpl, sw, bias, residual, y, amax_rec, g, s, nullptr, 0, zb);
 }
-extern "C" int wdno_conv_fwd_bf16_zbox(const void* x16, const void* wp16, const float* bias, const float* residual, float* y, float* amax_rec,
-                                       const wdno_conv_geom* g, const wdno_zero_box* zb, wdno_stream_t s) {
-  return conv_fwd_16<true>(x16, x16, nullptr, wp16, wp16, nullptr, bias, residual, y, amax_rec, g, s, nullptr, 0, zb);
+// single-product form with both options: zb (may be NULL) as above; y_bf16 != 0: y is bf16 storage [rows][K] -- the output of a convolution whose
+// only reader is a GroupNorm (and the data gradient whose only reader is a GroupNorm's backward): wdno_groupnorm_*_t take it as it is
+extern "C" int wdno_conv_fwd_bf16_ex(const void* x16, const void* wp16, const float* bias, const float* residual, void* y, int y_bf16, float* amax_rec,
+                                     const wdno_conv_geom* g, const wdno_zero_box* zb, wdno_stream_t s) {
+  return conv_fwd_16<true>(x16, x16, nullptr, wp16, wp16, nullptr, bias, residual, (float*)y, amax_rec, g, s, nullptr, 0, zb, y_bf16);
 }
 extern "C" size_t wdno_conv_fwd_split_ws_bytes(const wdno_conv_geom* g) {
   if (!g || check_geom(g) || (g->C & 7)) return 0;

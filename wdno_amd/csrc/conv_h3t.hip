@@ -490,6 +490,29 @@ __global__ __launch_bounds__(512) void conv_fwd_h3t_kernel(const _Float16* __res
       }
       float* yrow = y + yr * g.K;
       const float* rrow = res ? res + yr * g.K : nullptr;
+      if (LP && p.out_bf16) {                     // bf16 storage (no residual; K % 8 == 0): 16-byte stores of eight channels per lane
+        unsigned short* y16 = reinterpret_cast<unsigned short*>(y) + yr * g.K;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; e4 += 2) {
+            const int k0 = n0 + n_base + b * 32 + 8 * e4;          // first channel of group e4; group e4 + 1 starts at k0 + 8
+            if (k0 >= g.K) continue;
+            const int ka = k0 + 4 * hh, kb = ka + 8;
+            float4 va = make_float4(acc[a][b][4 * e4] * inv, acc[a][b][4 * e4 + 1] * inv, acc[a][b][4 * e4 + 2] * inv, acc[a][b][4 * e4 + 3] * inv);
+            float4 vb = make_float4(acc[a][b][4 * e4 + 4] * inv, acc[a][b][4 * e4 + 5] * inv, acc[a][b][4 * e4 + 6] * inv, acc[a][b][4 * e4 + 7] * inv);
+            if (bias) {
+              const float4 ta = *reinterpret_cast<const float4*>(bias + ka);
+              va.x += ta.x; va.y += ta.y; va.z += ta.z; va.w += ta.w;
+              if (k0 + 8 < g.K) { const float4 tb = *reinterpret_cast<const float4*>(bias + kb); vb.x += tb.x; vb.y += tb.y; vb.z += tb.z; vb.w += tb.w; }
+            }
+            const uint4 o = bf16x8_from_runs(va, vb);
+            if (k0 + 8 * hh < g.K) *reinterpret_cast<uint4*>(y16 + k0 + 8 * hh) = o;
+            am = amax4(amax4(am, va), vb);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
 #pragma unroll

@@ -7,9 +7,29 @@
 // Backward mirrors it: per-channel sums of dz and dz*xhat, a per-sample finalize producing the parameter
 // gradients and the two group means, then one elementwise pass for dx.
 #include "common.h"
+#include <type_traits>
 extern int wdno_debug_mode;      // 58 / 59: GroupNorm timing experiments -- the forward statistics pass / the backward reduction pass is launched TWICE (same results): the step-time difference is what the pass costs inside the step
 
 #define GN_MAXC 1024
+
+// Element type of an activation operand: float, or bf16 storage (single-product mode, WDNO_CONV_MATH=bf16: the convolution in front of a norm
+// writes its output -- and the data gradient that reaches a norm's backward -- as bf16, train_diffusion.py:61-62 mixed-precision semantics;
+// the arithmetic here stays fp32 / fp64). e = element offset of four / eight consecutive channels.
+struct gn_bf16 {};
+template <typename T> struct gn_ld;
+template <> struct gn_ld<float> {
+  static __device__ __forceinline__ float4 ld4(const void* p, int64_t e) { return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + e); }
+};
+template <> struct gn_ld<gn_bf16> {
+  static __device__ __forceinline__ float4 ld4(const void* p, int64_t e) {
+    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p) + e);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  }
+};
+template <typename T> __device__ __forceinline__ void gn_ld8(const void* p, int64_t e, float (&v)[8]) {
+  const float4 a = gn_ld<T>::ld4(p, e), b = gn_ld<T>::ld4(p, e + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 
 static inline int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static inline int gn_chunks(int64_t S, int64_t N, int C) {
@@ -30,8 +50,8 @@ static inline int gn_chunks(int64_t S, int64_t N, int C) {
 
 // ---------------------------------------------------------------------------------------------- per-channel partial sums
 // MODE 0: (sum x, sum x^2)         MODE 1: (sum dz, sum dz*xhat) with dz = dy * act'(a x + b)
-template <int MODE>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <int MODE, typename XT = float, typename DT = float>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                           const float* __restrict__ cb /*[N][C][4]*/, const float* __restrict__ gb /*[N][G][4]*/,
                                                           double* __restrict__ part, int64_t S, int C, int cg, int G, int txp,
                                                           int64_t rows_per_chunk, int silu, float* __restrict__ mx = nullptr) {
@@ -60,20 +80,22 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
         rstd[j] = gb[((int64_t)n * G + g) * 4 + 1];
       }
     }
-    const float* xp = x + ((int64_t)n * S) * C + tx * 4;
-    const float* dp = MODE == 1 ? dy + ((int64_t)n * S) * C + tx * 4 : nullptr;
-    // four rows per round, all loads requested before the first is used (one row at a time leaves ~4 MB in flight chip-wide)
-    for (int64_t rb = r0 + ty; rb < r1; rb += 4 * nty) {
-      float4 vv[4], dd[4];
+    const int64_t e0 = ((int64_t)n * S) * C + tx * 4;             // element offset of this thread's four channels in row 0 of the sample
+    // four rows per round (eight of bf16 storage: the same bytes in flight -- with four, the bf16 form of the backward reduction was SLOWER than
+    // the fp32 one, 105 vs 93 us per launch at Burgers batch 256), all loads requested before the first is used (one row at a time leaves
+    // ~4 MB in flight chip-wide)
+    constexpr int RIF = std::is_same<XT, gn_bf16>::value ? 8 : 4;
+    for (int64_t rb = r0 + ty; rb < r1; rb += RIF * nty) {
+      float4 vv[RIF], dd[RIF];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RIF; ++u) {
         const int64_t r = rb + u * nty;
         const bool ok = r < r1;
-        vv[u] = ok ? *reinterpret_cast<const float4*>(xp + r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 1) dd[u] = ok ? *reinterpret_cast<const float4*>(dp + r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[u] = ok ? gn_ld<XT>::ld4(x, e0 + r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1) dd[u] = ok ? gn_ld<DT>::ld4(dy, e0 + r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RIF; ++u) {
         if (rb + u * nty >= r1) break;
         const float4 v = vv[u];
         float xv[4] = {v.x, v.y, v.z, v.w};
@@ -246,19 +268,20 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ cb, float* __restrict__ y,
+template <typename XT = float>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, const float* __restrict__ cb, float* __restrict__ y,
                                                         int64_t S, int C, int silu, float* __restrict__ amax_rec) {
   const int n = blockIdx.y;
   const int C4 = C >> 2;
   const int64_t total4 = S * C4;
-  const float4* xp = reinterpret_cast<const float4*>(x + (int64_t)n * S * C);
+  const int64_t xe = (int64_t)n * S * C;
   float4* yp = reinterpret_cast<float4*>(y + (int64_t)n * S * C);
   const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
   const int64_t stride = (int64_t)gridDim.x * 256;
   float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += stride) {
     int c4 = (int)(i % C4);
-    float4 v = xp[i];
+    float4 v = gn_ld<XT>::ld4(x, xe + i * 4);
     float4 k0 = cbp[c4 * 4 + 0], k1 = cbp[c4 * 4 + 1], k2 = cbp[c4 * 4 + 2], k3 = cbp[c4 * 4 + 3];
     float4 o;
     o.x = k0.x * v.x + k0.y; o.y = k1.x * v.y + k1.y; o.z = k2.x * v.z + k2.y; o.w = k3.x * v.w + k3.y;
@@ -380,7 +403,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // y as (hi, lo) fp16 planes (scale from the bound gn_finalize_kernel left in `rec`): the output of a Block whose only reader is the
 // next convolution. A thread owns 8 channels.
 typedef _Float16 gn_half8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+template <typename XT = float>
+__global__ __launch_bounds__(256) void gn_apply_planes_kernel(const void* __restrict__ x, const float* __restrict__ cb,
                                                                _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                                float* __restrict__ scale_out, const float* __restrict__ rec,
                                                                int64_t S, int C, int silu) {
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __res
   const bool single = lo == nullptr;                 // one bf16 plane, no scale (WDNO_CONV_MATH=bf16)
   const float s = single ? 1.0f : scale_from_amax(amax_record_read(rec));
   if (!single && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
-  const float* xp = x + (int64_t)n * S * C;
+  const int64_t xe = (int64_t)n * S * C;
   _Float16* hp = hi + (int64_t)n * S * C;
   _Float16* lp = single ? nullptr : lo + (int64_t)n * S * C;
   const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
@@ -400,8 +424,8 @@ __global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < 8; ++j) { const float4 k = cbp[c0 + j]; ka[j] = k.x; kb[j] = k.y; }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += stride) {
-    const float4 v0 = *reinterpret_cast<const float4*>(xp + i * 8), v1 = *reinterpret_cast<const float4*>(xp + i * 8 + 4);
-    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float xv[8];
+    gn_ld8<XT>(x, xe + i * 8, xv);
     gn_half8 h, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -420,7 +444,8 @@ __global__ __launch_bounds__(256) void gn_apply_planes_kernel(const float* __res
 // (unet.py:167-176, conv3d.py:286-300). The sum is the next block's skip (fp32) and the operand of its first convolution (planes): this
 // replaces the apply pass, the add and the split (28 bytes per element over three launches) by one pass of 16. Scale from
 // max|a| max|x| + max|b| (gn_finalize_kernel, in `rec`) + max|res| (the amax record of res).
-__global__ __launch_bounds__(256) void gn_apply_add_planes_kernel(const float* __restrict__ x, const float* __restrict__ cb,
+template <typename XT = float>
+__global__ __launch_bounds__(256) void gn_apply_add_planes_kernel(const void* __restrict__ x, const float* __restrict__ cb,
                                                                    const float* __restrict__ res, float* __restrict__ y,
                                                                    _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                                    float* __restrict__ scale_out, const float* __restrict__ rec,
@@ -433,7 +458,7 @@ __global__ __launch_bounds__(256) void gn_apply_add_planes_kernel(const float* _
   const bool single = lo == nullptr;                 // one bf16 plane, no scale (WDNO_CONV_MATH=bf16)
   const float s = single ? 1.0f : scale_from_amax(amax_record_read(rec) + amax_record_read(rec_res));
   if (!single && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
-  const float* xp = x + (int64_t)n * S * C;
+  const int64_t xe = (int64_t)n * S * C;
   const float* rp = res + (int64_t)n * S * C;
   float* yp = y + (int64_t)n * S * C;
   _Float16* hp = planes ? hi + (int64_t)n * S * C : nullptr;
@@ -446,9 +471,10 @@ __global__ __launch_bounds__(256) void gn_apply_add_planes_kernel(const float* _
   for (int j = 0; j < 8; ++j) { const float4 k = cbp[c0 + j]; ka[j] = k.x; kb[j] = k.y; }
   float am = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += stride) {
-    const float4 v0 = *reinterpret_cast<const float4*>(xp + i * 8), v1 = *reinterpret_cast<const float4*>(xp + i * 8 + 4);
+    float xv[8];
+    gn_ld8<XT>(x, xe + i * 8, xv);
     const float4 r0 = *reinterpret_cast<const float4*>(rp + i * 8), r1 = *reinterpret_cast<const float4*>(rp + i * 8 + 4);
-    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const float rv[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     float ov[8];
     gn_half8 h, l;
 #pragma unroll
@@ -473,7 +499,8 @@ __global__ __launch_bounds__(256) void gn_apply_add_planes_kernel(const float* _
 // dx as (hi, lo) fp16 planes (scale from the bound gn_bwd_finalize_kernel left in `rec`) + per-block column sums of dx (the bias
 // gradient of the convolution in front of the norm). A thread owns 8 channels: 16-byte plane stores; its channel group is fixed
 // ((gridDim.x * 256) % (C / 8) == 0), so the column sums stay in registers until the block reduces them.
-__global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename XT = float, typename DT = float>
+__global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const void* __restrict__ x, const void* __restrict__ dy,
                                                                    const float* __restrict__ cb, const float* __restrict__ gb,
                                                                    _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                                    float* __restrict__ scale_out, const float* __restrict__ rec,
@@ -485,8 +512,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* _
   const bool single = lo == nullptr;                 // one bf16 plane, no scale (WDNO_CONV_MATH=bf16)
   const float s = single ? 1.0f : scale_from_amax(amax_record_read(rec));
   if (!single && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = s;
-  const float* xp = x + (int64_t)n * S * C;
-  const float* dp = dy + (int64_t)n * S * C;
+  const int64_t xe = (int64_t)n * S * C;
   _Float16* hp = hi + (int64_t)n * S * C;
   _Float16* lp = single ? nullptr : lo + (int64_t)n * S * C;
   const float4* cbp = reinterpret_cast<const float4*>(cb + (int64_t)n * C * 4);
@@ -498,9 +524,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_planes_kernel(const float* _
   for (int j = 0; j < 8; ++j) { kk[j] = cbp[c0 + j]; gq[j] = gbp[(c0 + j) / cg]; }
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += stride) {
-    const float4 v0 = *reinterpret_cast<const float4*>(xp + i * 8), v1 = *reinterpret_cast<const float4*>(xp + i * 8 + 4);
-    const float4 d0 = *reinterpret_cast<const float4*>(dp + i * 8), d1 = *reinterpret_cast<const float4*>(dp + i * 8 + 4);
-    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    float xv[8], dv[8];
+    gn_ld8<XT>(x, xe + i * 8, xv);
+    gn_ld8<DT>(dy, xe + i * 8, dv);
     gn_half8 h, l;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -547,7 +573,9 @@ static int gn_check(int64_t N, int64_t S, int C, int G) {
   if ((C & 3) || C > GN_MAXC || (C % G) != 0) return WDNO_EUNSUPPORTED;
   return WDNO_OK;
 }
-extern "C" int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+// x_bf16 / dy_bf16 (the _t entry points): the tensor is bf16 storage (gn_bf16); arithmetic and every other operand unchanged
+#define GN_PARTIAL0(XB, ...) do { if (XB) gn_partial_kernel<0, gn_bf16><<<__VA_ARGS__; else gn_partial_kernel<0, float><<<__VA_ARGS__; } while (0)
+extern "C" int wdno_groupnorm_act_fwd_amax_t(const void* x, int x_bf16, const float* gamma, const float* beta, const float* ss, float* y,
                                       float* stats, float* amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
                                       void* ws, size_t ws_bytes, wdno_stream_t s) {
   int rc = gn_check(N, S, C, G);
@@ -560,12 +588,19 @@ extern "C" int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, c
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_) gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_)
+    GN_PARTIAL0(x_bf16, dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0));
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps);
   int gx = stream_grid(S * (C / 4), 256);
   if (gx > 512) gx = 512;
-  gn_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, y, S, C, silu, amax_rec);
+  if (x_bf16) gn_apply_kernel<gn_bf16><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, y, S, C, silu, amax_rec);
+  else gn_apply_kernel<float><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, y, S, C, silu, amax_rec);
   return wdno_check_launch();
+}
+extern "C" int wdno_groupnorm_act_fwd_amax(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+                                      float* stats, float* amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                      void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_groupnorm_act_fwd_amax_t(x, 0, gamma, beta, ss, y, stats, amax_rec, N, S, C, G, eps, silu, ws, ws_bytes, s);
 }
 extern "C" int wdno_groupnorm_act_fwd(const float* x, const float* gamma, const float* beta, const float* ss, float* y,
                                       float* stats, int64_t N, int64_t S, int C, int G, float eps, int silu,
@@ -602,7 +637,7 @@ extern "C" int wdno_groupnorm_act_bwd(const float* x, const float* dy, const flo
 extern "C" size_t wdno_groupnorm_fwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
   return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S, N, C) * 2 * sizeof(float) + 128;
 }
-extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
+extern "C" int wdno_groupnorm_act_fwd_planes_t(const void* x, int x_bf16, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
                                              float* y_scale, float* stats, float* bound_rec, int64_t N, int64_t S, int C, int G, float eps,
                                              int silu, void* ws, size_t ws_bytes, wdno_stream_t s) {
   int rc = gn_check(N, S, C, G);
@@ -618,15 +653,22 @@ extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma,
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_) gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_)
+    GN_PARTIAL0(x_bf16, dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr));
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
-  gn_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, S, C, silu);
+  if (x_bf16) gn_apply_planes_kernel<gn_bf16><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, S, C, silu);
+  else gn_apply_planes_kernel<float><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, S, C, silu);
   return wdno_check_launch();
 }
+extern "C" int wdno_groupnorm_act_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, void* y_hi, void* y_lo,
+                                             float* y_scale, float* stats, float* bound_rec, int64_t N, int64_t S, int C, int G, float eps,
+                                             int silu, void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_groupnorm_act_fwd_planes_t(x, 0, gamma, beta, ss, y_hi, y_lo, y_scale, stats, bound_rec, N, S, C, G, eps, silu, ws, ws_bytes, s);
+}
 
-extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, const float* residual,
+extern "C" int wdno_groupnorm_act_add_fwd_planes_t(const void* x, int x_bf16, const float* gamma, const float* beta, const float* ss, const float* residual,
                                                  const float* res_rec, float* y, void* y_hi, void* y_lo, float* y_scale, float* stats,
                                                  float* bound_rec, float* y_amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
                                                  void* ws, size_t ws_bytes, wdno_stream_t s) {
@@ -644,13 +686,23 @@ extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* ga
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_) gn_partial_kernel<0><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr);
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_)
+    GN_PARTIAL0(x_bf16, dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr));
   gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
-  gn_apply_add_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, residual, y, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, res_rec,
-                                                                   y_amax_rec, S, C, silu);
+  if (x_bf16) gn_apply_add_planes_kernel<gn_bf16><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, residual, y, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec,
+                                                                                       res_rec, y_amax_rec, S, C, silu);
+  else gn_apply_add_planes_kernel<float><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, residual, y, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, res_rec,
+                                                                           y_amax_rec, S, C, silu);
   return wdno_check_launch();
+}
+extern "C" int wdno_groupnorm_act_add_fwd_planes(const float* x, const float* gamma, const float* beta, const float* ss, const float* residual,
+                                                 const float* res_rec, float* y, void* y_hi, void* y_lo, float* y_scale, float* stats,
+                                                 float* bound_rec, float* y_amax_rec, int64_t N, int64_t S, int C, int G, float eps, int silu,
+                                                 void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_groupnorm_act_add_fwd_planes_t(x, 0, gamma, beta, ss, residual, res_rec, y, y_hi, y_lo, y_scale, stats, bound_rec, y_amax_rec, N, S, C, G, eps, silu,
+                                             ws, ws_bytes, s);
 }
 
 __global__ __launch_bounds__(PRS_THREADS) void gn_bwd_tail_kernel(const double* __restrict__ csp, float* __restrict__ dx_colsum, int nb, int C, int nbx,
@@ -676,7 +728,7 @@ static inline int gn_planes_grid(int64_t N, int64_t S, int C) {
 extern "C" size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
   return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S, N, C) * 2 * sizeof(float) + (size_t)N * 128 * C * sizeof(double) + 64;
 }
-extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+extern "C" int wdno_groupnorm_act_bwd_planes_t(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* gamma, const float* beta, const float* ss,
                                              const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
                                              float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
                                              void* ws, size_t ws_bytes, wdno_stream_t s) {
@@ -695,16 +747,29 @@ extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, co
   const int txp = pow2ceil(C / 4);
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
-  for (int rep_ = 0; rep_ < (wdno_debug_mode == 59 ? 2 : 1); ++rep_) gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
+#define GN_BWD_TYPES(KERNEL, ...) do { \
+    if (x_bf16 && dy_bf16) KERNEL(gn_bf16, gn_bf16, __VA_ARGS__); else if (x_bf16) KERNEL(gn_bf16, float, __VA_ARGS__); \
+    else if (dy_bf16) KERNEL(float, gn_bf16, __VA_ARGS__); else KERNEL(float, float, __VA_ARGS__); } while (0)
+#define GN_K_PARTIAL1(XT, DT, ...) gn_partial_kernel<1, XT, DT><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(__VA_ARGS__)
+#define GN_K_BWD_APPLY(XT, DT, ...) gn_bwd_apply_planes_kernel<XT, DT><<<dim3(gx, (unsigned)N), 256, 0, st>>>(__VA_ARGS__)
+  for (int rep_ = 0; rep_ < (wdno_debug_mode == 59 ? 2 : 1); ++rep_)
+    GN_BWD_TYPES(GN_K_PARTIAL1, x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
   gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, dx_lo ? bound_rec : nullptr);
   const int gx = gn_planes_grid(N, S, C);
-  gn_bwd_apply_planes_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp,
-                                                                   S, C, C / G, G, silu);
+  GN_BWD_TYPES(GN_K_BWD_APPLY, x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp, S, C, C / G, G, silu);
   // one launch for both reductions that end the backward: the column sums of dx (partials of the apply pass) and, when dgb_sum is given, the
   // sum over the samples of the per-sample parameter-gradient pieces (was a colsum_rows launch of the caller: same fp64 sum in row order)
   const int nbx = cdiv(C, 32), nby = dgb_sum ? cdiv(2 * C, 32) : 0;
   gn_bwd_tail_kernel<<<nbx + nby, PRS_THREADS, 0, st>>>(csp, dx_colsum, (int)N * gx, C, nbx, dgb_partial, dgb_sum, (int)N);
   return wdno_check_launch();
+}
+
+extern "C" int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* gamma, const float* beta, const float* ss,
+                                             const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
+                                             float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
+                                             void* ws, size_t ws_bytes, wdno_stream_t s) {
+  return wdno_groupnorm_act_bwd_planes_t(x, 0, dy, 0, gamma, beta, ss, stats, dx_hi, dx_lo, dx_scale, dx_colsum, dgb_partial, dgb_sum, dss, bound_rec, N, S, C, G,
+                                         silu, ws, ws_bytes, s);
 }
 
 // ---------------------------------------------------------------------------------------------- channel LayerNorm

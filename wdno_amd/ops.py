@@ -91,6 +91,15 @@ def _chk(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _chk_act(t, name='tensor'):
+    """An activation that may be bf16 storage (single-product mode: the output of a convolution in front of a GroupNorm, ops.ACT16)."""
+    if t.dtype != torch.bfloat16:
+        return _chk(t, name)
+    if not t.is_cuda:
+        raise RuntimeError(f'wdno_amd: {name} must live on the GPU (no CPU fallback on the hot path)')
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -712,6 +721,8 @@ def split_weight(w, kind, cp8, kp, pack=None):
     return pl.hi, pl.lo, pl.sc
 
 
+ACT16 = os.environ.get('WDNO_ACT16', '0') == '1'      # (OFF: measured slower) single-product mode: a convolution whose only reader is a GroupNorm stores its output as bf16, and so does the data gradient
+                          # whose only reader is that norm's backward (accelerate mixed-precision semantics; test knob: fp32 storage as in round 4)
 ZERO_BOX = True           # structural-zero hints reach the kernels that can use them (test knob: results are bit-identical without)
 
 
@@ -739,7 +750,7 @@ def carry_zero_box(dst, src):
 
 
 def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp, out=None, osp=None, ostride=(1, 1, 1), ooff=(0, 0, 0),
-                amax_rec=None, zero_box=None):
+                amax_rec=None, zero_box=None, out16=False):
     """planes = (hi, lo, scale) of a CL tensor with logical shape4 = (N, D, H, W) and C8 channels; w raw weight;
     pack = pack_fwd / pack_dgrad. Returns y [N, OD, OH, OW, kp] fp32. With `out` ([N, YD, YH, YW, kp]) the osp output
     pixels are placed at ooff + ostride * index (parity classes of the transposed convolution)."""
@@ -749,8 +760,9 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
     wh, wl, sw = split_weight(w, kind, cp8, kp, pack)
     if osp is None:
         osp = tuple(_out_size(a, k, s_, p_) for a, k, s_, p_ in zip((d, h, ww), ks, st, pd))
+    out16 = bool(out16 and xl is None and out is None and residual is None)      # bf16 storage of y: single-product mode only
     if out is None:
-        y = torch.empty((n, *osp, kp), device=xh.device, dtype=torch.float32)
+        y = torch.empty((n, *osp, kp), device=xh.device, dtype=torch.bfloat16 if out16 else torch.float32)
         g = _geom((n, d, h, ww), cp8, kp, ks, st, pd, osp)
     else:
         y = out
@@ -763,9 +775,9 @@ def conv_fwd_h3(planes, shape4, w, pack, kind, bias_p, residual, ks, st, pd, kp,
         if zero_box is not None and tap and ks[2] == 7:      # the 7-wide stem skips the reduction stages that only see the caller's zeros (csrc/conv_h3t.hip)
             zb = _ZeroBox(*zero_box)
         if xl is None:       # single bf16 plane per operand
-            if zb is not None:
-                _lib.check(_lib_().wdno_conv_fwd_bf16_zbox(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), C.byref(zb), _stream()),
-                           'conv_fwd_bf16_zbox')
+            if zb is not None or out16:
+                _lib.check(_lib_().wdno_conv_fwd_bf16_ex(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), int(out16), _p(amax_rec), C.byref(g),
+                                                         None if zb is None else C.byref(zb), _stream()), 'conv_fwd_bf16_ex')
                 return y
             _lib.check(_lib_().wdno_conv_fwd_bf16(_p(xh), _p(wh), _p(bias_p), _p(residual), _p(y), _p(amax_rec), C.byref(g), _stream()), 'conv_fwd_bf16')
             return y
@@ -1046,8 +1058,9 @@ class _Conv(torch.autograd.Function):
     """y = conv(x, weight) + bias (+ residual). weight in the reference layout [K, C, (kd,) (kh, kw)] or [K, C]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, padding, with_skip=False, grad_planes=False):
+    def forward(ctx, x, weight, bias, residual, stride, padding, with_skip=False, grad_planes=False, to_norm=False):
         ctx.with_skip = with_skip
+        ctx.to_norm = to_norm and grad_planes          # the caller's statement: y goes to a GroupNorm and nowhere else
         y = _Conv._forward(ctx, x, weight, bias, residual, stride, padding)
         # grad_planes: the caller states that y goes to a GroupNorm and nowhere else; if this convolution's backward reads dy
         # only through the split kernels, the norm may deliver dy as planes (and leave the fp32 tensor unwritten)
@@ -1064,7 +1077,13 @@ class _Conv(torch.autograd.Function):
     def _forward(ctx, x, weight, bias, residual, stride, padding):
         xrec = _known_amax(x)
         x_in = x
-        x = _chk(x, 'x')
+        ctx.x16 = x.dtype == torch.bfloat16           # a GroupNorm's planes-only output in single-product mode: never read, its gradient is bf16 too
+        if ctx.x16:
+            if not (getattr(x, '_wdno_unwritten', False) and x.is_cuda):
+                raise RuntimeError('wdno_amd: a bf16 tensor that is not a planes-only placeholder reached a convolution')
+            x = x if x.is_contiguous() else x.contiguous()
+        else:
+            x = _chk(x, 'x')
         lead = None
         if x.dim() != 5:       # [P, C] rows (nn.Linear) or [N, H, W, C]
             lead = x.shape[:-1]
@@ -1108,8 +1127,14 @@ class _Conv(torch.autograd.Function):
             c8w = pad8(cp) + 8 if (ks[2] == 7 and kp <= 64 and tuple(stride) == (1, 1, 1) and pad8(cp) % 16) else None
             planes = split_f16_of(x_in, x5.reshape(-1, cp), xrec, c8w)
             yrec = _new_amax_record(x5.device)
+            # bf16 storage of y (single-product mode): its only reader is a GroupNorm whose backward will hand dy over as planes (the same test as
+            # in forward() below for _wdno_grad_planes, plus the norm's own channel conditions), so no fp32 gradient of y ever has to exist
+            nx_, dx_, hx_, wx_ = x5.shape[:4]
+            out16 = (ACT16 and _lp() and getattr(ctx, 'to_norm', False) and GRAD_PLANES and residual is None and x.dim() in (4, 5) and kp % 8 == 0
+                     and kp // 8 <= 256 and (kp // 8) & (kp // 8 - 1) == 0
+                     and (not ctx.needs_input_grad[0] or (tuple(stride) == (1, 1, 1) and _use_h3(nx_ * dx_ * hx_ * wx_, kp * ks[0] * ks[1] * ks[2]))))
             y = _leave_amax(conv_fwd_h3(planes, tuple(x5.shape[:4]), weight, pack_fwd, 'f', bias_p, res5, ks, stride, padding, kp,
-                                        amax_rec=yrec, zero_box=zero_box_of(x_in) if x_in.dim() == 5 else None), yrec)
+                                        amax_rec=yrec, zero_box=zero_box_of(x_in) if x_in.dim() == 5 else None, out16=out16), yrec)
             ctx.save_for_backward(planes[0], planes[1], planes[2], weight)     # the split planes replace x for wgrad
         else:
             y = conv_fwd_raw(x5, pack_fwd(weight, cp, kp), bias_p, res5, ks, stride, padding, kp)
@@ -1124,8 +1149,8 @@ class _Conv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gskip=None):
         if ctx.rows:
-            return _linear_rows_backward(ctx, gy) + (None, None)
-        return _Conv._backward(ctx, gy, gskip) + (None, None)
+            return _linear_rows_backward(ctx, gy) + (None, None, None)
+        return _Conv._backward(ctx, gy, gskip) + (None, None, None)
 
     @staticmethod
     def _backward(ctx, gy, gskip):
@@ -1137,7 +1162,10 @@ class _Conv(torch.autograd.Function):
         ks, stride, padding, k, c, cp, kp, has_bias, has_res, lead, xdim = ctx.meta
         grec = _known_amax(gy)
         po = getattr(gy, '_wdno_planes_only', None)        # GroupNorm backward delivered dy as planes + column sums; gy itself is unwritten
-        gy = _chk(gy, 'grad')
+        if po is not None and gy.dtype == torch.bfloat16:   # (the unwritten placeholder of a bf16-stored output)
+            gy = gy if gy.is_contiguous() else gy.contiguous()
+        else:
+            gy = _chk(gy, 'grad')
         n, d, h, w, _ = ctx.xshape
         gyplanes = None
         gb_given = None
@@ -1169,7 +1197,7 @@ class _Conv(torch.autograd.Function):
                         gyplanes = split_f16(gy5.reshape(-1, kp), grec)
                     drec = _new_amax_record(gy5.device)       # dx is often the dy of the next convolution (projections on a residual path)
                     gx5 = _leave_amax(conv_fwd_h3(gyplanes, tuple(gy5.shape[:4]), weight, lambda w_, c8_, k_: pack_dgrad(w_, k_, c8_), 'd', None, gs5,
-                                                  ks, (1, 1, 1), pd, cp, amax_rec=drec), drec)
+                                                  ks, (1, 1, 1), pd, cp, amax_rec=drec, out16=getattr(ctx, 'x16', False) and gs5 is None), drec)
                 else:
                     wd = pack_dgrad(weight, cp, kp)
                     gx5 = conv_fwd_raw(gy5, wd, None, gs5, ks, (1, 1, 1), pd, cp)
@@ -1199,6 +1227,8 @@ class _Conv(torch.autograd.Function):
                 raise RuntimeError(f'wdno_amd: unsupported convolution geometry for dgrad {ks} {stride} {padding}')
             if gs5 is not None:
                 gx5 = gx5 + gs5
+            if getattr(ctx, 'x16', False) and gx5.dtype != torch.bfloat16:
+                gx5 = gx5.to(torch.bfloat16)         # (a bf16 placeholder input whose gradient could not be written as bf16 by the kernel itself)
             gx = gx5
             if lead is not None:
                 gx = gx5.reshape(*lead, cp) if xdim != 4 else gx5.squeeze(1)
@@ -1244,7 +1274,7 @@ def _patch2_dgrad(gy5, weight, cp, kp, gyplanes=None, amax_rec=None):
     return gx
 
 
-def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None, with_skip=False, grad_planes=False):
+def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None, with_skip=False, grad_planes=False, to_norm=False):
     """Channels-last convolution / linear layer with the reference's weight layout.
 
     x: [N, D, H, W, Cp] or [N, H, W, Cp] with a conv weight [K, C, (kd,) kh, kw]; any [..., Cp] with a 2-D
@@ -1256,14 +1286,14 @@ def conv_cl(x, weight, bias=None, stride=1, padding=0, residual=None, with_skip=
             return (fill,) * 3
         v = (v,) * nd if isinstance(v, int) else tuple(v)
         return (fill,) * (3 - nd) + v
-    return _Conv.apply(x, weight, bias, residual, trip(stride, 1), trip(padding, 0) if nd else (0, 0, 0), with_skip, grad_planes)
+    return _Conv.apply(x, weight, bias, residual, trip(stride, 1), trip(padding, 0) if nd else (0, 0, 0), with_skip, grad_planes, to_norm)
 
 
-def conv_cl_skip(x, weight, bias=None, stride=1, padding=0, grad_planes=False):
+def conv_cl_skip(x, weight, bias=None, stride=1, padding=0, grad_planes=False, to_norm=False):
     """-> (conv(x), x'): x' is x handed through the operator, for blocks whose input also feeds a skip connection
     (ResnetBlock: h = block1(x) ...; out = h + x  or  res_conv(x) + h). The gradient that comes back over x' is added in the
     epilogue of this convolution's data-gradient kernel instead of by a separate accumulation launch."""
-    return conv_cl(x, weight, bias, stride, padding, None, True, grad_planes)
+    return conv_cl(x, weight, bias, stride, padding, None, True, grad_planes, to_norm)
 
 
 class _ConvT(torch.autograd.Function):
@@ -1445,13 +1475,13 @@ class _GroupNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, ss, groups, act_silu, eps, out_planes=False):
         x_in = x
-        x = _chk(x, 'x')
+        x = _chk_act(x, 'x')
+        x16 = int(x.dtype == torch.bfloat16)
         n, c = x.shape[0], x.shape[-1]
         s = x.numel() // (n * c)
         lib = _lib_()
         nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
-        y = torch.empty_like(x)
         stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
         ctx.ss_slot = _claim_grad_slot(ss) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
@@ -1465,16 +1495,20 @@ class _GroupNormAct(torch.autograd.Function):
                 lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
                 brec = _amax_slot(x.device)
                 scale = brec[1:2]
-            _lib.check(lib.wdno_groupnorm_act_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(hi), _p(lo), _p(scale), _p(stats), _p(brec),
-                                                         n, s, c, groups, float(eps), int(act_silu), _p(wsp), nbp, _stream()), 'groupnorm_fwd_planes')
+            _lib.check(lib.wdno_groupnorm_act_fwd_planes_t(_p(x), x16, _p(gamma), _p(beta), _p(ssc), _p(hi), _p(lo), _p(scale), _p(stats), _p(brec),
+                                                           n, s, c, groups, float(eps), int(act_silu), _p(wsp), nbp, _stream()), 'groupnorm_fwd_planes')
             ctx.save_for_backward(x, gamma, beta, ssc, stats)
             ctx.meta = (n, s, c, groups, int(act_silu))
             ctx.epoch = _param_epoch(gamma)
             ctx.grad_planes = GRAD_PLANES and getattr(x_in, '_wdno_grad_planes', False)
+            # the placeholder of the planes-only output (never written). In single-product mode it is bf16-typed: the gradient the reading
+            # convolution returns for it -- read by this norm's backward and by nothing else -- is then stored as bf16 as well
+            y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16 if (x16 or (ACT16 and _lp())) else torch.float32)
             return _planes_only(y, (hi, lo, scale))
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
         rec = _new_amax_record(x.device)
-        _lib.check(lib.wdno_groupnorm_act_fwd_amax(_p(x), _p(gamma), _p(beta), _p(ssc), _p(y), _p(stats), _p(rec), n, s, c, groups,
-                                                   float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
+        _lib.check(lib.wdno_groupnorm_act_fwd_amax_t(_p(x), x16, _p(gamma), _p(beta), _p(ssc), _p(y), _p(stats), _p(rec), n, s, c, groups,
+                                                     float(eps), int(act_silu), _p(ws), nb, _stream()), 'groupnorm_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)
         ctx.meta = (n, s, c, groups, int(act_silu))
         ctx.epoch = _param_epoch(gamma)
@@ -1494,7 +1528,8 @@ class _GroupNormAct(torch.autograd.Function):
         # parked means are not safe under two concurrent backward passes of the same graph on different streams.)
         if getattr(ctx, 'epoch', None) not in (None, _param_epoch(gamma)):
             raise RuntimeError('wdno_amd GroupNorm backward: the parameters were updated (optimiser step / checkpoint load) between this forward and its backward')
-        gy = _chk(gy, 'grad')
+        gy = _chk_act(gy, 'grad')
+        x16, dy16 = int(x.dtype == torch.bfloat16), int(gy.dtype == torch.bfloat16)
         lib = _lib_()
         dgb = torch.empty((n, 2, c), device=x.device, dtype=torch.float32)
         dss = None if ss is None else (ctx.ss_slot if getattr(ctx, 'ss_slot', None) is not None else torch.empty_like(ss))
@@ -1509,14 +1544,17 @@ class _GroupNormAct(torch.autograd.Function):
                 rec = _amax_slot(x.device)
                 scale = rec[1:2]
             red = torch.empty((2 * c,), device=x.device, dtype=torch.float32) if n > 1 else None      # sum over the samples, from the same launch
-            _lib.check(lib.wdno_groupnorm_act_bwd_planes(_p(x), _p(gy), _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), _p(cs),
-                                                         _p(dgb), _p(red), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
+            _lib.check(lib.wdno_groupnorm_act_bwd_planes_t(_p(x), x16, _p(gy), dy16, _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), _p(cs),
+                                                           _p(dgb), _p(red), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
                        'groupnorm_bwd_planes')
             dx = _poison(torch.empty_like(x))     # never written: the convolution reads the planes (and fails loudly if it cannot)
             dx._wdno_planes_only = ((hi, lo, scale), cs, dx._version, CONV_MATH)
             if red is None:
                 red = dgb.reshape(2 * c)
             return dx, red[:c].contiguous(), red[c:].contiguous(), dss, None, None, None, None
+        if x16 or dy16:
+            raise RuntimeError('wdno_amd GroupNorm backward: bf16-stored activations reach the norm only together with the planes hand-over of dx '
+                               '(ops.GRAD_PLANES / CONV_MATH changed between forward and backward?)')
         nb = lib.wdno_groupnorm_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
         dx = torch.empty_like(x)
@@ -1532,19 +1570,20 @@ class _GroupNormActAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, ss, residual, groups, act_silu, eps):
         x_in = x
-        x = _chk(x, 'x')
+        x = _chk_act(x, 'x')
+        x16 = int(x.dtype == torch.bfloat16)
         res = _chk(residual, 'residual')
         n, c = x.shape[0], x.shape[-1]
         s = x.numel() // (n * c)
         lib = _lib_()
         nb = lib.wdno_groupnorm_fwd_planes_ws_bytes(n, s, c, groups)
         ws = _ws(nb, x.device)
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
         stats = torch.empty((lib.wdno_groupnorm_stats_floats(n, c, groups),), device=x.device, dtype=torch.float32)      # (mean, rstd) + the affine tables the backward reads
         ssc = None if ss is None else _chk(ss, 'scale_shift')
         ctx.ss_slot = _claim_grad_slot(ss) if ssc is ss else None      # (ops.linear_multi: d(scale_shift) goes straight into its buffer)
         yrec = _new_amax_record(x.device)
-        _lib.check(lib.wdno_groupnorm_act_add_fwd_planes(_p(x), _p(gamma), _p(beta), _p(ssc), _p(res), None, _p(y), None, None, None, _p(stats),
+        _lib.check(lib.wdno_groupnorm_act_add_fwd_planes_t(_p(x), x16, _p(gamma), _p(beta), _p(ssc), _p(res), None, _p(y), None, None, None, _p(stats),
                                                          None, _p(yrec), n, s, c, groups, float(eps), int(act_silu), _p(ws), nb, _stream()),
                    'groupnorm_add_fwd')
         ctx.save_for_backward(x, gamma, beta, ssc, stats)

@@ -130,9 +130,9 @@ class Block(nn.Module):
 
     def forward(self, x, scale_shift=None, with_skip=False, out_planes=False, residual=None):
         if with_skip:              # block input that also feeds the skip connection: handed through the convolution (ops.conv_cl_skip)
-            x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)
+            x, xs = ops.conv_cl_skip(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True, to_norm=True)
             return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes), xs
-        x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True)     # x goes to the norm and nowhere else
+        x = ops.conv_cl(x, self.proj.weight, self.proj.bias, padding=1, grad_planes=True, to_norm=True)     # x goes to the norm and nowhere else
         if residual is not None:   # identity skip of the ResnetBlock: added in the norm's apply pass
             return ops.groupnorm_act_add(x, self.norm.weight, self.norm.bias, self.groups, residual, scale_shift, act=True, eps=self.norm.eps)
         return ops.groupnorm_act(x, self.norm.weight, self.norm.bias, self.groups, scale_shift, act=True, eps=self.norm.eps, out_planes=out_planes)
