@@ -125,8 +125,10 @@ def test_bf16_transposed_conv(ops):
     assert torch.isfinite(wd.grad).all()
 
 
-def test_bf16_burgers_train_step_vs_autocast_arbiter(ops):
-    """Full-width Unet2D(dim=128) training step [4, 9, 64, 64] on the single-product bf16 path (BASELINE configs[1]). The reference's
+@pytest.mark.parametrize('batch', [4, 32])
+def test_bf16_burgers_train_step_vs_autocast_arbiter(ops, batch):
+    """Full-width Unet2D(dim=128) training step [B, 9, 64, 64] on the single-product bf16 path (BASELINE configs[1]); B = 32 is the smallest batch
+    at which the level-0 layers take the 256 x 128 single-plane tiles that carry configs[1]'s batch of 256 (asserted). The reference's
     semantics for that configuration are accelerate's mixed precision (train_diffusion.py:62, 71-74): fp32 master weights, the forward under
     torch.autocast(bfloat16). Three evaluations of the same step on the same weights and inputs: HIP bf16, the oracle under CPU
     autocast(bfloat16) (= what the reference computes), the oracle in fp64 (the arbiter). Gate: the HIP path is no further from exact than
@@ -142,10 +144,12 @@ def test_bf16_burgers_train_step_vs_autocast_arbiter(ops):
     torch.manual_seed(1)
     net = Unet2D(dim=128, dim_mults=(1, 2, 4, 8), channels=9, resnet_block_groups=1)
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    import os
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     gen = torch.Generator().manual_seed(6)
-    x0 = torch.randn(4, 9, 64, 64, generator=gen) * 0.5
-    noise = torch.randn(4, 9, 64, 64, generator=gen)
-    t = torch.tensor([77, 805, 310, 999])
+    x0 = torch.randn(batch, 9, 64, 64, generator=gen) * 0.5
+    noise = torch.randn(batch, 9, 64, 64, generator=gen)
+    t = torch.tensor(([77, 805, 310, 999] * 8)[:batch])
     lw = torch.ones(1, 9, 1, 1)
 
     def oracle(dt, autocast):
@@ -167,6 +171,7 @@ def test_bf16_burgers_train_step_vs_autocast_arbiter(ops):
     torch.cuda.synchronize()
     used, ops.PROFILE = set(ops.PROFILE), None
     assert any('h3d' in k or 'h3t' in k for k in used)
+    assert ('conv_fwd_h3t_kernel<256,128>' in used) == (batch >= 32), used
     names = [k for k, _ in net.named_parameters()]
     e_h = sorted(rel_l2(p.grad, g_e[k]) for k, p in net.named_parameters())
     e_a = sorted(rel_l2(g_a[k], g_e[k]) for k in names)
