@@ -1124,7 +1124,10 @@ extern "C" int wdno_attn_bwd_planes(const float* qkv, const float* rot_cos, cons
 static int attn_bwd_rows(const float* qkv, const float* rot_cos, const float* rot_sin, const float* bias, const float* out,
                          const float* dout, float* dqkv, float* dbias, AttnP& p, const wdno_attn_desc* d, wdno_stream_t s) {
   const int n = d->n_tok;
-  if (n > ATT_BWD_THREADS) {                               // 129 .. 576 tokens: nothing n x n is stored (attn_bwd_big_kernel)
+  // 129 .. 576 tokens: nothing n x n is stored (attn_bwd_big_kernel) -- and 64 .. 128 tokens too when the kernel takes the case (no rotation, no bias):
+  // the thread-per-row kernel keeps P and dS (2 n^2 floats: 81 KB at the mid block's 100 tokens) in LDS, one block per CU; 27 KB and five blocks per CU
+  // here: 305 -> 246 us for the mid spatial attention of the smoke U-Net (debug 61: the old routing)
+  if (n > ATT_BWD_THREADS || (wdno_debug_mode != 61 && n >= 64 && !rot_cos && !bias && !dbias)) {
     if (n > ATT_BIG_MAXTOK || rot_cos || bias || dbias) return WDNO_EUNSUPPORTED;
     const size_t lds = ((size_t)2 * n * DH + 3 * n) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_bwd_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
