@@ -129,7 +129,10 @@ int wdno_split_f16_colsum(const float* x, const float* amax_rec, void* hi, void*
  * [kd][kh][A>=K][kw][B>=C]; mode 1: data-gradient operand [kd][kh][A>=C][kw][B>=K] with flipped taps. amax = max|w| (device).
  * modes 2 + 2 py + px: forward operand of parity class (py, px) of the (1,4,4) / stride (1,2,2) transposed convolution (the stride-1
  * (1,2,2) convolution that produces the output pixels of that parity; Upsample of video_diffusion_pytorch_conv3d.py:96-98), gathered
- * from the ConvTranspose3d weight w[C = in][K = out][1][4][4] itself; kd, kh, kw = 1, 2, 2. */
+ * from the ConvTranspose3d weight w[C = in][K = out][1][4][4] itself; kd, kh, kw = 1, 2, 2.
+ * modes 10 / 11: the forward operand of a 1 x 1 projection -- to_qkv [A = 384][B = C] / to_out [A = C][B = 128] of a temporal attention block with
+ * 4 heads of 32 -- in the FRAGMENT ORDER wdno_tattn_fused_fwd reads at C = 128 / 256 (csrc/attn_fused_wide.hip streams its weights: the 64 lanes of
+ * one matrix-operand load then read 1 KB of contiguous memory). Same bytes as mode 0, 16-byte groups permuted (csrc/conv_h3.hip: pack_split_body). */
 int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh, int kw,
                            int A, int B, int mode, wdno_stream_t s);
 /* Multi-tensor forms of wdno_amax and wdno_pack_split_weight for the per-step refresh of all weights: one launch for any
@@ -358,8 +361,9 @@ int wdno_linattn_fwd_planes(const float* qkv, void* out_hi, void* out_lo, float*
  *   amax_rec: optional amax record of y; qkv_out: optional [rows][3*heads*32] raw projections for a backward pass that wants them;
  *   rec_v: optional zeroed amax record that receives max|v| (wdno_tattn_fused_bwd: the plane scale of the attention output).
  * wdno_tattn_fused_takes: 1 for the shapes the kernels are built for (C = 64, 4 heads, 24 frames -- the base-resolution model -- or 48 --
- * the super-resolution model of inference_2d.py; 48 frames forward only: qkv_out must be NULL and wdno_tattn_fused_bwd refuses them), else 0
- * (callers then run the block layer by layer). */
+ * the super-resolution model of inference_2d.py; 48 frames forward only: qkv_out must be NULL and wdno_tattn_fused_bwd refuses them; C = 128 /
+ * 256 with 24 frames -- the deeper levels, csrc/attn_fused_wide.hip -- forward only, qkv_out must be NULL, rec_v is left untouched, and
+ * wq_* / wo_* are the operands of pack modes 10 / 11), else 0 (callers then run the block layer by layer). */
 int wdno_tattn_fused_takes(int C, int n_tok, int heads);
 int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                          const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,

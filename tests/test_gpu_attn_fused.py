@@ -24,11 +24,11 @@ def mods():
     return ops, V
 
 
-def _block(V, seed):
+def _block(V, seed, dim=64):
     torch.manual_seed(seed)
     rot = V.RotaryEmbedding(32)
-    att = V.EinopsToAndFrom('b c f h w', 'b (h w) f c', V.Attention(64, heads=4, dim_head=32, rotary_emb=rot))
-    blk = V.Residual(V.PreNorm(64, att))
+    att = V.EinopsToAndFrom('b c f h w', 'b (h w) f c', V.Attention(dim, heads=4, dim_head=32, rotary_emb=rot))
+    blk = V.Residual(V.PreNorm(dim, att))
     with torch.no_grad():
         blk.fn.norm.gamma.add_(0.3 * torch.randn_like(blk.fn.norm.gamma))
         att.fn.to_qkv.weight.mul_(2.0)
@@ -77,6 +77,50 @@ def test_fused_block_vs_oracle_and_layers(mods, b, h, w):
     assert e_f < 1e-6 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
     # the attention branch alone (y - x), where the residual does not mask the error
     assert rel_l2(y.cpu().double() - x.double(), exact - x.double()) < 5e-6
+
+
+@pytest.mark.parametrize('c,b,h,w', [(128, 1, 8, 8), (128, 3, 7, 11), (128, 8, 20, 20), (256, 1, 8, 8), (256, 2, 9, 5), (256, 8, 10, 10)])
+def test_wide_block_forward(mods, c, b, h, w):
+    """csrc/attn_fused_wide.hip: the block of the 128- / 256-channel levels (weights streamed from L2), forward only: against the fp64 oracle
+    and the layer-by-layer HIP path; with and without rotary / bias; bit-reproducible; not taken when a gradient is needed."""
+    ops, V = mods
+    blk, att, rpb = _block(V, 11, dim=c)
+    x = torch.randn(b, 24, h, w, c) * 1.5 + 0.2
+    exact = _oracle(blk, att, rpb, x, torch.float64)
+    ref32 = _oracle(blk, att, rpb, x, torch.float32)
+    blk, rpb = blk.to(DEV), rpb.to(DEV)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        bias = rpb(24, device=DEV)
+        assert ops.tattn_fused_takes(xd, 4, (blk.fn.norm.gamma,))
+        ops.PROFILE = {}
+        y = blk(xd, pos_bias=bias)
+        used = set(ops.PROFILE)
+        ops.PROFILE = None
+        assert 'tattn_fused_fwd_kernel' in used and not any('conv' in k for k in used), used
+        assert ops._known_amax(y) is not None and abs(ops._known_amax(y).max().item() - y.abs().max().item()) == 0.0
+        assert torch.equal(y, blk(xd, pos_bias=bias))
+        ops.FUSED_TATTN_WIDE = False
+        try:
+            assert not ops.tattn_fused_takes(xd, 4, (blk.fn.norm.gamma,))
+            y_layers = blk(xd, pos_bias=bias)
+        finally:
+            ops.FUSED_TATTN_WIDE = True
+        y_plain = ops.temporal_attention_fused(xd, blk.fn.norm.gamma, blk.fn.norm.eps, att.to_qkv.weight, att.to_out.weight, None, None, 4, att.scale)
+    e_f, e_l, e_r = rel_l2(y, exact), rel_l2(y_layers, exact), rel_l2(ref32, exact)
+    print(f'wide block [{b},24,{h},{w},{c}]: fused vs exact {e_f:.2e}, layer by layer vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}, fused vs layers {rel_l2(y, y_layers):.2e}')
+    assert e_f < 1e-6 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    assert rel_l2(y.cpu().double() - x.double(), exact - x.double()) < 5e-6
+    from oracle import unet_ref as U
+    xe = x.double().permute(0, 4, 1, 2, 3)
+    yn = U.channel_layernorm(xe, blk.fn.norm.gamma.detach().double().cpu())
+    bb, cc, f, hh, ww = yn.shape
+    yn = yn.permute(0, 3, 4, 2, 1).reshape(bb, hh * ww, f, cc)
+    yn = U.token_attention(yn, att.to_qkv.weight.detach().double().cpu(), att.to_out.weight.detach().double().cpu(), 4, 32)
+    plain = (yn.reshape(bb, hh, ww, f, cc).permute(0, 4, 3, 1, 2) + xe).permute(0, 2, 3, 4, 1)
+    assert rel_l2(y_plain, plain) < 1e-6
+    xg = xd.clone().requires_grad_(True)
+    assert not ops.tattn_fused_takes(xg, 4, (blk.fn.norm.gamma,))          # a gradient: layer by layer
 
 
 @pytest.mark.parametrize('b,h,w', [(1, 8, 8), (2, 7, 11), (2, 40, 20)])
@@ -142,8 +186,9 @@ def test_fused_block_without_rotary_and_bias(mods):
 
 
 def test_unet_forward_uses_the_fused_block_when_sampling(mods):
-    """The whole denoiser under no_grad (sampling): the three level-0 temporal attentions run fused; result vs the oracle and vs the
-    layer-by-layer path. With gradients enabled the block is NOT fused (the training step keeps its layer-by-layer backward)."""
+    """The whole denoiser under no_grad (sampling): the four 64-channel temporal attentions run on csrc/attn_fused.hip and the 128-channel
+    one of the second level on csrc/attn_fused_wide.hip (the 4 x 4 levels of this small input have too few sequences); result vs the oracle
+    and vs the layer-by-layer path. With gradients the 64-channel blocks stay fused (one backward launch), the wide ones run layer by layer."""
     ops, V = mods
     from oracle import unet_ref as U
     torch.manual_seed(2)
@@ -154,25 +199,31 @@ def test_unet_forward_uses_the_fused_block_when_sampling(mods):
         ref = U.unet3d_forward(sd, x, t, dim=64, dim_mults=(1, 2, 4), groups=8)
         ref64 = U.unet3d_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double(), t, dim=64, dim_mults=(1, 2, 4), groups=8)
     net = net.to(DEV)
-    with torch.no_grad():
-        ops.PROFILE = {}
-        out = net(x.to(DEV), t.to(DEV))
-        n_fused = len(ops.PROFILE.get('tattn_fused_fwd_kernel', []))
-        ops.PROFILE = None
-        ops.FUSED_TATTN = False
-        try:
+    try:
+        with torch.no_grad():
+            ops.PROFILE = {}
+            out = net(x.to(DEV), t.to(DEV))
+            n_fused = len(ops.PROFILE.get('tattn_fused_fwd_kernel', []))
+            ops.PROFILE = None
+            ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = False      # the blocks a pass with gradients can fuse
+            ops.PROFILE = {}
+            out_narrow = net(x.to(DEV), t.to(DEV))
+            n_narrow = len(ops.PROFILE.get('tattn_fused_fwd_kernel', []))
+            ops.PROFILE = None
+            ops.FUSED_TATTN = False
             out_layers = net(x.to(DEV), t.to(DEV))
-        finally:
-            ops.FUSED_TATTN = True
-    assert n_fused == 4, n_fused          # init, downs[0], ups[2] at 40 x 40 and ups[1] (64 channels at the second level)
-    e_f, e_l, e_r = rel_l2(out, ref64), rel_l2(out_layers, ref64), rel_l2(ref, ref64)
-    print(f'U-Net forward: fused vs exact {e_f:.2e}, layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
-    assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    finally:
+        ops.FUSED_TATTN = ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = True
+    assert n_fused == 5, n_fused          # init, downs[0], ups[2] at 16 x 16, ups[1] (64 channels at the second level) + downs[1] (128 channels, 8 x 8)
+    assert n_narrow == 4, n_narrow
+    e_f, e_n, e_l, e_r = rel_l2(out, ref64), rel_l2(out_narrow, ref64), rel_l2(out_layers, ref64), rel_l2(ref, ref64)
+    print(f'U-Net forward: fused vs exact {e_f:.2e} (64-channel blocks only {e_n:.2e}), layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
+    assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7 and e_n <= 1.5 * max(e_l, e_r) + 1e-7
     ops.PROFILE = {}
-    out_g = net(x.to(DEV), t.to(DEV))               # parameters require gradients here: still fused (the backward is one launch too)
+    out_g = net(x.to(DEV), t.to(DEV))               # parameters require gradients here: the 64-channel blocks still fused (the backward is one launch too)
     assert len(ops.PROFILE.get('tattn_fused_fwd_kernel', [])) == 4
     ops.PROFILE = None
-    assert torch.equal(out_g.detach(), out)
+    assert torch.equal(out_g.detach(), out_narrow)
     ops.FUSED_TATTN_BWD = False
     try:
         ops.PROFILE = {}
@@ -202,11 +253,11 @@ def test_unet_forward_with_48_frames_when_sampling(mods):
         out = net(x.to(DEV), t.to(DEV))
         n_fused = len(ops.PROFILE.get('tattn_fused_fwd_kernel', []))
         ops.PROFILE = None
-        ops.FUSED_TATTN = False
+        ops.FUSED_TATTN = ops.FUSED_LATTN_WIDE = False        # (the wide linear-attention blocks too: a pass with gradients cannot take them)
         try:
             out_layers = net(x.to(DEV), t.to(DEV))
         finally:
-            ops.FUSED_TATTN = True
+            ops.FUSED_TATTN = ops.FUSED_LATTN_WIDE = True
     assert n_fused == 4, n_fused
     e_f, e_l, e_r = rel_l2(out, ref64), rel_l2(out_layers, ref64), rel_l2(ref, ref64)
     print(f'U-Net forward, 48 frames: fused vs exact {e_f:.2e}, layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')

@@ -74,9 +74,55 @@ def test_fused_linear_attention_block_vs_oracle_and_layers(mods, b, f, h, w):
     assert b_f < 5e-6 and b_f <= 1.5 * b_l + 5e-7
 
 
+def _block_c(V, seed, c):
+    torch.manual_seed(seed)
+    blk = V.Residual(V.PreNorm(c, V.SpatialLinearAttention(c, heads=4)))
+    with torch.no_grad():
+        blk.fn.norm.gamma.add_(0.3 * torch.randn_like(blk.fn.norm.gamma))
+        blk.fn.fn.to_qkv.weight.mul_(3.0)
+    return blk
+
+
+@pytest.mark.parametrize('c,b,f,h,w', [(128, 1, 2, 8, 8), (128, 2, 3, 7, 11), (128, 2, 24, 20, 20), (256, 1, 3, 6, 6), (256, 2, 5, 9, 5), (256, 2, 24, 10, 10)])
+def test_wide_linear_attention_block_forward(mods, c, b, f, h, w):
+    """csrc/linattn_fused_wide.hip: the block of the 128- / 256-channel levels (weights streamed in fragment order), forward only: against
+    the fp64 oracle and the layer-by-layer HIP path; bit-reproducible; not taken when a gradient is needed."""
+    ops, V = mods
+    blk = _block_c(V, 13, c)
+    x = torch.randn(b, f, h, w, c) * 1.5 + 0.2
+    exact = _oracle(blk, x, torch.float64)
+    ref32 = _oracle(blk, x, torch.float32)
+    blk = blk.to(DEV)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        assert ops.lattn_fused_takes(xd, 4, (blk.fn.norm.gamma,))
+        ops.PROFILE = {}
+        y = blk(xd)
+        used = set(ops.PROFILE)
+        ops.PROFILE = None
+        assert 'lattn_fused_fwd_kernels' in used and not any('conv' in k or 'linattn' in k for k in used), used
+        assert ops._known_amax(y) is not None and abs(ops._known_amax(y).max().item() - y.abs().max().item()) == 0.0
+        assert torch.equal(y, blk(xd))
+        ops.FUSED_LATTN_WIDE = False
+        try:
+            assert not ops.lattn_fused_takes(xd, 4, (blk.fn.norm.gamma,))
+            y_layers = blk(xd)
+        finally:
+            ops.FUSED_LATTN_WIDE = True
+    e_f, e_l, e_r = rel_l2(y, exact), rel_l2(y_layers, exact), rel_l2(ref32, exact)
+    b_f = rel_l2(y.cpu().double() - x.double(), exact - x.double())
+    b_l = rel_l2(y_layers.cpu().double() - x.double(), exact - x.double())
+    print(f'wide linear attention [{b},{f},{h},{w},{c}]: fused vs exact {e_f:.2e} (branch {b_f:.2e}), layer by layer {e_l:.2e} (branch {b_l:.2e}), fp32 oracle {e_r:.2e}')
+    assert e_f < 1e-6 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    assert b_f < 5e-6 and b_f <= 1.5 * b_l + 5e-7
+    xg = xd.clone().requires_grad_(True)
+    assert not ops.lattn_fused_takes(xg, 4, (blk.fn.norm.gamma,))          # a gradient: layer by layer
+
+
 def test_unet_forward_uses_the_fused_linear_attention_when_sampling(mods):
-    """The whole denoiser under no_grad: the three 64-channel SpatialLinearAttention blocks (downs[0], ups[1], ups[2]) run fused; result vs
-    the oracle and vs the layer-by-layer path; with gradients enabled they run layer by layer."""
+    """The whole denoiser under no_grad: the three 64-channel SpatialLinearAttention blocks (downs[0], ups[1], ups[2]) and the 128-channel one
+    of the second level (csrc/linattn_fused_wide.hip) run fused; result vs the oracle and vs the layer-by-layer path; with gradients the
+    64-channel blocks stay fused, the wide one runs layer by layer."""
     ops, V = mods
     from oracle import unet_ref as U
     torch.manual_seed(4)
@@ -87,25 +133,31 @@ def test_unet_forward_uses_the_fused_linear_attention_when_sampling(mods):
         ref = U.unet3d_forward(sd, x, t, dim=64, dim_mults=(1, 2, 4), groups=8)
         ref64 = U.unet3d_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double(), t, dim=64, dim_mults=(1, 2, 4), groups=8)
     net = net.to(DEV)
-    with torch.no_grad():
-        ops.PROFILE = {}
-        out = net(x.to(DEV), t.to(DEV))
-        n_fused = len(ops.PROFILE.get('lattn_fused_fwd_kernels', []))
-        ops.PROFILE = None
-        ops.FUSED_LATTN = False
-        try:
+    try:
+        with torch.no_grad():
+            ops.PROFILE = {}
+            out = net(x.to(DEV), t.to(DEV))
+            n_fused = len(ops.PROFILE.get('lattn_fused_fwd_kernels', []))
+            ops.PROFILE = None
+            ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = False      # the blocks a pass with gradients can fuse
+            ops.PROFILE = {}
+            out_narrow = net(x.to(DEV), t.to(DEV))
+            n_narrow = len(ops.PROFILE.get('lattn_fused_fwd_kernels', []))
+            ops.PROFILE = None
+            ops.FUSED_LATTN = False
             out_layers = net(x.to(DEV), t.to(DEV))
-        finally:
-            ops.FUSED_LATTN = True
-    assert n_fused == 3, n_fused
-    e_f, e_l, e_r = rel_l2(out, ref64), rel_l2(out_layers, ref64), rel_l2(ref, ref64)
-    print(f'U-Net forward: fused linear attention vs exact {e_f:.2e}, layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
-    assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7
+    finally:
+        ops.FUSED_LATTN = ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = True
+    assert n_fused == 4, n_fused            # downs[0], ups[1], ups[2] (64 channels) + downs[1] (128 channels on 8 x 8 = 64 tokens: csrc/linattn_fused_wide.hip)
+    assert n_narrow == 3, n_narrow
+    e_f, e_n, e_l, e_r = rel_l2(out, ref64), rel_l2(out_narrow, ref64), rel_l2(out_layers, ref64), rel_l2(ref, ref64)
+    print(f'U-Net forward: fused linear attention vs exact {e_f:.2e} (64-channel blocks only {e_n:.2e}), layers vs exact {e_l:.2e}, fp32 oracle vs exact {e_r:.2e}')
+    assert rel_l2(out, ref) < 1e-5 and e_f <= 1.5 * max(e_l, e_r) + 1e-7 and e_n <= 1.5 * max(e_l, e_r) + 1e-7
     ops.PROFILE = {}
-    out_g = net(x.to(DEV), t.to(DEV))       # parameters require gradients here: still fused (the backward is fused too)
+    out_g = net(x.to(DEV), t.to(DEV))       # parameters require gradients here: the 64-channel blocks still fused (the backward is fused too)
     assert len(ops.PROFILE.get('lattn_fused_fwd_kernels', [])) == 3
     ops.PROFILE = None
-    assert torch.equal(out_g.detach(), out)
+    assert torch.equal(out_g.detach(), out_narrow)
     ops.FUSED_LATTN_BWD = False
     try:
         ops.PROFILE = {}

@@ -23,6 +23,8 @@
 //     summed through LDS together with the residual x (kept in registers by the lanes that loaded it), one coalesced store per row.
 #include "attn_fused.h"
 
+extern int wdno_debug_mode;
+
 
 __global__ __launch_bounds__(256, 2) void tattn_fused_fwd_kernel(TFusedP p) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[32 * TF_AST];
@@ -271,7 +273,13 @@ static int tf_num_cus() {
 
 // 24 frames: this file (and attn_fused_bwd.hip for the gradients); 48 frames: attn_fused48.hip, forward only
 int wdno_tattn_fused_fwd48_launch(const TFusedP& p, hipStream_t st);
-extern "C" int wdno_tattn_fused_takes(int C, int n_tok, int heads) { return C == TF_C && (n_tok == TF_NT || n_tok == 48) && heads == TF_HEADS; }
+// 128 / 256 channels, 24 frames: attn_fused_wide.hip, forward only
+int wdno_tattn_fused_fwd_wide_launch(const TFusedP& p, int C, hipStream_t st);
+extern "C" int wdno_tattn_fused_takes(int C, int n_tok, int heads) {
+  if (heads != TF_HEADS) return 0;
+  if (C == TF_C) return n_tok == TF_NT || n_tok == 48;
+  return (C == 128 || C == 256) && n_tok == TF_NT && wdno_debug_mode != 62;
+}
 
 extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float eps, const void* wq_hi, const void* wq_lo, const float* wq_scale,
                                     const void* wo_hi, const void* wo_lo, const float* wo_scale, const float* rot_cos, const float* rot_sin,
@@ -279,7 +287,7 @@ extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float ep
                                     int64_t n_batch, int n_tok, int64_t hw, int C, int heads, float scale, wdno_stream_t s) {
   WDNO_REQUIRE(x && gamma && wq_hi && wq_lo && wq_scale && wo_hi && wo_lo && wo_scale && y && n_batch > 0 && hw > 0);
   WDNO_REQUIRE((rot_cos == nullptr) == (rot_sin == nullptr));
-  if (!wdno_tattn_fused_takes(C, n_tok, heads) || hw > 0x7fffffff / (TF_C * 48)) return WDNO_EUNSUPPORTED;
+  if (!wdno_tattn_fused_takes(C, n_tok, heads) || hw > 0x7fffffff / (C * 48)) return WDNO_EUNSUPPORTED;
   TFusedP p;
   p.x = x; p.gamma = gamma; p.eps = eps;
   p.wq_hi = (const _Float16*)wq_hi; p.wq_lo = (const _Float16*)wq_lo; p.wq_scale = wq_scale;
@@ -288,6 +296,10 @@ extern "C" int wdno_tattn_fused_fwd(const float* x, const float* gamma, float ep
   p.y = y; p.amax_rec = amax_rec; p.qkv_out = qkv_out;
   p.rec_v = rec_v;
   p.HW = (int)hw; p.scale = scale; p.nseq = n_batch * hw;
+  if (C != TF_C) {
+    if (qkv_out) return WDNO_EUNSUPPORTED;            // (nothing is kept for a backward: these levels train layer by layer; rec_v stays untouched)
+    return wdno_tattn_fused_fwd_wide_launch(p, C, as_stream(s));
+  }
   if (n_tok == 48) {
     if (qkv_out) return WDNO_EUNSUPPORTED;          // (only the un-fused backward of the 24-frame block asks for the projections)
     return wdno_tattn_fused_fwd48_launch(p, as_stream(s));

@@ -1158,8 +1158,13 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
   // modes 6 .. 9: data-gradient operand of tap (py, px) = ((mode - 6) >> 1, (mode - 6) & 1) of a (1,2,2) / stride (1,2,2) convolution (the folded
   // Downsample of the Burgers U-Net, unet.py:64-68), whose data gradient is four 1 x 1 convolutions of dy scattered to the four pixel parities:
   // out[a = c][b = k] = w[k][c][0][py][px]  (told kd, kh, kw = 1, 1, 1; data-gradient layout, only the gather differs)
+  // modes 10 / 11: the forward operand of a 1 x 1 projection in the FRAGMENT order of csrc/attn_fused_wide.hip (to_qkv [384][C] / to_out [C][128] of
+  // a temporal attention block): the 16-byte group (row a, channels 8 bg ..) moves so that the 64 lanes of one matrix-operand load read 1 KB
+  //   10: a = ti 128 + h 32 + li, bg = 4 t + 2 hh + s  ->  ((((h 3 + ti) B/32 + t) 2 + s) 64 + hh 32 + li
+  //   11: a = wv A/4 + mt 32 + li, bg = 4 t + 2 hh + s ->  ((((wv A/128 + mt) 4 + t) 2 + s) 64 + hh 32 + li
+  const int frag = mode_in >= 10 ? mode_in - 9 : 0;
   const int parity = mode_in >= 2 && mode_in < 6 ? mode_in - 2 : -1;
-  const int patch = mode_in >= 6 ? mode_in - 6 : -1;
+  const int patch = mode_in >= 6 && mode_in < 10 ? mode_in - 6 : -1;
   const int mode = mode_in == 1 || patch >= 0 ? 1 : 0;
   const bool lp = lo == nullptr;                     // one bf16 plane, no scale (amax / scale_out may be NULL)
   const float s = lp ? 1.0f : scale_from_amax(amax[0]);
@@ -1228,7 +1233,12 @@ __device__ __forceinline__ void pack_split_body(const float* __restrict__ w, con
         l[e] = (_Float16)(tv - (float)th);
         bq[e] = bf16_rne(v);
       }
-      const int64_t i = ((((int64_t)dz * kh + dy) * A + a) * kw + dx) * b8 + bg;
+      int64_t i = ((((int64_t)dz * kh + dy) * A + a) * kw + dx) * b8 + bg;
+      if (frag) {
+        const int li = a & 31, t = bg >> 2, hh2 = (bg >> 1) & 1, s2 = bg & 1;
+        if (frag == 1) { const int ti = a >> 7, hd = (a >> 5) & 3; i = ((((hd * 3 + ti) * (B >> 5) + t) * 2 + s2) * 64 + hh2 * 32 + li); }
+        else { const int q4 = A >> 2, wv = a / q4, mt = (a - wv * q4) >> 5; i = ((((wv * (A >> 7) + mt) * 4 + t) * 2 + s2) * 64 + hh2 * 32 + li); }
+      }
       if (lp) { *reinterpret_cast<us8*>(hi + i * 8) = bq; continue; }
       *reinterpret_cast<half8*>(hi + i * 8) = h;
       *reinterpret_cast<half8*>(lo + i * 8) = l;
@@ -1293,13 +1303,15 @@ extern "C" int wdno_pack_split_weight_multi(const void* table, int n_items, int 
 }
 extern "C" int wdno_pack_split_weight(const float* w, const float* amax, void* hi, void* lo, float* scale_out, int K, int C, int kd, int kh,
                                       int kw, int A, int B, int mode, wdno_stream_t s) {
-  WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && mode >= 0 && mode <= 9);
+  WDNO_REQUIRE(K > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && A > 0 && B > 0 && (B & 7) == 0 && mode >= 0 && mode <= 11);
   WDNO_REQUIRE(mode < 2 || mode > 5 || (kd == 1 && kh == 2 && kw == 2));      // parity classes of the (1,4,4) transposed convolution
   WDNO_REQUIRE(mode < 6 || (kd == 1 && kh == 1 && kw == 1));                  // taps of the (1,2,2) / stride 2 convolution
-  WDNO_REQUIRE(mode != 1 && mode < 6 ? (A >= K && B >= C) : (A >= C && B >= K));
+  WDNO_REQUIRE(mode != 1 && (mode < 6 || mode >= 10) ? (A >= K && B >= C) : (A >= C && B >= K));
+  WDNO_REQUIRE(mode != 10 || (A == 384 && (B & 31) == 0 && lo != nullptr));      // fragment order: to_qkv of 4 heads of 32, to_out onto C = 128 m channels
+  WDNO_REQUIRE(mode != 11 || (B == 128 && (A & 127) == 0 && lo != nullptr));
   WDNO_REQUIRE(lo == nullptr || (amax != nullptr && scale_out != nullptr));      // lo == NULL: one bf16 plane in `hi`
   int64_t total = (int64_t)kd * kh * A * kw * (B / 8);
-  const PackTile ptile = pack_tile(kd * kh * kw, A, B, mode == 1 || mode >= 6 ? 1 : 0);
+  const PackTile ptile = pack_tile(kd * kh * kw, A, B, mode == 1 || (mode >= 6 && mode < 10) ? 1 : 0);
   if ((int64_t)kd * kh * kw * ptile.KT * ptile.CTp > PS_LDS_FLOATS + 16) return WDNO_EUNSUPPORTED;      // > 640 taps (every operand passes here first)
   (void)total;
   pack_split_weight_kernel<<<std::min(2048, ptile.tiles_k * ptile.tiles_c), 256, 0, as_stream(s)>>>(w, amax, (_Float16*)hi, (_Float16*)lo, scale_out, K, C, kd, kh, kw,

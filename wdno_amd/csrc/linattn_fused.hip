@@ -15,32 +15,8 @@
 //   lattn_fused_out_kernel   q of a tile in the usual [feature][token] layout (softmax over d inside a lane pair), out^T = ctx^T qs^T on
 //                            the exact-fp32 MFMA with qs in place, to_out on the split MFMA straight from the accumulators, heads summed
 //                            through LDS with the bias and the residual (as attn_fused.hip).
-#include "attn_fused.h"
+#include "linattn_fused.h"
 
-#define LF_PART (32 + 32 + 32 * 32)          /* floats per (block, head) of the first pass: m[32], Z[32], ctx_raw[32][32] */
-
-struct LFusedP {
-  const float* x; const float* gamma; float eps;
-  const _Float16* wq_hi; const _Float16* wq_lo; const float* wq_scale;      // packed forward operand of to_qkv: [384][64]
-  const _Float16* wo_hi; const _Float16* wo_lo; const float* wo_scale;      // ... of to_out: [64][128]
-  const float* bias_out;
-  float* part;               // first pass: [units][chunks][heads][LF_PART]
-  const float* ctx;          // second pass: [units][heads][32][32] (ctx[d][e])
-  float* y; float* amax_rec;
-  int n_tok, chunks, tiles_per_chunk; float scale;
-};
-
-__device__ __forceinline__ f32x16 lf_zero() {
-  f32x16 z;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) z[e] = 0.f;
-  return z;
-}
-__device__ __forceinline__ f32x16 lf_mfma3(half8 ah, half8 al, half8 bh, half8 bl, f32x16 c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
-}
 // LayerNorm of one row by its 16 lanes (norm.hip: layernorm_kernel) -> (hi, lo) planes
 __device__ __forceinline__ void lf_ln_row(float4 xv, float4 g, float eps, float ps, _Float16* __restrict__ Ah, _Float16* __restrict__ Al, int row, int c4) {
   const float mean = tf_row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / TF_C);
@@ -332,7 +308,13 @@ static int lf_chunks(int64_t units, int n_tok) {
   return (int)c;
 }
 
-extern "C" int wdno_lattn_fused_takes(int C, int heads, int n_tok) { return C == TF_C && heads == TF_HEADS && n_tok >= 32; }
+// 128 / 256 channels: linattn_fused_wide.hip (forward only; operands of pack modes 10 / 11)
+int wdno_lattn_wide_ctx_launch(const LFusedP& p, int C, unsigned grid, hipStream_t st);
+int wdno_lattn_wide_out_launch(const LFusedP& p, int C, unsigned grid, hipStream_t st);
+extern int wdno_debug_mode;
+extern "C" int wdno_lattn_fused_takes(int C, int heads, int n_tok) {
+  return (C == TF_C || ((C == 128 || C == 256) && wdno_debug_mode != 62)) && heads == TF_HEADS && n_tok >= 32;
+}
 extern "C" size_t wdno_lattn_fused_ws_bytes(int64_t units, int n_tok) {
   return ((size_t)units * lf_chunks(units, n_tok) * TF_HEADS * LF_PART + (size_t)units * TF_HEADS * 1024) * sizeof(float);
 }
@@ -341,7 +323,7 @@ extern "C" int wdno_lattn_fused_fwd(const float* x, const float* gamma, float ep
                                     float* ctx_out, float* kstat_out, void* ws, size_t ws_bytes, int64_t units, int n_tok, int C, int heads,
                                     float scale, wdno_stream_t s) {
   WDNO_REQUIRE(x && gamma && wq_hi && wq_lo && wq_scale && wo_hi && wo_lo && wo_scale && y && ws && units > 0 && n_tok > 0);
-  if (!wdno_lattn_fused_takes(C, heads, n_tok) || units * (int64_t)n_tok * TF_C > 0x7fffffff0ll) return WDNO_EUNSUPPORTED;
+  if (!wdno_lattn_fused_takes(C, heads, n_tok) || units * (int64_t)n_tok * C > 0x7fffffff0ll) return WDNO_EUNSUPPORTED;
   if (ws_bytes < wdno_lattn_fused_ws_bytes(units, n_tok)) return WDNO_EWORKSPACE;
   LFusedP p;
   p.x = x; p.gamma = gamma; p.eps = eps;
@@ -357,8 +339,16 @@ extern "C" int wdno_lattn_fused_fwd(const float* x, const float* gamma, float ep
   p.ctx = ctx; p.y = y; p.amax_rec = amax_rec;
   if (units * p.chunks > 0x7fffffff) return WDNO_EUNSUPPORTED;
   hipStream_t st = as_stream(s);
-  lattn_fused_ctx_kernel<<<(unsigned)(units * p.chunks), 256, 0, st>>>(p);
+  const unsigned grid = (unsigned)(units * p.chunks);
+  if (C != TF_C) {
+    int rc = wdno_lattn_wide_ctx_launch(p, C, grid, st);
+    if (rc != WDNO_OK) return rc;
+    lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 256, 0, st>>>(p.part, ctx, p.chunks, kstat_out);
+    rc = wdno_lattn_wide_out_launch(p, C, grid, st);
+    return rc != WDNO_OK ? rc : wdno_check_launch();
+  }
+  lattn_fused_ctx_kernel<<<grid, 256, 0, st>>>(p);
   lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 256, 0, st>>>(p.part, ctx, p.chunks, kstat_out);
-  lattn_fused_out_kernel<<<(unsigned)(units * p.chunks), 256, 0, st>>>(p);
+  lattn_fused_out_kernel<<<grid, 256, 0, st>>>(p);
   return wdno_check_launch();
 }

@@ -558,6 +558,8 @@ def _wmode(kind):
     """pack mode of csrc/conv_h3.hip: 'f' forward operand, 'd' data-gradient operand, 'p{py}{px}' parity class of a transposed convolution."""
     if kind[0] == 'q':              # tap (py, px) of a (1,2,2) / stride-2 convolution as the data-gradient operand of a 1x1 convolution
         return 6 + 2 * int(kind[1]) + int(kind[2])
+    if kind[0] == 'a':              # 'aq' / 'ao': to_qkv / to_out of a temporal attention block in the fragment order of csrc/attn_fused_wide.hip
+        return 10 if kind == 'aq' else 11
     return 0 if kind == 'f' else 1 if kind == 'd' else 2 + 2 * int(kind[1]) + int(kind[2])
 
 
@@ -1831,6 +1833,7 @@ def linear_attention(qkv, units, n_tok, heads, scale, out_planes=False):
 
 FUSED_TATTN = True        # the level-0 temporal attention block as one launch where the kernel takes the shape (test knob: layer by layer otherwise)
 FUSED_TATTN_BWD = True    # ... with gradients too: forward + ONE backward launch (csrc/attn_fused_bwd.hip); False: a training step runs the block layer by layer
+FUSED_TATTN_WIDE = True   # the blocks of the 128- / 256-channel levels as one launch when nothing needs a gradient (csrc/attn_fused_wide.hip; test knob)
 
 
 def tattn_fused_takes(x, heads, weights):
@@ -1841,12 +1844,16 @@ def tattn_fused_takes(x, heads, weights):
     if not FUSED_TATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights)):
         return False
     b, f, h, w, c = x.shape
-    if f != 24 and torch.is_grad_enabled() and (x.requires_grad or any(w_ is not None and w_.requires_grad for w_ in weights)):
-        return False                             # 48 frames (the super-resolution model): forward only
+    if (f != 24 or c != 64) and torch.is_grad_enabled() and (x.requires_grad or any(w_ is not None and w_.requires_grad for w_ in weights)):
+        return False                             # 48 frames (the super-resolution model), 128 / 256 channels (csrc/attn_fused_wide.hip): forward only
+    if c != 64 and not FUSED_TATTN_WIDE:
+        return False
     return bool(_lib_().wdno_tattn_fused_takes(c, f, heads)) and b * h * w >= 64
 
 
 def _tattn_operands(w_qkv, w_out, c, hd):
+    if c != 64:                     # csrc/attn_fused_wide.hip streams its operands: fragment order (one load instruction = 1 KB of contiguous memory)
+        return split_weight(w_qkv, 'aq', pad8(c), 3 * hd, pack_fwd) + split_weight(w_out, 'ao', hd, pad4(c), pack_fwd)
     return split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd) + split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
 
 
@@ -1927,6 +1934,7 @@ def temporal_attention_fused(x, gamma, eps, w_qkv, w_out, rot, bias, heads, scal
 
 FUSED_LATTN = True        # the 64-channel SpatialLinearAttention block as two passes + a merge (test knob: layer by layer otherwise)
 FUSED_LATTN_BWD = True    # ... with gradients too (csrc/linattn_fused_bwd.hip); False: a training step runs the block layer by layer
+FUSED_LATTN_WIDE = True   # the blocks of the 128- / 256-channel levels in two passes + a merge when nothing needs a gradient (csrc/linattn_fused_wide.hip; test knob)
 
 
 def lattn_fused_takes(x, heads, weights):
@@ -1934,9 +1942,12 @@ def lattn_fused_takes(x, heads, weights):
     needs a gradient, csrc/linattn_fused_bwd.hip its backward)?"""
     if not (FUSED_LATTN and CONV_MATH in ('f16x3', 'bf16') and x.dim() == 5 and x.is_cuda and x.dtype == torch.float32) or getattr(x, '_wdno_unwritten', False):
         return False
-    if not FUSED_LATTN_BWD and torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights)):
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(w is not None and w.requires_grad for w in weights))
+    if not FUSED_LATTN_BWD and needs_grad:
         return False
     b, f, h, w, c = x.shape
+    if c != 64 and (needs_grad or not FUSED_LATTN_WIDE):
+        return False                             # 128 / 256 channels (csrc/linattn_fused_wide.hip): forward only
     return bool(_lib_().wdno_lattn_fused_takes(c, heads, h * w))
 
 
@@ -1952,8 +1963,7 @@ class _LAttnFused(torch.autograd.Function):
         b, f, h, w, c = x.shape
         hd = heads * 32
         lib = _lib_()
-        wqh, wql, wqs = split_weight(w_qkv, 'f', pad8(c), 3 * hd, pack_fwd)
-        woh, wol, wos = split_weight(w_out, 'f', hd, pad4(c), pack_fwd)
+        wqh, wql, wqs, woh, wol, wos = _tattn_operands(w_qkv, w_out, c, hd)       # (fragment order at 128 / 256 channels)
         units, n = b * f, h * w
         nb = lib.wdno_lattn_fused_ws_bytes(units, n)
         ws = _ws(nb, x.device)
