@@ -6,6 +6,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
+// Streamed weight fragments (attn_fused_wide.hip, linattn_fused_wide.hip): raw buffer loads, address = descriptor (SGPRs) + one loop-invariant
+// 32-bit lane offset (VGPR) + a uniform offset (SGPR) -- no address arithmetic in the vector registers.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tf_rsrc(const void* ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ half8 tf_frag(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned uniform_bytes) {
+  return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)uniform_bytes, 0));
+}
+// Hand-over of streamed fragments: a trip of the streaming loops requests two sets, waits for them IN FULL (s_waitcnt vmcnt(0)), then runs their
+// matrix instructions -- no fragment load is in flight while the matrix pipe reads fragments. The overlapped form (the loads of set B in
+// flight while the matrix instructions consume set A, handed over by the counted waits vmcnt(5), vmcnt(1), ... the compiler derives -- or
+// by full waits) gave run-to-run differences of ~1e-6 in the first pass of the 256-channel linear-attention block whenever two blocks shared
+// a CU: not with one block per CU, not with constant fragments or constant token planes, not with this serial form; unchanged by 64-bit lane
+// vs buffer addressing, by extra barriers, by idle cycles behind the matrix instructions (tools/probes/lattn_wide_repro.py; the cause was not
+// found -- the counted waits are correct for in-order returns). The other waves of the SIMD fill the wait: no time lost (measured), so every
+// streaming loop of the wide kernels uses the serial form; tests/test_gpu_wide_repro.py repeats each kernel 40 times under two blocks per CU.
+// The fragments are tied to the asm statements so that no consumer is scheduled above the wait and no later load above the consumers.
+#define TF_WAIT_SET4(a, b, c, d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+#define TF_WAIT_SET8(a, b, c, d, e, f, g, h) asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "memory")
+
 #define TF_C 64
 #define TF_NT 24
 #define TF_HEADS 4

@@ -63,9 +63,11 @@ __global__ __launch_bounds__(256, 2) void tattn_wide_fwd_kernel(TFusedP p) {
   const float sw_o = p.wo_scale[0];
   const int64_t fstride = (int64_t)p.HW * C;
   // operands in fragment order (pack modes 10 / 11 of csrc/conv_h3.hip): [head][q|k|v][pair][step][lane][8] and [wave][tile][head][step][lane][8]
-  // (one 32-bit lane offset per operand, added to the uniform plane pointers: four 64-bit lane pointers cost the allocator eight registers it does not have)
-  const unsigned wq_off = (unsigned)(h * 3 * NP * 2 * 64 + lane) * 8u;      // + ((ti NP + t) 2 + s) 512
-  const unsigned wo_off = (unsigned)(h * MT * 4 * 2 * 64 + lane) * 8u;      // + ((mt 4 + t) 2 + s) 512
+  // (raw buffer loads: descriptor + one 32-bit lane offset + a uniform offset, see attn_fused.h)
+  const unsigned wq_off = (unsigned)(h * 3 * NP * 2 * 64 + lane) * 16u;     // bytes; + ((ti NP + t) 2 + s) 1024
+  const unsigned wo_off = (unsigned)(h * MT * 4 * 2 * 64 + lane) * 16u;     // + ((mt 4 + t) 2 + s) 1024
+  const __amdgpu_buffer_rsrc_t rqh = tf_rsrc(p.wq_hi, 3 * TF_HD * C * 2), rql = tf_rsrc(p.wq_lo, 3 * TF_HD * C * 2);
+  const __amdgpu_buffer_rsrc_t roh = tf_rsrc(p.wo_hi, C * TF_HD * 2), rol = tf_rsrc(p.wo_lo, C * TF_HD * 2);
   float am = 0.f;
 
   float4 nx0[NJ], nx1[NJ];
@@ -123,15 +125,15 @@ __global__ __launch_bounds__(256, 2) void tattn_wide_fwd_kernel(TFusedP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { aq[e] = 0.f; ak[e] = 0.f; av[e] = 0.f; }
     {
-      // two fragment sets; the loop over pairs is NOT unrolled (unrolled, the scheduler hoists every load to the top: 162 spilled registers
-      // at C = 256), so at most one set is in flight while the other feeds the matrix instructions
+      // two fragment sets per trip; the loop over pairs is NOT unrolled (unrolled, the scheduler hoists every load to the top: 162 spilled
+      // registers at C = 256)
       half8 w0h[3][2], w0l[3][2], w1h[3][2], w1l[3][2];
       auto wload = [&](half8 (&wh)[3][2], half8 (&wl)[3][2], int t) {
 #pragma unroll
         for (int ti = 0; ti < 3; ++ti) {
-          const unsigned o = wq_off + (unsigned)(ti * NP + t) * 1024u;
-          wh[ti][0] = *reinterpret_cast<const half8*>(p.wq_hi + o); wh[ti][1] = *reinterpret_cast<const half8*>(p.wq_hi + o + 512);
-          wl[ti][0] = *reinterpret_cast<const half8*>(p.wq_lo + o); wl[ti][1] = *reinterpret_cast<const half8*>(p.wq_lo + o + 512);
+          const unsigned o = (unsigned)(ti * NP + t) * 2048u;
+          wh[ti][0] = tf_frag(rqh, wq_off, o); wh[ti][1] = tf_frag(rqh, wq_off, o + 1024);
+          wl[ti][0] = tf_frag(rql, wq_off, o); wl[ti][1] = tf_frag(rql, wq_off, o + 1024);
         }
       };
       auto wmma = [&](const half8 (&wh)[3][2], const half8 (&wl)[3][2], int t) {
@@ -150,13 +152,17 @@ __global__ __launch_bounds__(256, 2) void tattn_wide_fwd_kernel(TFusedP p) {
           av = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[2][s], ah, av, 0, 0, 0);
         }
       };
-      wload(w0h, w0l, 0);
 #pragma unroll 1
-      for (int t = 0; t < NP; t += 2) {
+      for (int t = 0; t < NP; t += 2) {        // both sets requested, waited for in full, consumed (attn_fused.h: the hand-over note)
+        wload(w0h, w0l, t);
         wload(w1h, w1l, t + 1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0h[0][0]), "+v"(w0h[0][1]), "+v"(w0h[1][0]), "+v"(w0h[1][1]), "+v"(w0h[2][0]), "+v"(w0h[2][1]),
+                     "+v"(w0l[0][0]), "+v"(w0l[0][1]), "+v"(w0l[1][0]), "+v"(w0l[1][1]), "+v"(w0l[2][0]), "+v"(w0l[2][1]) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w1h[0][0]), "+v"(w1h[0][1]), "+v"(w1h[1][0]), "+v"(w1h[1][1]), "+v"(w1h[2][0]), "+v"(w1h[2][1]),
+                     "+v"(w1l[0][0]), "+v"(w1l[0][1]), "+v"(w1l[1][0]), "+v"(w1l[1][1]), "+v"(w1l[2][0]), "+v"(w1l[2][1]) :: "memory");
         wmma(w0h, w0l, t);
-        if (t + 2 < NP) wload(w0h, w0l, t + 2);
         wmma(w1h, w1l, t + 1);
+        asm volatile("" : "+v"(aq), "+v"(ak), "+v"(av) :: "memory");
       }
     }
     // rows of the next sequence: requested now, needed after this sequence's attention and to_out (not before the projection: its two
@@ -258,9 +264,9 @@ __global__ __launch_bounds__(256, 2) void tattn_wide_fwd_kernel(TFusedP p) {
       for (int e = 0; e < 16; ++e) y[e] = 0.f;
       half8 u0h[2], u0l[2], u1h[2], u1l[2];                 // two fragment sets, as in the projection
       auto uload = [&](half8 (&uh)[2], half8 (&ul)[2], int t) {
-        const unsigned o = wo_off + (unsigned)(mt * 4 + t) * 1024u;
-        uh[0] = *reinterpret_cast<const half8*>(p.wo_hi + o); uh[1] = *reinterpret_cast<const half8*>(p.wo_hi + o + 512);
-        ul[0] = *reinterpret_cast<const half8*>(p.wo_lo + o); ul[1] = *reinterpret_cast<const half8*>(p.wo_lo + o + 512);
+        const unsigned o = (unsigned)(mt * 4 + t) * 2048u;
+        uh[0] = tf_frag(roh, wo_off, o); uh[1] = tf_frag(roh, wo_off, o + 1024);
+        ul[0] = tf_frag(rol, wo_off, o); ul[1] = tf_frag(rol, wo_off, o + 1024);
       };
       auto umma = [&](const half8 (&uh)[2], const half8 (&ul)[2], int t) {
 #pragma unroll
@@ -272,13 +278,15 @@ __global__ __launch_bounds__(256, 2) void tattn_wide_fwd_kernel(TFusedP p) {
           y = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh[s], oh, y, 0, 0, 0);
         }
       };
-      uload(u0h, u0l, 0);
 #pragma unroll 1
       for (int t = 0; t < TF_HEADS; t += 2) {
+        uload(u0h, u0l, t);
         uload(u1h, u1l, t + 1);
+        TF_WAIT_SET4(u0h[0], u0h[1], u0l[0], u0l[1]);
+        TF_WAIT_SET4(u1h[0], u1h[1], u1l[0], u1l[1]);
         umma(u0h, u0l, t);
-        if (t + 2 < TF_HEADS) uload(u0h, u0l, t + 2);
         umma(u1h, u1l, t + 1);
+        asm volatile("" : "+v"(y) :: "memory");
       }
       // the residual values this lane adds (L2 hits: the block read these rows for the LayerNorm)
       float4 xr[4];

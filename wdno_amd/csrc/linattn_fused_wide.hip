@@ -62,13 +62,15 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_ctx_kernel(LFusedP p) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[32 * AST];
   __shared__ __attribute__((aligned(16))) _Float16 Al[32 * AST];
   __shared__ __attribute__((aligned(16))) float Fs[TF_HEADS][32];
+
   const int tid = threadIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, li = lane & 31, hh = lane >> 5;
   const int lrow = tid >> 4, lc4 = tid & 15;
   const int unit = (int)(blockIdx.x / (unsigned)p.chunks), chunk = (int)(blockIdx.x - (unsigned)unit * (unsigned)p.chunks);
   // k rows (ti = 1) and v rows (ti = 2) of this head, as the COLUMN operand of the swapped product: + ((ti NP + t) 2 + s) 512
-  const unsigned wq_off = (unsigned)(h * 3 * NP * 2 * 64 + lane) * 8u;
+  const unsigned wq_off = (unsigned)(h * 3 * NP * 2 * 64 + lane) * 16u;      // bytes
+  const __amdgpu_buffer_rsrc_t rqh = tf_rsrc(p.wq_hi, 3 * TF_HD * C * 2), rql = tf_rsrc(p.wq_lo, 3 * TF_HD * C * 2);
   const float ps = lw_plane_scale<C>(p.gamma, lc4);
   const float inv_qkv = 1.0f / (ps * p.wq_scale[0]);
   const float* xu = p.x + (int64_t)unit * p.n_tok * C;
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_ctx_kernel(LFusedP p) {
       auto wload = [&](half8 (&w)[2][2][2], int t) {
 #pragma unroll
         for (int kv = 0; kv < 2; ++kv) {
-          const unsigned o = wq_off + (unsigned)((kv + 1) * NP + t) * 1024u;
-          w[kv][0][0] = *reinterpret_cast<const half8*>(p.wq_hi + o); w[kv][0][1] = *reinterpret_cast<const half8*>(p.wq_hi + o + 512);
-          w[kv][1][0] = *reinterpret_cast<const half8*>(p.wq_lo + o); w[kv][1][1] = *reinterpret_cast<const half8*>(p.wq_lo + o + 512);
+          const unsigned o = (unsigned)((kv + 1) * NP + t) * 2048u;
+          w[kv][0][0] = tf_frag(rqh, wq_off, o); w[kv][0][1] = tf_frag(rqh, wq_off, o + 1024);
+          w[kv][1][0] = tf_frag(rql, wq_off, o); w[kv][1][1] = tf_frag(rql, wq_off, o + 1024);
         }
       };
       auto wmma = [&](const half8 (&w)[2][2][2], int t) {
@@ -113,13 +115,17 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_ctx_kernel(LFusedP p) {
           av = lf_mfma3(ah, al, w[1][0][s], w[1][1][s], av);
         }
       };
-      wload(w0, 0);
+      // No fragment load is in flight while the matrix instructions of a pair run (attn_fused.h: the hand-over note): both sets are
+      // requested, waited for in full, consumed. (The other three waves of the SIMD's two blocks fill the wait: no time lost, measured.)
 #pragma unroll 1
       for (int t = 0; t < NP; t += 2) {
+        wload(w0, t);
         wload(w1, t + 1);
+        TF_WAIT_SET8(w0[0][0][0], w0[0][0][1], w0[0][1][0], w0[0][1][1], w0[1][0][0], w0[1][0][1], w0[1][1][0], w0[1][1][1]);
+        TF_WAIT_SET8(w1[0][0][0], w1[0][0][1], w1[0][1][0], w1[0][1][1], w1[1][0][0], w1[1][0][1], w1[1][1][0], w1[1][1][1]);
         wmma(w0, t);
-        if (t + 2 < NP) wload(w0, t + 2);
         wmma(w1, t + 1);
+        asm volatile("" : "+v"(ak), "+v"(av) :: "memory");          // (the next loads stay behind these matrix instructions)
       }
     }
     if (tile + 1 < tile1) fetch(tile + 1);
@@ -179,8 +185,10 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_out_kernel(LFusedP p) {
   const int lane = tid & 63, li = lane & 31, hh = lane >> 5;
   const int lrow = tid >> 4, lc4 = tid & 15;
   const int unit = (int)(blockIdx.x / (unsigned)p.chunks), chunk = (int)(blockIdx.x - (unsigned)unit * (unsigned)p.chunks);
-  const unsigned wq_off = (unsigned)(h * 3 * NP * 2 * 64 + lane) * 8u;      // q rows (ti = 0): + (t 2 + s) 512
-  const unsigned wo_off = (unsigned)(h * MT * 4 * 2 * 64 + lane) * 8u;      // + ((mt 4 + t) 2 + s) 512
+  const unsigned wq_off = (unsigned)(h * 3 * NP * 2 * 64 + lane) * 16u;     // bytes; q rows (ti = 0): + (t 2 + s) 1024
+  const unsigned wo_off = (unsigned)(h * MT * 4 * 2 * 64 + lane) * 16u;     // + ((mt 4 + t) 2 + s) 1024
+  const __amdgpu_buffer_rsrc_t rqh = tf_rsrc(p.wq_hi, 3 * TF_HD * C * 2), rql = tf_rsrc(p.wq_lo, 3 * TF_HD * C * 2);
+  const __amdgpu_buffer_rsrc_t roh = tf_rsrc(p.wo_hi, C * TF_HD * 2), rol = tf_rsrc(p.wo_lo, C * TF_HD * 2);
   // ctx^T fragments of this (frame, head): step r contracts the features d = tf_key(r, hh); lane li = output feature e
   float ctxf[16];
   float amc = 0.f;
@@ -222,9 +230,9 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_out_kernel(LFusedP p) {
     {
       half8 w0[2][2], w1[2][2];                          // [hi | lo][step]
       auto wload = [&](half8 (&w)[2][2], int t) {
-        const unsigned o = wq_off + (unsigned)t * 1024u;
-        w[0][0] = *reinterpret_cast<const half8*>(p.wq_hi + o); w[0][1] = *reinterpret_cast<const half8*>(p.wq_hi + o + 512);
-        w[1][0] = *reinterpret_cast<const half8*>(p.wq_lo + o); w[1][1] = *reinterpret_cast<const half8*>(p.wq_lo + o + 512);
+        const unsigned o = (unsigned)t * 2048u;
+        w[0][0] = tf_frag(rqh, wq_off, o); w[0][1] = tf_frag(rqh, wq_off, o + 1024);
+        w[1][0] = tf_frag(rql, wq_off, o); w[1][1] = tf_frag(rql, wq_off, o + 1024);
       };
       auto wmma = [&](const half8 (&w)[2][2], int t) {
 #pragma unroll
@@ -234,13 +242,15 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_out_kernel(LFusedP p) {
           aq = lf_mfma3(w[0][s], w[1][s], bh, bl, aq);
         }
       };
-      wload(w0, 0);
 #pragma unroll 1
-      for (int t = 0; t < NP; t += 2) {
+      for (int t = 0; t < NP; t += 2) {        // (requested, waited for in full, consumed: see the first pass)
+        wload(w0, t);
         wload(w1, t + 1);
+        TF_WAIT_SET4(w0[0][0], w0[0][1], w0[1][0], w0[1][1]);
+        TF_WAIT_SET4(w1[0][0], w1[0][1], w1[1][0], w1[1][1]);
         wmma(w0, t);
-        if (t + 2 < NP) wload(w0, t + 2);
         wmma(w1, t + 1);
+        asm volatile("" : "+v"(aq) :: "memory");
       }
     }
     if (tile + 1 < tile1) fetch(tile + 1);
@@ -287,9 +297,9 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_out_kernel(LFusedP p) {
       f32x16 y = lf_zero();
       half8 u0[2][2], u1[2][2];
       auto uload = [&](half8 (&u)[2][2], int t) {
-        const unsigned o = wo_off + (unsigned)(mt * 4 + t) * 1024u;
-        u[0][0] = *reinterpret_cast<const half8*>(p.wo_hi + o); u[0][1] = *reinterpret_cast<const half8*>(p.wo_hi + o + 512);
-        u[1][0] = *reinterpret_cast<const half8*>(p.wo_lo + o); u[1][1] = *reinterpret_cast<const half8*>(p.wo_lo + o + 512);
+        const unsigned o = (unsigned)(mt * 4 + t) * 2048u;
+        u[0][0] = tf_frag(roh, wo_off, o); u[0][1] = tf_frag(roh, wo_off, o + 1024);
+        u[1][0] = tf_frag(rol, wo_off, o); u[1][1] = tf_frag(rol, wo_off, o + 1024);
       };
       auto umma = [&](const half8 (&u)[2][2], int t) {
 #pragma unroll
@@ -299,13 +309,15 @@ __global__ __launch_bounds__(256, 2) void lattn_wide_out_kernel(LFusedP p) {
           y = lf_mfma3(u[0][s], u[1][s], oh, ol, y);
         }
       };
-      uload(u0, 0);
 #pragma unroll 1
       for (int t = 0; t < TF_HEADS; t += 2) {
+        uload(u0, t);
         uload(u1, t + 1);
+        TF_WAIT_SET4(u0[0][0], u0[0][1], u0[1][0], u0[1][1]);
+        TF_WAIT_SET4(u1[0][0], u1[0][1], u1[1][0], u1[1][1]);
         umma(u0, t);
-        if (t + 2 < TF_HEADS) uload(u0, t + 2);
         umma(u1, t + 1);
+        asm volatile("" : "+v"(y) :: "memory");
       }
       if (tok) {
         const int ch0 = h * (C / 4) + 32 * mt + 4 * hh;
