@@ -383,3 +383,37 @@ def test_bf16_training_reduces_the_loss(ops):
     print('loss bf16 ', [round(v, 4) for v in losses['bf16'][::4]], '\nloss f16x3', [round(v, 4) for v in losses['f16x3'][::4]])
     assert losses['bf16'][-1] < 0.8 * losses['bf16'][0]
     assert abs(losses['bf16'][-1] - losses['f16x3'][-1]) < 0.1 * losses['f16x3'][-1]
+
+
+def test_bf16_mode_sampling_uses_the_wide_attention_blocks(ops):
+    """The single-product mode keeps the fused attention blocks on their split-fp16 projections (ops._in_f16x3), the 128- / 256-channel ones
+    (csrc/attn_fused_wide.hip, csrc/linattn_fused_wide.hip, fragment-ordered operands from the f16x3 family of weight plans) included: the
+    denoiser under no_grad with every convolution on one bf16 plane runs them, and its output agrees with the same pass with those blocks layer
+    by layer (bf16 projections there) to the bf16 tolerance while being closer to the fp32-equivalent pass."""
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from video_diffusion_pytorch import video_diffusion_pytorch_conv3d as V
+    torch.manual_seed(21)
+    net = V.Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42).to(DEV)
+    x, t = (torch.randn(2, 24, 42, 16, 16) * 0.7).to(DEV), torch.tensor([433, 17], device=DEV)
+    with torch.no_grad():
+        ops.PROFILE = {}
+        out = net(x, t)
+        n_t, n_l = len(ops.PROFILE.get('tattn_fused_fwd_kernel', [])), len(ops.PROFILE.get('lattn_fused_fwd_kernels', []))
+        ops.PROFILE = None
+        assert torch.equal(out, net(x, t))
+        ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = False
+        try:
+            out_narrow = net(x, t)
+        finally:
+            ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = True
+        ops.CONV_MATH = 'f16x3'
+        ref = net(x, t)
+        ops.CONV_MATH = 'bf16'
+    assert n_t == 5 and n_l == 4, (n_t, n_l)          # 2 x 16 x 16 sequences / 8 x 8 tokens: the second level's blocks are taken, the 4 x 4 ones are not
+    e_w, e_n, e_wn = rel_l2(out, ref), rel_l2(out_narrow, ref), rel_l2(out, out_narrow)
+    print(f'bf16-mode U-Net forward vs fp32-equivalent: wide blocks fused {e_w:.2e}, layer by layer {e_n:.2e}; between them {e_wn:.2e}')
+    assert e_w < 3e-2 and e_w <= 1.1 * e_n and e_wn < 3e-2

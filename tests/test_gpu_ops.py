@@ -361,6 +361,32 @@ def test_pack_split_weight_patch_taps(ops, k, c):
             assert float(rec[c:].abs().max() if cp > c else 0.0) == 0.0 and float(rec[:, k:].abs().max() if k8 > k else 0.0) == 0.0
 
 
+@pytest.mark.parametrize('c', [128, 256])
+def test_pack_split_weight_fragment_order(ops, c):
+    """Pack modes 10 / 11 (kinds 'aq' / 'ao'): the forward operands of to_qkv [384][C] / to_out [C][128] in the fragment order the wide attention
+    kernels stream (csrc/attn_fused_wide.hip): the same values as the row-major forward operand (mode 0), 16-byte groups permuted to
+    [head][q|k|v][k-step pair][step][lane half][row of 32][8] and [wave][tile][head][step][lane half][row][8] -- bit for bit, also through the
+    multi-tensor refresh after an in-place weight update."""
+    wq = dev(g((384, c), 51, 0.3))
+    wo = dev(g((c, 128), 52, 0.3))
+    for rep in range(2):
+        fh, fl, fs = ops.split_weight(wq, 'f', c, 384)
+        ah, al, as_ = ops.split_weight(wq, 'aq', c, 384)
+        assert torch.equal(fs, as_)
+        for pf, pa in ((fh, ah), (fl, al)):
+            want = pf.view(3, 4, 32, c // 32, 2, 2, 8).permute(1, 0, 3, 5, 4, 2, 6).contiguous().view(384, c)
+            assert torch.equal(pa, want)
+        fh, fl, fs = ops.split_weight(wo, 'f', 128, c)
+        ah, al, as_ = ops.split_weight(wo, 'ao', 128, c)
+        assert torch.equal(fs, as_)
+        for pf, pa in ((fh, ah), (fl, al)):
+            want = pf.view(4, c // 128, 32, 4, 2, 2, 8).permute(0, 1, 3, 5, 4, 2, 6).contiguous().view(c, 128)
+            assert torch.equal(pa, want)
+        with torch.no_grad():                 # an optimiser step: every operand is refreshed by the two multi-tensor launches
+            wq.mul_(1.37); wo.add_(0.01)
+        ops.bump_weight_epoch()
+
+
 def test_conv_split_reduction_without_workspace(ops):
     """wdno_conv_fwd_f16x3_ws with no (or too small a) workspace computes the same convolution unsplit; with the workspace the runs'
     partial sums are added in a fixed order -- the three results agree to the accumulation-order tolerance, the split one bit for bit with itself."""
