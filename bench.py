@@ -298,6 +298,43 @@ def sampling_leg(dif, device, batch, steps, barrier=None, roofline=True):
     return out
 
 
+def sampling_wide_ab(dif, device, batch, steps):
+    """Same-process A/B of the graph-replayed sampling step: the temporal / linear attention blocks of the 128- / 256-channel levels on
+    csrc/attn_fused_wide.hip / linattn_fused_wide.hip (default) against the layer-by-layer launches of round 4 (test knobs off), two alternating
+    repetitions of `steps` replays each."""
+    from wdno_amd import ops, diffusion_core as K
+    shape = (batch, 24, 42, 40, 40)
+    x0 = torch.randn(shape, device=device)
+    init = torch.randn(batch, 24, 40, 40, device=device)
+    control = torch.randn(batch, 24, 16, 40, 40, device=device)
+    desc = dif._desc(shape, dif.padded_shape)
+    src = dif._condition_source(shape, device, init, control, None)
+    res = {'fused': [], 'layer_by_layer': []}
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                for name, wide in (('fused', True), ('layer_by_layer', False)):
+                    ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = wide
+                    K._graph_cache.pop(dif, None)
+                    sg = K._step_graph(dif, shape, desc, False, False, device)
+                    sg.src.copy_(src)
+                    sg.x.copy_(x0)
+                    for _ in range(3):
+                        sg.graph.replay()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(steps):
+                        sg.t.fill_(500 - i)
+                        sg.noise.normal_()
+                        sg.graph.replay()
+                    torch.cuda.synchronize()
+                    res[name].append(round(steps / (time.perf_counter() - t0), 2))
+    finally:
+        ops.FUSED_TATTN_WIDE = ops.FUSED_LATTN_WIDE = True
+        K._graph_cache.pop(dif, None)
+    return {'graph_steps_per_sec': res, 'note': 'same process, alternating; ops.FUSED_TATTN_WIDE / FUSED_LATTN_WIDE on / off'}
+
+
 def sampling_roofline(dif, shape, x, src, desc, steps_per_sec):
     """The sampling half of the metric against the rooflines (SURVEY 8d counting rule: one p_sample step = one U-Net forward, 326.3 GFLOP and
     2.02 GB of un-fused leaf-op traffic per sample, + 5 streams of the state): the kernel with the largest total time in one eager step
@@ -755,6 +792,7 @@ def main():
             try:
                 if smoke:
                     extras['sampling'] = sampling_leg(dif, device, batch, args.sample_steps)
+                    extras['sampling']['wide_attention_ab'] = sampling_wide_ab(dif, device, batch, args.sample_steps)
                     extras['fields_pipeline'] = smoke_pipeline_leg(ts, device, batch, 10)
                     extras['train_step_graph'] = train_graph_leg(ts, x, 20, cap)
                 extras['dwt'] = dwt_leg(device)
