@@ -140,3 +140,34 @@ def test_training_step_and_sampling_do_not_change_with_the_hint(ops, trees):
     l1, g1, x1_ = run(True)
     assert torch.equal(l0, l1) and torch.equal(x0_, x1_)
     assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)
+
+
+def test_sampling_step_kernel_selection_full_size():
+    """One p_sample step of the smoke base model at the bench size [8,24,42,40,40] under no_grad: which timed launches it is made of. Every
+    temporal attention block (four at 64 channels, four at 128 / 256: csrc/attn_fused.hip, attn_fused_wide.hip) and every linear attention
+    block (three + three: linattn_fused.hip, linattn_fused_wide.hip) is ONE profiled launch group; the only layer-by-layer attention left is
+    the mid spatial block -- a silent fall-back to LayerNorm -> to_qkv -> attention -> to_out chains would show up here, not only as a timing."""
+    import os
+    from tests.helpers import GOLDEN
+    sys.path.insert(0, os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0])
+    import bench
+    from wdno_amd import ops
+    dev = torch.device('cuda', 0)
+    dif = bench.build_model(dev, 8)
+    shape = (8, 24, 42, 40, 40)
+    x = torch.randn(shape, device=dev)
+    with torch.no_grad():
+        x, _ = dif.p_sample(shape, x, 500)
+        ops.PROFILE = {}
+        try:
+            dif.p_sample(shape, x, 499)
+            torch.cuda.synchronize()
+            got = {k: len(v) for k, v in ops.PROFILE.items()}
+        finally:
+            ops.PROFILE = None
+    assert got.get('tattn_fused_fwd_kernel') == 8 and got.get('lattn_fused_fwd_kernels') == 6, got
+    assert not any(k.startswith('tattn_fused_bwd') or k.startswith('lattn_fused_bwd') or 'wgrad' in k for k in got), got
+    # 1 x 1 projections that remain: the mid spatial block's to_qkv / to_out, the ResnetBlocks' res_conv, the output head
+    assert got.get('conv_fwd_h3d_kernel<192,128>', 0) + got.get('conv_fwd_h3d_kernel<128,128>', 0) <= 6, got
+    ops.drop_weight_caches()
+    torch.cuda.empty_cache()
