@@ -47,5 +47,47 @@ def main():
               f'   repeats that differ {same}/20', flush=True)
 
 
+def main_bwd():
+    lib = ops._lib_()
+    torch.manual_seed(1)
+    for units, h, w in ((192, 10, 10), (96, 20, 20), (192, 9, 9)):
+        n = h * w
+        qkv = torch.randn(units * n, 384, device='cuda', requires_grad=True)
+        go = torch.randn(units * n, 128, device='cuda')
+
+        def fb():
+            qkv.grad = None
+            out = ops.softmax_attention(qkv, 4, units, 1, n, n, 0, 1, 32 ** -0.5)
+            out.backward(go)
+            return qkv.grad
+
+        def t(reps=20):              # forward + backward replayed from one captured graph (launch by launch the host is the limit)
+            for _ in range(3):
+                fb()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(reps):
+                    fb()
+            g.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) * 1e3 / reps
+        g_new = fb().clone()
+        same = sum(int(not torch.equal(g_new, fb())) for _ in range(20))
+        t_new = t()
+        lib.wdno_set_debug(68)
+        g_old = fb().clone()
+        t_old = t()
+        lib.wdno_set_debug(0)
+        print(f'forward + backward, {units} units x {n} tokens: tiled MFMA backward {t_new:7.1f} us   thread per row {t_old:7.1f} us   '
+              f'rel. difference of dqkv {float((g_new - g_old).norm() / g_old.norm()):.2e}   repeats that differ {same}/20', flush=True)
+
+
 if __name__ == '__main__':
     main()
+    main_bwd()

@@ -793,6 +793,243 @@ __global__ __launch_bounds__(64 * AM_WAVES, 3) void attn_fwd_mfma_tiled_kernel(c
   if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * AM_WAVES + wave);
 }
 
+// The backward of the same case (n_tok > 64, no rotation, no bias), one block of four waves per (unit, head) item, nothing n x n stored and
+// every product on the exact-fp32 matrix instruction with operands loaded straight into the layout the product wants (rows of q / k / v / dO as
+// four 16-byte loads of a token's features, or column d = li of 16 tokens):
+//   phase A, a wave per tile of 32 queries: pass 1 over the key tiles for the softmax statistics (m_i, 1 / l_i); delta_i = <dO_i, O_i>; pass 2:
+//     S^T = K Q^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T (dS^T feeds the product in place); statistics to LDS;
+//   phase B, a wave per tile of 32 keys, over the query tiles: S = Q K^T, dP = dO V^T, P and dS from the statistics, dV^T += dO^T P, dK^T += Q^T dS.
+// The thread-per-row kernel (attn_bwd_big_kernel: 246 us for the 768 items of 100 tokens of a training step) remains for rotation / bias.
+// STAGED (n <= 128, the training case): q (scaled), k, v, dO of the item are staged once in LDS tiles [128][36] and every operand is read from
+// there (a global round trip per product stage of a tile left the matrix pipe idle: 107 us; staged: see DESIGN.md); larger n reads global memory.
+#define ATT_TILED_MAXTOK 576
+#define ATT_TILED_STAGE 128
+#define ATT_TILED_TS 36
+template <bool STAGED>
+__global__ __launch_bounds__(64 * AM_WAVES, 2) void attn_bwd_mfma_tiled_kernel(const float* __restrict__ qkv, const float* __restrict__ fout,
+                                                                                const float* __restrict__ dout, float* __restrict__ dqkv, AttnP p) {
+  __shared__ __attribute__((aligned(16))) float Ms[STAGED ? ATT_TILED_STAGE : ATT_TILED_MAXTOK], Ls[STAGED ? ATT_TILED_STAGE : ATT_TILED_MAXTOK],
+      Dl[STAGED ? ATT_TILED_STAGE : ATT_TILED_MAXTOK];
+  __shared__ __attribute__((aligned(16))) float Stg[STAGED ? 4 * ATT_TILED_STAGE * ATT_TILED_TS : 4];      // q | k | v | dO
+  const int n = p.d.n_tok, ntile = (n + 31) >> 5;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+  const unsigned tq = (unsigned)(p.d.st * p.RW), to = (unsigned)(p.d.st * p.HD);
+  float am = 0.f;
+  for (int64_t item = blockIdx.x; item < p.n_items; item += gridDim.x) {
+    const int h = (int)(item % p.d.heads);
+    const int64_t unit = item / p.d.heads;
+    const int uo = (int)(unit / p.d.n_ui), ui = (int)(unit - (int64_t)uo * p.d.n_ui);
+    const int64_t row0 = (int64_t)uo * p.d.so + (int64_t)ui * p.d.si;
+    const float* qb = am_uniform(qkv + row0 * p.RW + h * DH);           // q of token 0; k at + HD, v at + 2 HD
+    const float* gb = am_uniform(dout + row0 * p.HD + h * DH);
+    const float* ob = am_uniform(fout + row0 * p.HD + h * DH);
+    float* db = dqkv + row0 * p.RW + h * DH;
+    // row `t` of a [token][feature] operand as the 16 values (features 8 c + 4 hh + 0..3) a lane feeds to a product over the features
+    // (STAGED: `base` is matched to its LDS tile -- q, k, v at column offsets 0, HD, 2 HD of qkv; dO -- and rows beyond n hold zeros)
+    auto tile_of = [&](const float* base, unsigned col0) -> const float* {
+      return Stg + (base == gb ? 3 : col0 == 0 ? 0 : col0 == (unsigned)p.HD ? 1 : 2) * (ATT_TILED_STAGE * ATT_TILED_TS);
+    };
+    auto row16 = [&](const float* base, unsigned stride, int t, unsigned col0, float mul, float (&v)[16]) {
+      if (STAGED) {
+        const float* T = tile_of(base, col0) + t * ATT_TILED_TS;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 v4 = *reinterpret_cast<const float4*>(T + 8 * c + 4 * hh);
+          v[4 * c] = v4.x; v[4 * c + 1] = v4.y; v[4 * c + 2] = v4.z; v[4 * c + 3] = v4.w;
+        }
+        return;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 v4 = t < n ? *reinterpret_cast<const float4*>(base + (unsigned)t * stride + col0 + 8 * c + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[4 * c] = v4.x * mul; v[4 * c + 1] = v4.y * mul; v[4 * c + 2] = v4.z * mul; v[4 * c + 3] = v4.w * mul;
+      }
+    };
+    // column d = li of the 16 tokens t0 + am_key(m, hh): what a lane feeds to a product over the tokens
+    auto col16 = [&](const float* base, unsigned stride, int t0, unsigned col0, float mul, float (&v)[16]) {
+      if (STAGED) {
+        const float* T = tile_of(base, col0) + t0 * ATT_TILED_TS + li;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = T[am_key(m, hh) * ATT_TILED_TS];
+        return;
+      }
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int t = t0 + am_key(m, hh);
+        v[m] = t < n ? base[(unsigned)t * stride + col0 + li] * mul : 0.f;
+      }
+    };
+    __syncthreads();                                  // the previous item's phase B has finished with the statistics (and the tiles)
+    if (STAGED) {                                     // 4 tiles x 128 rows x 8 chunks of 16 bytes; q scaled here; rows beyond n zero
+      for (int i = threadIdx.x; i < 4 * ATT_TILED_STAGE * 8; i += 64 * AM_WAVES) {
+        const int tl = i >> 10, r = (i >> 3) & (ATT_TILED_STAGE - 1), ch = i & 7;
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) v4 = tl < 3 ? *reinterpret_cast<const float4*>(qb + (unsigned)r * tq + (unsigned)(tl * p.HD + 4 * ch)) : *reinterpret_cast<const float4*>(gb + (unsigned)r * to + 4 * ch);
+        if (tl == 0) { v4.x *= p.scale; v4.y *= p.scale; v4.z *= p.scale; v4.w *= p.scale; }
+        *reinterpret_cast<float4*>(Stg + (tl * ATT_TILED_STAGE + r) * ATT_TILED_TS + 4 * ch) = v4;
+      }
+      __syncthreads();
+    }
+    // ------------------------------------------------------------------ phase A
+#pragma unroll 1
+    for (int it = wave; it < ntile; it += AM_WAVES) {
+      const int qi = 32 * it + li;
+      float qs[16], gs[16];
+      row16(qb, tq, qi, 0, p.scale, qs);
+      row16(gb, to, qi, 0, 1.0f, gs);
+      float delta = 0.f;
+      {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                 // (the forward output: always from global memory)
+          const float4 o4 = qi < n ? *reinterpret_cast<const float4*>(ob + (unsigned)qi * to + 8 * c + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+          delta = fmaf(gs[4 * c], o4.x, delta); delta = fmaf(gs[4 * c + 1], o4.y, delta);
+          delta = fmaf(gs[4 * c + 2], o4.z, delta); delta = fmaf(gs[4 * c + 3], o4.w, delta);
+        }
+        delta += __shfl_xor(delta, 32);
+      }
+      float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll 1
+      for (int jt = 0; jt < ntile; ++jt) {
+        float ks[16];
+        row16(qb, tq, 32 * jt + li, p.HD, 1.0f, ks);
+        f32x16 sT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sT[e] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[m], qs[m], sT, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = 32 * jt + am_key(e, hh) < n ? sT[e] : -INFINITY;
+          sT[e] = v;
+          mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        float l = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) l += expf(sT[e] - m_new);
+        l += __shfl_xor(l, 32);
+        l_run = l_run * expf(m_run - m_new) + l;
+        m_run = m_new;
+      }
+      const float inv_l = 1.0f / l_run;
+      f32x16 dqT;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dqT[e] = 0.f;
+#pragma unroll 1
+      for (int jt = 0; jt < ntile; ++jt) {
+        f32x16 sT, dpT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sT[e] = 0.f; dpT[e] = 0.f; }
+        {
+          float ks[16], vs[16];
+          row16(qb, tq, 32 * jt + li, p.HD, 1.0f, ks);
+          row16(qb, tq, 32 * jt + li, 2 * p.HD, 1.0f, vs);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[m], qs[m], sT, 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) dpT = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[m], gs[m], dpT, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = 32 * jt + am_key(e, hh) < n ? expf(sT[e] - m_run) * inv_l : 0.f;
+          sT[e] = pe * (dpT[e] - delta);              // dS^T
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          float kc[16];
+          col16(qb, tq, 32 * jt, p.HD, 1.0f, kc);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) dqT = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[m], sT[m], dqT, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (qi < n) {
+        float* dr = db + (unsigned)qi * tq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 vv = make_float4(dqT[4 * c] * p.scale, dqT[4 * c + 1] * p.scale, dqT[4 * c + 2] * p.scale, dqT[4 * c + 3] * p.scale);
+          *reinterpret_cast<float4*>(dr + 8 * c + 4 * hh) = vv;
+          am = amax4(am, vv);
+        }
+        if (hh == 0) { Ms[qi] = m_run; Ls[qi] = inv_l; Dl[qi] = delta; }
+      }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase B
+#pragma unroll 1
+    for (int jt = wave; jt < ntile; jt += AM_WAVES) {
+      const int kj = 32 * jt + li;
+      float kb[16], vb[16];
+      row16(qb, tq, kj, p.HD, 1.0f, kb);
+      row16(qb, tq, kj, 2 * p.HD, 1.0f, vb);
+      f32x16 dkT, dvT;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { dkT[e] = 0.f; dvT[e] = 0.f; }
+#pragma unroll 1
+      for (int it = 0; it < ntile; ++it) {
+        f32x16 S, dP;
+        {
+          float qa[16], ga[16];
+          row16(qb, tq, 32 * it + li, 0, p.scale, qa);
+          row16(gb, to, 32 * it + li, 0, 1.0f, ga);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { S[e] = 0.f; dP[e] = 0.f; }
+#pragma unroll
+          for (int m = 0; m < 16; ++m) S = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m], kb[m], S, 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) dP = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[m], vb[m], dP, 0, 0, 0);
+        }
+        // rows of S are the queries 32 it + 8 c + 4 hh + (0..3): their statistics, four at a time
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int r0 = 32 * it + 8 * c + 4 * hh;
+          float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), l4 = m4, d4 = m4;
+          if (r0 < n) {                                // (n is a multiple of 4 or the tail rows read statistics nobody wrote: masked below)
+            m4 = *reinterpret_cast<const float4*>(Ms + r0); l4 = *reinterpret_cast<const float4*>(Ls + r0); d4 = *reinterpret_cast<const float4*>(Dl + r0);
+          }
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * c + j;
+            const float pe = r0 + j < n ? expf(S[e] - mm[j]) * ll[j] : 0.f;
+            S[e] = pe;                                 // P
+            dP[e] = pe * (dP[e] - dd[j]);              // dS
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);             // (the column loads stay behind the row operands: registers)
+        {
+          float gc[16];
+          col16(gb, to, 32 * it, 0, 1.0f, gc);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) dvT = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[m], S[m], dvT, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          float qc[16];
+          col16(qb, tq, 32 * it, 0, p.scale, qc);
+#pragma unroll
+          for (int m = 0; m < 16; ++m) dkT = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[m], dP[m], dkT, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kj < n) {
+        float* dr = db + (unsigned)kj * tq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 kk = make_float4(dkT[4 * c], dkT[4 * c + 1], dkT[4 * c + 2], dkT[4 * c + 3]);
+          const float4 vv = make_float4(dvT[4 * c], dvT[4 * c + 1], dvT[4 * c + 2], dvT[4 * c + 3]);
+          *reinterpret_cast<float4*>(dr + p.HD + 8 * c + 4 * hh) = kk;
+          *reinterpret_cast<float4*>(dr + 2 * p.HD + 8 * c + 4 * hh) = vv;
+          am = amax4(amax4(am, kk), vv);
+        }
+      }
+    }
+  }
+  if (p.amax_rec) wave_amax_emit(am, p.amax_rec, (int)blockIdx.x * AM_WAVES + wave);
+}
+
 // element (row j, channel li) of a rotated q / k row, read column-wise (coalesced 128-byte rows): the rotation partner sits in
 // the neighbouring lane
 __device__ __forceinline__ float am_rot_elem(float x, const float* __restrict__ rc, const float* __restrict__ rs, int j, int li, bool ok) {
@@ -1191,6 +1428,16 @@ extern "C" int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const 
     (d->n_tok == 24 && wdno_debug_mode != 44 ? attn_bwd_mfma_kernel<24> : attn_bwd_mfma_kernel<0>)<<<(unsigned)nb, 64 * AM_WAVES, lds2, as_stream(s)>>>(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, part, p);
     rc = wdno_check_launch();
     return (rc || !dbias) ? rc : attn_dbias_reduce(part, nb, dbias, d, s);
+  }
+  // more than 64 tokens without rotation / bias (the mid spatial block): key / query tiles on the exact-fp32 matrix instruction (debug 68: thread per row)
+  if (n > 64 && n <= ATT_TILED_MAXTOK && !rot_cos && !bias && !dbias && out && wdno_debug_mode != 5 && wdno_debug_mode != 68) {
+    int64_t nb = p.n_items;
+    const int64_t cap = 2LL * attn_num_cus();
+    if (nb > cap) nb = cap;
+    p.amax_rec = amax_rec;
+    if (n <= ATT_TILED_STAGE) attn_bwd_mfma_tiled_kernel<true><<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, out, dout, dqkv, p);
+    else attn_bwd_mfma_tiled_kernel<false><<<(unsigned)nb, 64 * AM_WAVES, 0, as_stream(s)>>>(qkv, out, dout, dqkv, p);
+    return wdno_check_launch();
   }
   rc = attn_amax_sweep(attn_bwd_rows(qkv, rot_cos, rot_sin, bias, out, dout, dqkv, part, p, d, s), dqkv, d, p.RW, amax_rec, s);
   return (rc || !dbias) ? rc : attn_dbias_reduce(part, attn_bwd_blocks(d), dbias, d, s);
