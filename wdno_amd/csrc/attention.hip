@@ -1348,7 +1348,7 @@ extern "C" int wdno_attn_fwd_amax(const float* qkv, const float* rot_cos, const 
     attn_fwd_mfma64_launch(qkv, rot_cos, rot_sin, bias, out, p, as_stream(s));
     return wdno_check_launch();
   }
-  if (!rot_cos && !bias && wdno_debug_mode != 5 && wdno_debug_mode != 67) {      // key tiles with an online softmax, one wave per tile of 32 queries (debug 67: thread per row)
+  if (!rot_cos && !bias && wdno_debug_mode != 5 && wdno_debug_mode != 67 && wdno_debug_mode != 69) {      // (debug 69: forward and backward thread per row)      // key tiles with an online softmax, one wave per tile of 32 queries (debug 67: thread per row)
     const int ntile = (d->n_tok + 31) / 32;
     const int64_t nb = attn_grid(p.n_items * ntile, 3, (int64_t)3 * attn_num_cus());
     p.amax_rec = amax_rec;
@@ -1430,7 +1430,7 @@ extern "C" int wdno_attn_bwd_amax(const float* qkv, const float* rot_cos, const 
     return (rc || !dbias) ? rc : attn_dbias_reduce(part, nb, dbias, d, s);
   }
   // more than 64 tokens without rotation / bias (the mid spatial block): key / query tiles on the exact-fp32 matrix instruction (debug 68: thread per row)
-  if (n > 64 && n <= ATT_TILED_MAXTOK && !rot_cos && !bias && !dbias && out && wdno_debug_mode != 5 && wdno_debug_mode != 68) {
+  if (n > 64 && n <= ATT_TILED_MAXTOK && !rot_cos && !bias && !dbias && out && wdno_debug_mode != 5 && wdno_debug_mode != 68 && wdno_debug_mode != 69) {
     int64_t nb = p.n_items;
     const int64_t cap = 2LL * attn_num_cus();
     if (nb > cap) nb = cap;
