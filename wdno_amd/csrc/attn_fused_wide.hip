@@ -5,8 +5,8 @@
 //
 // These levels are small (3 200 sequences at 20 x 20, 800 at 10 x 10) and ran layer by layer as LayerNorm -> to_qkv -> attention -> to_out,
 // four launches of 10-50 us that each wait for the one before. What differs from the 64-channel kernel: the head's 96 rows of W_qkv no longer
-// fit the register file (96 x C halves x 2 planes per wave), so the weight fragments are STREAMED from L2 per sequence, the fragments of
-// k-step pair t + 1 requested while the matrix instructions of pair t run. They are packed in FRAGMENT ORDER (pack modes 10 / 11 of
+// fit the register file (96 x C halves x 2 planes per wave), so the weight fragments are STREAMED from L2 per sequence, two k-step pairs per
+// trip: requested, waited for in full, consumed (attn_fused.h: why not overlapped). They are packed in FRAGMENT ORDER (pack modes 10 / 11 of
 // csrc/conv_h3.hip): the 64 lanes of one operand load read 1 KB of contiguous memory. Read from the row-major [384][C] operand the same
 // instruction touches 32 rows = 64 half-used cache lines, and the kernel is bound by the address / tag rate of the CU's one vector cache:
 // measured 132 -> 85 us at [8,24,20,20,128], 77 -> 46 us at [8,24,10,10,256], 42 -> 28 us at [8,24,10,10,128] (layer by layer: 153 / 74 /

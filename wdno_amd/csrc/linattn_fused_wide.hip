@@ -8,7 +8,8 @@
 //
 // with what attn_fused_wide.hip changes for the wider levels: the head's weight rows no longer fit the register file, so the fragments
 // of to_qkv / to_out are STREAMED per tile from the fragment-ordered operands (pack modes 10 / 11 of csrc/conv_h3.hip: one load instruction
-// = 1 KB of contiguous memory), two fragment sets in flight, k-step pair t of lane half hh = channels 32 t + 16 hh .. + 15; and to_out
+// = 1 KB of contiguous memory), two fragment sets per trip (requested, waited for in full, consumed: attn_fused.h), k-step pair t of lane half
+// hh = channels 32 t + 16 hh .. + 15; and to_out
 // contracts over all 128 features per wave (wave w = output channels w C/4 ..) from (hi, lo) planes of the four heads' out tiles in LDS
 // under ONE scale (scale x max|ctx| over the heads of the frame) instead of summing per-head partial tiles.
 #include "linattn_fused.h"
