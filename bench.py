@@ -44,14 +44,15 @@ def _trees():
             sys.path.insert(0, p)
 
 
-def build_model(device, batch=8):
-    """The smoke base model exactly as smoke/train_2d.py:94-121 builds it."""
+def build_model(device, batch=8, channels=42):
+    """The smoke base model exactly as smoke/train_2d.py:94-121 builds it. channels = 42: the reference's five fields (5 x 8 sub-bands + initial
+    density + smoke-out); 34: BASELINE's four synthetic fields [B, 4, 32, 64, 64] (smoke/ddpm/utils.py:62-63's rule scaled: 4 x 8 + 2)."""
     _trees()
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     from ddpm.diffusion_2d import GaussianDiffusion
     torch.manual_seed(0)                      # identical replicas on every rank
-    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
-    rescaler = torch.linspace(1.0, 22.0, 42).reshape(1, 1, 42, 1, 1)     # stand-in for data_2d.py:143-147 (only its mean matters)
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=channels)
+    rescaler = torch.linspace(1.0, 22.0, channels).reshape(1, 1, channels, 1, 1)     # stand-in for data_2d.py:143-147 (only its mean matters)
     dif = GaussianDiffusion(net, rescaler, True, True, True, False, 'bior1.3', 'zero', (18, 34, 34), (32, 64, 64),
                             image_size=40, frames=24, timesteps=1000, sampling_timesteps=250, loss_type='l2')
     return dif.to(device)
@@ -105,9 +106,10 @@ def _median(v):
 
 
 def cpu_baseline(budget_s=30.0):
-    """The oracle (CPU restatement of the reference's path, torch fp32 / numpy on the host cores) on bounded samples of the same
-    workloads: train step and p_sample step of both models, and the four wavelet transforms. One warm-up,
-    then >= 3 timed iterations (median) where the budget allows."""
+    """The oracle (CPU restatement of the reference's path, torch fp32 / numpy on the host cores) timed on the GPU box's host: the training
+    step and the p_sample step of both models AT THE BENCH BATCH (smoke 8, Burgers 16) where one such step fits what is left of the budget --
+    a warm-up at batch 1 (smoke) / 4 (Burgers) pages the code in and predicts the cost -- and the four wavelet transforms (BASELINE.md
+    section 3). A leg that cannot afford its real batch is timed on the small batch, scaled, and its key says `..._extrapolated`."""
     from oracle import diffusion_ref as D, unet_ref as U, dwt_ref as R
     import numpy as np
     _trees()
@@ -116,18 +118,29 @@ def cpu_baseline(budget_s=30.0):
     torch.set_num_threads(cores)
     t_begin = time.perf_counter()
     out = {'cores': cores, 'cpu_model': _cpu_model(), 'kind': 'port'}
+    left = lambda: budget_s - (time.perf_counter() - t_begin)
 
-    def timed(fn, n=3, warm=1):
-        for _ in range(warm):
-            fn()
-        ts = []
-        for _ in range(n):
-            t0 = time.perf_counter()
-            fn()
-            ts.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_begin > budget_s:
-                break
-        return _median(ts), len(ts)
+    def once(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    def leg(name, make, small, full, share):
+        """make(batch) -> a callable running one step at that batch. One step at `small` (warm-up, untimed), one more (timed: the prediction),
+        then one at `full` if `share` of the remaining budget covers the predicted cost."""
+        f_small = make(small)
+        once(f_small)
+        s_small = once(f_small)
+        predicted = s_small * full / small
+        if predicted <= share * max(left(), 0.0):
+            f_full = make(full)
+            s_full = once(f_full)
+            out[name] = {'batch': full, 'seconds_per_step': round(s_full, 3), 'steps_per_sec': round(1.0 / s_full, 4), 'iters': 1,
+                         'warmup': f'2 steps at batch {small} ({s_small:.2f} s the second)'}
+            return out[name]['steps_per_sec'], False
+        out[name + '_extrapolated'] = {'batch': small, 'seconds_per_step_at_that_batch': round(s_small, 3), f'steps_per_sec_at_batch{full}_extrapolated': round(1.0 / predicted, 4),
+                                       'iters': 1, 'note': f'one step at batch {full} was predicted at {predicted:.1f} s, more than this leg\'s share of the {budget_s:.0f} s budget'}
+        return round(1.0 / predicted, 4), True
 
     # ---- smoke
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
@@ -139,24 +152,30 @@ def cpu_baseline(budget_s=30.0):
     lw = torch.linspace(1.0, 22.0, 42).reshape(1, 1, 42, 1, 1)
     model = lambda x, t: U.unet3d_forward(sd, x, t, dim=64, dim_mults=(1, 2, 4), groups=8)
     g = torch.Generator().manual_seed(1)
-    x0 = torch.randn(1, 24, 42, 40, 40, generator=g) * 0.5
-    noise = torch.randn(1, 24, 42, 40, 40, generator=g)
-    t = torch.randint(0, 1000, (1,), generator=g)
 
-    def smoke_train():
-        loss = D.smoke_p_losses(model, buf, x0, t, noise, padded_shape=(18, 34, 34), loss_layer_weight=lw)
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
+    def smoke_train(b):
+        x0 = torch.randn(b, 24, 42, 40, 40, generator=g) * 0.5
+        noise = torch.randn(b, 24, 42, 40, 40, generator=g)
+        t = torch.randint(0, 1000, (b,), generator=g)
 
-    def smoke_sample():
-        with torch.no_grad():
-            D.smoke_p_sample(model, buf, x0, 500, noise)
-    s, n = timed(smoke_train)
-    out['smoke_train_step'] = {'seconds_per_sample': round(s, 3), 'iters': n, 'steps_per_sec_at_batch8': round(1.0 / (8 * s), 4), 'batch': 1}
-    s2, n = timed(smoke_sample)
-    out['smoke_p_sample_step'] = {'seconds_per_sample': round(s2, 3), 'iters': n, 'steps_per_sec_at_batch8': round(1.0 / (8 * s2), 4), 'batch': 1}
+        def step():
+            loss = D.smoke_p_losses(model, buf, x0, t, noise, padded_shape=(18, 34, 34), loss_layer_weight=lw)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+        return step
+
+    def smoke_sample(b):
+        x0 = torch.randn(b, 24, 42, 40, 40, generator=g) * 0.5
+        noise = torch.randn(b, 24, 42, 40, 40, generator=g)
+
+        def step():
+            with torch.no_grad():
+                D.smoke_p_sample(model, buf, x0, 500, noise)
+        return step
+    value, extrapolated = leg('smoke_train_step', smoke_train, 1, 8, 0.55)
+    leg('smoke_p_sample_step', smoke_sample, 1, 8, 0.45)
     del sd, params, opt, net
 
     # ---- Burgers
@@ -167,30 +186,36 @@ def cpu_baseline(budget_s=30.0):
     optb = torch.optim.Adam(pb, lr=1e-4, betas=(0.9, 0.99))
     bufb = D.make_buffers('cosine', 1000)
     modelb = lambda x, t: U.unet2d_forward(sdb, x, t, dim=128, dim_mults=(1, 2, 4, 8), groups=1)
-    xb = torch.randn(4, 9, 64, 64, generator=g) * 0.5
-    nb = torch.randn(4, 9, 64, 64, generator=g)
-    tb = torch.randint(0, 1000, (4,), generator=g)
     flags = dict(pad=True, u0=True, uT=False, f=True)
 
-    def burgers_train():
-        loss = D.burgers_p_losses(modelb, bufb, xb, tb, nb, padded_shape=[41, 60], loss_layer_weight=torch.ones(1, 9, 1, 1), flags=flags)
-        optb.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(pb, 1.0)
-        optb.step()
+    def burgers_train(b):
+        xb = torch.randn(b, 9, 64, 64, generator=g) * 0.5
+        nb = torch.randn(b, 9, 64, 64, generator=g)
+        tb = torch.randint(0, 1000, (b,), generator=g)
 
-    def burgers_sample():
-        with torch.no_grad():
-            tt = torch.full((4,), 500, dtype=torch.long)
-            _, xs = D.burgers_model_predictions(modelb, bufb, xb, tt)
-            D.posterior_step(bufb, xb, 500, xs.clamp(-1., 1.), nb)
-    s, n = timed(burgers_train)
-    out['burgers_train_step'] = {'seconds_per_batch4': round(s, 3), 'iters': n, 'steps_per_sec_at_batch16': round(1.0 / (4 * s), 4), 'batch': 4}
-    s, n = timed(burgers_sample)
-    out['burgers_p_sample_step'] = {'seconds_per_batch4': round(s, 3), 'iters': n, 'steps_per_sec_at_batch16': round(1.0 / (4 * s), 4), 'batch': 4}
+        def step():
+            loss = D.burgers_p_losses(modelb, bufb, xb, tb, nb, padded_shape=[41, 60], loss_layer_weight=torch.ones(1, 9, 1, 1), flags=flags)
+            optb.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(pb, 1.0)
+            optb.step()
+        return step
+
+    def burgers_sample(b):
+        xb = torch.randn(b, 9, 64, 64, generator=g) * 0.5
+        nb = torch.randn(b, 9, 64, 64, generator=g)
+
+        def step():
+            with torch.no_grad():
+                tt = torch.full((b,), 500, dtype=torch.long)
+                _, xs = D.burgers_model_predictions(modelb, bufb, xb, tt)
+                D.posterior_step(bufb, xb, 500, xs.clamp(-1., 1.), nb)
+        return step
+    leg('burgers_train_step', burgers_train, 4, 16, 0.6)
+    leg('burgers_p_sample_step', burgers_sample, 4, 16, 0.6)
     del sdb, pb, optb, netb
 
-    # ---- wavelet transforms (numpy restatement), 1/8 of the synthetic batch, scaled
+    # ---- wavelet transforms (numpy restatement, 1 thread), 1/8 of the synthetic batch: scaled, and named so
     x2 = np.random.default_rng(0).standard_normal((8, 2, 160, 128)).astype(np.float32)
     x3 = np.random.default_rng(1).standard_normal((4, 32, 64, 64)).astype(np.float32)
     yl, yh = R.dwt2(x2, 'bior2.4', 'periodization')
@@ -199,15 +224,17 @@ def cpu_baseline(budget_s=30.0):
                                    ('dwt2_inv', lambda: R.idwt2(yl, yh, 'bior2.4', 'periodization'), 8, 20.97e6),
                                    ('dwt3_fwd', lambda: R.dwt3(x3, 'bior1.3'), 8, 38.08e6),
                                    ('dwt3_inv', lambda: R.idwt3(lll, det, 'bior1.3'), 8, 38.08e6)):
-        s, n = timed(fn, n=3, warm=1)
-        out[key] = {'ms_full_shape': round(s * scale * 1e3, 2), 'GB/s': round(nbytes / (s * scale) / 1e9, 3), 'iters': n, 'threads': 1}
+        once(fn)
+        s_ = _median([once(fn) for _ in range(3)])
+        out[key + '_extrapolated'] = {'ms_full_shape_extrapolated': round(s_ * scale * 1e3, 2), 'GB/s': round(nbytes / (s_ * scale) / 1e9, 3), 'iters': 3, 'threads': 1,
+                                      'sample': f'1/{scale} of the synthetic batch'}
     out['seconds_total'] = round(time.perf_counter() - t_begin, 1)
     # the JSON contract's required keys: the baseline of the main metric
-    s = out['smoke_train_step']['seconds_per_sample']
-    out.update(value=round(1.0 / (8 * s), 4), unit='steps/s (8-sample steps)',
-               sample=f'oracle/ (CPU restatement, torch fp32) on {cores} of {os.cpu_count()} hardware threads of {out["cpu_model"]} (torch CPU convolutions regress beyond ~32): median of '
-                      f'{out["smoke_train_step"]["iters"]} training steps at batch 1 of the same [24,42,40,40] workload after one warm-up, '
-                      f'{s:.2f} s per sample; value = 1 / (8 x that). Other entries: p_sample step, the Burgers model at batch 4, and the numpy DWT oracle on 1/8 of the synthetic batch (1 thread).')
+    how = (f'ONE training step at the bench batch [8,24,42,40,40] (q_sample + conditioning, U-Net forward, loss, backward, clip, Adam) after two warm-up steps at batch 1'
+           if not extrapolated else 'one training step at batch 1, scaled to 8 samples (EXTRAPOLATED: the batch-8 step did not fit the budget)')
+    out.update(value=value, unit='steps/s (8-sample steps)', extrapolated=extrapolated,
+               sample=f'oracle/ (CPU restatement, torch fp32) on {cores} of {os.cpu_count()} hardware threads of {out["cpu_model"]} (torch CPU convolutions regress beyond ~32): '
+                      + how + '. Other entries: the p_sample step, the Burgers model at batch 16, the numpy DWT oracle on 1/8 of the synthetic batch (1 thread); keys that end in _extrapolated were scaled.')
     return out
 
 
@@ -425,12 +452,26 @@ def burgers_leg(device, batch, steps, lowp=None, grid=(64, 64)):
         x = (torch.randn(batch, 9, gh, gw) * 0.5).to(device)
         for _ in range(3):
             ts.step(x)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss, _ = ts.step(x)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+
+        def rate(fn, n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n, r
+        # launch by launch (~930 launches per step at batch 16: the host enqueue time is about the kernel time, so this number follows the
+        # box's CPU), then the same step replayed from ONE captured HIP graph like the main line (trainer.CapturedStep; bit-identical,
+        # tests/test_gpu_graph.py) -- the Trainers' default and the number that measures the GPU
+        dt_eager, (loss, _) = rate(lambda: ts.step(x), max(3, steps // 2))
+        launch = 'hip_graph_replay'
+        try:
+            ts.capture(x, warmup=1)
+            ts.step(x)
+        except Exception as e:
+            launch, ts._cap = 'launch by launch (capture failed: ' + repr(e)[:120] + ')', None
+            torch.cuda.synchronize()
+        dt, (loss, _) = rate(lambda: ts.step(x), steps)
         pipe = None
         if tuple(grid) != (64, 64):
             fields = torch.randn(batch, 2, 2 * gh, 2 * gw, device=device)
@@ -443,6 +484,8 @@ def burgers_leg(device, batch, steps, lowp=None, grid=(64, 64)):
                 loss, _ = ts.step(burgers_fields_to_state(fields, resc))
             torch.cuda.synchronize()
             pipe = (time.perf_counter() - t0) / steps
+        ts._cap = None
+        from wdno_amd import diffusion_core as K
         with torch.no_grad():
             xs = torch.randn(batch, 9, gh, gw, device=device)
             for t in (500, 499):
@@ -452,9 +495,29 @@ def burgers_leg(device, batch, steps, lowp=None, grid=(64, 64)):
             for i in range(steps):
                 xs = dif.p_sample(xs, 400 - i)[0]
             torch.cuda.synchronize()
+            ds_eager = (time.perf_counter() - t0) / steps
+            # the sampling step as replays of one captured graph (conditions -> U-Net -> posterior update), as diffusion_1d's loops run it
+            shape = (batch, 9, gh, gw)
+            cw = dif.padded_shape[-1]
+            src, desc = dif._sampling_setup(shape, dict(u_init=torch.randn(batch, gh // 2, cw, device=device), f=torch.randn(batch, 4, gh, gw, device=device)))
+            sg = K._step_graph(dif, shape, desc, False, True, device)
+            sg.src.copy_(src)
+            sg.x.copy_(xs)
+            for _ in range(2):
+                sg.graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                sg.t.fill_(400 - i)
+                sg.noise.normal_()
+                sg.graph.replay()
+            torch.cuda.synchronize()
             ds = (time.perf_counter() - t0) / steps
-        out = {'batch': batch, 'tensor': [batch, 9, gh, gw], 'conv_math': ops.CONV_MATH, 'train_ms_per_step': round(dt * 1e3, 2), 'train_steps_per_sec': round(1 / dt, 2),
-               'train_samples_per_sec': round(batch / dt, 1), 'p_sample_ms_per_step': round(ds * 1e3, 2), 'final_loss': float(loss)}
+            K._graph_cache.pop(dif, None)
+        out = {'batch': batch, 'tensor': [batch, 9, gh, gw], 'conv_math': ops.CONV_MATH, 'step_launch': launch,
+               'train_ms_per_step': round(dt * 1e3, 2), 'train_steps_per_sec': round(1 / dt, 2), 'train_samples_per_sec': round(batch / dt, 1),
+               'train_ms_per_step_eager': round(dt_eager * 1e3, 2),
+               'p_sample_ms_per_step': round(ds * 1e3, 2), 'p_sample_ms_per_step_eager': round(ds_eager * 1e3, 2), 'final_loss': float(loss)}
         if pipe is not None:
             out['fields_to_step'] = {'fields': [batch, 2, 2 * gh, 2 * gw], 'ms_per_step': round(pipe * 1e3, 2), 'steps_per_sec': round(1 / pipe, 2),
                                      'note': 'HIP DWT + packing + condition channel + train step, fields resident in HBM'}
@@ -551,6 +614,76 @@ def train_graph_leg(ts, x, steps, cap=None):
     return {'eager': {'host_enqueue_ms_per_step': e_enq, 'ms_per_step': e_ms}, 'graph': {'host_enqueue_ms_per_step': g_enq, 'ms_per_step': g_ms}}
 
 
+def smoke_fields_to_state(fields, rs):
+    """fields [B, nf, 32, 64, 64] resident in HBM -> the training tensor [B, 24, 8 nf + 2, 40, 40] (data_2d.py:156-221): one fused 3-D DWT launch
+    (bior1.3 / zero) for the fields, the 2-D transform of the initial density, the 1-D transform of the smoke-out curve, packing + RESCALER."""
+    from wdno_amd import wavelets as Wv
+    from ddpm.data_2d import pack_smoke_batch
+    b, nf = fields.shape[:2]
+    coef = Wv.dwt_packed(fields.reshape(b * nf, 32, 64, 64), 'bior1.3', 'zero', 3).reshape(b, nf, 8, 18, 34, 34)
+    init_coef = Wv.dwt_packed(fields[:, 0, 0].reshape(b, 1, 64, 64).contiguous(), 'bior1.3', 'zero', 2).reshape(b, 4, 34, 34)
+    so = fields[:, 0].mean((-2, -1))                                       # stand-in for the smoke-out curve [B, 32]
+    lo, hi = Wv.DWT1DForward(J=1, mode='zero', wave='bior1.3')(so.unsqueeze(1).contiguous())
+    smokeout = torch.cat((lo, hi[0]), dim=1)                                # [B, 2, 18]
+    return pack_smoke_batch(coef, init_coef, smokeout, rs)
+
+
+def smoke34_leg(device, batch, steps, sample_steps):
+    """BASELINE's own synthetic tensors through the U-Net (VERDICT r5 missing #4): fields [B, 4, 32, 64, 64] -> HIP DWT + packing ->
+    [B, 24, 34, 40, 40] -> Unet3D_with_Conv3D(dim=64, (1,2,4), channels=34): the training step (graph replay, fields resident in HBM, transform
+    inside the timed step) and the DDPM sampling step (graph replay). 3.0 % less matrix work than the reference-native 42 channels (881.1 vs 908.2
+    GFLOP per sample): the 34 -> 64 stem and the 64 -> 34 head are the only layers that differ."""
+    from wdno_amd import diffusion_core as K
+    from wdno_amd.trainer import TrainStep, multistep_lr
+    from ddpm.data_2d import _RESCALERS
+    dif = build_model(device, batch, channels=34)
+    ts = TrainStep(dif, lr=1e-3, betas=(0.9, 0.99), max_grad_norm=1.0, lr_schedule=multistep_lr, use_ema=True)
+    r42 = torch.tensor(_RESCALERS['bior1.3'], dtype=torch.float32, device=device).reshape(1, 42, 1, 1)
+    r34 = torch.cat((r42[:, :32], r42[:, -2:]), dim=1)
+    fields = torch.randn(batch, 4, 32, 64, 64, device=device)
+    x = smoke_fields_to_state(fields, r34)
+    assert tuple(x.shape) == (batch, 24, 34, 40, 40)
+    for _ in range(3):
+        ts.step(x)
+    launch = 'hip_graph_replay'
+    try:
+        ts.capture(x, warmup=1)
+        ts.step(x)
+    except Exception as e:
+        launch, ts._cap = 'launch by launch (capture failed: ' + repr(e)[:120] + ')', None
+        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = ts.step(smoke_fields_to_state(fields, r34))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ts._cap = None
+    shape = (batch, 24, 34, 40, 40)
+    with torch.no_grad():
+        desc = dif._desc(shape, dif.padded_shape)
+        src = dif._condition_source(shape, device, torch.randn(batch, 24, 40, 40, device=device), torch.randn(batch, 24, 10, 40, 40, device=device), None)
+        sg = K._step_graph(dif, shape, desc, False, False, device)
+        sg.src.copy_(src)
+        sg.x.copy_(K.apply_cond(torch.randn(shape, device=device), src, desc))
+        for _ in range(2):
+            sg.graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(sample_steps):
+            sg.t.fill_(500 - i)
+            sg.noise.normal_()
+            sg.graph.replay()
+        torch.cuda.synchronize()
+        sps = sample_steps / (time.perf_counter() - t0)
+    K._graph_cache.pop(dif, None)
+    gf, gb, par_mb = 881.1, 6.05, 95.2
+    return {'fields': [batch, 4, 32, 64, 64], 'tensor': list(shape), 'channels': 34, 'step_launch': launch, 'train_ms_per_step': round(dt * 1e3, 3),
+            'train_steps_per_sec': round(1 / dt, 2), 'final_loss': float(loss), 'ddpm_sample_steps_per_sec': round(sps, 2),
+            'tflops_algorithmic': round(batch * gf / 1e3 / dt, 1), 'frac_hbm': round((batch * gb + 8 * par_mb / 1e3) / dt / (PEAK_HBM_TBS * 1e3), 4),
+            'note': 'train step = DWT + packing of the fields + q_sample ... Adam + EMA; conditioning predicates at the reference\'s channel positions (C - 2, C - 1, 24:40 clipped to C)'}
+
+
 def smoke_pipeline_leg(ts, device, batch, steps):
     """The smoke pipeline end to end on the GPU: fields [B, 5, 32, 64, 64] (rho, vx, vy, cx, cy) resident in HBM -> ONE fused 3-D HIP DWT
     launch (bior1.3 / zero) -> [B*5, 8, 18, 34, 34] -> pack_smoke_batch (+ init-density and smoke-out condition channels, / RESCALER)
@@ -558,19 +691,10 @@ def smoke_pipeline_leg(ts, device, batch, steps):
     is the reference's (its conditioning predicates sit at fixed channel positions); the north-star's 4-field synthetic tensor
     [B, 4, 32, 64, 64] -> [B, 24, 34, 40, 40] differs in the channel count of the first and last convolution only and is timed through
     the transform + packing as well."""
-    from wdno_amd import wavelets as Wv
-    from ddpm.data_2d import pack_smoke_batch, _RESCALERS
+    from ddpm.data_2d import _RESCALERS
     out = {}
     resc = torch.tensor(_RESCALERS['bior1.3'], dtype=torch.float32, device=device).reshape(1, 42, 1, 1)
-
-    def to_state(fields, rs):
-        b, nf = fields.shape[:2]
-        coef = Wv.dwt_packed(fields.reshape(b * nf, 32, 64, 64), 'bior1.3', 'zero', 3).reshape(b, nf, 8, 18, 34, 34)
-        init_coef = Wv.dwt_packed(fields[:, 0, 0].reshape(b, 1, 64, 64).contiguous(), 'bior1.3', 'zero', 2).reshape(b, 4, 34, 34)
-        so = fields[:, 0].mean((-2, -1))                                       # stand-in for the smoke-out curve [B, 32]
-        lo, hi = Wv.DWT1DForward(J=1, mode='zero', wave='bior1.3')(so.unsqueeze(1).contiguous())
-        smokeout = torch.cat((lo, hi[0]), dim=1)                                # [B, 2, 18]
-        return pack_smoke_batch(coef, init_coef, smokeout, rs)
+    to_state = smoke_fields_to_state
     fields = torch.randn(batch, 5, 32, 64, 64, device=device)
     st = to_state(fields, resc)
     assert tuple(st.shape) == (batch, 24, 42, 40, 40)
@@ -668,7 +792,10 @@ def main():
     ap.add_argument('--eager', action='store_true', help='timed steps launch by launch instead of replaying the captured HIP graph')
     ap.add_argument('--sample-steps', type=int, default=20)
     ap.add_argument('--burgers-grid', default='64x64', help="tensor size of the Burgers workloads: 64x64 (reference-native) or 80x64 (north-star synthetic: fields [B,2,160,128] through the HIP DWT)")
+    ap.add_argument('--max-seconds', type=float, default=float(os.environ.get('WDNO_BENCH_MAX_SECONDS', '1500')),
+                    help='wall-clock guard for the whole run: a SIDE leg is skipped (and named in `skipped_legs`) when its budgeted cost no longer fits; the main line is never dropped')
     args = ap.parse_args()
+    t_run0 = time.perf_counter()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the reference's
@@ -755,7 +882,15 @@ def main():
         ts.step(x)              # rank 0's profiled extra step below contains the gradient all-reduce: every rank has to take part in it
     if rank == 0:
         roofline = conv_roofline(lambda: ts.step(x), ops)
-    if world > 1 and smoke and not args.no_extras:
+    run_multi_side = world > 1 and smoke and not args.no_extras
+    if run_multi_side:
+        # every rank has to take the same decision (the legs end in an all_gather): rank 0's clock decides, broadcast to all
+        flag = torch.tensor([1.0 if (time.perf_counter() - t_run0) + 150 <= args.max_seconds else 0.0], device=device)
+        dist.broadcast(flag, 0)
+        run_multi_side = bool(flag.item() == 1.0)
+        if not run_multi_side and rank == 0:
+            extras['skipped_legs'] = [{'leg': 'sampling + sr_sampling at N > 1', 'budgeted_s': 150, 'elapsed_s': round(time.perf_counter() - t_run0, 1)}]
+    if run_multi_side:
         # The sampling half of the metric at N > 1 (BASELINE configs[3] / [4]): every rank samples its own batch -- the path shards with no
         # collective (smoke/inference_2d.py:123-152, 155-232) -- from loops that start together (barrier); the global rate is what the slowest
         # rank allows: world x min over ranks = samples of all ranks / max-over-ranks time.
@@ -787,37 +922,64 @@ def main():
                                          'per_rank': {'graph_ddim_steps_per_sec': col(3), 'eager_ddim_steps_per_sec': col(2), 'idwt_reconstruction_ms': col(4)},
                                          'fields': sr.get('fields'),
                                          'note': 'BASELINE configs[4]: the global batch shards over the ranks, each replays its captured DDIM step and reconstructs its fields (IDWT); rank-steps/s'}
+    skipped = []
+
+    def fits(name, cost_s):
+        """--max-seconds guard: may a side leg with this budgeted cost (seconds, generous) still start? The main line above is never subject to it."""
+        ok = (time.perf_counter() - t_run0) + cost_s <= args.max_seconds
+        if not ok:
+            skipped.append({'leg': name, 'budgeted_s': cost_s, 'elapsed_s': round(time.perf_counter() - t_run0, 1)})
+        return ok
     if rank == 0:
         if world == 1 and not args.no_extras:
             try:
                 if smoke:
-                    extras['sampling'] = sampling_leg(dif, device, batch, args.sample_steps)
-                    extras['sampling']['wide_attention_ab'] = sampling_wide_ab(dif, device, batch, args.sample_steps)
-                    extras['fields_pipeline'] = smoke_pipeline_leg(ts, device, batch, 10)
-                    extras['train_step_graph'] = train_graph_leg(ts, x, 20, cap)
-                extras['dwt'] = dwt_leg(device)
+                    if fits('sampling', 40):
+                        extras['sampling'] = sampling_leg(dif, device, batch, args.sample_steps)
+                        if fits('sampling.wide_attention_ab', 30):
+                            extras['sampling']['wide_attention_ab'] = sampling_wide_ab(dif, device, batch, args.sample_steps)
+                    if fits('fields_pipeline', 20):
+                        extras['fields_pipeline'] = smoke_pipeline_leg(ts, device, batch, 10)
+                    if fits('train_step_graph', 20):
+                        extras['train_step_graph'] = train_graph_leg(ts, x, 20, cap)
+                if fits('dwt', 15):
+                    extras['dwt'] = dwt_leg(device)
                 if smoke:
                     del ts, dif
                     torch.cuda.empty_cache()
-                    extras['sr_sampling'] = sr_leg(device)
-                    torch.cuda.empty_cache()
-                    if args.workload == 'smoke' and ops.LOWP_AVAILABLE:
+                    if args.workload == 'smoke' and fits('smoke_synthetic_34ch', 40):
+                        extras['smoke_synthetic_34ch'] = smoke34_leg(device, batch, 20, args.sample_steps)
+                        torch.cuda.empty_cache()
+                    if fits('sr_sampling', 60):
+                        extras['sr_sampling'] = sr_leg(device)
+                        torch.cuda.empty_cache()
+                    if args.workload == 'smoke' and ops.LOWP_AVAILABLE and fits('smoke_bf16', 40):
                         extras['smoke_bf16'] = smoke_bf16_leg(device, batch, 20)
                         torch.cuda.empty_cache()
-                    extras['burgers'] = {'fp32_equivalent_batch16': burgers_leg(device, 16, 20),
-                                         'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16') if ops.LOWP_AVAILABLE else 'bf16 path not built',
-                                         'north_star_80x64': {'fp32_equivalent_batch16': burgers_leg(device, 16, 20, grid=(80, 64)),
-                                                              'bf16_batch256': burgers_leg(device, 256, 5, lowp='bf16', grid=(80, 64))}}
-                elif bgrid != (64, 64):
+                    bl = {}
+                    if fits('burgers.fp32_equivalent_batch16', 40):
+                        bl['fp32_equivalent_batch16'] = burgers_leg(device, 16, 20)
+                    if ops.LOWP_AVAILABLE and fits('burgers.bf16_batch256', 60):
+                        bl['bf16_batch256'] = burgers_leg(device, 256, 5, lowp='bf16')
+                    if fits('burgers.north_star_80x64.fp32_equivalent_batch16', 40):
+                        bl.setdefault('north_star_80x64', {})['fp32_equivalent_batch16'] = burgers_leg(device, 16, 20, grid=(80, 64))
+                    if ops.LOWP_AVAILABLE and fits('burgers.north_star_80x64.bf16_batch256', 70):
+                        bl.setdefault('north_star_80x64', {})['bf16_batch256'] = burgers_leg(device, 256, 5, lowp='bf16', grid=(80, 64))
+                    if bl:
+                        extras['burgers'] = bl
+                elif bgrid != (64, 64) and fits('fields_pipeline', 60):
                     extras['fields_pipeline'] = burgers_leg(device, batch, 10, lowp='bf16' if args.workload == 'burgers-bf16' else None, grid=bgrid).get('fields_to_step')
             except Exception as e:      # side legs never invalidate the main line
                 import traceback
                 extras['error'] = repr(e) + ' | ' + traceback.format_exc()[-600:]
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                cpu = cpu_baseline()
-            except Exception as e:      # the baseline is informative only
-                cpu = {'error': repr(e)}
+            if fits('cpu_baseline', 45):
+                try:
+                    cpu = cpu_baseline()
+                except Exception as e:      # the baseline is informative only
+                    cpu = {'error': repr(e)}
+            else:
+                cpu = {'skipped': '--max-seconds'}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -854,8 +1016,12 @@ def main():
                          'bound': 'mfma', 'gflop_per_sample': round(gf, 1), 'GB_per_sample_unfused': round(gb, 3),
                          'note': 'the step is bound by matrix work (about 160 flop per un-fused byte against a ridge of 2500 / 8 = 312 flop/B for ONE '
                                  '16-bit product and 104 flop/B for the 3-product fp32-equivalent split); both fractions are of the whole driver-timed step'}
+        # value = RANK-steps/s: under weak scaling every rank advances its own 8 samples per step, so the whole-job aggregate of the metric's unit is
+        # world x (global optimiser steps/s); global_steps_per_sec is the rate of optimiser steps on the global batch (8 x world samples each)
         out = {
             'metric': metric, 'value': round(world * args.steps / elapsed, 4), 'unit': 'steps/s',
+            'value_definition': f'{batch}-sample rank-steps/s summed over the {world} rank(s) = samples_per_sec / {batch} (weak scaling: the per-GPU batch is fixed)',
+            'global_steps_per_sec': round(args.steps / elapsed, 4), 'global_batch': batch * world,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': wl, 'global_batch': batch * world, 'parallelism': f'dp{world}', 'grad_allreduce_MB': grad_mb if world > 1 else 0,
@@ -872,6 +1038,9 @@ def main():
                                                 extras['sampling'][f'batch{batch}']['graph_steps_per_sec'])
             out['sampling_roofline'] = extras['sampling'].pop('roofline', None)
         out['per_rank'] = per_rank
+        if skipped:
+            extras.setdefault('skipped_legs', []).extend(skipped)
+        out['wall_seconds'] = {'total': round(time.perf_counter() - t_run0, 1), 'max_seconds': args.max_seconds}
         out.update(extras)
         print(json.dumps(out))
     if world > 1:

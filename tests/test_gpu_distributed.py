@@ -157,7 +157,7 @@ def test_two_ranks_one_gpu_smoke_trainer(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ RCCL itself, one rank (round 3)
-def _worker_rccl_one_rank(port, overlap, out, graph=False):
+def _worker_rccl_one_rank(port, overlap, out, graph=False, in_graph=False):
     """A ONE-rank "nccl" (= RCCL) process group on the box's GPU: the exchange is forced (WDNO_DP_FORCE_EXCHANGE), so every
     torch.distributed call of the data-parallel step runs over RCCL -- broadcast of the flat parameter buffer, the async bucket
     all-reduces on RCCL's own stream started from gradient hooks during backward, finish() ordering them against the HIP launch
@@ -194,8 +194,9 @@ def _worker_rccl_one_rank(port, overlap, out, graph=False):
     dist.init_process_group('nccl', rank=0, world_size=1)
     os.environ['WDNO_DP_FORCE_EXCHANGE'] = '1'
     os.environ['WDNO_DP_OVERLAP'] = '1' if overlap else '0'
+    os.environ['WDNO_DP_GRAPH_OVERLAP'] = '1' if in_graph else '0'
     ts1, l1, w1 = run(captured=graph)
-    info = dict(graph=ts1._graph is not None, backend=dist.get_backend(), exchange=ts1.exchange, overlap=ts1.overlap is not None,
+    info = dict(graph=ts1._graph is not None, exchanged=bool(getattr(getattr(ts1, '_cap', None), 'exchanged', False)), backend=dist.get_backend(), exchange=ts1.exchange, overlap=ts1.overlap is not None,
                 buckets=0 if ts1.overlap is None else len(ts1.overlap.bounds), losses_equal=l0 == l1, weights_equal=bool(torch.equal(w0, w1)),
                 finite=bool(torch.isfinite(w1).all()))
     # the plain collectives on device memory as well
@@ -208,18 +209,21 @@ def _worker_rccl_one_rank(port, overlap, out, graph=False):
     torch.save(info, out)
 
 
-@pytest.mark.parametrize('overlap,graph', [(False, False), (True, False), (False, True), (True, True)])
-def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overlap, graph):
-    """graph = True: the step replayed from a captured HIP graph with the RCCL all-reduce between the replay and clip + Adam; overlap AND
-    graph: the four bucket all-reduces are started by the gradient hooks while the backward is being captured and become
-    nodes of the graph -- the replay carries the exchange."""
+@pytest.mark.parametrize('overlap,graph,in_graph', [(False, False, False), (True, False, False), (False, True, False), (True, True, False), (True, True, True)])
+def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overlap, graph, in_graph):
+    """graph = True: the step replayed from a captured HIP graph with the RCCL all-reduce between the replay and clip + Adam. overlap AND
+    graph: by default the graph holds no collective -- one all-reduce of the flat buffer follows every replay; in_graph
+    (WDNO_DP_GRAPH_OVERLAP=1, opt-in): the four bucket all-reduces are started by the gradient hooks while the backward is being captured and
+    become nodes of the graph -- the replay carries the exchange -- and TrainStep.capture has checked one replay against the eager overlapped
+    step bit for bit (_verify_overlap_capture)."""
     out = str(tmp_path / 'rccl.pt')
     ctx = mp.get_context('spawn')
-    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), overlap, out, graph))
+    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), overlap, out, graph, in_graph))
     p.start()
     p.join(300)
     assert p.exitcode == 0, f'worker exit code {p.exitcode}'
     info = torch.load(out)
     print(info)
+    assert info['exchanged'] == in_graph
     assert info['backend'] == 'nccl' and info['exchange'] and info['overlap'] == overlap and (info['buckets'] == 4) == overlap and info['graph'] == graph
     assert info['losses_equal'] and info['weights_equal'] and info['finite'] and info['allreduce_identity']

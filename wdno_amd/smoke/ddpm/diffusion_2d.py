@@ -353,6 +353,10 @@ class Trainer(_TrainerCore):
     i.e. from whichever tree provides it), or -- an extension -- any map-style dataset object yielding
     `(state [F, C, H, W], shape, ori_shape, sim_id)` tuples."""
 
+    mixed_precision_type = None       # None: fp32-equivalent steps; 'bf16': BASELINE configs[1]'s single-product mode for this Trainer's steps
+                                      # (wdno_amd.trainer.conv_math_of). A class attribute: the constructor keeps the reference's parameter list,
+                                      # whose only precision keyword, fp16=True, selects accelerate's fp16 + GradScaler mode (refused, see there)
+
     def __init__(
         self,
         diffusion_model,
@@ -381,14 +385,16 @@ class Trainer(_TrainerCore):
         resume=False,
         resume_step=0,
     ):
-        if amp or fp16:
-            raise ValueError('mixed precision is not part of the fp32 WDNO path (train_2d.py passes amp=False)')
+        # diffusion_2d.py:1093-1098: Accelerator(mixed_precision='fp16' if fp16 else 'no'); `amp` only sets accelerator.native_amp (no effect on
+        # the arithmetic). The reference has no bf16 keyword here: the class attribute `mixed_precision_type` (None / 'bf16') selects the
+        # single-product mode for this Trainer, like `use_graph` / `num_workers` without touching the constructor's parameter list.
         assert has_int_squareroot(num_samples), 'number of samples must have an integer square root'
         schedule = (lambda base, step: _multistep_lr(base, step, (50000, 150000, 300000), 0.1)) if is_schedule else (lambda base, step: base)
         super().__init__(diffusion_model, train_batch_size=train_batch_size, gradient_accumulate_every=gradient_accumulate_every,
                          train_lr=train_lr, train_num_steps=train_num_steps, ema_update_every=ema_update_every, ema_decay=ema_decay,
                          adam_betas=adam_betas, save_and_sample_every=save_and_sample_every, split_batches=split_batches,
-                         max_grad_norm=1.0, results_dir=results_path, lr_schedule=schedule)
+                         max_grad_norm=1.0, results_dir=results_path, lr_schedule=schedule,
+                         mixed_precision='fp16' if fp16 else (self.mixed_precision_type or 'no'))
         self.dataset = dataset
         self.num_samples = num_samples
         self.image_size = diffusion_model.image_size

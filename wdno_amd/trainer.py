@@ -398,6 +398,41 @@ def multistep_lr(base_lr, step, milestones=(50000, 150000, 300000), gamma=0.1):
     return base_lr * gamma ** sum(1 for m in milestones if step >= m)
 
 
+def conv_math_of(mixed_precision):
+    """accelerate's `mixed_precision` keyword -- what the reference Trainers build from `amp` / `mixed_precision_type` (train_diffusion.py:61-62,
+    71-74) and `fp16` (diffusion_2d.py:1093-1098) -- -> the convolution arithmetic of wdno_amd.ops for the training step.
+      'no'   : the process default (ops.CONV_MATH: the fp32-equivalent 3 x fp16 split; WDNO_CONV_MATH overrides);
+      'bf16' : BASELINE configs[1] -- ONE bf16 plane per operand on v_mfma_f32_32x32x16_bf16, fp32 master weights, accumulators, norms, softmax
+               and optimiser (what autocast(bfloat16) + fp32 Adam amounts to; tolerances: tests/test_gpu_bf16.py);
+      'fp16' : refused. accelerate's fp16 mode is autocast(float16) + a GradScaler whose dynamic loss scale (skipped steps on overflow, growth
+               every 2000 steps) is part of the training trajectory; there is no single-plane fp16 kernel family here (one fp16 plane needs the
+               per-tensor scale of the split path AND loss scaling for the gradients) -- use 'bf16', which needs neither."""
+    mp = 'no' if mixed_precision in (None, False, 'no') else str(mixed_precision)
+    if mp == 'no':
+        return ops.CONV_MATH
+    if mp == 'bf16':
+        if not ops.LOWP_AVAILABLE:
+            raise RuntimeError('wdno_amd: the single-product bf16 kernels are not in this build')
+        return 'bf16'
+    if mp == 'fp16':
+        raise ValueError("wdno_amd Trainer: mixed_precision 'fp16' (autocast(float16) + GradScaler) is not built on MI355X -- pass "
+                         "mixed_precision_type='bf16' (Burgers: Trainer(amp=True, mixed_precision_type='bf16'); smoke: Trainer.mixed_precision_type = 'bf16'): "
+                         'one bf16 plane per operand needs no loss scaling')
+    raise ValueError(f'wdno_amd Trainer: unknown mixed_precision {mixed_precision!r}')
+
+
+def is_capture_failure(err):
+    """Is `err` a failure of HIP stream capture itself (survivable: the same step runs launch by launch) rather than an error of the step
+    being captured? Out-of-memory for the graph's private pool, and RuntimeErrors that name the capture: HIP's
+    hipErrorStreamCapture{Unsupported, Invalidated, ...} ("operation not permitted when stream is capturing"), torch's own capture checks."""
+    if isinstance(err, torch.cuda.OutOfMemoryError):
+        return True
+    if not isinstance(err, RuntimeError):
+        return False
+    msg = str(err).lower()
+    return 'captur' in msg or 'hipgraph' in msg or 'cudagraph' in msg
+
+
 class CapturedStep:
     """loss -> backward -> gradient gather of `diffusion.p_losses` on static inputs, captured once in a HIP graph (ops.graph_capture) and
     replayed per step. Shared by TrainStep.capture and the drop-in Trainers (TrainerCore.use_graph). What a capture needs (each item
@@ -519,18 +554,44 @@ class TrainStep:
         consume the generator identically), the gradient exchange (RCCL) and clip + Adam (two launches whose learning rate and step
         count are host scalars). Runs `warmup` eager optimisation steps on the example first: packed weight operands, pixel tables
         and the gradient-coverage check have to exist before a capture."""
-        if self.overlap is not None and os.environ.get('WDNO_DP_GRAPH_OVERLAP', '1') == '0':
-            raise RuntimeError('wdno_amd TrainStep.capture: WDNO_DP_GRAPH_OVERLAP=0 -- the overlapped bucket exchange is not to be captured; use WDNO_DP_OVERLAP=0')
-        if self.overlap is not None and dist.get_backend(self.group) != 'nccl':
+        # The overlapped bucket exchange INSIDE the graph is opt-in (WDNO_DP_GRAPH_OVERLAP=1, RCCL only): it has run on a one-rank RCCL group
+        # only (no multi-GPU node in any round), and a mis-ordered fork / join of RCCL's stream under capture would leave gradients
+        # un-reduced without an error. Default: the graph holds loss -> backward -> gather, and ONE all-reduce of the flat buffer follows
+        # every replay (_step_graph) -- the hooks of OverlappedAllReduce stay inactive (begin() is not called). Opted in, the capture is
+        # checked once against an eager overlapped step on the same inputs (_verify_overlap_capture) and dropped on any differing bit.
+        in_graph = self.overlap is not None and os.environ.get('WDNO_DP_GRAPH_OVERLAP', '0') == '1'
+        if in_graph and dist.get_backend(self.group) != 'nccl':
             raise RuntimeError('wdno_amd TrainStep.capture: only RCCL collectives can be recorded in a HIP graph (backend '
-                               f'{dist.get_backend(self.group)!r} synchronises with the host); the overlapped exchange stays launch by launch')
+                               f'{dist.get_backend(self.group)!r} synchronises with the host); unset WDNO_DP_GRAPH_OVERLAP')
         for _ in range(max(1, warmup)):
             self.step(example_batch)
-        # With the overlapped bucket exchange the hooks run while the backward is being captured: the async all-reduces they start are recorded
+        # With the exchange in the graph the hooks run while the backward is being captured: the async all-reduces they start are recorded
         # as graph nodes on RCCL's stream (forked from / joined to the capturing stream), so a replay overlaps them with the rest of the backward
         # like the eager step does. A capture that RCCL refuses raises here; callers fall back to launch-by-launch steps (bench.py does).
-        self._cap = CapturedStep(self.model, self.opt.buf, example_batch, overlap=self.overlap)
+        self._cap = CapturedStep(self.model, self.opt.buf, example_batch, overlap=self.overlap if in_graph else None)
+        if in_graph and not self._verify_overlap_capture():
+            import warnings
+            warnings.warn('wdno_amd TrainStep.capture: a replay of the graph that holds the overlapped bucket all-reduces did not return the bits of the '
+                          'eager overlapped step; the exchange stays outside the graph (one all-reduce after every replay)')
+            self._cap = CapturedStep(self.model, self.opt.buf, example_batch, overlap=None)
         return self
+
+    def _verify_overlap_capture(self):
+        """One replay of the captured step (bucket all-reduces inside the graph) against the eager overlapped step on the SAME static inputs:
+        the reduced flat gradients must agree bit for bit on every rank (same kernels, same order, RCCL's reduction order is fixed by the
+        communicator). All ranks take the same decision (the verdict is min-reduced)."""
+        cap, buf = self._cap, self.opt.buf
+        cap.graph.replay()
+        buf._gathered = True
+        got = buf.flat_grad.clone()
+        self.opt.zero_grad()
+        loss = self.model.p_losses(cap.x, cap.t, noise=cap.noise)
+        self._backward_and_exchange(loss)
+        ok = torch.tensor([1.0 if torch.equal(got, buf.flat_grad) else 0.0], device=got.device)
+        if self.world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        self.opt.zero_grad()
+        return bool(ok.item() == 1.0)
 
     @property
     def _graph(self):
@@ -716,10 +777,11 @@ class TrainerCore:
     (RCCL): if a process group is initialised (torchrun) the flat gradient is all-reduced once per step."""
 
     def __init__(self, diffusion_model, *, train_batch_size, gradient_accumulate_every, train_lr, train_num_steps, ema_update_every,
-                 ema_decay, adam_betas, save_and_sample_every, split_batches, max_grad_norm, lr_schedule, results_dir):
+                 ema_decay, adam_betas, save_and_sample_every, split_batches, max_grad_norm, lr_schedule, results_dir, mixed_precision='no'):
         from pathlib import Path
         if not torch.cuda.is_available():
             raise RuntimeError('wdno_amd Trainer needs an MI355X (no CPU fallback on the hot path)')
+        self.conv_math = conv_math_of(mixed_precision)           # the arithmetic of THIS trainer's steps (forward, backward, captured graph)
         self.rank, self.world, local = init_distributed()          # torchrun: set_device(LOCAL_RANK) + RCCL process group
         self._device = torch.device('cuda', local)
         self.model = diffusion_model.to(self._device)
@@ -771,7 +833,13 @@ class TrainerCore:
                                 # Bit-identical to the launch-by-launch step (tests/test_gpu_trainer.py); False: every step launch by launch.
 
     def optimisation_step(self, next_batch):
-        """next_batch() -> device tensor. Returns the python float loss of this rank (the reference logs it per rank)."""
+        """next_batch() -> device tensor. Returns the python float loss of this rank (the reference logs it per rank). Runs under this
+        trainer's arithmetic (conv_math_of): like accelerate's autocast around `self.model(data)` (train_diffusion.py:205-208), the mode covers
+        the training step only -- sampling from the EMA copy between steps stays fp32-equivalent."""
+        with ops._math(self.conv_math):
+            return self._optimisation_step(next_batch)
+
+    def _optimisation_step(self, next_batch):
         total = None
         if self.use_graph and self.gradient_accumulate_every == 1:
             batch = next_batch()
@@ -801,15 +869,23 @@ class TrainerCore:
                 self._caps.pop(next(iter(self._caps)))
             try:
                 self._caps[tuple(batch.shape)] = CapturedStep(self.model, self.opt.buf, batch)
-            except Exception as e:                           # an op that is illegal under capture, a host sync, no memory for the private pool:
-                self._capture_failed(e)                      # the run continues launch by launch, as it did before graphs were the default
+            except Exception as e:
+                # Only failures OF THE CAPTURE are survivable (an op that is illegal under stream capture, a host sync, no memory for the
+                # private pool): the run continues launch by launch, as it did before graphs were the default. Anything else raised by the
+                # captured forward / backward -- a shape error, the GroupNorm parameter-epoch guard, a WDNO_E* library error -- is a bug that
+                # the eager step would hit as well and is re-raised; WDNO_STRICT_GRAPH=1 re-raises capture failures too (tests).
+                if not is_capture_failure(e) or os.environ.get('WDNO_STRICT_GRAPH', '0') == '1':
+                    self._capture_failed(e, warn=False)
+                    raise
+                self._capture_failed(e)
         return total
 
-    def _capture_failed(self, err):
+    def _capture_failed(self, err, warn=True):
         import gc
         import warnings
-        warnings.warn(f'wdno_amd Trainer: capturing the training step in a HIP graph failed ({err!r:.300}); continuing launch by launch '
-                      '(use_graph = False for this trainer)')
+        if warn:
+            warnings.warn(f'wdno_amd Trainer: capturing the training step in a HIP graph failed ({err!r:.300}); continuing launch by launch '
+                          '(use_graph = False for this trainer)')
         self.use_graph = False
         self._caps.clear()                                   # frees the private pools and operand snapshots of the captures made so far
         ops._CAPTURE = None
