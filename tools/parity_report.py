@@ -143,7 +143,7 @@ def _grad_table(named_hip, ref32, ref64):
     return {'n_params': len(rows), 'hip_vs_cpu32': stat(1), 'hip_vs_exact': stat(2), 'cpu32_vs_exact': stat(3)}
 
 
-def smoke_full(batch=2, frames=24, size=40, modes=('f16x3', 'f32'), channels=channels):
+def smoke_full(batch=2, frames=24, size=40, modes=('f16x3', 'f32'), channels=42):
     """channels: 42 = the reference's five fields (8 sub-bands each + initial density + smoke-out); 34 = BASELINE's four synthetic fields
     (smoke/ddpm/utils.py:62-63 scaled to 4 fields: 4 x 8 + 2). The conditioning predicates keep the reference's channel positions (C - 2, C - 1, 24:40
     clipped to C), in the oracle and in csrc/diffusion.hip alike."""
