@@ -182,6 +182,24 @@ int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float* sx, const
 int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
                                 const void* pixel_table, float* dw, int Kn, int Cn, void* ws, size_t ws_bytes,
                                 const wdno_conv_geom* g, wdno_stream_t s);
+/* The same weight gradient in two steps, for callers that collect the split reductions of a whole backward pass (autograd through every
+ * nn.Conv*d of the U-Nets, unet.py:129-259 / conv3d.py:189-230: only the optimiser reads a weight gradient): wdno_conv_wgrad_partials runs the
+ * partial-sum kernels into ws ([splits][kd*kh][K8][kw*C8]) and fills `item`; wdno_wgrad_reduce_multi then performs the ordered reductions of any
+ * number of items in one launch (items travel by value in the kernel arguments: no table upload, capturable in a HIP graph) -- the same additions
+ * in the same order as wdno_conv_wgrad_f16x3_param / _bf16_param, i.e. bit-identical results. ws must stay alive and unmodified in between.
+ * xl == NULL (and sx == sdy == NULL): single bf16 planes. `items` is a HOST array. */
+#define WDNO_WGRAD_REDUCE_MAX 64
+typedef struct wdno_wgrad_reduce_item {
+  const float* ws; float* dw;      /* partial sums [splits][n]; destination in the parameter's layout dw[Kn][Cn][kd][kh][kw] */
+  int n, splits;                   /* n = kd*kh*K8*kw*C8 */
+  int K8, C8, kw, ntap, Kn, Cn;
+  int tiled;                       /* which of the two reduction bodies (chosen by the library) */
+  int reserved;
+} wdno_wgrad_reduce_item;
+int wdno_conv_wgrad_partials(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                             const void* pixel_table, float* dw, int Kn, int Cn, void* ws, size_t ws_bytes,
+                             const wdno_conv_geom* g, wdno_wgrad_reduce_item* item, wdno_stream_t s);
+int wdno_wgrad_reduce_multi(const wdno_wgrad_reduce_item* items, int n_items, wdno_stream_t s);
 /* dwp[kd][kh][K][kw*C] = sum over output pixels of dy (x) shifted x. ws: caller workspace. */
 size_t wdno_conv_wgrad_ws_bytes(const wdno_conv_geom* g);
 int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_t ws_bytes,

@@ -235,6 +235,10 @@ CONV_CASES_TAP = [
     ('tap_3d_w2', (1, 32, 3, 4, 2), (32, 32, 3, 3, 3), 1, 1),              # both W-neighbours missing somewhere in every row
     ('tap_3d_multi', (8, 64, 6, 40, 40), (64, 64, 3, 3, 3), 1, 1),         # 300 tiles: persistent blocks prefetch across tile boundaries
     ('tap_3d_multi_wide', (4, 128, 6, 20, 20), (192, 128, 3, 3, 3), 1, 1),
+    # round 6, split-pair items of the window weight gradient (the odd tap row paired across two pixel splits; 'tap_3d_multi' above takes them too):
+    ('tap_3d_splitpair_odd', (3, 64, 6, 40, 40), (64, 64, 3, 3, 3), 1, 1),  # 53 splits: the last pair holds one window
+    ('tap_2d_splitpair', (16, 128, 64, 64), (128, 128, 3, 3), 1, 1),        # three tap rows = one ordinary pair + split pairs; two k tiles x two channel tiles
+    ('tap_3d_splitpair_k40', (2, 128, 6, 40, 40), (40, 128, 3, 3, 3), 1, 1),  # ragged output channels, two channel tiles
     # 7-wide taps on 48 plane channels (the smoke stem): 16-channel-block forward kernel, seven-wide window weight gradient
     ('tap_stem_w7', (2, 42, 5, 9, 7), (64, 42, 7, 7, 7), 1, 3),            # rows shorter than the 32-pixel step
     ('tap_stem_k40', (1, 42, 4, 10, 33), (40, 42, 7, 7, 7), 1, 3),         # ragged output channels, odd row length

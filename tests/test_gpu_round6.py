@@ -1,0 +1,118 @@
+"""Round 6: the window weight-gradient kernel's split-pair items, the deferred multi-tensor split reduction, and the drop-in surfaces that came with
+them. GPU box only.
+
+Reference lines: every nn.Conv3d / Conv2d of the U-Nets (smoke/video_diffusion_pytorch/video_diffusion_pytorch_conv3d.py:189-230,
+burgers/ddpm_burgers/unet.py:129-181) -- autograd's weight gradient of them is what these kernels compute."""
+import ctypes as C
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def trees():
+    from wdno_amd import tree_path
+    for t in ('third_party', 'smoke', 'burgers'):
+        p = tree_path(t)
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion as GD1
+    from video_diffusion_pytorch.video_diffusion_pytorch_conv3d import Unet3D_with_Conv3D
+    from ddpm.diffusion_2d import GaussianDiffusion as GD2
+    return dict(Unet2D=Unet2D, GD1=GD1, Unet3D=Unet3D_with_Conv3D, GD2=GD2)
+
+
+WG_CASES = [('3d 64->64', (2, 24, 40, 40, 64), (64, 64, 3, 3, 3)), ('3d 128->64', (1, 24, 40, 40, 128), (64, 128, 3, 3, 3)),
+            ('2d 128->128', (16, 1, 64, 64, 128), (128, 128, 1, 3, 3)), ('3d 64->64 odd split count', (3, 6, 40, 40, 64), (64, 64, 3, 3, 3))]
+
+
+@pytest.mark.parametrize('name,xs,ws', WG_CASES, ids=[c[0] for c in WG_CASES])
+@pytest.mark.parametrize('math', ['f16x3', 'bf16'])
+def test_split_pair_plan_equals_the_round5_plan(name, xs, ws, math):
+    """The same weight gradient under the split-pair item plan (default) and under round 5's (library debug mode 70: the odd tap row paired with an
+    empty window): other split boundaries, so fp32 sums in another order -- equal to 1e-5 relative (measured ~1e-6), each plan bit-reproducible;
+    and, through the two-step API (partial sums, then wdno_wgrad_reduce_multi), bit-identical to the one-call API."""
+    from wdno_amd import ops, _lib
+    lib = ops._lib_()
+    prev = ops.CONV_MATH
+    ops.CONV_MATH = math
+    try:
+        g = torch.Generator(device=DEV).manual_seed(3)
+        x = torch.randn(*xs, device=DEV, generator=g)
+        k, c, ks = ws[0], ws[1], tuple(ws[2:])
+        dy = torch.randn(*xs[:4], k, device=DEV, generator=g)
+        xpl, ypl = ops.split_f16(x.reshape(-1, c)), ops.split_f16(dy.reshape(-1, k))
+        pd = tuple(v // 2 for v in ks)
+        f = lambda: ops.conv_wgrad_h3(xpl, tuple(xs[:4]), ypl, tuple(xs[1:4]), ks, (1, 1, 1), pd, param_kc=(k, c))
+        res = {}
+        for mode in (0, 70):
+            lib.wdno_set_debug(mode)
+            try:
+                res[mode] = f().clone()
+                assert torch.equal(res[mode], f())
+            finally:
+                lib.wdno_set_debug(0)
+        rel = ((res[0] - res[70]).norm() / res[70].norm()).item()
+        print(name, math, 'split-pair vs round-5 plan', rel)
+        assert 0 < rel < 1e-5                               # the plans really differ (another split count), the sums agree
+        with ops.flat_wgrad_scope():                        # deferred: partial sums now, the ordered reduction at the end of the scope
+            dw = f()
+            assert len(ops._WGRAD_PENDING) == 1
+        assert ops._WGRAD_PENDING is None and torch.equal(dw, res[0])
+    finally:
+        ops.CONV_MATH = prev
+
+
+def test_deferred_weight_gradient_reductions_leave_a_training_step_bit_identical(trees):
+    """ops.DEFER_WGRAD_REDUCE: inside a trainer's backward the split reductions of all weight gradients run as ONE launch when the backward has
+    returned (wdno_wgrad_reduce_multi, items by value in the kernel arguments) instead of one launch behind every weight-gradient kernel. Same
+    additions in the same order: two optimisation steps of the full-width smoke model end in the same bits, eager and graph-replayed."""
+    from wdno_amd import ops
+    from wdno_amd.trainer import TrainStep
+    out = {}
+    for defer in (True, False):
+        ops.DEFER_WGRAD_REDUCE = defer
+        try:
+            torch.manual_seed(0)
+            net = trees['Unet3D'](dim=64, dim_mults=(1, 2, 4), channels=42)
+            dif = trees['GD2'](net, torch.ones(1, 1, 42, 1, 1), True, True, True, False, 'bior1.3', 'zero', (9, 17, 17), (16, 32, 32), image_size=20, frames=12).to(DEV)
+            ts = TrainStep(dif, lr=1e-3, use_ema=False)
+            x = (torch.randn(2, 12, 42, 20, 20, generator=torch.Generator().manual_seed(5)) * 0.5).to(DEV)
+            torch.manual_seed(9)
+            launches = {}
+            ops.PROFILE = launches
+            try:
+                l0, _ = ts.step(x)
+            finally:
+                ops.PROFILE = None
+            assert any('wgrad_h3' in k for k in launches)
+            ts.capture(x, warmup=1)
+            l2, _ = ts.step(x)
+            torch.cuda.synchronize()
+            out[defer] = (float(l0), float(l2), ts.opt.buf.flat_param.clone())
+            del ts
+        finally:
+            ops.DEFER_WGRAD_REDUCE = True
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1] and torch.equal(out[True][2], out[False][2])
+
+
+def test_reduce_multi_takes_more_items_than_one_launch_holds():
+    """wdno_wgrad_reduce_multi chunks its host list into launches of WDNO_WGRAD_REDUCE_MAX (64) items: 70 small items, every destination right."""
+    from wdno_amd import ops, _lib
+    lib = ops._lib_()
+    n_items, splits, K, Cc = 70, 3, 8, 8
+    n = 1 * K * 3 * Cc                                  # ntap = 1, kw = 3
+    ws = torch.randn(n_items, splits, n, device=DEV)
+    dw = torch.zeros(n_items, K, Cc, 1, 1, 3, device=DEV)
+    items = (_lib.WgradReduceItem * n_items)()
+    for i in range(n_items):
+        items[i] = _lib.WgradReduceItem(ws[i].data_ptr(), dw[i].data_ptr(), n, splits, K, Cc, 3, 1, K, Cc, i % 2, 0)
+    _lib.check(lib.wdno_wgrad_reduce_multi(C.cast(items, C.c_void_p), n_items, ops._stream()), 'wgrad_reduce_multi')
+    torch.cuda.synchronize()
+    want = ws.sum(1).reshape(n_items, 1, K, 3, Cc).permute(0, 2, 4, 1, 3).reshape(n_items, K, Cc, 1, 1, 3)      # [tap][k][dx][c] -> [k][c][tap][dx]
+    assert torch.allclose(dw, want, rtol=1e-6, atol=1e-6)

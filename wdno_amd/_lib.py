@@ -37,6 +37,11 @@ class CondDesc(C.Structure):
                                  'cond_c', 'cond_low', 'u_rows', 'uT_rows')]
 
 
+class WgradReduceItem(C.Structure):          # include/wdno_hip.h: wdno_wgrad_reduce_item
+    _fields_ = [('ws', C.c_void_p), ('dw', C.c_void_p), ('n', I), ('splits', I), ('K8', I), ('C8', I), ('kw', I), ('ntap', I), ('Kn', I), ('Cn', I),
+                ('tiled', I), ('reserved', I)]
+
+
 PD, PG, PA, PC = C.POINTER(DwtDesc), C.POINTER(ConvGeom), C.POINTER(AttnDesc), C.POINTER(CondDesc)
 PF = C.POINTER(C.c_float)
 
@@ -77,6 +82,8 @@ PROTOTYPES = {
     'wdno_conv_pixel_table': (I, [P, PG, P]),
     'wdno_conv_wgrad_f16x3': (I, [P, P, P, P, P, P, P, P, P, Z, PG, P]),
     'wdno_conv_wgrad_f16x3_param': (I, [P, P, P, P, P, P, P, P, I, I, P, Z, PG, P]),
+    'wdno_conv_wgrad_partials': (I, [P, P, P, P, P, P, P, P, I, I, P, Z, PG, P, P]),
+    'wdno_wgrad_reduce_multi': (I, [P, I, P]),
     'wdno_cast_bf16': (I, [P, P, L, I, I, P]),
     'wdno_cast_bf16_colsum': (I, [P, P, P, P, Z, L, I, I, P]),
     'wdno_conv_fwd_bf16': (I, [P, P, P, P, P, P, PG, P]),

@@ -59,7 +59,7 @@ static inline int check_geom(const wdno_conv_geom* g) {
 }
 extern int wdno_debug_mode;
 // conv_wgrad_h3d.hip: LDS-DMA variant of the split-fp16 weight-gradient kernel and its split plan
-void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits, int* pix_per_split);
+void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits, int* pix_per_split, int* splitpair = nullptr);
 int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, const void* dyl, const float* sx, const float* sdy,
                            const void* table, float* wsf, const wdno_conv_geom* g, hipStream_t st);
 // conv_h3d.hip: LDS-DMA variant of the split-fp16 forward / data-gradient kernel (WDNO_EUNSUPPORTED -> use conv_h3.hip's)

@@ -930,8 +930,8 @@ extern "C" size_t wdno_conv_wgrad_f16x3_ws_bytes(const wdno_conv_geom* g) {
   if (check_geom(g) != WDNO_OK) return 0;
   WgradHP w;
   wgrad_h3_plan(w, g);
-  int bm, bn, splits, pps;
-  wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps);                 // the DMA kernel's plan may use a different split count
+  int bm, bn, splits, pps, sp_mode;
+  wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps, &sp_mode);       // the DMA kernel's plan may use a different split count
   if (splits > w.splits) w.splits = splits;
   return (size_t)w.splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
 }
@@ -964,8 +964,8 @@ static int wgrad_h3_partials(const void* xh, const void* xl, const float* sx, co
   wgrad_h3_plan(w, g);
   // persistent LDS-DMA kernel for everything it takes (debug 5 = never); the register-staged kernels below are the fallback
   if (wdno_debug_mode != 5) {
-    int bm, bn, splits, pps;
-    wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps);
+    int bm, bn, splits, pps, sp_mode;
+    wdno_wgrad_h3d_plan(g, &bm, &bn, &splits, &pps, &sp_mode);
     size_t need_d = (size_t)splits * g->kd * g->kh * (size_t)g->K * w.c.R * sizeof(float);
     float* dst = (splits == 1 && single) ? single : (float*)ws;
     if (dst == (float*)ws && ws_bytes < need_d) return WDNO_EWORKSPACE;
@@ -1005,13 +1005,13 @@ extern "C" int wdno_conv_wgrad_f16x3(const void* xh, const void* xl, const float
 // A block = 32 groups of four consecutive elements x 8 slices of the split list: with ~56 splits of a few hundred KB each, one
 // thread per element walking all splits is a chain of 14 dependent loads on a few hundred blocks (14.5 us per launch, 72
 // launches per train step); here a thread adds 7 float4 and the eight slices meet in LDS.
-__global__ __launch_bounds__(256) void wgrad_h3_reduce_nat_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
-                                                                   int K8, int C8, int kw, int ntap, int Kn, int Cn) {
-  __shared__ float4 part[8][33];
+// (bid of nb blocks: the kernel's own grid, or the blocks one item owns inside a multi-tensor launch)
+__device__ __forceinline__ void wgrad_h3_reduce_nat_body(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
+                                                         int K8, int C8, int kw, int ntap, int Kn, int Cn, float4 (*part)[33], int bid, int nb) {
   const int R = kw * C8;
   const int j = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int64_t n4 = n >> 2;
-  for (int64_t i4 = (int64_t)blockIdx.x * 32 + j; i4 - j < n4; i4 += (int64_t)gridDim.x * 32) {      // block-uniform trip count
+  for (int64_t i4 = (int64_t)bid * 32 + j; i4 - j < n4; i4 += (int64_t)nb * 32) {      // block-uniform trip count
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (i4 < n4) {
       const float4* src = reinterpret_cast<const float4*>(ws) + i4;
@@ -1047,15 +1047,19 @@ __global__ __launch_bounds__(256) void wgrad_h3_reduce_nat_kernel(const float* _
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256) void wgrad_h3_reduce_nat_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
+                                                                   int K8, int C8, int kw, int ntap, int Kn, int Cn) {
+  __shared__ float4 part[8][33];
+  wgrad_h3_reduce_nat_body(ws, dw, n, splits, K8, C8, kw, ntap, Kn, Cn, part, (int)blockIdx.x, (int)gridDim.x);
+}
 // The same reduction with coalesced stores. Above, consecutive threads hold consecutive (dx, c) of one (tap row, k) and scatter them
 // ntap * kw floats apart in the parameter layout [K][C][taps]. Here a block owns one k and 64 input channels: it reads its T = ntap * kw
 // segments of 64 contiguous floats per split (one wave per segment, lane = channel), sums the splits in order, turns the [T][64] tile
 // through LDS and writes 64 * T contiguous floats of dw. T <= 64 (everything but the 7 x 7 x 7 stem).
-__global__ __launch_bounds__(256) void wgrad_h3_reduce_tile_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
-                                                                    int K8, int C8, int kw, int ntap, int Kn, int Cn) {
-  __shared__ float tile[64][65];
+__device__ __forceinline__ void wgrad_h3_reduce_tile_body(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
+                                                          int K8, int C8, int kw, int ntap, int Kn, int Cn, float (*tile)[65], int bx, int by) {
   const int T = ntap * kw, R = kw * C8;
-  const int k = blockIdx.y, c0 = blockIdx.x * 64;
+  const int k = by, c0 = bx * 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int sgm = wave; sgm < T; sgm += 4) {
     const int t = sgm / kw, dx = sgm - t * kw;
@@ -1076,14 +1080,71 @@ __global__ __launch_bounds__(256) void wgrad_h3_reduce_tile_kernel(const float* 
     out[e] = tile[c][sgm];
   }
 }
-static void wgrad_h3_reduce_launch(const float* ws, float* dw, int64_t n, int splits, const wdno_conv_geom* g, int Kn, int Cn, hipStream_t st) {
+__global__ __launch_bounds__(256) void wgrad_h3_reduce_tile_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n, int splits,
+                                                                    int K8, int C8, int kw, int ntap, int Kn, int Cn) {
+  __shared__ float tile[64][65];
+  wgrad_h3_reduce_tile_body(ws, dw, n, splits, K8, C8, kw, ntap, Kn, Cn, tile, (int)blockIdx.x, (int)blockIdx.y);
+}
+// which of the two reductions a layer takes, and with how many blocks (shared by the per-layer launch and the multi-tensor one)
+static bool wgrad_h3_reduce_tiled(int splits, const wdno_conv_geom* g, int Kn, int Cn) {
   const int T = g->kd * g->kh * g->kw;
+  const bool big = (int64_t)Kn * cdiv(Cn, 64) >= 512 && splits <= 8 && wdno_debug_mode != 39;
+  return T <= 64 && (splits <= 2 || big) && wdno_debug_mode != 38;             // debug 38: the scatter kernel (A/B)
+}
+
+// ---- every pending split reduction of a backward pass in ONE launch (round 6). A training step ran 58 of these reductions, 5-10 us each, one behind
+// every weight-gradient kernel (0.43 ms per smoke step, profiles/r05_smoke_kernel_stats.md); only the optimiser reads their results. The callers
+// now run the partial-sum kernels alone (wdno_conv_wgrad_*_partials: the workspace stays alive) and hand the list of reductions over at the end of
+// the backward: the items travel BY VALUE in the kernel arguments (<= WDNO_WGRAD_REDUCE_MAX per launch), so the launch needs no table upload and
+// replays unchanged from a captured graph. A block finds its item by its first-block number and runs the same body as the per-layer kernels in
+// the same order of additions: results are bit-identical to them.
+struct WgradReduceArgs {
+  wdno_wgrad_reduce_item it[WDNO_WGRAD_REDUCE_MAX];
+  int first[WDNO_WGRAD_REDUCE_MAX + 1];          // first block of item i; first[n] = grid
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_h3_reduce_multi_kernel(const WgradReduceArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[64 * 65];                // tile[64][65] of the tiled body / part[8][33] float4 of the scatter body
+  int lo = 0, hi = a.n - 1;                      // last item whose first block is <= blockIdx.x (block-uniform: scalar loads of the arguments)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const wdno_wgrad_reduce_item& w = a.it[lo];
+  const int bid = (int)blockIdx.x - a.first[lo], nb = a.first[lo + 1] - a.first[lo];
+  if (w.tiled) {
+    const int bxn = (w.Cn + 63) >> 6;
+    wgrad_h3_reduce_tile_body(w.ws, w.dw, w.n, w.splits, w.K8, w.C8, w.kw, w.ntap, w.Kn, w.Cn, reinterpret_cast<float (*)[65]>(smem), bid % bxn, bid / bxn);
+  } else {
+    wgrad_h3_reduce_nat_body(w.ws, w.dw, w.n, w.splits, w.K8, w.C8, w.kw, w.ntap, w.Kn, w.Cn, reinterpret_cast<float4 (*)[33]>(smem), bid, nb);
+  }
+}
+extern "C" int wdno_wgrad_reduce_multi(const wdno_wgrad_reduce_item* items, int n_items, wdno_stream_t s) {
+  WDNO_REQUIRE(items && n_items >= 0);
+  hipStream_t st = as_stream(s);
+  for (int base = 0; base < n_items; base += WDNO_WGRAD_REDUCE_MAX) {
+    WgradReduceArgs a;
+    a.n = n_items - base < WDNO_WGRAD_REDUCE_MAX ? n_items - base : WDNO_WGRAD_REDUCE_MAX;
+    int grid = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.it[i] = items[base + i];
+      const wdno_wgrad_reduce_item& w = a.it[i];
+      WDNO_REQUIRE(w.ws && w.dw && w.n > 0 && w.splits >= 1 && w.Kn > 0 && w.Cn > 0 && w.Kn <= w.K8 && w.Cn <= w.C8);
+      a.first[i] = grid;
+      grid += w.tiled ? cdiv(w.Cn, 64) * w.Kn : stream_grid(w.n / 4, 32);      // the per-layer launches' grids
+    }
+    a.first[a.n] = grid;
+    if (grid > 0) wgrad_h3_reduce_multi_kernel<<<grid, 256, 0, st>>>(a);
+  }
+  return wdno_check_launch();
+}
+
+static void wgrad_h3_reduce_launch(const float* ws, float* dw, int64_t n, int splits, const wdno_conv_geom* g, int Kn, int Cn, hipStream_t st) {
   // (layers with many splits are the small ones: K * C / 64 blocks that each walk T x splits segments are too few and too serial there --
   // 64 -> 64 channels with 18 splits took 2x the scatter kernel's time, +1.1 ms per smoke step when used everywhere)
   // ... but a layer with >= 512 (k, 64-channel) blocks and a handful of splits (256 -> 256 at level 2: 1024 blocks, 3 splits) has enough of them, and
   // the scatter kernel's 4-byte stores 27 floats apart are what it pays for (31-33 us per launch, 7 launches per smoke step)
-  const bool big = (int64_t)Kn * cdiv(Cn, 64) >= 512 && splits <= 8 && wdno_debug_mode != 39;
-  if (T <= 64 && (splits <= 2 || big) && wdno_debug_mode != 38) {             // debug 38: the scatter kernel (A/B)
+  if (wgrad_h3_reduce_tiled(splits, g, Kn, Cn)) {
     wgrad_h3_reduce_tile_kernel<<<dim3(cdiv(Cn, 64), Kn), 256, 0, st>>>(ws, dw, n, splits, g->K, g->C, g->kw, g->kd * g->kh, Kn, Cn);
     return;
   }
@@ -1099,6 +1160,21 @@ extern "C" int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const
   if (rc) return rc;
   const int64_t n = (int64_t)g->kd * g->kh * g->K * (int64_t)g->kw * g->C;
   wgrad_h3_reduce_launch((const float*)ws, dw, n, splits, g, Kn, Cn, st);
+  return wdno_check_launch();
+}
+
+// The partial-sum kernels alone: `item` comes back filled for wdno_wgrad_reduce_multi (ws must stay alive and unmodified until that launch).
+extern "C" int wdno_conv_wgrad_partials(const void* xh, const void* xl, const float* sx, const void* dyh, const void* dyl, const float* sdy,
+                                        const void* pixel_table, float* dw, int Kn, int Cn, void* ws, size_t ws_bytes,
+                                        const wdno_conv_geom* g, wdno_wgrad_reduce_item* item, wdno_stream_t s) {
+  WDNO_REQUIRE(g && item && dw && Kn > 0 && Cn > 0 && Kn <= g->K && Cn <= g->C);
+  int splits = 0;
+  int rc = wgrad_h3_partials(xh, xl, sx, dyh, dyl, sdy, pixel_table, nullptr, ws, ws_bytes, g, as_stream(s), &splits);      // xl == NULL: one bf16 plane per operand
+  if (rc) return rc;
+  const int64_t n = (int64_t)g->kd * g->kh * g->K * (int64_t)g->kw * g->C;
+  if (n >= 0x7fffffff) return WDNO_EUNSUPPORTED;
+  item->ws = (const float*)ws; item->dw = dw; item->n = (int)n; item->splits = splits; item->K8 = g->K; item->C8 = g->C; item->kw = g->kw;
+  item->ntap = g->kd * g->kh; item->Kn = Kn; item->Cn = Cn; item->tiled = wgrad_h3_reduce_tiled(splits, g, Kn, Cn) ? 1 : 0;
   return wdno_check_launch();
 }
 

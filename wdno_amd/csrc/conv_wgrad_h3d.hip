@@ -41,6 +41,7 @@ struct WgradDP {
   int items;                                // tiles_k * ntap * tiles_r * splits
   int pix_per_split;
   int xcd_chunk;                            // items per XCD (grid is a multiple of 8), or 0: items dealt round-robin over the blocks
+  int splitpair, n_a;                       // window kernel: the odd tap row paired across two pixel splits (items >= n_a), see conv_wgrad_h3w_kernel
 };
 
 __device__ __forceinline__ int4v wd_rsrc(const void* ptr, unsigned bytes) {
@@ -391,7 +392,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3d_kernel(const _Float16* __r
 //   * (dz, dy) validity: from the pixel-table record of the pixel the window row is the centre tap of.
 //   * 14 (hi, lo) piece pairs per step: producer waves 0 / 1 carry four, 2 / 3 three (the vmcnt immediates differ, so the
 //     producer body is instantiated for both counts).
-//   * an odd number of tap rows leaves the second window of the last pair empty (zeros; its result is not stored).
+//   * an odd number of tap rows (3 x 3 x 3: nine; 2-D 3 x 3: three) used to leave the second window of the last pair empty: 1 / 10 (1 / 4 in 2-D)
+//     of the matrix instructions multiplied zeros (SQ_INSTS_MFMA 1.11 x the work of the layer, profiles/r05_smoke_pmc.md). Round 6: in SPLIT-PAIR
+//     mode (wp.splitpair, the plan's choice when it shortens the round) the items with id >= wp.n_a pair the last tap row ACROSS TWO PIXEL SPLITS:
+//     window s of such an item is that tap row over split 2 j + s, and because the two windows then belong to different pixels each gets its own dy
+//     tile (the second dy plane of a stage; ordinary items leave it unused and both wave pairs read the first). Every item still has wp.nsteps
+//     steps and writes whole [split][tap] slots of the workspace, so the counting of producers and consumers and the ordered reduction are
+//     untouched. A block walks items of ONE kind only (the plan keeps items <= blocks in this mode), so the kind is a block-uniform branch around
+//     the producer body (18 (hi, lo) piece pairs per step instead of 14: five / four per producer wave) and one scalar in the compute waves.
+//   * without split-pair mode an odd number of tap rows still leaves the second window of the last pair empty (zeros; its result is not stored).
+//   * dx-invalid lanes read a zero row IN THE BANK SLOT of the row they replace (rows 36 .. 39 of a window are never fetched): the constant
+//     stand-in address of round 2 collided with the lanes of window row 3 mod 4 -- the 1.03e6 SQ_LDS_BANK_CONFLICT per dispatch of round 5.
 template <int NS, bool LP>
 __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __restrict__ xh, const _Float16* __restrict__ xl,
                                                               const _Float16* __restrict__ dyh, const _Float16* __restrict__ dyl,
@@ -403,13 +414,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
   constexpr int ACH = BM / 8, XCH = CT / 8;               // 16-byte chunks per pixel row
   constexpr int XROWS = 32 + KW - 1;                      // window rows that carry data
   constexpr int A_PLANE = 32 * ACH * 16, W_PLANE = 5 * 1024, B_PLANE = 2 * W_PLANE;      // a window: 40 rows x 128 B, rows >= XROWS stay zero
-  constexpr int ZADDR = 9 * (XCH * 64) + 3 * 64;          // window row 39
+  constexpr int ZROWS = 9 * (XCH * 64);                   // window rows 36 .. 39: never fetched, i.e. zero
+  constexpr int NDY = 2;                                  // dy tiles per stage (the second one is filled by split-pair items only)
   constexpr int NPL = LP ? 1 : 2;
-  constexpr int A_LO = A_PLANE, B_HI = NPL * A_PLANE, B_LO = B_HI + B_PLANE;
-  constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+  constexpr int A_LO = NDY * A_PLANE, B_HI = NPL * NDY * A_PLANE, B_LO = B_HI + B_PLANE;
+  constexpr int STAGE = NPL * (NDY * A_PLANE + B_PLANE);
   constexpr int APC = A_PLANE / 1024, WPC = W_PLANE / 1024;
-  constexpr int NPAIR = APC + 2 * WPC;
-  static_assert(NPAIR == 14, "pairs 0-3 dy, 4-8 window 0, 9-13 window 1");
+  static_assert(APC == 4 && WPC == 5, "ordinary items: pairs 0-3 dy, 4-8 window 0, 9-13 window 1; split-pair items: 0-3 dy 0, 4-7 dy 1, 8-12 window 0, 13-17 window 1");
   constexpr int LA = 2;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const ConvP& p = wp.c;
@@ -427,14 +438,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
     it_first = (int)blockIdx.x; it_stride = (int)gridDim.x;
     my_items = (wp.items - it_first + it_stride - 1) / it_stride;
   }
-  const int ntap = g.kd * g.kh, npair = (ntap + 1) >> 1;
-  auto decode_item = [&](int t, int& tile_k, int& tpair, int& tile_c, int& split) {
+  const int ntap = g.kd * g.kh, npair = wp.splitpair ? ntap >> 1 : (ntap + 1) >> 1;
+  // item -> (k tile, channel tile, and per window s: tap row tp[s], pixel split sp[s]). Ordinary items: tap rows 2 q, 2 q + 1 of one split;
+  // split-pair items (id >= n_a): the last tap row over splits 2 j, 2 j + 1. A window whose tap row or split does not exist is empty.
+  auto decode_item = [&](int t, int& tile_k, int& tile_c, int (&tp)[2], int (&sp)[2]) {
     int id = it_first + t * it_stride;
-    tile_c = id % wp.tiles_r; id /= wp.tiles_r;
-    tpair = id % npair; id /= npair;
-    tile_k = id % wp.tiles_k;
-    split = id / wp.tiles_k;
+    if (id < wp.n_a) {
+      tile_c = id % wp.tiles_r; id /= wp.tiles_r;
+      const int q = id % npair; id /= npair;
+      tile_k = id % wp.tiles_k;
+      sp[0] = sp[1] = id / wp.tiles_k;
+      tp[0] = 2 * q; tp[1] = 2 * q + 1;
+    } else {
+      id -= wp.n_a;
+      tile_c = id % wp.tiles_r; id /= wp.tiles_r;
+      tile_k = id % wp.tiles_k;
+      const int j = id / wp.tiles_k;
+      sp[0] = 2 * j; sp[1] = 2 * j + 1;
+      tp[0] = tp[1] = ntap - 1;
+    }
   };
+  const bool kind_b = wp.splitpair && it_first >= wp.n_a;      // block-uniform: this block's items are split-pair items (one kind per block)
 
   if (wave >= 4) {
     // ================================================================== producer waves
@@ -443,45 +467,50 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
     int4v rtb = wd_rsrc(table, tbl_bytes);
     asm volatile("s_nop 4" : "+s"(rxh), "+s"(rxl), "+s"(rdh), "+s"(rdl), "+s"(rtb));
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
-    auto producer = [&](auto RC) {
+    auto producer = [&](auto RC, auto KBC) {
       constexpr int R = decltype(RC)::value;          // pairs of this wave: global pairs pq + 4 j
+      constexpr bool KB = decltype(KBC)::value;       // split-pair items: two dy tiles
+      constexpr int APCT = KB ? 2 * APC : APC;        // dy pairs per step
       constexpr int PW = NPL * R;
       static_assert(R + (NS - 2) * (R + PW) <= 63, "vmcnt is a 6-bit counter");
       // Lane L of piece q of a plane covers its 16-byte slot f = 64 q + L: row 4 (f / 32) + (f / 4) % 4 (pixel of the step / window row),
       // 64-byte unit (f / 16) % 2, chunk f % 4 of the unit.
-      int row[R], chk[R];
+      int row[R], chk[R], slot[R];
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const int gp = pq + 4 * j;
-        const int f = 64 * (gp < APC ? gp : (gp - APC) % WPC) + lane;
+        const bool isdy = gp < APCT;
+        const int piece = isdy ? gp % APC : (gp - APCT) % WPC;
+        slot[j] = isdy ? gp / APC : (gp - APCT) / WPC;                 // window (and, in split-pair items, dy tile) the pair belongs to
+        const int f = 64 * piece + lane;
         row[j] = 4 * (f >> 5) + ((f >> 2) & 3);
         chk[j] = (((f >> 4) & 1) * 4 + (f & 3)) * 8;
       }
       struct Cur { int t, s; };
       Cur rc{0, 0}, pc{0, 0};          // record cursor, piece cursor
-      int r_pbeg = 0;
+      int r_pbeg[2] = {0, 0};
       int c_dz[2], c_dy[2], c_tapoff[2];
       bool c_on[2];
       int i_off[R];
       bool i_ok[R];
       auto load_item_r = [&]() {
-        int tk, tp, tc, sp;
-        decode_item(rc.t, tk, tp, tc, sp);
-        r_pbeg = sp * wp.pix_per_split;
+        int tk, tc, tp[2], sp[2];
+        decode_item(rc.t, tk, tc, tp, sp);
+        r_pbeg[0] = sp[0] * wp.pix_per_split; r_pbeg[1] = sp[1] * wp.pix_per_split;
       };
       auto load_item_p = [&]() {
-        int tk, tp, tc, sp;
-        decode_item(pc.t, tk, tp, tc, sp);
+        int tk, tc, tp[2], sp[2];
+        decode_item(pc.t, tk, tc, tp, sp);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const int tap = 2 * tp + s2;
-          c_on[s2] = tap < ntap;
+          const int tap = tp[s2];
+          c_on[s2] = tap < ntap && sp[s2] < wp.splits;
           c_dz[s2] = tap / g.kh; c_dy[s2] = tap - c_dz[s2] * g.kh;
           c_tapoff[s2] = (c_dz[s2] * g.H + c_dy[s2]) * g.W * g.C;
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          if (pq + 4 * j < APC) {
+          if (pq + 4 * j < APCT) {
             const int k = tk * BM + chk[j];
             i_ok[j] = k < g.K;
             i_off[j] = k * 2;
@@ -499,7 +528,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
         const bool live = rc.t < my_items;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const int pm = r_pbeg + rc.s * 32 + row[j] - (pq + 4 * j < APC ? 0 : g.pw);
+          const int pm = r_pbeg[slot[j]] + rc.s * 32 + row[j] - (pq + 4 * j < APCT ? 0 : g.pw);
           rok[S][j] = live && pm >= 0 && pm < (int)p.P;
           rec[S][j] = wd_load_rec(rtb, rok[S][j] ? pm * 16 : WD_OOB);
         }
@@ -516,17 +545,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
           asm volatile("" : "+v"(e));                                   // consumers of the record stay below the counted wait
           const int gp = pq + 4 * j;                                    // pq is wave-uniform: scalar branches
           const bool ok0 = live && rok[S][j] && i_ok[j];
-          if (gp < APC) {
+          if (gp < APCT) {
             const int off = ok0 ? e.x * k2 + i_off[j] : WD_OOB;
-            wd_piece(rdh, off, sb + gp * 1024);
-            if (!LP) wd_piece(rdl, off, sb + A_LO + gp * 1024);
+            const unsigned dst = sb + (gp / APC) * A_PLANE + (gp % APC) * 1024;
+            wd_piece(rdh, off, dst);
+            if (!LP) wd_piece(rdl, off, dst + A_LO);
           } else {
-            const int s2 = gp - APC < WPC ? 0 : 1;
+            const int s2 = gp - APCT < WPC ? 0 : 1;
             const int d = (e.z >> 16) + c_dz[s2], h = (int)(short)(e.z & 0xffff) + c_dy[s2];
             const bool ok = ok0 && c_on[s2] && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H;
             const int off = ok ? (e.y + c_tapoff[s2] + i_off[j]) * 2 : WD_OOB;
-            wd_piece(rxh, off, sb + B_HI + (gp - APC) * 1024);
-            if (!LP) wd_piece(rxl, off, sb + B_LO + (gp - APC) * 1024);
+            wd_piece(rxh, off, sb + B_HI + (gp - APCT) * 1024);
+            if (!LP) wd_piece(rxl, off, sb + B_LO + (gp - APCT) * 1024);
           }
         }
         if (live && ++pc.s == wp.nsteps) { pc.s = 0; if (++pc.t < my_items) load_item_p(); }
@@ -538,14 +568,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
         constexpr int S = decltype(SLOT)::value;
         constexpr int N = decltype(COUNT)::value;
         constexpr bool WITH_BARRIER = decltype(BAR)::value;
-        static_assert(R == 3 || R == 4, "record count");
-        int4v &r0 = rec[S][0], &r1 = rec[S][1], &r2 = rec[S][2], &r3 = rec[S][R > 3 ? 3 : 0];
+        static_assert(R >= 3 && R <= 5, "record count");
+        int4v &r0 = rec[S][0], &r1 = rec[S][1], &r2 = rec[S][2], &r3 = rec[S][R > 3 ? 3 : 0], &r4 = rec[S][R > 4 ? 4 : 0];
         if (WITH_BARRIER) {
           if (R == 3) asm volatile("s_waitcnt vmcnt(%3)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+          else if (R == 4) asm volatile("s_waitcnt vmcnt(%4)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%5)\n\ts_barrier" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "n"(N) : "memory");
         } else {
           if (R == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r0), "+v"(r1), "+v"(r2) : "n"(N) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+          else if (R == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(N) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4) : "n"(N) : "memory");
         }
       };
       using YES = std::true_type;
@@ -577,8 +609,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
       }
       asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
     };
-    if (pq < 2) producer(std::integral_constant<int, 4>{});
-    else producer(std::integral_constant<int, 3>{});
+    // 14 pairs per step (ordinary items): producer waves 0 / 1 carry four, 2 / 3 three; 18 (split-pair items): five / four
+    if (kind_b) {
+      if (pq < 2) producer(std::integral_constant<int, 5>{}, std::true_type{});
+      else producer(std::integral_constant<int, 4>{}, std::true_type{});
+    } else {
+      if (pq < 2) producer(std::integral_constant<int, 4>{}, std::false_type{});
+      else producer(std::integral_constant<int, 3>{}, std::false_type{});
+    }
     return;
   }
 
@@ -586,7 +624,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
   const int wslot = wave >> 1, whalf = wave & 1;            // tap row of the pair, half of its six (dx, channel half) tiles
   const int li = lane & 31;
   const int gq = lane >> 4, xq = lane & 15;
-  const int offA = (2 * (gq >> 1)) * (ACH * 64) + (xq >> 2) * 64 + (gq & 1) * 32 + (xq & 3) * 8;
+  // (split-pair items: the wave pair of window 1 reads ITS dy tile, the second dy plane of the stage)
+  const int offA = (2 * (gq >> 1)) * (ACH * 64) + (xq >> 2) * 64 + (gq & 1) * 32 + (xq & 3) * 8 + (kind_b ? wslot * A_PLANE : 0);
   const int chan = (gq & 1) * 32 + (xq & 3) * 8;                // byte position of this lane's 8 bytes inside a 64-byte unit
   const int pix_l = 8 * (gq >> 1) + (xq >> 2);                 // pixel (of 16) this lane addresses in the first transpose read; second: + 4
   typedef short short4v __attribute__((ext_vector_type(4)));
@@ -613,7 +652,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         if (DX[b] == 1) rd[b][c] = base[b][c];                         // pw == 1: the centre tap always exists
-        else rd[b][c] = (unsigned)(ow[c] - g.pw + DX[b]) < (unsigned)g.W ? base[b][c] : ZADDR;
+        else rd[b][c] = (unsigned)(ow[c] - g.pw + DX[b]) < (unsigned)g.W ? base[b][c] : (base[b][c] & (XCH * 64 - 1)) + ZROWS;      // same (unit, row & 3, chan): same banks
       }
     };
     auto advance = [&](int c) {
@@ -671,8 +710,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
     using B1 = std::integral_constant<int, 1>;
     int stage = 0;
     for (int t = 0; t < my_items; ++t) {
-      int tile_k, tpair, tile_c, split;
-      decode_item(t, tile_k, tpair, tile_c, split);
+      int tile_k, tile_c, tps[2], sps[2];
+      decode_item(t, tile_k, tile_c, tps, sps);
+      const int tap = wslot ? tps[1] : tps[0], split = wslot ? sps[1] : sps[0];      // this wave pair's window
       const int pbeg = split * wp.pix_per_split;
 #pragma unroll
       for (int c = 0; c < 4; ++c) ow[c] = (pbeg + 16 * (c >> 1) + 4 * (c & 1) + pix_l) % g.OW;
@@ -711,8 +751,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3w_kernel(const _Float16* __r
       mfma_set(B1{});
       __builtin_amdgcn_sched_barrier(0);
       // acc[a][b]: rows = run index dx C + channel (tile b -> DX[b], UH[b]; 8 (e >> 2) + 4 hh + (e & 3) inside the tile), column = k
-      const int tap = 2 * tpair + wslot;
-      if (tap < ntap) {
+      if (tap < ntap && split < wp.splits) {
         float* out = ws + ((int64_t)split * ntap + tap) * (int64_t)g.K * p.R;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -1015,9 +1054,10 @@ static bool wd_stem_takes(const wdno_conv_geom* g) {
          g->C == 48 && (g->K % 8) == 0 && g->K <= 64 && g->kd <= 8 && g->kh <= 8;
 }
 // plan shared by the workspace query and the launch (conv_h3.hip calls both)
-void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits, int* pix_per_split) {
+void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits, int* pix_per_split, int* splitpair) {
   ConvP c;
   fill_params(c, g);
+  if (splitpair) *splitpair = 0;
   if (wd_stem_takes(g)) {                                   // items = tap rows x splits, one round of the CUs
     *bm = 64; *bn = 352;
     int64_t want = 256 / (g->kd * g->kh);
@@ -1031,7 +1071,8 @@ void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits,
   }
   if (wd_window_takes(g)) {                                 // items = k tiles x tap-row pairs x channel tiles x splits, one round of the CUs
     *bm = 64; *bn = 192;
-    const int tiles = cdiv(g->K, 64) * ((g->kd * g->kh + 1) / 2) * (g->C / 64);
+    const int ntap = g->kd * g->kh, tkc = cdiv(g->K, 64) * (g->C / 64);
+    const int tiles = tkc * ((ntap + 1) / 2);
     int64_t want = 256 / tiles;
     int64_t max_splits = cdiv64(c.P, 16 * 32);
     if (want > max_splits) want = max_splits;
@@ -1039,6 +1080,20 @@ void wdno_wgrad_h3d_plan(const wdno_conv_geom* g, int* bm, int* bn, int* splits,
     int64_t pps = cdiv64(cdiv64(c.P, want), 32) * 32;
     *pix_per_split = (int)pps;
     *splits = (int)cdiv64(c.P, pps);
+    if (splitpair) *splitpair = 0;
+    // Split-pair mode (conv_wgrad_h3w_kernel): with an odd number of tap rows the last one is paired across two pixel splits instead of with an
+    // empty window: tkc * (ntap / 2) * S + tkc * ceil(S / 2) items of equal length for S splits. Taken when one round of the CUs still holds
+    // them (a block then sees items of one kind only) and the items get SHORTER than in the plan above (debug 70: never -- the A/B).
+    if (splitpair && (ntap & 1) && wdno_debug_mode != 70) {
+      const int blocks = wd_num_cus() >= 256 ? 256 : (wd_num_cus() & ~7);      // what launch_ww starts at most (it walks items <= blocks one per block)
+      int64_t S = max_splits < 256 ? max_splits : 256;
+      while (S >= 2 && (int64_t)tkc * (ntap / 2) * S + (int64_t)tkc * ((S + 1) / 2) > blocks) --S;
+      if (S >= 2) {
+        const int64_t pps2 = cdiv64(cdiv64(c.P, S), 32) * 32;
+        const int64_t s2 = cdiv64(c.P, pps2);
+        if (s2 >= 2 && pps2 < pps) { *pix_per_split = (int)pps2; *splits = (int)s2; *splitpair = 1; }
+      }
+    }
     return;
   }
   *bm = g->K > 64 ? 128 : 64;
@@ -1086,7 +1141,7 @@ static void launch_ww(const void* xh, const void* xl, const void* dyh, const voi
   const unsigned dy_bytes = (unsigned)((int64_t)g.N * g.YD * g.YH * g.YW * g.K * 2);
   const unsigned tbl_bytes = (unsigned)(w.c.P * 16);
   constexpr int NS = 3;
-  const size_t lds = (size_t)NS * (LP ? 1 : 2) * (4096 + 2 * 5120);
+  const size_t lds = (size_t)NS * (LP ? 1 : 2) * (2 * 4096 + 2 * 5120);      // two dy tiles + two windows per plane set and stage
   static bool done = false;
   if (!done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_h3w_kernel<NS, LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = true; }
   int grid = wd_num_cus();
@@ -1129,7 +1184,8 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
   WgradDP w;
   fill_params(w.c, g);
   int bm, bn;
-  wdno_wgrad_h3d_plan(g, &bm, &bn, &w.splits, &w.pix_per_split);
+  wdno_wgrad_h3d_plan(g, &bm, &bn, &w.splits, &w.pix_per_split, &w.splitpair);
+  w.n_a = 0x7fffffff;
   if (w.c.P * 16 >= WD_OOB) return WDNO_EUNSUPPORTED;
   w.tiles_k = cdiv(g->K, bm);
   w.tiles_r = cdiv(w.c.R, bn);
@@ -1145,6 +1201,10 @@ int wdno_conv_wgrad_h3_dma(const void* xh, const void* xl, const void* dyh, cons
   }
   if (wd_window_takes(g)) {      // tiles_r = C / 64 channel tiles, tap rows in pairs
     w.items = w.tiles_k * w.tiles_r * ((g->kd * g->kh + 1) / 2) * w.splits;
+    if (w.splitpair) {           // ordinary items of the even tap rows, then the last tap row over pairs of splits
+      w.n_a = w.tiles_k * w.tiles_r * ((g->kd * g->kh) / 2) * w.splits;
+      w.items = w.n_a + w.tiles_k * w.tiles_r * ((w.splits + 1) / 2);
+    }
     if (xl == nullptr) launch_ww<true>(xh, xh, dyh, dyh, sx, sdy, table, wsf, w, st);
     else launch_ww<false>(xh, xl, dyh, dyl, sx, sdy, table, wsf, w, st);
     return WDNO_OK;

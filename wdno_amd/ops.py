@@ -859,19 +859,44 @@ def _wgrad_h3_kernel_name(k, run, window=False):
 
 FLAT_WGRAD = True         # weight gradients of split convolutions land in the trainer's flat gradient buffer (no gather copy for them)
 _FLAT_ARMED = False       # ... only inside flat_wgrad_scope(): the trainers wrap THEIR backward in it
+DEFER_WGRAD_REDUCE = True  # ... and their split reductions are collected and run as ONE launch at the end of that backward (test knob: bit-identical without)
+_WGRAD_PENDING = None     # [(item, workspace, dw), ...] while a trainer's backward is running
+
+
+def flush_wgrad_reduces():
+    """The ordered split reductions of every weight gradient whose partial sums are waiting (conv_wgrad_h3 inside flat_wgrad_scope), in one launch
+    of wdno_wgrad_reduce_multi. Until it has run, those gradient tensors are UNWRITTEN: the scope flushes when the backward returns, and anything that
+    reads a gradient earlier (the bucket all-reduces that OverlappedAllReduce starts from gradient hooks) calls this first."""
+    global _WGRAD_PENDING
+    pend = _WGRAD_PENDING
+    if not pend:
+        return
+    _WGRAD_PENDING = [] if _FLAT_ARMED else None
+    items = (_lib.WgradReduceItem * len(pend))(*[it for it, _, _ in pend])
+    _lib.check(_lib_().wdno_wgrad_reduce_multi(C.cast(items, C.c_void_p), len(pend), _stream()), 'wgrad_reduce_multi')
 
 
 @contextlib.contextmanager
 def flat_wgrad_scope():
     """Arms the direct write of weight gradients into the trainer's flat gradient buffer for the backward pass run inside this scope
     (TrainStep / TrainerCore / CapturedStep). Any other backward over a FlatBuffers-registered model -- torch.autograd.grad for a
-    guidance term, a user's own loss.backward() -- allocates its gradients as usual and leaves the flat buffer alone."""
-    global _FLAT_ARMED
+    guidance term, a user's own loss.backward() -- allocates its gradients as usual and leaves the flat buffer alone. Inside the scope the
+    split reductions of the weight gradients are deferred (flush_wgrad_reduces): one launch when the backward has returned instead of one
+    behind every weight-gradient kernel."""
+    global _FLAT_ARMED, _WGRAD_PENDING
     prev, _FLAT_ARMED = _FLAT_ARMED, True
+    outer = _WGRAD_PENDING
+    if DEFER_WGRAD_REDUCE and outer is None:
+        _WGRAD_PENDING = []
     try:
         yield
     finally:
         _FLAT_ARMED = prev
+        if outer is None:
+            try:
+                flush_wgrad_reduces()
+            finally:
+                _WGRAD_PENDING = None
 
 
 def _flat_grad_out(w, shape):
@@ -907,6 +932,16 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None, out
     window = tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 3 and pd[2] == 1 and c8 % 64 == 0
     if tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 7 and pd[2] == 3 and c8 == 48 and k8 <= 64 and max(ks) <= 8:
         window = 'stem'                    # csrc/conv_wgrad_h3d.hip: wd_stem_takes
+    if param_kc is not None and _WGRAD_PENDING is not None:
+        # a trainer's backward: the partial sums now, the ordered reduction with all the others when the backward has returned
+        kn, cn = param_kc
+        dw = out if out is not None else torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
+        item = _lib.WgradReduceItem()
+        with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8, window), flops):
+            _lib.check(lib.wdno_conv_wgrad_partials(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dw), kn, cn, _p(ws), nb, C.byref(g),
+                                                    C.byref(item), _stream()), 'conv_wgrad_partials')
+        _WGRAD_PENDING.append((item, ws, dw))         # (the workspace and the destination stay alive until the flush)
+        return dw
     if xl is None:           # single bf16 plane per operand
         assert param_kc is not None
         kn, cn = param_kc

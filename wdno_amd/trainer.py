@@ -250,6 +250,7 @@ class OverlappedAllReduce:
             self._launch(b)
 
     def _launch(self, b):
+        ops.flush_wgrad_reduces()                     # weight gradients whose split reductions are still pending are unwritten until this launch
         flat = self.buf.flat_grad
         for i in self.members[b]:                     # autograd adds in place into the flat views; anything else is copied in first
             p, (o, n) = self.buf.params[i], self.spans[i]
