@@ -188,7 +188,7 @@ int wdno_conv_wgrad_f16x3_param(const void* xh, const void* xl, const float* sx,
  * number of items in one launch (items travel by value in the kernel arguments: no table upload, capturable in a HIP graph) -- the same additions
  * in the same order as wdno_conv_wgrad_f16x3_param / _bf16_param, i.e. bit-identical results. ws must stay alive and unmodified in between.
  * xl == NULL (and sx == sdy == NULL): single bf16 planes. `items` is a HOST array. */
-#define WDNO_WGRAD_REDUCE_MAX 64
+#define WDNO_WGRAD_REDUCE_MAX 40
 typedef struct wdno_wgrad_reduce_item {
   const float* ws; float* dw;      /* partial sums [splits][n]; destination in the parameter's layout dw[Kn][Cn][kd][kh][kw] */
   int n, splits;                   /* n = kd*kh*K8*kw*C8 */

@@ -1095,7 +1095,7 @@ static bool wgrad_h3_reduce_tiled(int splits, const wdno_conv_geom* g, int Kn, i
 // ---- every pending split reduction of a backward pass in ONE launch (round 6). A training step ran 58 of these reductions, 5-10 us each, one behind
 // every weight-gradient kernel (0.43 ms per smoke step, profiles/r05_smoke_kernel_stats.md); only the optimiser reads their results. The callers
 // now run the partial-sum kernels alone (wdno_conv_wgrad_*_partials: the workspace stays alive) and hand the list of reductions over at the end of
-// the backward: the items travel BY VALUE in the kernel arguments (<= WDNO_WGRAD_REDUCE_MAX per launch), so the launch needs no table upload and
+// the backward: the items travel BY VALUE in the kernel arguments (<= WDNO_WGRAD_REDUCE_MAX per launch: 2.4 KB of arguments, well inside the 4 KB a launch takes together with the implicit ones), so the launch needs no table upload and
 // replays unchanged from a captured graph. A block finds its item by its first-block number and runs the same body as the per-layer kernels in
 // the same order of additions: results are bit-identical to them.
 struct WgradReduceArgs {

@@ -434,7 +434,12 @@ def graph_capture(graph, stream=None):
     Run the step once eagerly first (packed / split weight operands and pixel tables are built on first use)."""
     global _CAPTURE
     assert _CAPTURE is None, 'nested graph captures are not supported'
-    with torch.cuda.graph(graph, stream=stream):
+    # capture_error_mode 'thread_local': only THIS thread is held to the capture rules. Under the default ('global') any thread that touches the
+    # HIP API in a capture-unsafe way fails -- and a process group's watchdog thread polls the events of earlier collectives (hipEventQuery) whenever
+    # it wakes up: a capture that follows eager data-parallel steps then dies with "operation not permitted when stream is capturing" a few times in
+    # a hundred (tests/test_gpu_distributed.py caught it on a one-rank RCCL group). Launches of other threads INTO the capturing stream -- autograd's
+    # worker thread running the backward -- are recorded in every mode.
+    with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
         _CAPTURE = [None, 0]
         try:
             yield graph
@@ -860,7 +865,9 @@ def _wgrad_h3_kernel_name(k, run, window=False):
 FLAT_WGRAD = True         # weight gradients of split convolutions land in the trainer's flat gradient buffer (no gather copy for them)
 _FLAT_ARMED = False       # ... only inside flat_wgrad_scope(): the trainers wrap THEIR backward in it
 DEFER_WGRAD_REDUCE = True  # ... and their split reductions are collected and run as ONE launch at the end of that backward (test knob: bit-identical without)
-_WGRAD_PENDING = None     # [(item, workspace, dw), ...] while a trainer's backward is running
+_WGRAD_PENDING = None     # [(item, workspace), ...] while a trainer's backward is running. NOT the destination tensor: autograd's AccumulateGrad
+#                           steals a gradient only when nobody else references it, and CLONES it otherwise -- a clone of a still unwritten tensor
+_DEFERRED_DSTS = set()    # flat-buffer addresses the flushed reductions wrote to (FlatBuffers.gather_grads checks that autograd kept those views)
 
 
 def flush_wgrad_reduces():
@@ -872,8 +879,17 @@ def flush_wgrad_reduces():
     if not pend:
         return
     _WGRAD_PENDING = [] if _FLAT_ARMED else None
-    items = (_lib.WgradReduceItem * len(pend))(*[it for it, _, _ in pend])
+    items = (_lib.WgradReduceItem * len(pend))(*[it for it, _ in pend])
     _lib.check(_lib_().wdno_wgrad_reduce_multi(C.cast(items, C.c_void_p), len(pend), _stream()), 'wgrad_reduce_multi')
+    _DEFERRED_DSTS.update(int(it.dw) for it, _ in pend)
+
+
+def take_deferred_dsts():
+    """The flat-buffer addresses written by deferred reductions since the last call (trainer.FlatBuffers.gather_grads: the gradient autograd holds
+    for such a parameter must BE that span -- a clone made before the reduction ran would be garbage)."""
+    global _DEFERRED_DSTS
+    d, _DEFERRED_DSTS = _DEFERRED_DSTS, set()
+    return d
 
 
 @contextlib.contextmanager
@@ -932,15 +948,18 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None, out
     window = tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 3 and pd[2] == 1 and c8 % 64 == 0
     if tuple(st) == (1, 1, 1) and tuple(osp) == (d, h, ww) and ks[2] == 7 and pd[2] == 3 and c8 == 48 and k8 <= 64 and max(ks) <= 8:
         window = 'stem'                    # csrc/conv_wgrad_h3d.hip: wd_stem_takes
-    if param_kc is not None and _WGRAD_PENDING is not None:
-        # a trainer's backward: the partial sums now, the ordered reduction with all the others when the backward has returned
+    if param_kc is not None and out is not None and _WGRAD_PENDING is not None:
+        # a trainer's backward and the parameter's FIRST gradient since zero_grad() (`out` is its span of the flat gradient buffer, _flat_grad_out):
+        # the partial sums now, the ordered reduction with all the others when the backward has returned. Until then `out` is unwritten -- safe
+        # because autograd only stores (steals) the returned view; a second gradient of the same parameter (gradient accumulation) gets out = None
+        # and is reduced at once, like every weight gradient outside a trainer's backward.
         kn, cn = param_kc
-        dw = out if out is not None else torch.empty((kn, cn, *ks), device=xh.device, dtype=torch.float32)
+        dw = out
         item = _lib.WgradReduceItem()
         with _timed(_wgrad_h3_kernel_name(k8, ks[2] * c8, window), flops):
             _lib.check(lib.wdno_conv_wgrad_partials(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dw), kn, cn, _p(ws), nb, C.byref(g),
                                                     C.byref(item), _stream()), 'conv_wgrad_partials')
-        _WGRAD_PENDING.append((item, ws, dw))         # (the workspace and the destination stay alive until the flush)
+        _WGRAD_PENDING.append((item, ws))             # (the workspace stays alive until the flush; the destination is the trainer's buffer)
         return dw
     if xl is None:           # single bf16 plane per operand
         assert param_kc is not None
@@ -1373,7 +1392,8 @@ class _ConvT(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = conv_fwd_h3(gyplanes, gshape4, weight, pack_fwd, 'f', None, None, ks, st, pd, cin_p)
             if ctx.needs_input_grad[1]:
-                gw = conv_wgrad_h3(gyplanes, gshape4, (xh, xl, sx), xshape4[1:], ks, st, pd, param_kc=(cin, cout))    # [in, out, 1, 4, 4]
+                gw = conv_wgrad_h3(gyplanes, gshape4, (xh, xl, sx), xshape4[1:], ks, st, pd, param_kc=(cin, cout),
+                                   out=_flat_grad_out(weight, (cin, cout, 1, 4, 4)))                                   # [in, out, 1, 4, 4]
             if has_bias and ctx.needs_input_grad[2]:
                 gb = colsum(gy.reshape(-1, cout_p))[:cout].contiguous()
             return gx, gw, gb

@@ -143,6 +143,12 @@ class FlatBuffers:
             return
         grads = [p.grad for p in self.params]
         ptrs = [0 if g is None else g.data_ptr() for g in grads]
+        deferred = ops.take_deferred_dsts()           # spans that deferred split reductions wrote (ops.flush_wgrad_reduces) after autograd took the gradient
+        if deferred:
+            lost = [i for i, (a, v) in enumerate(zip(ptrs, self._view_ptrs)) if v in deferred and a != v]
+            if lost:
+                raise RuntimeError(f'wdno_amd FlatBuffers: autograd did not keep the flat-buffer view of {len(lost)} weight gradient(s) whose split reduction was '
+                                   f'deferred (parameter indices {lost[:8]}): it holds a copy made before the reduction ran. Set ops.DEFER_WGRAD_REDUCE = False.')
         if ptrs == self._view_ptrs:                  # accumulated in place into the flat views (WDNO_GRAD_GATHER=0 / a second call)
             self._gathered = True
             return
