@@ -71,6 +71,17 @@ int wdno_dwt_inv_adjoint(const float* dx, float* dcoef, const wdno_dwt_desc* d, 
 /* nearest x2 up-sampling of coefficient tensors (burgers/ddpm_burgers/wavelet_utils.py:5-16,
  * smoke/ddpm/wave_utils.py:1-14): in [outer, a, mid, b, c] -> out [outer, a*fa, mid, b*fb, c*fc]. */
 int wdno_upsample_coef(const float* in, float* out, int64_t outer, int a, int mid, int b, int c, int fa, int fb, int fc, wdno_stream_t s);
+/* Dataset packing of the smoke task for a batch, one launch (smoke/ddpm/data_2d.py:156-221, Smoke_wave.__getitem__ of a base-resolution model):
+ *   state[b][f][c][h][w] = value / rescaler[c],   state [B][pad_t][8 F + 2][pad_x][pad_x]
+ *   c <  8 F    : coef[sim][c / 8][c % 8][f][h][w] inside the [nt][nx][nx] box, 0 in the padding           (coef [.][F][8][nt][nx][nx])
+ *   c == 8 F    : init_coef[sim][f / (pad_t / 4)][h][w] inside [nx][nx], 0 outside                          (the 4 sub-bands of the DWT of rho(t = 0))
+ *   c == 8 F + 1: smokeout[sim][h >= pad_x / 2][f] for f < nt, 0 beyond                                     (smokeout [.][2][nt])
+ * sim = idx[b] (device int64; NULL: b) selects the simulation inside resident stores whose per-simulation strides (in elements) are given --
+ * the stores may hold the files exactly as the offline transform wrote them ([5][4][nx][nx] initial coefficients: field 0 is read).
+ * IEEE division: bit-identical to the torch formulation. pad_t % 4 == 0, pad_x % 4 == 0. */
+int wdno_pack_smoke_state(const float* coef, int64_t coef_sim_stride, const float* init_coef, int64_t init_sim_stride, const float* smokeout,
+                          int64_t so_sim_stride, const int64_t* idx, const float* rescaler, float* state, int64_t B, int F, int nt, int nx,
+                          int pad_t, int pad_x, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ layout
  * API layout [N, C, S] (S = product of spatial dims) <-> channels-last [N, S, Cp] (Cp >= C, zero padded). */

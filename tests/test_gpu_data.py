@@ -139,3 +139,117 @@ def test_smoke_guidance_gradient_vs_reference_run(trees, name):
     # through the callable the sampler receives (design_fn(x, low=, init=, init_u=), inference_2d.py:81-93)
     dfn = Gd.GuidanceFn(shape, ori, rd, **kw)
     assert rel_l2(dfn(xd, low=None, init=None, init_u=ud), g_ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ round 6: packing kernel + resident loaders
+def _smoke_files(root, n, seed=0):
+    """n synthetic simulations in the offline transform's on-disk format (wave_trans_2d.py:172-185): level 0 only."""
+    g = torch.Generator().manual_seed(seed)
+    d = root / 'train' / 'bior1.3_zero' / 'time_downsample'
+    d.mkdir(parents=True, exist_ok=True)
+    for i in range(n):
+        f = {'coef': [torch.randn(5, 8, 18, 34, 34, generator=g)], 'init_coef': [torch.randn(5, 4, 34, 34, generator=g)], 'smokeout': [torch.rand(2, 18, generator=g)],
+             'shape': [(18, 34, 34)], 'ori_shape': (32, 64, 64)}
+        torch.save(f, str(d / f'{i:06d}'))
+
+
+def test_pack_smoke_kernel_is_bit_identical_to_the_index_formulation(trees):
+    """wdno_pack_smoke_state (csrc/pack.hip; f1, data_2d.py:156-221) against the torch formulation of the same packing -- which
+    tests/test_host.py pins to the reference's golden -- for 5 and 4 fields, with and without an index list into larger resident stores, the
+    [N, 5, 4, nx, nx] form of the initial coefficients, and other pad sizes: torch.equal (IEEE division in both)."""
+    from ddpm.data_2d import pack_smoke_batch, pack_smoke_gpu, _RESCALERS
+    g = torch.Generator().manual_seed(1)
+    for nf, nt, nx, pad_t, pad_x in ((5, 18, 34, 24, 40), (4, 18, 34, 24, 40), (5, 10, 18, 12, 20), (2, 3, 7, 4, 8)):
+        n = 6
+        coef = torch.randn(n, nf, 8, nt, nx, nx, generator=g)
+        init5 = torch.randn(n, 5, 4, nx, nx, generator=g)
+        so = torch.rand(n, 2, nt, generator=g)
+        r = torch.tensor(_RESCALERS['bior1.3'], dtype=torch.float32)
+        r = torch.cat((r[:8 * nf], r[-2:]))
+        want = pack_smoke_batch(coef, init5[:, 0].contiguous(), so, r.reshape(1, -1, 1, 1), pad_t, pad_x)          # host tensors: the index formulation
+        got = pack_smoke_batch(coef.to(DEV), init5[:, 0].contiguous().to(DEV), so.to(DEV), r.reshape(1, -1, 1, 1).to(DEV), pad_t, pad_x)
+        assert got.is_cuda and torch.equal(got.cpu(), want)
+        idx = torch.tensor([4, 0, 0, 5], device=DEV)
+        got2 = pack_smoke_gpu(coef.to(DEV), init5.to(DEV), so.to(DEV), r, idx, pad_t, pad_x)                      # stores as the files hold them
+        assert torch.equal(got2.cpu(), want[[4, 0, 0, 5]])
+
+
+def test_resident_smoke_loader_equals_the_dataset(trees, tmp_path):
+    """ResidentSmokeLoader: every epoch is a permutation of the simulations, every batch equals Smoke_wave's own items (torch.load + host packing
+    per sample) bit for bit; files are read exactly once (the second epoch reads none); two ranks see disjoint shards that reshuffle per epoch."""
+    from ddpm.data_2d import Smoke_wave
+    from wdno_amd.loader import ResidentSmokeLoader
+    _smoke_files(tmp_path, 11)
+    ds = Smoke_wave(str(tmp_path), 'bior1.3', 'zero')
+    ds.n_simu = 11
+    loads = []
+    raw0 = ds.raw
+    ds.raw = lambda i: (loads.append(i), raw0(i))[1]
+    ld = ResidentSmokeLoader(ds, 4, DEV, shuffle=True, seed=3, num_workers=0)
+    for epoch in range(2):
+        ld.sampler.set_epoch(epoch)
+        seen = []
+        for state, shape, _, ids in ld:
+            assert state.is_cuda and shape == [18, 34, 34]
+            for j, i in enumerate(ids.tolist()):
+                assert torch.equal(state[j].cpu(), ds[i][0])
+            seen += ids.tolist()
+        assert sorted(seen) == list(range(11))
+        assert len(loads) == 11                       # the second epoch is served from HBM
+    assert ld.resident_bytes() == 11 * __import__('wdno_amd.loader', fromlist=['x']).SMOKE_SIM_BYTES
+    a = ResidentSmokeLoader(ds, 4, DEV, rank=0, world=2, seed=0, num_workers=0)
+    b = ResidentSmokeLoader(ds, 4, DEV, rank=1, world=2, seed=0, num_workers=0)
+    ia, ib = a.sampler.indices(), b.sampler.indices()
+    assert len(ia) == len(ib) == 6 and sorted(set(ia) | set(ib)) == list(range(11))
+    a.sampler.set_epoch(1)
+    assert a.sampler.indices() != ia
+    # the same order as torch's DistributedSampler gives for this seed / epoch
+    from torch.utils.data.distributed import DistributedSampler
+    s = DistributedSampler(ds, num_replicas=2, rank=0, shuffle=True, seed=0)
+    s.set_epoch(1)
+    assert list(s) == a.sampler.indices()
+
+
+def test_resident_tensor_loader_and_trainer_pick_it_up(trees, tmp_path):
+    """ResidentTensorLoader (DiffusionDataset.x in HBM, a batch = one gather) and TrainerCore.make_loader choosing the resident pipelines for the
+    datasets they serve, the reference's DataLoader for everything else and when Trainer.resident_data is off."""
+    import ddpm_burgers.data_burgers_1d as DB
+    from ddpm_burgers.unet import Unet2D
+    from ddpm_burgers.diffusion_1d import GaussianDiffusion
+    from ddpm_burgers.train_diffusion import Trainer
+    from wdno_amd.loader import ResidentTensorLoader, ResidentSmokeLoader
+    from wdno_amd.trainer import TrainerCore
+    x = torch.randn(10, 9, 8, 8)
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self):
+            self.x = x
+
+        def __len__(self):
+            return 10
+
+        def __getitem__(self, i):
+            return self.x[i]
+    ld = ResidentTensorLoader(DS(), 4, DEV, seed=5)
+    got = torch.cat([b.cpu() for b in ld])
+    assert got.shape == x.shape and sorted(got.reshape(10, -1).sum(1).tolist()) == sorted(x.reshape(10, -1).sum(1).tolist())
+    torch.manual_seed(0)
+    net = Unet2D(dim=8, dim_mults=(1, 2), channels=9, resnet_block_groups=1)
+    dif = GaussianDiffusion(net, seq_length=(8, 8), padded_shape=[6, 7], ori_shape=[10, 14], loss_layer_weight=torch.ones(1, 9, 1, 1),
+                            is_condition_pad=True, is_condition_u0=True, is_condition_f=True)
+    prev = TrainerCore.num_workers
+    TrainerCore.num_workers = 0
+    try:
+        tr = Trainer(dif, DS(), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=3, results_folder=str(tmp_path / 'a'))
+        assert isinstance(tr.dl.gi_frame.f_locals['dl'], ResidentTensorLoader)
+        for _ in range(3):                              # crosses an epoch boundary (10 samples, batches of 4)
+            tr.optimisation_step(lambda: next(tr.dl).to(tr.device, non_blocking=True))
+        assert next(tr.dl).is_cuda
+
+        class NoRes(Trainer):
+            resident_data = False
+        tr2 = NoRes(dif, DS(), rescaler=torch.ones(1), train_batch_size=4, train_num_steps=3, results_folder=str(tmp_path / 'b'))
+        assert isinstance(tr2.dl.gi_frame.f_locals['dl'], torch.utils.data.DataLoader)
+    finally:
+        TrainerCore.num_workers = prev
+    torch.cuda.synchronize()

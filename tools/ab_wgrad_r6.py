@@ -20,6 +20,9 @@ CASES = [
     ('burgers l0 3x3 128->128 b256', (256, 1, 64, 64, 128), (128, 128, 1, 3, 3)),
 ]
 lib = ops._lib_()
+only = [a for a in sys.argv[1:] if not a.startswith('-')]
+if only:
+    CASES = [c for c in CASES if any(o in c[0] for o in only)]
 bf16 = '--bf16' in sys.argv
 if bf16:
     ops.CONV_MATH = 'bf16'

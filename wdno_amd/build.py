@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libwdno_hip.so')
-SOURCES = ['api.cpp', 'pointwise.hip', 'diffusion.hip', 'dwt.hip', 'conv.hip', 'conv_h3.hip', 'conv_h3d.hip', 'conv_h3t.hip', 'conv_wgrad_h3d.hip', 'norm.hip', 'attention.hip', 'attn_fused.hip', 'attn_fused48.hip', 'attn_fused_wide.hip', 'attn_fused_bwd.hip', 'linattn_fused.hip', 'linattn_fused_wide.hip', 'linattn_fused_bwd.hip', 'linear_rows.hip']
+SOURCES = ['api.cpp', 'pointwise.hip', 'diffusion.hip', 'pack.hip', 'dwt.hip', 'conv.hip', 'conv_h3.hip', 'conv_h3d.hip', 'conv_h3t.hip', 'conv_wgrad_h3d.hip', 'norm.hip', 'attention.hip', 'attn_fused.hip', 'attn_fused48.hip', 'attn_fused_wide.hip', 'attn_fused_bwd.hip', 'linattn_fused.hip', 'linattn_fused_wide.hip', 'linattn_fused_bwd.hip', 'linear_rows.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-fast-math']
 RESOURCES = os.path.join(HERE, 'build', 'kernel_resources.json')     # per-kernel registers / scratch from the last build
 

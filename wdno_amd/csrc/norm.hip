@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const void* __restrict_
 // threads take part -- for C <= 128 a channel's chunk list is cut into 256 / C pieces that are folded through LDS -- so the
 // chains of dependent loads are nchunk * C / 256 long instead of nchunk (these one-block-per-sample kernels are pure latency:
 // 8.6 and 16.6 us per launch before, ~100 launches per train step).
-__device__ __forceinline__ void gn_chunk_totals(const double* __restrict__ part, int n, int nchunk, int C, double* sa, double* sb) {
+// (cb0, cn: the channels cb0 .. cb0 + cn - 1 only, results at sa / sb[0 .. cn) -- the finalize kernels run one block per (sample, slice of groups))
+__device__ __forceinline__ void gn_chunk_totals(const double* __restrict__ part, int n, int nchunk, int Call, double* sa, double* sb, int cb0 = 0, int cn = -1) {
+  const int C = cn < 0 ? Call : cn;
+  part += cb0 * 2;
   const int nsub = C <= 128 ? 256 / C : 1;
   for (int idx = threadIdx.x; idx < C * nsub; idx += 256) {
     const int q = idx / C, c = idx - q * C;
@@ -157,20 +160,20 @@ __device__ __forceinline__ void gn_chunk_totals(const double* __restrict__ part,
     // requested before the first is added: the adds were chained behind one L2 round trip per pair of chunks (16 chunks per thread at
     // C = 64: ~6 of the 8.8 us of a launch that 8 blocks make 30 times per step, forward and backward)
     for (; k + 7 < k1; k += 8) {
-      const double* q0 = part + (((int64_t)n * nchunk + k) * C + c) * 2;
+      const double* q0 = part + (((int64_t)n * nchunk + k) * Call + c) * 2;
       double va[8], vb[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { va[u] = q0[(int64_t)u * C * 2]; vb[u] = q0[(int64_t)u * C * 2 + 1]; }
+      for (int u = 0; u < 8; ++u) { va[u] = q0[(int64_t)u * Call * 2]; vb[u] = q0[(int64_t)u * Call * 2 + 1]; }
 #pragma unroll
       for (int u = 0; u < 8; u += 2) { a0 += va[u]; b0 += vb[u]; a1 += va[u + 1]; b1 += vb[u + 1]; }
     }
     for (; k + 1 < k1; k += 2) {
-      const double* q0 = part + (((int64_t)n * nchunk + k) * C + c) * 2;
-      const double* q1 = q0 + (int64_t)C * 2;
+      const double* q0 = part + (((int64_t)n * nchunk + k) * Call + c) * 2;
+      const double* q1 = q0 + (int64_t)Call * 2;
       a0 += q0[0]; b0 += q0[1]; a1 += q1[0]; b1 += q1[1];
     }
     if (k < k1) {
-      const double* q0 = part + (((int64_t)n * nchunk + k) * C + c) * 2;
+      const double* q0 = part + (((int64_t)n * nchunk + k) * Call + c) * 2;
       a0 += q0[0]; b0 += q0[1];
     }
     sa[idx] = a0 + a1; sb[idx] = b0 + b1;               // idx = q * C + c
@@ -198,8 +201,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   __shared__ double chs[GN_MAXC], chq[GN_MAXC];
   __shared__ float gmean[GN_MAXC], grstd[GN_MAXC];
   const int n = blockIdx.x, cg = C / G;
+  // round 6: gridDim.y slices of the groups (their statistics are independent): with one block per sample the launch was a chain of dependent loads
+  // over nchunk x C partials -- 7.5 us per norm, 60 such launches per training step; a slice of one group of 8 channels reads 8 KB of them.
+  // LDS tables are indexed from the slice's first channel / group.
+  const int gps = (G + (int)gridDim.y - 1) / (int)gridDim.y, gs0 = (int)blockIdx.y * gps, gs1 = min(G, gs0 + gps);
+  if (gs0 >= gs1) return;
+  const int cs0 = gs0 * cg, csn = (gs1 - gs0) * cg;
+  gamma += cs0; beta += cs0;
+  if (ss) ss += cs0;
+  cb += (int64_t)cs0 * 4; gb += (int64_t)gs0 * 4;
+  if (stats_out) stats_out += (int64_t)gs0 * 2;
+  if (stats_in) stats_in += (int64_t)gs0 * 2;
+  const int Call = C, Gall = G;
+  C = csn; G = gs1 - gs0;
   if (part) {
-    gn_chunk_totals(part, n, nchunk, C, chs, chq);
+    gn_chunk_totals(part, n, nchunk, Call, chs, chq, cs0, csn);
     if (cg > 64) {
       // few, wide groups (GroupNorm(1, C) of the Burgers U-Net): the whole block reduces each group
       __shared__ double ra[256], rb[256];
@@ -226,29 +242,29 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
       if (var < 0) var = 0;
       float rstd = (float)(1.0 / sqrt(var + (double)eps));
       gmean[g] = (float)mean; grstd[g] = rstd;
-      stats_out[((int64_t)n * G + g) * 2 + 0] = (float)mean;
-      stats_out[((int64_t)n * G + g) * 2 + 1] = rstd;
+      stats_out[((int64_t)n * Gall + g) * 2 + 0] = (float)mean;
+      stats_out[((int64_t)n * Gall + g) * 2 + 1] = rstd;
     }
   } else {
     for (int g = threadIdx.x; g < G; g += 256) {
-      gmean[g] = stats_in[((int64_t)n * G + g) * 2 + 0];
-      grstd[g] = stats_in[((int64_t)n * G + g) * 2 + 1];
+      gmean[g] = stats_in[((int64_t)n * Gall + g) * 2 + 0];
+      grstd[g] = stats_in[((int64_t)n * Gall + g) * 2 + 1];
     }
   }
   __syncthreads();
   for (int g = threadIdx.x; g < G; g += 256) {
-    float* o = gb + ((int64_t)n * G + g) * 4;
+    float* o = gb + ((int64_t)n * Gall + g) * 4;
     o[0] = gmean[g]; o[1] = grstd[g]; o[2] = 0.f; o[3] = 0.f;
   }
   float ma = 0.f, mb = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) {
     int g = c / cg;
-    float sc1 = ss ? ss[(int64_t)n * 2 * C + c] + 1.0f : 1.0f;
-    float sh = ss ? ss[(int64_t)n * 2 * C + C + c] : 0.0f;
+    float sc1 = ss ? ss[(int64_t)n * 2 * Call + c] + 1.0f : 1.0f;
+    float sh = ss ? ss[(int64_t)n * 2 * Call + Call + c] : 0.0f;
     float k1 = grstd[g] * gamma[c];
     float a = k1 * sc1;
     float b = (beta[c] - gmean[g] * k1) * sc1 + sh;
-    float* o = cb + ((int64_t)n * C + c) * 4;
+    float* o = cb + ((int64_t)n * Call + c) * 4;
     o[0] = a; o[1] = b; o[2] = a; o[3] = 0.f;   // k1*(s+1) == a
     ma = fmaxf(ma, fabsf(a)); mb = fmaxf(mb, fabsf(b));
   }
@@ -301,16 +317,27 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
                                                                const float* __restrict__ mx = nullptr, float* __restrict__ bound_rec = nullptr) {
   __shared__ double chA[GN_MAXC], chB[GN_MAXC];
   const int n = blockIdx.x, cg = C / G;
-  gn_chunk_totals(part, n, nchunk, C, chA, chB);
+  // a block = (sample, slice of groups), as gn_finalize_kernel
+  const int gps = (G + (int)gridDim.y - 1) / (int)gridDim.y, gs0 = (int)blockIdx.y * gps, gs1 = min(G, gs0 + gps);
+  if (gs0 >= gs1) return;
+  const int cs0 = gs0 * cg, csn = (gs1 - gs0) * cg;
+  gamma += cs0; beta += cs0;
+  if (ss) ss += cs0;
+  if (dss) dss += cs0;
+  dgb += cs0; gb += (int64_t)gs0 * 4;
+  if (cb) cb += (int64_t)cs0 * 4;
+  const int Call = C, Gall = G;
+  C = csn; G = gs1 - gs0;
+  gn_chunk_totals(part, n, nchunk, Call, chA, chB, cs0, csn);
   for (int c = threadIdx.x; c < C; c += 256) {
     const double a = chA[c], b = chB[c];
-    float sc1 = ss ? ss[(int64_t)n * 2 * C + c] + 1.0f : 1.0f;
+    float sc1 = ss ? ss[(int64_t)n * 2 * Call + c] + 1.0f : 1.0f;
     if (dss) {
-      dss[(int64_t)n * 2 * C + c] = (float)((double)gamma[c] * b + (double)beta[c] * a);   // d scale
-      dss[(int64_t)n * 2 * C + C + c] = (float)a;                                          // d shift
+      dss[(int64_t)n * 2 * Call + c] = (float)((double)gamma[c] * b + (double)beta[c] * a);   // d scale
+      dss[(int64_t)n * 2 * Call + Call + c] = (float)a;                                          // d shift
     }
-    dgb[((int64_t)n * 2 + 0) * C + c] = (float)((double)sc1 * b);   // d gamma (this sample)
-    dgb[((int64_t)n * 2 + 1) * C + c] = (float)((double)sc1 * a);   // d beta
+    dgb[((int64_t)n * 2 + 0) * Call + c] = (float)((double)sc1 * b);   // d gamma (this sample)
+    dgb[((int64_t)n * 2 + 1) * Call + c] = (float)((double)sc1 * a);   // d beta
     double w = (double)gamma[c] * (double)sc1;
     chA[c] = w * a; chB[c] = w * b;
   }
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
     if (cg > 64) { a = chA[g * cg]; b = chB[g * cg]; }
     else for (int c = g * cg; c < (g + 1) * cg; ++c) { a += chA[c]; b += chB[c]; }
     double m = (double)cg * (double)S;
-    float* o = gb + ((int64_t)n * G + g) * 4;
+    float* o = gb + ((int64_t)n * Gall + g) * 4;
     float rstd = o[1];
     o[2] = (float)(a / m) * rstd;
     o[3] = (float)(b / m) * rstd;
@@ -348,9 +375,9 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
     for (int k = threadIdx.x; k < nchunk; k += 256) {
       mdz = fmaxf(mdz, mx[((int64_t)n * nchunk + k) * 2]); mxh = fmaxf(mxh, mx[((int64_t)n * nchunk + k) * 2 + 1]);
     }
-    for (int c = threadIdx.x; c < C; c += 256) mk = fmaxf(mk, fabsf(cb[((int64_t)n * C + c) * 4 + 2]));
+    for (int c = threadIdx.x; c < C; c += 256) mk = fmaxf(mk, fabsf(cb[((int64_t)n * Call + c) * 4 + 2]));
     for (int g = threadIdx.x; g < G; g += 256) {
-      mz = fmaxf(mz, fabsf(gb[((int64_t)n * G + g) * 4 + 2])); mw = fmaxf(mw, fabsf(gb[((int64_t)n * G + g) * 4 + 3]));
+      mz = fmaxf(mz, fabsf(gb[((int64_t)n * Gall + g) * 4 + 2])); mw = fmaxf(mw, fabsf(gb[((int64_t)n * Gall + g) * 4 + 3]));
     }
     __shared__ float bm[5][4];
     float v[5] = {wave_max(mdz), wave_max(mxh), wave_max(mk), wave_max(mz), wave_max(mw)};
@@ -568,6 +595,9 @@ extern "C" size_t wdno_groupnorm_ws_bytes(int64_t N, int64_t S, int C, int G) {
 extern "C" size_t wdno_groupnorm_stats_floats(int64_t N, int C, int G) { return (size_t)N * G * 2 + (size_t)N * C * 4 + (size_t)N * G * 4; }
 static inline float* gn_cb(float* stats, int64_t N, int G) { return stats + (size_t)N * G * 2; }
 static inline float* gn_gb(float* stats, int64_t N, int C, int G) { return stats + (size_t)N * G * 2 + (size_t)N * C * 4; }
+// slices of groups per sample for the finalize kernels: every group its own block while the groups are narrow (the statistics of wide groups --
+// GroupNorm(1, C) of the Burgers U-Net -- are reduced by a whole block)
+static inline unsigned gn_slices(int C, int G) { return (C / G > 64 || wdno_debug_mode == 71) ? 1u : (unsigned)(G < 32 ? G : 32); }      // debug 71: one block per sample (round 5, the A/B)
 static int gn_check(int64_t N, int64_t S, int C, int G) {
   if (N <= 0 || S <= 0 || C <= 0 || G <= 0 || N > 65535) return WDNO_EINVAL;
   if ((C & 3) || C > GN_MAXC || (C % G) != 0) return WDNO_EUNSUPPORTED;
@@ -590,7 +620,7 @@ extern "C" int wdno_groupnorm_act_fwd_amax_t(const void* x, int x_bf16, const fl
   hipStream_t st = as_stream(s);
   for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_)
     GN_PARTIAL0(x_bf16, dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0));
-  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps);
+  gn_finalize_kernel<<<dim3((unsigned)N, gn_slices(C, G)), 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps);
   int gx = stream_grid(S * (C / 4), 256);
   if (gx > 512) gx = 512;
   if (x_bf16) gn_apply_kernel<gn_bf16><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, y, S, C, silu, amax_rec);
@@ -621,7 +651,7 @@ extern "C" int wdno_groupnorm_act_bwd_amax(const float* x, const float* dy, cons
   const int64_t rpc = cdiv64(S, nchunk);
   hipStream_t st = as_stream(s);
   for (int rep_ = 0; rep_ < (wdno_debug_mode == 59 ? 2 : 1); ++rep_) gn_partial_kernel<1><<<dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu);
-  gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk);
+  gn_bwd_finalize_kernel<<<dim3((unsigned)N, gn_slices(C, G)), 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk);
   int gx = stream_grid(S * (C / 4), 256);
   if (gx > 512) gx = 512;
   gn_bwd_apply_kernel<<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, dy, cb, gb, dx, S, C, C / G, G, silu, amax_rec);
@@ -655,7 +685,7 @@ extern "C" int wdno_groupnorm_act_fwd_planes_t(const void* x, int x_bf16, const 
   hipStream_t st = as_stream(s);
   for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_)
     GN_PARTIAL0(x_bf16, dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr));
-  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
+  gn_finalize_kernel<<<dim3((unsigned)N, gn_slices(C, G)), 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
   if (x_bf16) gn_apply_planes_kernel<gn_bf16><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec, S, C, silu);
@@ -688,7 +718,7 @@ extern "C" int wdno_groupnorm_act_add_fwd_planes_t(const void* x, int x_bf16, co
   hipStream_t st = as_stream(s);
   for (int rep_ = 0; rep_ < (wdno_debug_mode == 58 ? 2 : 1); ++rep_)
     GN_PARTIAL0(x_bf16, dim3(nchunk, (unsigned)N), 256, 0, st>>>(x, nullptr, nullptr, nullptr, part, S, C, C / G, G, txp, rpc, 0, y_lo ? mx : nullptr));
-  gn_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
+  gn_finalize_kernel<<<dim3((unsigned)N, gn_slices(C, G)), 256, 0, st>>>(part, nullptr, gamma, beta, ss, stats, cb, gb, S, C, G, nchunk, eps, mx, y_lo ? bound_rec : nullptr);
   int gx = stream_grid(S * (C / 8), 256);
   if (gx > 512) gx = 512;
   if (x_bf16) gn_apply_add_planes_kernel<gn_bf16><<<dim3(gx, (unsigned)N), 256, 0, st>>>(x, cb, residual, y, (_Float16*)y_hi, (_Float16*)y_lo, y_scale, bound_rec,
@@ -754,7 +784,7 @@ extern "C" int wdno_groupnorm_act_bwd_planes_t(const void* x, int x_bf16, const 
 #define GN_K_BWD_APPLY(XT, DT, ...) gn_bwd_apply_planes_kernel<XT, DT><<<dim3(gx, (unsigned)N), 256, 0, st>>>(__VA_ARGS__)
   for (int rep_ = 0; rep_ < (wdno_debug_mode == 59 ? 2 : 1); ++rep_)
     GN_BWD_TYPES(GN_K_PARTIAL1, x, dy, cb, gb, part, S, C, C / G, G, txp, rpc, silu, dx_lo ? mx : nullptr);
-  gn_bwd_finalize_kernel<<<(unsigned)N, 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, dx_lo ? bound_rec : nullptr);
+  gn_bwd_finalize_kernel<<<dim3((unsigned)N, gn_slices(C, G)), 256, 0, st>>>(part, gamma, beta, ss, gb, dgb_partial, dss, S, C, G, nchunk, cb, mx, dx_lo ? bound_rec : nullptr);
   const int gx = gn_planes_grid(N, S, C);
   GN_BWD_TYPES(GN_K_BWD_APPLY, x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp, S, C, C / G, G, silu);
   // one launch for both reductions that end the backward: the column sums of dx (partials of the apply pass) and, when dgb_sum is given, the

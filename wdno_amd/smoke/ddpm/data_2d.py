@@ -74,6 +74,8 @@ def pack_smoke_batch(coef, init_coef, smokeout, rescaler, pad_t=24, pad_x=40):
     rescaler. Index work only; equal to stacking pack_smoke_state per sample (tests/test_host.py)."""
     b, nf = coef.shape[0], coef.shape[1]
     nt, nx = coef.shape[-3], coef.shape[-1]
+    if coef.is_cuda:                     # one launch of csrc/pack.hip (bit-identical to the index work below, tests/test_gpu_data.py)
+        return pack_smoke_gpu(coef, init_coef, smokeout, rescaler, None, pad_t, pad_x)
     data = F.pad(coef.reshape(b, nf * 8, nt, nx, nx), (0, pad_x - nx, 0, pad_x - nx, 0, pad_t - nt))
     cond = init_coef.unsqueeze(2).expand(b, init_coef.shape[1], pad_t // 4, nx, nx).reshape(b, -1, nx, nx)
     cond = F.pad(cond, (0, pad_x - nx, 0, pad_x - nx))
@@ -82,6 +84,30 @@ def pack_smoke_batch(coef, init_coef, smokeout, rescaler, pad_t=24, pad_x=40):
     so = F.pad(so, (0, 0, 0, 0, 0, pad_t - nt))
     state = torch.cat((data, cond.unsqueeze(1), so), dim=1)
     return (state.permute(0, 2, 1, 3, 4) / rescaler).contiguous()
+
+
+def pack_smoke_gpu(coef, init_coef, smokeout, rescaler, idx=None, pad_t=24, pad_x=40):
+    """wdno_pack_smoke_state (csrc/pack.hip): states [B, pad_t, 8 F + 2, pad_x, pad_x] / rescaler from device-resident coefficient arrays in one
+    launch. coef [N, F, 8, nt, nx, nx], init_coef [N, 4, nx, nx] or [N, 5, 4, nx, nx] as the offline transform stores it (field 0 is used),
+    smokeout [N, 2, nt]; idx (int64 device tensor [B]) picks the simulations of the batch from the N resident ones (None: all of them, in order)."""
+    from wdno_amd import _lib
+    from wdno_amd.ops import _lib_, _p, _stream
+    for t, name in ((coef, 'coef'), (init_coef, 'init_coef'), (smokeout, 'smokeout')):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f'wdno_amd pack_smoke_gpu: {name} must be a contiguous float32 tensor on the GPU')
+    n, nf = coef.shape[0], coef.shape[1]
+    nt, nx = coef.shape[-3], coef.shape[-1]
+    assert tuple(coef.shape[2:]) == (8, nt, nx, nx) and tuple(init_coef.shape[-3:]) == (4, nx, nx) and tuple(smokeout.shape[1:]) == (2, nt)
+    c = 8 * nf + 2
+    r = torch.as_tensor(rescaler, dtype=torch.float32).reshape(-1).to(coef.device)
+    assert r.numel() == c, f'rescaler has {r.numel()} entries, the state {c} channels'
+    if idx is not None:
+        idx = idx.to(device=coef.device, dtype=torch.int64).contiguous()
+    b = n if idx is None else idx.numel()
+    out = torch.empty((b, pad_t, c, pad_x, pad_x), device=coef.device, dtype=torch.float32)
+    _lib.check(_lib_().wdno_pack_smoke_state(_p(coef), coef[0].numel(), _p(init_coef), init_coef[0].numel(), _p(smokeout), smokeout[0].numel(), _p(idx), _p(r),
+                                             _p(out), b, nf, nt, nx, pad_t, pad_x, _stream()), 'pack_smoke_state')
+    return out
 
 
 class Smoke_wave(Dataset):
@@ -106,6 +132,14 @@ class Smoke_wave(Dataset):
 
     def path(self, sim_id):
         return os.path.join(self.root, self.dirname, f'{self.wave_type}_{self.pad_mode}', f'{self.downsample_type}_downsample', f'{sim_id:06d}')
+
+    def raw(self, sim_id):
+        """The arrays of simulation sim_id as the offline transform stored them, for the base-resolution model: (coef [5, 8, nt, nx, nx],
+        init_coef [4, nx, nx] of the density, smokeout [2, nt]) -- what wdno_amd.loader.ResidentSmokeLoader keeps in HBM and packs on the GPU."""
+        db = torch.load(self.path(sim_id), weights_only=False)
+        lvl = self.N_downsample
+        return (db['coef'][lvl].to(torch.float32).contiguous(), db['init_coef'][lvl][0].to(torch.float32).contiguous(),
+                db['smokeout'][lvl].to(torch.float32).contiguous())
 
     def __getitem__(self, sim_id):
         db = torch.load(self.path(sim_id), weights_only=False)

@@ -826,9 +826,22 @@ class TrainerCore:
     num_workers = None          # DataLoader workers; None = the reference's choice (cpu_count() / 16). Class attribute, not a constructor
                                 # argument: the constructors keep exactly the reference's parameter lists (tests/test_host.py)
 
+    resident_data = True        # datasets that fit keep their tensors / raw coefficient files in HBM and form batches on the GPU (wdno_amd.loader:
+                                # no worker processes, per-sample torch.load or host packing on the step's critical path). A class attribute like
+                                # use_graph; False: the reference's DataLoader pipeline
+
     def make_loader(self, dataset, batch_size, num_workers, shuffle=True):
         from torch.utils.data import DataLoader
         from torch.utils.data.distributed import DistributedSampler
+        if self.resident_data:
+            from . import loader as L
+            free = torch.cuda.mem_get_info(self._device)[0]
+            seed = 0 if self.world > 1 else int(torch.empty((), dtype=torch.int64).random_().item())      # ranks must agree on the permutation (DistributedSampler's seed)
+            x = getattr(dataset, 'x', None)
+            if torch.is_tensor(x) and x.dim() >= 2 and x.is_floating_point() and 4 * x.numel() < free // 4:
+                return L.ResidentTensorLoader(dataset, batch_size, self._device, shuffle, self.rank, self.world, seed)
+            if hasattr(dataset, 'raw') and not getattr(dataset, 'is_super_model', True) and len(dataset) * L.SMOKE_SIM_BYTES < free // 2:
+                return L.ResidentSmokeLoader(dataset, batch_size, self._device, shuffle, self.rank, self.world, seed, num_workers=num_workers)
         sampler = DistributedSampler(dataset, num_replicas=self.world, rank=self.rank, shuffle=shuffle) if self.world > 1 else None
         return DataLoader(dataset, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler, pin_memory=True,
                           num_workers=num_workers, drop_last=False)
