@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_f16 / _bf16, dense (the 3 x fp16-split kernels spend 3 MFMA flop per algorithmic flop)
 PEAK_HBM_TBS = 8.0
-PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
+PROFILE_JSON = os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json')
 
 
 def _trees():
@@ -614,18 +614,15 @@ def train_graph_leg(ts, x, steps, cap=None):
     return {'eager': {'host_enqueue_ms_per_step': e_enq, 'ms_per_step': e_ms}, 'graph': {'host_enqueue_ms_per_step': g_enq, 'ms_per_step': g_ms}}
 
 
-def smoke_fields_to_state(fields, rs):
-    """fields [B, nf, 32, 64, 64] resident in HBM -> the training tensor [B, 24, 8 nf + 2, 40, 40] (data_2d.py:156-221): one fused 3-D DWT launch
-    (bior1.3 / zero) for the fields, the 2-D transform of the initial density, the 1-D transform of the smoke-out curve, packing + RESCALER."""
-    from wdno_amd import wavelets as Wv
-    from ddpm.data_2d import pack_smoke_batch
-    b, nf = fields.shape[:2]
-    coef = Wv.dwt_packed(fields.reshape(b * nf, 32, 64, 64), 'bior1.3', 'zero', 3).reshape(b, nf, 8, 18, 34, 34)
-    init_coef = Wv.dwt_packed(fields[:, 0, 0].reshape(b, 1, 64, 64).contiguous(), 'bior1.3', 'zero', 2).reshape(b, 4, 34, 34)
-    so = fields[:, 0].mean((-2, -1))                                       # stand-in for the smoke-out curve [B, 32]
-    lo, hi = Wv.DWT1DForward(J=1, mode='zero', wave='bior1.3')(so.unsqueeze(1).contiguous())
-    smokeout = torch.cat((lo, hi[0]), dim=1)                                # [B, 2, 18]
-    return pack_smoke_batch(coef, init_coef, smokeout, rs)
+def smoke_fields_to_state(fields, rs, curve=None):
+    """fields [B, nf, 32, 64, 64] and the smoke-out curve [B, 32], resident in HBM -> the training tensor [B, 24, 8 nf + 2, 40, 40]
+    (wave_trans_2d.py:150-170 + data_2d.py:156-221) in TWO launches (ddpm.data_2d.pack_smoke_fields): the fused 3-D DWT of the fields (bior1.3 /
+    zero) and a packing launch that pads, divides by the RESCALER and transforms the two condition channels (2-D DWT of rho(t = 0), 1-D DWT of
+    the curve) on the fly. curve None: a synthetic curve per call (one more launch)."""
+    from ddpm.data_2d import pack_smoke_fields
+    if curve is None:
+        curve = torch.rand(fields.shape[0], fields.shape[2], device=fields.device)
+    return pack_smoke_fields(fields, curve, rs)
 
 
 def smoke34_leg(device, batch, steps, sample_steps):
@@ -641,7 +638,8 @@ def smoke34_leg(device, batch, steps, sample_steps):
     r42 = torch.tensor(_RESCALERS['bior1.3'], dtype=torch.float32, device=device).reshape(1, 42, 1, 1)
     r34 = torch.cat((r42[:, :32], r42[:, -2:]), dim=1)
     fields = torch.randn(batch, 4, 32, 64, 64, device=device)
-    x = smoke_fields_to_state(fields, r34)
+    curve = torch.rand(batch, 32, device=device)
+    x = smoke_fields_to_state(fields, r34, curve)
     assert tuple(x.shape) == (batch, 24, 34, 40, 40)
     for _ in range(3):
         ts.step(x)
@@ -655,7 +653,7 @@ def smoke34_leg(device, batch, steps, sample_steps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss, _ = ts.step(smoke_fields_to_state(fields, r34))
+        loss, _ = ts.step(smoke_fields_to_state(fields, r34, curve))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ts._cap = None
@@ -755,22 +753,34 @@ def smoke_pipeline_leg(ts, device, batch, steps):
     resc = torch.tensor(_RESCALERS['bior1.3'], dtype=torch.float32, device=device).reshape(1, 42, 1, 1)
     to_state = smoke_fields_to_state
     fields = torch.randn(batch, 5, 32, 64, 64, device=device)
-    st = to_state(fields, resc)
+    curve = torch.rand(batch, 32, device=device)
+    st = to_state(fields, resc, curve)
     assert tuple(st.shape) == (batch, 24, 42, 40, 40)
-    out['transform_and_pack_ms'] = round(_ev_time(lambda: to_state(fields, resc), 20), 3)
+
+    def both(fn):
+        """per Python call (host enqueue included) and per replay of 20 calls captured in one graph (the two launches alone)"""
+        ms_call = _ev_time(fn, 20)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                fn()
+        return round(ms_call, 3), round(_ev_time(g.replay, 10) / 20, 4)
+    out['transform_and_pack_ms'], out['transform_and_pack_kernels_ms'] = both(lambda: to_state(fields, resc, curve))
+    out['launches'] = 'dwt_analysis_fused (3-D, all fields) + pack_smoke_state_kernel<fields>'
     for _ in range(2):
-        ts.step(to_state(fields, resc))
+        ts.step(to_state(fields, resc, curve))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        ts.step(to_state(fields, resc))
+        ts.step(to_state(fields, resc, curve))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     out.update(fields=[batch, 5, 32, 64, 64], state=[batch, 24, 42, 40, 40], fields_to_step_ms=round(dt * 1e3, 2), steps_per_sec=round(1 / dt, 2))
     f4 = torch.randn(batch, 4, 32, 64, 64, device=device)
     r4 = torch.cat((resc[:, :32], resc[:, -2:]), dim=1)
-    s4 = to_state(f4, r4)
-    out['four_field_synthetic'] = {'fields': [batch, 4, 32, 64, 64], 'state': list(s4.shape), 'transform_and_pack_ms': round(_ev_time(lambda: to_state(f4, r4), 20), 3)}
+    s4 = to_state(f4, r4, curve)
+    t4 = both(lambda: to_state(f4, r4, curve))
+    out['four_field_synthetic'] = {'fields': [batch, 4, 32, 64, 64], 'state': list(s4.shape), 'transform_and_pack_ms': t4[0], 'transform_and_pack_kernels_ms': t4[1]}
     return out
 
 

@@ -82,6 +82,12 @@ int wdno_upsample_coef(const float* in, float* out, int64_t outer, int a, int mi
 int wdno_pack_smoke_state(const float* coef, int64_t coef_sim_stride, const float* init_coef, int64_t init_sim_stride, const float* smokeout,
                           int64_t so_sim_stride, const int64_t* idx, const float* rescaler, float* state, int64_t B, int F, int nt, int nx,
                           int pad_t, int pad_x, wdno_stream_t s);
+/* The same with the two condition channels transformed inside the launch from the physical inputs (the online pipeline fields -> DWT -> state,
+ * smoke/wave_trans_2d.py:150-170 + data_2d.py:156-221): rho0 [.][H0][W0] = the density field at t = 0 (e.g. a view into the fields tensor),
+ * curve [.][T0] = the smoke-out curve; zero-mode analysis with the decomposition filters (host arrays of L <= 16 taps). */
+int wdno_pack_smoke_fields(const float* coef, int64_t coef_sim_stride, const float* rho0, int64_t rho0_sim_stride, const float* curve,
+                           int64_t curve_sim_stride, const float* dec_lo_host, const float* dec_hi_host, int L, const float* rescaler,
+                           float* state, int64_t B, int F, int nt, int nx, int pad_t, int pad_x, int H0, int W0, int T0, wdno_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------ layout
  * API layout [N, C, S] (S = product of spatial dims) <-> channels-last [N, S, Cp] (Cp >= C, zero padded). */

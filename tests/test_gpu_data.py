@@ -253,3 +253,29 @@ def test_resident_tensor_loader_and_trainer_pick_it_up(trees, tmp_path):
     finally:
         TrainerCore.num_workers = prev
     torch.cuda.synchronize()
+
+
+def test_pack_smoke_fields_equals_the_transform_then_pack_chain(trees):
+    """wdno_pack_smoke_fields: fields + smoke-out curve -> states in two launches (3-D analysis + a packing launch that transforms the two condition
+    channels itself) against the chain it replaces -- offline-style transforms (3-D, 2-D of rho(t = 0), 1-D of the curve: csrc/dwt.hip, pinned to
+    PyWavelets by tests/test_gpu_ops.py) followed by the packing of data_2d.py:156-221. Coefficient channels are the same launches' bits; the condition
+    channels agree to fp32 rounding (another order of the same fused multiply-adds)."""
+    from ddpm.data_2d import pack_smoke_batch, pack_smoke_fields, _RESCALERS
+    from wdno_amd import wavelets as Wv
+    g = torch.Generator().manual_seed(2)
+    for nf in (5, 4):
+        b = 3
+        fields = torch.randn(b, nf, 32, 64, 64, generator=g).to(DEV)
+        curve = torch.rand(b, 32, generator=g).to(DEV)
+        r = torch.tensor(_RESCALERS['bior1.3'], dtype=torch.float32)
+        r = torch.cat((r[:8 * nf], r[-2:])).to(DEV)
+        got = pack_smoke_fields(fields, curve, r)
+        coef = Wv.dwt_packed(fields.reshape(b * nf, 32, 64, 64), 'bior1.3', 'zero', 3).reshape(b, nf, 8, 18, 34, 34)
+        init = Wv.dwt_packed(fields[:, 0, 0].reshape(b, 1, 64, 64).contiguous(), 'bior1.3', 'zero', 2).reshape(b, 4, 34, 34)
+        lo, hi = Wv.DWT1DForward(J=1, mode='zero', wave='bior1.3')(curve.unsqueeze(1).contiguous())
+        want = pack_smoke_batch(coef, init, torch.cat((lo, hi[0]), dim=1).contiguous(), r.reshape(1, -1, 1, 1))
+        assert got.shape == want.shape == (b, 24, 8 * nf + 2, 40, 40)
+        assert torch.equal(got[:, :, :8 * nf], want[:, :, :8 * nf])
+        for ch in (-2, -1):
+            assert float(want[:, :, ch].abs().max()) > 0.05
+            assert float((got[:, :, ch] - want[:, :, ch]).abs().max()) < 2e-6 * float(want[:, :, ch].abs().max()) + 1e-7

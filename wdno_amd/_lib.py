@@ -58,6 +58,7 @@ PROTOTYPES = {
     'wdno_dwt_inv_adjoint': (I, [P, P, PD, PF, P, Z, P]),
     'wdno_upsample_coef': (I, [P, P, L, I, I, I, I, I, I, I, P]),
     'wdno_pack_smoke_state': (I, [P, L, P, L, P, L, P, P, P, L, I, I, I, I, I, P]),
+    'wdno_pack_smoke_fields': (I, [P, L, P, L, P, L, PF, PF, I, P, P, L, I, I, I, I, I, I, I, I, P]),
     'wdno_nc_to_cl': (I, [P, P, L, I, L, I, P]),
     'wdno_cl_to_nc': (I, [P, P, L, I, L, I, P]),
     'wdno_concat2_cl': (I, [P, I, P, I, P, L, P]),

@@ -910,7 +910,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_h3s_kernel(const _Float16* __r
     }
     auto select = [&](int c) {
 #pragma unroll
-      for (int b = 0; b < TN; ++b) rd[b][c] = (unsigned)(ow[c] - dlo[b]) < (unsigned)g.W ? xbase[b][c] : ZADDR;
+      // (round 6: an invalid (pixel, dx) reads zeros in the BANK SLOT of the address it replaces -- bytes 3840 + (address mod 256) of the window plane
+      // lie in the 448 out-of-range bytes behind the 38 rows -- instead of the one stand-in address ZADDR, which collided with every lane whose own
+      // address fell on its banks: 1.2e7 SQ_LDS_BANK_CONFLICT per dispatch, 8 % of the kernel's LDS cycles, profiles/r06_smoke_pmc.md)
+      for (int b = 0; b < TN; ++b) rd[b][c] = (unsigned)(ow[c] - dlo[b]) < (unsigned)g.W ? xbase[b][c] : 3840 + (xbase[b][c] & 255);
     };
     auto advance = [&](int c) {
       ow[c] += step_ow;
