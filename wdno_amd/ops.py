@@ -867,7 +867,7 @@ _FLAT_ARMED = False       # ... only inside flat_wgrad_scope(): the trainers wra
 DEFER_WGRAD_REDUCE = True  # ... and their split reductions are collected and run as ONE launch at the end of that backward (test knob: bit-identical without)
 _WGRAD_PENDING = None     # [(item, workspace), ...] while a trainer's backward is running. NOT the destination tensor: autograd's AccumulateGrad
 #                           steals a gradient only when nobody else references it, and CLONES it otherwise -- a clone of a still unwritten tensor
-WGRAD_FLUSH_BYTES = int(os.environ.get('WDNO_WGRAD_FLUSH_MB', '96')) << 20
+WGRAD_FLUSH_BYTES = int(os.environ.get('WDNO_WGRAD_FLUSH_MB', '0')) << 20      # 0: one flush when the backward has returned (measured best, see conv_wgrad_h3)
 _DEFERRED_DSTS = set()    # flat-buffer addresses the flushed reductions wrote to (FlatBuffers.gather_grads checks that autograd kept those views)
 
 
@@ -961,10 +961,11 @@ def conv_wgrad_h3(xplanes, shape4, gyplanes, osp, ks, st, pd, param_kc=None, out
             _lib.check(lib.wdno_conv_wgrad_partials(_p(xh), _p(xl), _p(sx), _p(gh), _p(gl), _p(sg), _p(table), _p(dw), kn, cn, _p(ws), nb, C.byref(g),
                                                     C.byref(item), _stream()), 'conv_wgrad_partials')
         _WGRAD_PENDING.append((item, ws))             # (the workspace stays alive until the flush; the destination is the trainer's buffer)
-        # partial sums waiting for their reduction should still be in the 256 MB memory-side cache when it runs: a backward pass of the smoke step
-        # leaves ~400 MB of them (the two-launch form of the first cut read them back from HBM: 2 x 127 us against 0.43 ms for the 58 launches it
-        # replaced, profiles/r06_smoke_kernel_stats.md) -> flush whenever ~96 MB have accumulated
-        if sum(w.numel() for _, w in _WGRAD_PENDING) > WGRAD_FLUSH_BYTES:
+        # (A backward pass of the smoke step leaves ~400 MB of partial sums, more than the 256 MB memory-side cache: the reductions at the end read
+        # them back from HBM, 2 x 127 us against 0.43 ms for the 58 launches they replace, profiles/r06_smoke_kernel_stats.md. Flushing whenever
+        # ~96 MB wait keeps them cache-resident but puts five launches back between the kernels of the backward: same-box the step gained 0.07 ms
+        # that way against 0.18 ms with the single flush, profiles/r06_ab_same_box.txt -- WDNO_WGRAD_FLUSH_MB stays as the knob, off.)
+        if WGRAD_FLUSH_BYTES and sum(w.numel() for _, w in _WGRAD_PENDING) > WGRAD_FLUSH_BYTES:
             flush_wgrad_reduces()
         return dw
     if xl is None:           # single bf16 plane per operand
