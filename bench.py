@@ -766,7 +766,7 @@ def smoke_pipeline_leg(ts, device, batch, steps):
                 fn()
         return round(ms_call, 3), round(_ev_time(g.replay, 10) / 20, 4)
     out['transform_and_pack_ms'], out['transform_and_pack_kernels_ms'] = both(lambda: to_state(fields, resc, curve))
-    out['launches'] = 'dwt_analysis_fused (3-D, all fields) + pack_smoke_state_kernel<fields>'
+    out['launches'] = 'dwt_analysis_fused<packed store> (3-D, all fields, sub-bands -> channels of the state, / RESCALER) + pack_smoke_state_kernel<fill> (padding + condition channels)'
     for _ in range(2):
         ts.step(to_state(fields, resc, curve))
     torch.cuda.synchronize()

@@ -68,6 +68,17 @@ int wdno_dwt_fwd(const float* x, float* coef, const wdno_dwt_desc* d, const floa
 int wdno_dwt_inv(const float* coef, float* x, const wdno_dwt_desc* d, const float* filters_host, void* ws, size_t ws_bytes, wdno_stream_t s);
 int wdno_dwt_fwd_adjoint(const float* dcoef, float* dx, const wdno_dwt_desc* d, const float* filters_host, void* ws, size_t ws_bytes, wdno_stream_t s);
 int wdno_dwt_inv_adjoint(const float* dx, float* dcoef, const wdno_dwt_desc* d, const float* filters_host, void* ws, size_t ws_bytes, wdno_stream_t s);
+/* 3-D zero-mode analysis whose coefficients go straight into a larger, differently ordered tensor, divided by a per-channel constant (the smoke
+ * task's network input: smoke/ddpm/data_2d.py:156-221 does cat + pad + permute + `/ RESCALER` on the transform's output; here the transform's store
+ * does it). Image i = (outer, inner) = (i / img_inner, i % img_inner) is stored at state + outer * cs_outer + inner * d->cs_img + band * d->cs_band +
+ * k0 * d->cs0 + k1 * d->cs1 + k2, as value / rescaler[inner * 8 + band] (IEEE division: the bits of torch's `coef / RESCALER`). Rows are written
+ * row_w columns wide (row_w >= out_dims[2], row_w % 4 == 0; 0 / rescaler beyond the coefficients; all strides % 4 == 0, state 16-byte aligned:
+ * aligned 16-byte stores). One fused launch;
+ * WDNO_EUNSUPPORTED for anything it does not take (nd != 3, mode != zero, filters longer than 10 taps, rows too wide for LDS): the caller then
+ * transforms into a coefficient tensor (wdno_dwt_fwd) and packs (wdno_pack_smoke_fields). Nothing but the rows [k0 < out_dims[0]][k1 < out_dims[1]] of
+ * the 8 channels of an image is written: wdno_pack_smoke_fields(coef = NULL, ...) fills the rest of the state. */
+int wdno_dwt_fwd_packed(const float* x, float* state, const wdno_dwt_desc* d, const float* filters_host, int img_inner, int64_t cs_outer, int row_w,
+                        const float* rescaler, wdno_stream_t s);
 /* nearest x2 up-sampling of coefficient tensors (burgers/ddpm_burgers/wavelet_utils.py:5-16,
  * smoke/ddpm/wave_utils.py:1-14): in [outer, a, mid, b, c] -> out [outer, a*fa, mid, b*fb, c*fc]. */
 int wdno_upsample_coef(const float* in, float* out, int64_t outer, int a, int mid, int b, int c, int fa, int fb, int fc, wdno_stream_t s);
@@ -84,7 +95,9 @@ int wdno_pack_smoke_state(const float* coef, int64_t coef_sim_stride, const floa
                           int pad_t, int pad_x, wdno_stream_t s);
 /* The same with the two condition channels transformed inside the launch from the physical inputs (the online pipeline fields -> DWT -> state,
  * smoke/wave_trans_2d.py:150-170 + data_2d.py:156-221): rho0 [.][H0][W0] = the density field at t = 0 (e.g. a view into the fields tensor),
- * curve [.][T0] = the smoke-out curve; zero-mode analysis with the decomposition filters (host arrays of L <= 16 taps). */
+ * curve [.][T0] = the smoke-out curve; zero-mode analysis with the decomposition filters (host arrays of L <= 16 taps).
+ * coef == NULL: the rows [f < nt][h < nx] of the 8 F channels are left untouched (wdno_dwt_fwd_packed wrote them pad_x wide, already divided); the
+ * zero rows / frames around them and the two condition channels are written -- together the two launches produce the same bits as the one-tensor form. */
 int wdno_pack_smoke_fields(const float* coef, int64_t coef_sim_stride, const float* rho0, int64_t rho0_sim_stride, const float* curve,
                            int64_t curve_sim_stride, const float* dec_lo_host, const float* dec_hi_host, int L, const float* rescaler,
                            float* state, int64_t B, int F, int nt, int nx, int pad_t, int pad_x, int H0, int W0, int T0, wdno_stream_t s);

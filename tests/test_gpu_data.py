@@ -279,3 +279,30 @@ def test_pack_smoke_fields_equals_the_transform_then_pack_chain(trees):
         for ch in (-2, -1):
             assert float(want[:, :, ch].abs().max()) > 0.05
             assert float((got[:, :, ch] - want[:, :, ch]).abs().max()) < 2e-6 * float(want[:, :, ch].abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize('wave, shape, pads', [('bior1.3', (3, 5, 32, 64, 64), (24, 40)), ('bior1.3', (2, 4, 32, 64, 64), (24, 40)),
+                                               ('db2', (2, 5, 32, 64, 64), (24, 40)), ('haar', (2, 3, 16, 32, 32), (8, 16)),
+                                               ('bior1.3', (1, 2, 14, 30, 30), (12, 20)), ('db3', (9, 1, 20, 40, 40), (16, 24))])
+def test_transform_store_into_the_state_is_bit_identical_to_the_two_tensor_form(trees, wave, shape, pads):
+    """wdno_dwt_fwd_packed + wdno_pack_smoke_fields(coef = NULL): the 3-D analysis stores sub-bands as channels of the padded state, already divided by
+    RESCALER, and the packing launch fills the padding and the condition channels -- against the form it replaces (analysis into a coefficient tensor,
+    packing launch reads it): the same fused multiply-adds and the same IEEE division, so every bit agrees, also where a row's last float4 straddles
+    the box edge (nx = 33, 34), where the box fills the padded row (nx = pad_x) and for one image per sample. The padded tensor is NaN-poisoned first:
+    every element is written by exactly one of the two launches."""
+    from ddpm.data_2d import pack_smoke_fields
+    g = torch.Generator().manual_seed(5)
+    b, nf, t0, h0, w0 = shape
+    fields = torch.randn(*shape, generator=g).to(DEV)
+    curve = torch.rand(b, t0, generator=g).to(DEV)
+    r = (torch.rand(8 * nf + 2, generator=g) * 3 + 0.25).to(DEV)
+    real_empty = torch.empty
+    try:
+        torch.empty = lambda *a, **k: real_empty(*a, **k).fill_(float('nan')) if k.get('dtype') == torch.float32 else real_empty(*a, **k)
+        got = pack_smoke_fields(fields, curve, r, wave=wave, pad_t=pads[0], pad_x=pads[1])
+    finally:
+        torch.empty = real_empty
+    want = pack_smoke_fields(fields, curve, r, wave=wave, pad_t=pads[0], pad_x=pads[1], direct=False)
+    assert not torch.isnan(got).any()
+    assert torch.equal(got, want)
+    assert float(got[:, :, :8 * nf].abs().max()) > 0.1

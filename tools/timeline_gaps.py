@@ -72,5 +72,13 @@ for k, (tot, n) in sorted(after.items(), key=lambda kv: -kv[1][0])[:25]:
 lines.append('\nlargest single gaps (us, after -> before):')
 for g, a, b in sorted(gaps, key=lambda x: -x[0])[:12]:
     lines.append(f'- {g / 1e3:.1f}: `{a[:60]}` -> `{b[:60]}`')
+pairs = defaultdict(lambda: [0, 0])
+for g, a, b in gaps:
+    if 1e3 <= g < 3e5:                      # inside a step (a replayed graph): 1 us .. 300 us
+        pairs[(a, b)][0] += g
+        pairs[(a, b)][1] += 1
+lines.append('\n| gap of 1-300 us: after | before | gaps | total us | mean us |\n|---|---|---:|---:|---:|')
+for (a, b), (tot, n) in sorted(pairs.items(), key=lambda kv: -kv[1][0])[:40]:
+    lines.append(f'| `{a[:48]}` | `{b[:48]}` | {n} | {tot / 1e3:.1f} | {tot / n / 1e3:.2f} |')
 open(out, 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines[:6]))

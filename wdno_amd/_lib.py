@@ -53,6 +53,7 @@ PROTOTYPES = {
     'wdno_set_debug': (I, [I]),
     'wdno_dwt_ws_bytes': (Z, [PD]),
     'wdno_dwt_fwd': (I, [P, P, PD, PF, P, Z, P]),
+    'wdno_dwt_fwd_packed': (I, [P, P, PD, PF, I, L, I, P, P]),
     'wdno_dwt_inv': (I, [P, P, PD, PF, P, Z, P]),
     'wdno_dwt_fwd_adjoint': (I, [P, P, PD, PF, P, Z, P]),
     'wdno_dwt_inv_adjoint': (I, [P, P, PD, PF, P, Z, P]),

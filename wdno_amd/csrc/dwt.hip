@@ -166,6 +166,13 @@ struct FusedGeom {
   int qt0, qh0, qw0;      // synthesis: first q along each axis (off >> 1)
   int QH, QT;             // synthesis: number of q rows / frames in total
   int debug;              // tools only: 12 / 13 / 14 skip the W / H / T pass of the synthesis kernel (timing breakdown, wrong results)
+  // PACKED analysis (wdno_dwt_fwd_packed): image = (outer, inner) = (img / img_inner, img % img_inner), coefficient base = outer * cs_outer +
+  // inner * cs_img, every coefficient divided (IEEE) by resc[inner * 2^ND + band] on its way out
+  // Rows are written in full: row_w (a multiple of 4, >= Wo) columns, zeros (/ resc) beyond the coefficients, as aligned 16-byte stores.
+  FastDiv dInner;
+  int img_inner, row_w;
+  int64_t cs_outer;
+  const float* resc;
 };
 
 __device__ __forceinline__ int xcd_tile(int bid, int nb) {
@@ -193,7 +200,7 @@ __device__ __forceinline__ int smap(int K, int M) {               // coefficient
 }
 
 // ND = 3: register pass along T, NK coefficient frames per block.  ND = 2: register pass along H, NK coefficient rows per item.
-template <int ND, int L, int MODE, int NK>
+template <int ND, int L, int MODE, int NK, bool PACKED = false>
 __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __restrict__ x, float* __restrict__ coef, FusedGeom g, Taps t) {
   extern __shared__ float lds[];
   int b = xcd_tile(blockIdx.x, g.n_blocks);
@@ -320,11 +327,17 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
   __syncthreads();
   // pass W: LDS -> packed coefficients. float2 reads (index 2 kw + m): conflict-free, and m ascends inside each pair
   float* __restrict__ ci = coef + (int64_t)img * g.cs_img;
+  const float* __restrict__ rs = nullptr;
+  if (PACKED) {
+    const int io = fd_div(img, g.dInner), ii = img - io * g.img_inner;
+    ci = coef + (int64_t)io * g.cs_outer + (int64_t)ii * g.cs_img;
+    rs = g.resc + ii * (1 << ND);
+  }
   const int Wo = g.Wo;
   constexpr bool PERIOD_ROWS = ND == 2 && MODE == 0;          // S2 rows hold one period: float2 index kw + i wraps at Wo
   // an item = FOUR consecutive coefficients of one row: a window of L / 2 + 3 float2 reads (instead of 4 L / 2) and one row decode
   constexpr int HLW = L / 2;
-  const int Wo4 = (Wo + 3) >> 2;
+  const int Wo4 = PACKED ? g.row_w >> 2 : (Wo + 3) >> 2;
   const int rmax = PERIOD_ROWS ? Wo - 1 : (FW >> 1) - 1;       // last float2 of a row
   for (int it = threadIdx.x; it < NP * 2 * NH * Wo4; it += 256) {
     int q = fd_div(it, g.dQW4);
@@ -346,6 +359,9 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
     const int band_lo = (ND == 3) ? bt * 4 + bh * 2 : bh;
     const int band_hi = (ND == 3) ? band_lo + 1 : bh + 2;
     float* o = ci + (int64_t)kt * g.cs0 + (int64_t)(kh0 + kh) * g.cs1 + kw0;
+    float r_lo = 1.f, r_hi = 1.f;
+    if (PACKED) { r_lo = rs[band_lo]; r_hi = rs[band_hi]; }
+    float pl[4], ph[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float lo = 0.f, hi = 0.f;
@@ -356,10 +372,19 @@ __global__ __launch_bounds__(256) void dwt_analysis_fused_kernel(const float* __
         lo = fmaf(t.lo[L - 2 - 2 * i], v[u + i].y, lo);
         hi = fmaf(t.hi[L - 2 - 2 * i], v[u + i].y, hi);
       }
+      if (PACKED) {
+        const bool in = kw0 + u < Wo;
+        pl[u] = (in ? lo : 0.f) / r_lo; ph[u] = (in ? hi : 0.f) / r_hi;
+        continue;
+      }
       if (kw0 + u < Wo) {
         o[band_lo * g.cs_band + u] = lo;
         o[band_hi * g.cs_band + u] = hi;
       }
+    }
+    if (PACKED) {
+      *reinterpret_cast<float4*>(o + band_lo * g.cs_band) = make_float4(pl[0], pl[1], pl[2], pl[3]);
+      *reinterpret_cast<float4*>(o + band_hi * g.cs_band) = make_float4(ph[0], ph[1], ph[2], ph[3]);
     }
   }
 }
@@ -876,8 +901,10 @@ static size_t fused_lds_budget(long default_kb) {
   return (size_t)kb * 1024;
 }
 
+struct PackedStore { int img_inner, row_w; int64_t cs_outer; const float* resc; };     // wdno_dwt_fwd_packed
+
 template <int ND, int L, int MODE>
-static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
+static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st, const PackedStore* pk = nullptr) {
   FusedGeom g = {};
   g.n_img = d->n_img;
   g.T = d->in_dims[0]; g.H = d->in_dims[1]; g.W = d->in_dims[2];
@@ -915,6 +942,19 @@ static bool fused_analysis(const float* src, float* dst, const wdno_dwt_desc* d,
   g.n_blocks = (int)nb;
   g.dFW = make_fastdiv(g.FW); g.dNH = make_fastdiv(g.NH); g.dWo = make_fastdiv(g.Wo); g.dQW4 = make_fastdiv((g.Wo + 3) / 4);
   if ((int64_t)2 * NK * 2 * g.NH * std::max(g.FW, g.Wo) * (int64_t)std::max(g.FW, g.NH) >= (1ll << 32)) return false;   // fd_div range
+  if (pk) {
+    if constexpr (ND == 3 && MODE == 1) {        // the smoke pipeline's transform (zero mode, 3-D); other shapes: not instantiated
+      g.img_inner = pk->img_inner; g.cs_outer = pk->cs_outer; g.resc = pk->resc; g.row_w = pk->row_w;
+      g.dInner = make_fastdiv(g.img_inner);
+      g.dQW4 = make_fastdiv(g.row_w / 4);
+      if (g.row_w < g.Wo || (g.row_w & 3) || ((g.cs_img | g.cs_band | g.cs0 | g.cs1 | g.cs_outer) & 3) || ((uintptr_t)dst & 15)) return false;
+      if ((int64_t)2 * NK * 2 * g.NH * g.row_w * (int64_t)std::max(g.FW, g.NH) >= (1ll << 32)) return false;   // fd_div range
+      if ((int64_t)g.n_img * g.img_inner >= (1ll << 32)) return false;
+      dwt_analysis_fused_kernel<ND, L, MODE, NK, true><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
+      return true;
+    }
+    return false;
+  }
   dwt_analysis_fused_kernel<ND, L, MODE, NK><<<(int)nb, 256, lds, st>>>(src, dst, g, taps);
   return true;
 }
@@ -1007,32 +1047,35 @@ static bool fused_synthesis(const float* src, float* dst, const wdno_dwt_desc* d
 }
 
 template <int ND, int L>
-static bool fused_dispatch2(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
-  if (d->mode == 1) return analysis_dir ? fused_analysis<ND, L, 1>(src, dst, d, taps, odd_rule, st) : fused_synthesis<ND, L, 1>(src, dst, d, taps, st);
-  return analysis_dir ? fused_analysis<ND, L, 0>(src, dst, d, taps, odd_rule, st) : fused_synthesis<ND, L, 0>(src, dst, d, taps, st);
+static bool fused_dispatch2(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st,
+                            const PackedStore* pk) {
+  if (d->mode == 1) return analysis_dir ? fused_analysis<ND, L, 1>(src, dst, d, taps, odd_rule, st, pk) : fused_synthesis<ND, L, 1>(src, dst, d, taps, st);
+  return analysis_dir ? fused_analysis<ND, L, 0>(src, dst, d, taps, odd_rule, st, pk) : fused_synthesis<ND, L, 0>(src, dst, d, taps, st);
 }
 template <int ND>
-static bool fused_dispatch(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
+static bool fused_dispatch(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st,
+                           const PackedStore* pk) {
   switch (d->L) {
-    case 2: return fused_dispatch2<ND, 2>(analysis_dir, src, dst, d, taps, odd_rule, st);
-    case 4: return fused_dispatch2<ND, 4>(analysis_dir, src, dst, d, taps, odd_rule, st);
-    case 6: return fused_dispatch2<ND, 6>(analysis_dir, src, dst, d, taps, odd_rule, st);
-    case 8: return fused_dispatch2<ND, 8>(analysis_dir, src, dst, d, taps, odd_rule, st);
-    case 10: return fused_dispatch2<ND, 10>(analysis_dir, src, dst, d, taps, odd_rule, st);
+    case 2: return fused_dispatch2<ND, 2>(analysis_dir, src, dst, d, taps, odd_rule, st, pk);
+    case 4: return fused_dispatch2<ND, 4>(analysis_dir, src, dst, d, taps, odd_rule, st, pk);
+    case 6: return fused_dispatch2<ND, 6>(analysis_dir, src, dst, d, taps, odd_rule, st, pk);
+    case 8: return fused_dispatch2<ND, 8>(analysis_dir, src, dst, d, taps, odd_rule, st, pk);
+    case 10: return fused_dispatch2<ND, 10>(analysis_dir, src, dst, d, taps, odd_rule, st, pk);
     default: return false;
   }
 }
 // true = the transform was launched as ONE fused kernel; false = not covered (1-D, long filters, rows that do not fit LDS, the
 // odd-length synthesis-shaped adjoint), the caller falls back to the per-axis passes.
-static bool fused_try(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st) {
-  if (wdno_debug_mode == 11 || d->nd < 2) return false;
+static bool fused_try(bool analysis_dir, const float* src, float* dst, const wdno_dwt_desc* d, const Taps& taps, bool odd_rule, hipStream_t st,
+                      const PackedStore* pk = nullptr) {
+  if ((wdno_debug_mode == 11 && !pk) || d->nd < 2) return false;
   if (!analysis_dir && d->mode == 0 && odd_rule)
     for (int a = 3 - d->nd; a < 3; ++a)
       if (d->in_dims[a] & 1) return false;
   if (!analysis_dir && d->mode == 0)
     for (int a = 3 - d->nd; a < 3; ++a)
       if (d->in_dims[a] != 2 * d->out_dims[a]) return false;
-  return d->nd == 3 ? fused_dispatch<3>(analysis_dir, src, dst, d, taps, odd_rule, st) : fused_dispatch<2>(analysis_dir, src, dst, d, taps, odd_rule, st);
+  return d->nd == 3 ? fused_dispatch<3>(analysis_dir, src, dst, d, taps, odd_rule, st, pk) : fused_dispatch<2>(analysis_dir, src, dst, d, taps, odd_rule, st, pk);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1185,6 +1228,27 @@ extern "C" int wdno_dwt_fwd(const float* x, float* coef, const wdno_dwt_desc* d,
   for (int a = 3 - d->nd; a < 3; ++a)
     if (d->mode == 1 && d->out_dims[a] != (d->in_dims[a] + d->L - 1) / 2) return WDNO_EINVAL;
   return run(x, coef, d, f, f + d->L, false, true, true, ws, ws_bytes, as_stream(s));
+}
+// Analysis with the coefficients stored straight into a larger, differently ordered tensor and divided by a per-channel constant: image
+// i = (outer, inner) = (i / img_inner, i % img_inner) writes at outer * cs_outer + inner * d->cs_img (+ band * cs_band + k0 * cs0 + k1 * cs1 + k2),
+// value / rescaler[inner * 8 + band] (IEEE division); rows are written row_w (>= the coefficient count, % 4 == 0) columns wide, 0 / rescaler beyond
+// the coefficients (whole 16-byte stores: strides and `state` 16-byte aligned). The smoke task's state [B][pad_t][8 F + 2][pad_x][pad_x] takes the F fields of a sample
+// with cs_outer = pad_t C pad_x^2, cs_img = 8 pad_x^2, cs_band = pad_x^2, cs0 = C pad_x^2, cs1 = pad_x (data_2d.py:156-221: cat, pad, permute,
+// / RESCALER -- the padding and the two condition channels are wdno_pack_smoke_fill's). ONE fused launch, 3-D zero mode only: anything the fused
+// kernel does not take is WDNO_EUNSUPPORTED (the caller then transforms into a coefficient tensor and packs, wdno_pack_smoke_fields).
+extern "C" int wdno_dwt_fwd_packed(const float* x, float* state, const wdno_dwt_desc* d, const float* f, int img_inner, int64_t cs_outer, int row_w,
+                                   const float* rescaler, wdno_stream_t s) {
+  int rc = validate(d);
+  if (rc) return rc;
+  WDNO_REQUIRE(x && state && f && rescaler && img_inner > 0 && d->n_img % img_inner == 0);
+  if (d->nd != 3 || d->mode != 1) return WDNO_EUNSUPPORTED;
+  for (int a = 0; a < 3; ++a)
+    if (d->out_dims[a] != (d->in_dims[a] + d->L - 1) / 2) return WDNO_EINVAL;
+  Taps taps;
+  fill_taps(taps, f, f + d->L, d->L, false);
+  PackedStore ps = {img_inner, row_w, cs_outer, rescaler};
+  if (!fused_try(true, x, state, d, taps, true, as_stream(s), &ps)) return WDNO_EUNSUPPORTED;
+  return wdno_check_launch();
 }
 extern "C" int wdno_dwt_inv(const float* coef, float* x, const wdno_dwt_desc* d, const float* f, void* ws, size_t ws_bytes, wdno_stream_t s) {
   int rc = validate(d);

@@ -110,30 +110,47 @@ def pack_smoke_gpu(coef, init_coef, smokeout, rescaler, idx=None, pad_t=24, pad_
     return out
 
 
-def pack_smoke_fields(fields, curve, rescaler, wave='bior1.3', pad_t=24, pad_x=40):
+def pack_smoke_fields(fields, curve, rescaler, wave='bior1.3', pad_t=24, pad_x=40, direct=True):
     """fields [B, F, T, H, W] (field 0 = density) and the smoke-out curve [B, T], resident in HBM -> states [B, pad_t, 8 F + 2, pad_x, pad_x] /
-    rescaler in TWO launches: the fused 3-D analysis of all fields (csrc/dwt.hip, sub-bands stacked in coef_to_tensor order) and
-    wdno_pack_smoke_fields (csrc/pack.hip), which pads, divides and transforms the two condition channels -- the 2-D DWT of rho(t = 0) and the
-    1-D DWT of the curve, zero mode -- on the fly. The online form of wave_trans_2d.transform_simulation + Smoke_wave.__getitem__
+    rescaler in TWO launches: the fused 3-D analysis of all fields whose store lands in the state (sub-band -> channel, frame -> frame, already
+    divided: wdno_dwt_fwd_packed, csrc/dwt.hip) and wdno_pack_smoke_fields(coef = NULL) (csrc/pack.hip), which writes the zero padding and
+    transforms the two condition channels -- the 2-D DWT of rho(t = 0) and the 1-D DWT of the curve, zero mode -- on the fly. direct=False (and
+    whatever the direct store does not take): the analysis into a coefficient tensor, then the packing launch reads it (round 6's first form: the
+    same bits, 26.6 MB written and read once more). The online form of wave_trans_2d.transform_simulation + Smoke_wave.__getitem__
     (smoke/wave_trans_2d.py:150-170, data_2d.py:156-221); equal to that chain to fp32 rounding (tests/test_gpu_data.py)."""
     import ctypes as C
     from wdno_amd import _lib, wavelets as Wv
     from wdno_amd.filters import filter_bank
-    from wdno_amd.ops import _lib_, _p, _stream
+    from wdno_amd.ops import _dwt_desc, _lib_, _p, _stream
     if not (fields.is_cuda and fields.dtype == torch.float32 and fields.is_contiguous() and curve.is_cuda and curve.dtype == torch.float32 and curve.is_contiguous()):
         raise RuntimeError('wdno_amd pack_smoke_fields: fields and curve must be contiguous float32 tensors on the GPU')
     b, nf, t0, h0, w0 = fields.shape
-    coef = Wv.dwt_packed(fields.reshape(b * nf, t0, h0, w0), wave, 'zero', 3)             # [B F, 8, nt, nx, nx]
-    nt, nx = coef.shape[-3], coef.shape[-1]
     dl, dh, _, _ = filter_bank(wave)
     L = len(dl)
+    nt, nx = (t0 + L - 1) // 2, (w0 + L - 1) // 2
     c = 8 * nf + 2
     r = torch.as_tensor(rescaler, dtype=torch.float32).reshape(-1).to(fields.device)
     assert r.numel() == c and tuple(curve.shape) == (b, t0)
     out = torch.empty((b, pad_t, c, pad_x, pad_x), device=fields.device, dtype=torch.float32)
     fl, fh = (C.c_float * L)(*[float(v) for v in dl]), (C.c_float * L)(*[float(v) for v in dh])
-    _lib.check(_lib_().wdno_pack_smoke_fields(_p(coef), nf * 8 * nt * nx * nx, _p(fields), nf * t0 * h0 * w0, _p(curve), t0, fl, fh, L, _p(r), _p(out),
-                                              b, nf, nt, nx, pad_t, pad_x, h0, w0, t0, _stream()), 'pack_smoke_fields')
+    lib = _lib_()
+    coef = None
+    if direct and h0 == w0 and nt <= pad_t and nx <= pad_x:
+        filt, _ = Wv._filters(wave)
+        px2 = pad_x * pad_x
+        d = _dwt_desc(3, Wv.MODES['zero'], L, b * nf, [t0, h0, w0], [nt, (h0 + L - 1) // 2, nx], (8 * px2, px2, c * px2, pad_x))
+        rc = lib.wdno_dwt_fwd_packed(_p(fields), _p(out), C.byref(d), (C.c_float * len(filt))(*filt), nf, pad_t * c * px2, pad_x, _p(r), _stream())
+        if rc == -3:                                   # WDNO_EUNSUPPORTED: the fused kernel does not take this shape
+            direct = False
+        else:
+            _lib.check(rc, 'dwt_fwd_packed')
+    else:
+        direct = False
+    if not direct:
+        coef = Wv.dwt_packed(fields.reshape(b * nf, t0, h0, w0), wave, 'zero', 3)             # [B F, 8, nt, nx, nx]
+        assert coef.shape[-3] == nt and coef.shape[-1] == nx
+    _lib.check(lib.wdno_pack_smoke_fields(_p(coef), nf * 8 * nt * nx * nx, _p(fields), nf * t0 * h0 * w0, _p(curve), t0, fl, fh, L, _p(r), _p(out),
+                                          b, nf, nt, nx, pad_t, pad_x, h0, w0, t0, _stream()), 'pack_smoke_fields')
     return out
 
 
