@@ -120,3 +120,32 @@ def test_reduce_multi_takes_more_items_than_one_launch_holds():
     want = ws.sum(1).reshape(n_items, 1, K, 3, Cc).permute(0, 2, 4, 1, 3).reshape(n_items, K, Cc, 1, 1, 3)      # [tap][k][dx][c] -> [k][c][tap][dx]
     bad = [i for i in range(n_items) if not torch.allclose(dw[i], want[i], rtol=1e-6, atol=1e-6)]
     assert not bad, bad
+
+
+@pytest.mark.parametrize('xs', [(1, 24, 40, 40), (2, 6, 40, 40), (2, 5, 9, 7)], ids=['batch1', '19200px', 'tiny'])
+def test_stem_forward_on_192_pixel_tiles_equals_the_256_pixel_tiles(xs):
+    """The 7 x 7 x 7 stem (42 -> 64 channels, video_diffusion_pytorch_conv3d.py:405-407 init_conv) when the launch is less than one round of
+    256-pixel tiles: 192-pixel tiles (csrc/conv_h3t.hip, the batch-1 sampling step) -- every output element is the same chain of products in
+    the same order, so the bits equal those of the 256-pixel tiles (library debug mode 72)."""
+    from wdno_amd import ops
+    lib = ops._lib_()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(*xs, 44, device=DEV, generator=g)
+    x[..., 42:] = 0
+    w = torch.randn(64, 42, 7, 7, 7, device=DEV, generator=g) * 0.05
+    b = torch.randn(64, device=DEV, generator=g)
+    res = {}
+    with torch.no_grad():
+        for mode in (0, 72):
+            lib.wdno_set_debug(mode)
+            try:
+                ops.PROFILE = {}
+                res[mode] = ops.conv_cl(x, w, b, stride=1, padding=3).clone()
+                names, ops.PROFILE = list(ops.PROFILE), None
+            finally:
+                lib.wdno_set_debug(0)
+            if mode == 0 and xs[1] == 24:                    # (fewer than 100 tiles: the chunked kernel, both modes)
+                assert names == ['conv_fwd_h3t_kernel<192,64>'], names
+    assert torch.equal(res[0], res[72])
+    ref = torch.nn.functional.conv3d(x[..., :42].permute(0, 4, 1, 2, 3).double(), w.double(), b.double(), padding=3).permute(0, 2, 3, 4, 1).float()
+    assert float((res[0] - ref).abs().max()) < 2e-5 * float(ref.abs().max())

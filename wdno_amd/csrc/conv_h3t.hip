@@ -641,6 +641,11 @@ int wdno_conv_fwd_h3_tap(int shape, const void* xh, const void* xl, const void* 
   if (p.g.kw == 7) {
     const int ncb = (p.g.C + 15) / 16;
     if (p.zb_blocks >= ncb) p.zb_blocks = ncb - 1;          // (a tile must keep at least its centre stage: t_live_stages)
+    // less than one round of 256-pixel tiles (the stem at batch 1: 150 tiles on 256 CUs): 192-pixel tiles fill the chip and end a quarter
+    // earlier (128-pixel tiles would need a second round) -- debug 72: the 256-pixel tiles always
+    const int cus = t_num_cus();
+    if (xl != nullptr && cdiv64(p.P, 256) < cus && cdiv64(p.P, 192) <= cus && cdiv64(p.P, 192) > cdiv64(p.P, 256) && wdno_debug_mode != 72)
+      return launch_h3t<192, 64, 2, 2, 7, 16, false>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
     if (xl == nullptr) return launch_h3t<256, 64, 4, 1, 7, 16, true>(xh, xh, wh, wh, sx, sw, bias, residual, y, p, st);
     return launch_h3t<256, 64, 4, 1, 7, 16, false>(xh, xl, wh, wl, sx, sw, bias, residual, y, p, st);
   }

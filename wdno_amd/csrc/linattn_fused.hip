@@ -127,14 +127,16 @@ __global__ __launch_bounds__(256, 2) void lattn_fused_ctx_kernel(LFusedP p) {
 }
 
 // chunks of a frame merged in chunk order: ctx[d][e] = sum_c ctx_c[d][e] exp(m_c - M) / sum_c Z_c exp(m_c - M)
-__global__ __launch_bounds__(256) void lattn_fused_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, int chunks,
+// (1024 threads, one per context entry: with 256 a thread walked the chunks -- two dependent strided loads per chunk -- for four entries in turn,
+// 17 us per launch at batch 1, profiles/r06_sampling_b1_kernel_stats.md; the sums per entry are unchanged)
+__global__ __launch_bounds__(1024) void lattn_fused_merge_kernel(const float* __restrict__ part, float* __restrict__ ctx, int chunks,
                                                                   float* __restrict__ kstat /* optional [units][heads][2][32]: max_n k, 1 / Z */) {
   const int64_t unit = blockIdx.x / TF_HEADS;
   const int h = (int)(blockIdx.x - unit * TF_HEADS);
   const float* p0 = part + ((unit * chunks) * TF_HEADS + h) * (int64_t)LF_PART;
   const int64_t cstride = (int64_t)TF_HEADS * LF_PART;
   float* co = ctx + (int64_t)blockIdx.x * 1024;
-  for (int o = threadIdx.x; o < 1024; o += 256) {
+  for (int o = threadIdx.x; o < 1024; o += blockDim.x) {
     const int d = o >> 5;
     float M = -INFINITY;
     for (int c = 0; c < chunks; ++c) M = fmaxf(M, p0[c * cstride + d]);
@@ -343,12 +345,12 @@ extern "C" int wdno_lattn_fused_fwd(const float* x, const float* gamma, float ep
   if (C != TF_C) {
     int rc = wdno_lattn_wide_ctx_launch(p, C, grid, st);
     if (rc != WDNO_OK) return rc;
-    lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 256, 0, st>>>(p.part, ctx, p.chunks, kstat_out);
+    lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 1024, 0, st>>>(p.part, ctx, p.chunks, kstat_out);
     rc = wdno_lattn_wide_out_launch(p, C, grid, st);
     return rc != WDNO_OK ? rc : wdno_check_launch();
   }
   lattn_fused_ctx_kernel<<<grid, 256, 0, st>>>(p);
-  lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 256, 0, st>>>(p.part, ctx, p.chunks, kstat_out);
+  lattn_fused_merge_kernel<<<(unsigned)(units * TF_HEADS), 1024, 0, st>>>(p.part, ctx, p.chunks, kstat_out);
   lattn_fused_out_kernel<<<grid, 256, 0, st>>>(p);
   return wdno_check_launch();
 }

@@ -847,6 +847,8 @@ def _fwd_h3_kernel_name(pixels, k, ks, tap=False, c=None):
             best = (256, 128)                        # csrc/conv_h3t.hip: the wide tiles of the single-plane mode
         if tap and ks[2] == 7:
             best = (256, 64)                         # ... and the 16-channel-block kernel of 7-wide taps
+            if not _lp() and cdiv(pixels, 256) < cus and cdiv(pixels, 256) < cdiv(pixels, 192) <= cus:
+                best = (192, 64)                     # (less than one round of 256-pixel tiles: csrc/conv_h3t.hip)
         return f'conv_fwd_h3{"t" if tap else "d"}_kernel<{best[0]},{best[1]}>'
     return 'conv_fwd_h3_kernel<..,128>' if k > 64 else 'conv_fwd_h3_kernel<..,64>'
 
