@@ -151,7 +151,9 @@ int wdno_amax_record(const float* x, int64_t n, float* rec_zeroed, wdno_stream_t
 /* amax_rec: the amax record of x (from wdno_amax_record or from the kernel that produced x) */
 int wdno_split_f16(const float* x, const float* amax_rec, void* hi, void* lo, float* scale_out, int64_t rows, int C, int C8, wdno_stream_t s);
 /* wdno_split_f16 that also returns colsum_out[C8] = sum over rows (the bias gradient when x is dy), in the same pass.
- * WDNO_EUNSUPPORTED unless C8 / 8 is a power of two <= 256 (use wdno_split_f16 + wdno_colsum then). */
+ * WDNO_EUNSUPPORTED unless C8 / 8 is a power of two <= 256 (use wdno_split_f16 + wdno_colsum then).
+ * colsum_out == NULL (here and in wdno_cast_bf16_colsum): only the partials are written -- doubles [ws_bytes / (8 C8)][C8] in ws -- and the
+ * caller sums them later (wdno_rows_sum_multi, is_double = 1). */
 size_t wdno_split_colsum_ws_bytes(int64_t rows, int C8);
 int wdno_split_f16_colsum(const float* x, const float* amax_rec, void* hi, void* lo, float* scale_out, float* colsum_out,
                           void* ws, size_t ws_bytes, int64_t rows, int C, int C8, wdno_stream_t s);
@@ -234,6 +236,18 @@ int wdno_wgrad_reduce_multi(const wdno_wgrad_reduce_item* items, int n_items, wd
 size_t wdno_conv_wgrad_ws_bytes(const wdno_conv_geom* g);
 int wdno_conv_wgrad(const float* x, const float* dy, float* dwp, void* ws, size_t ws_bytes,
                     const wdno_conv_geom* g, wdno_stream_t s);
+/* The sums over rows that END a backward pass -- bias gradients from the column-sum partials of a dy sweep, GroupNorm's d(gamma) / d(beta) from the
+ * per-sample pieces -- feed parameters only (nn.Conv*d.bias, nn.GroupNorm.weight / .bias: unet.py:129-181, conv3d.py:189-204), so a caller may
+ * collect them and run ONE launch when the backward has returned: out[j] = sum_r part[r * stride + col0 + j], j < ncols, fp64 accumulation in the
+ * fixed order of the single-tensor launches they replace (partial_rows_sum: bit-identical). `items` is a HOST array (they travel by value in the
+ * kernel arguments); the partial matrices must stay alive and unmodified until the launch has run. */
+#define WDNO_ROWS_SUM_MAX 64
+typedef struct wdno_rows_sum_item {
+  const void* part; float* out;
+  int rows, stride, col0, ncols;
+  int is_double, reserved;
+} wdno_rows_sum_item;
+int wdno_rows_sum_multi(const wdno_rows_sum_item* items, int n_items, wdno_stream_t s);
 /* out[C] = sum_p in[p][C]  (bias gradients and other per-channel reductions). ws >= wdno_colsum_ws_bytes. */
 size_t wdno_colsum_ws_bytes(int64_t P, int C);
 int wdno_colsum(const float* in, float* out, int64_t P, int C, void* ws, size_t ws_bytes, wdno_stream_t s);
@@ -302,6 +316,9 @@ int wdno_groupnorm_act_bwd_planes(const float* x, const float* dy, const float* 
                                   const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
                                   float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
                                   void* ws, size_t ws_bytes, wdno_stream_t s);
+/* dx_colsum == NULL in the two backward entry points: the column sums of dx are left as partials -- doubles [rows][C] at byte offset csp_offset of ws
+ * (this call) -- for wdno_rows_sum_multi; likewise dgb_sum == NULL leaves the per-sample pieces dgb_partial [N][2 C] to be summed there. */
+int wdno_groupnorm_bwd_planes_tail(int64_t N, int64_t S, int C, int G, size_t* csp_offset, int* rows);
 /* The same four entry points for bf16-stored activations (single-product mode): x_bf16 / dy_bf16 != 0 say that x / dy is bf16 storage -- what
  * wdno_conv_fwd_bf16_ex(y_bf16 = 1) wrote. Statistics, affine, activation and every output are computed exactly as above (fp32 / fp64). */
 int wdno_groupnorm_act_fwd_amax_t(const void* x, int x_bf16, const float* gamma, const float* beta, const float* ss, float* y,

@@ -74,12 +74,22 @@ def test_split_pair_plan_equals_the_round5_plan(name, xs, ws, math):
 def test_deferred_weight_gradient_reductions_leave_a_training_step_bit_identical(trees):
     """ops.DEFER_WGRAD_REDUCE: inside a trainer's backward the split reductions of all weight gradients run as ONE launch when the backward has
     returned (wdno_wgrad_reduce_multi, items by value in the kernel arguments) instead of one launch behind every weight-gradient kernel. Same
-    additions in the same order: two optimisation steps of the full-width smoke model end in the same bits, eager and graph-replayed."""
+    additions in the same order: two optimisation steps of the full-width smoke model end in the same bits, eager and graph-replayed.
+    ops.DEFER_ROW_SUMS likewise for the row sums that end the backward (bias gradients from column-sum partials, GroupNorm d(gamma) / d(beta):
+    wdno_rows_sum_multi) -- third arm: weight gradients deferred, row sums not."""
     from wdno_amd import ops
     from wdno_amd.trainer import TrainStep
     out = {}
-    for defer in (True, False):
-        ops.DEFER_WGRAD_REDUCE = defer
+    for defer in (True, False, 'wgrad only'):
+        ops.DEFER_WGRAD_REDUCE = bool(defer)
+        ops.DEFER_ROW_SUMS = defer is True
+        queued = []
+        real_flush = ops.flush_wgrad_reduces
+
+        def counting_flush():
+            queued.append((len(ops._WGRAD_PENDING or ()), len(ops._ROWSUM_PENDING)))
+            real_flush()
+        ops.flush_wgrad_reduces = counting_flush
         try:
             torch.manual_seed(0)
             net = trees['Unet3D'](dim=64, dim_mults=(1, 2, 4), channels=42)
@@ -99,9 +109,16 @@ def test_deferred_weight_gradient_reductions_leave_a_training_step_bit_identical
             torch.cuda.synchronize()
             out[defer] = (float(l0), float(l2), ts.opt.buf.flat_param.clone())
             del ts
+            if defer is True:                # the backward really queued both kinds (GroupNorm tails, bias sums of split dy sweeps)
+                assert max(q[0] for q in queued) > 10 and max(q[1] for q in queued) > 10, queued
+            elif defer == 'wgrad only':
+                assert max(q[1] for q in queued) == 0, queued
         finally:
             ops.DEFER_WGRAD_REDUCE = True
-    assert out[True][0] == out[False][0] and out[True][1] == out[False][1] and torch.equal(out[True][2], out[False][2])
+            ops.DEFER_ROW_SUMS = True
+            ops.flush_wgrad_reduces = real_flush
+    for arm in (False, 'wgrad only'):
+        assert out[True][0] == out[arm][0] and out[True][1] == out[arm][1] and torch.equal(out[True][2], out[arm][2]), arm
 
 
 def test_reduce_multi_takes_more_items_than_one_launch_holds():

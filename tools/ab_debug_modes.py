@@ -16,6 +16,8 @@ reps = int(args[args.index('--reps') + 1]) if '--reps' in args else 3
 modes = [int(a) for a in args if a.lstrip('-').isdigit() and (args.index(a) == 0 or args[args.index(a) - 1] not in ('--steps', '--reps'))]
 if '--nodefer' in args:
     modes.append(-1)          # arm -1: debug 0 with ops.DEFER_WGRAD_REDUCE = False (one split reduction behind every weight-gradient kernel)
+if '--norowdefer' in args:
+    modes.append(-2)          # arm -2: debug 0 with ops.DEFER_ROW_SUMS = False (GroupNorm tails and bias sums launched where they arise)
 dev = torch.device('cuda', 0)
 lib = ops._lib_()
 dif = bench.build_model(dev, 8)
@@ -27,10 +29,12 @@ caps = {}
 for m in modes:
     lib.wdno_set_debug(max(m, 0))
     ops.DEFER_WGRAD_REDUCE = m != -1
+    ops.DEFER_ROW_SUMS = m != -2
     ts._cap = None
     ts.capture(x, warmup=1)
     caps[m] = ts._cap
 ops.DEFER_WGRAD_REDUCE = True
+ops.DEFER_ROW_SUMS = True
 res = {m: [] for m in modes}
 for r in range(reps):
     for m in modes:

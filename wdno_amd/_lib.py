@@ -42,6 +42,10 @@ class WgradReduceItem(C.Structure):          # include/wdno_hip.h: wdno_wgrad_re
                 ('tiled', I), ('reserved', I)]
 
 
+class RowsSumItem(C.Structure):              # include/wdno_hip.h: wdno_rows_sum_item
+    _fields_ = [('part', C.c_void_p), ('out', C.c_void_p), ('rows', I), ('stride', I), ('col0', I), ('ncols', I), ('is_double', I), ('reserved', I)]
+
+
 PD, PG, PA, PC = C.POINTER(DwtDesc), C.POINTER(ConvGeom), C.POINTER(AttnDesc), C.POINTER(CondDesc)
 PF = C.POINTER(C.c_float)
 
@@ -87,6 +91,7 @@ PROTOTYPES = {
     'wdno_conv_wgrad_f16x3_param': (I, [P, P, P, P, P, P, P, P, I, I, P, Z, PG, P]),
     'wdno_conv_wgrad_partials': (I, [P, P, P, P, P, P, P, P, I, I, P, Z, PG, P, P]),
     'wdno_wgrad_reduce_multi': (I, [P, I, P]),
+    'wdno_rows_sum_multi': (I, [P, I, P]),
     'wdno_cast_bf16': (I, [P, P, L, I, I, P]),
     'wdno_cast_bf16_colsum': (I, [P, P, P, P, Z, L, I, I, P]),
     'wdno_conv_fwd_bf16': (I, [P, P, P, P, P, P, PG, P]),
@@ -104,6 +109,7 @@ PROTOTYPES = {
     'wdno_groupnorm_act_bwd': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_groupnorm_act_bwd_amax': (I, [P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, P, Z, P]),
     'wdno_groupnorm_bwd_planes_ws_bytes': (Z, [L, L, I, I]),
+    'wdno_groupnorm_bwd_planes_tail': (I, [L, L, I, I, C.POINTER(Z), C.POINTER(I)]),
     'wdno_groupnorm_fwd_planes_ws_bytes': (Z, [L, L, I, I]),
     'wdno_groupnorm_act_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),
     'wdno_groupnorm_act_add_fwd_planes': (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, F, I, P, Z, P]),

@@ -119,22 +119,24 @@ __device__ __forceinline__ float group_max(float v) {
 // chain at nb/128 loads (256 threads x 1 sum: 12.9 us per launch at nb = 2048, ~90 launches per train step).
 #define PRS_GROUPS 32
 #define PRS_THREADS (32 * PRS_GROUPS)
+// (stride: elements between consecutive rows of `part`, >= C: a window of C columns of a wider matrix -- wdno_rows_sum_multi)
 template <typename T>
-__device__ __forceinline__ void partial_rows_sum_body(const T* __restrict__ part, float* __restrict__ out, int nb, int C, int bx) {
+__device__ __forceinline__ void partial_rows_sum_body(const T* __restrict__ part, float* __restrict__ out, int nb, int C, int bx, int stride = 0) {
   __shared__ double red[PRS_GROUPS][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = bx * 32 + tx;
+  if (stride == 0) stride = C;
   double acc = 0.0;
   if (c < C) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int b = ty;
     for (; b + 3 * PRS_GROUPS < nb; b += 4 * PRS_GROUPS) {
-      a0 += (double)part[(int64_t)b * C + c];
-      a1 += (double)part[(int64_t)(b + PRS_GROUPS) * C + c];
-      a2 += (double)part[(int64_t)(b + 2 * PRS_GROUPS) * C + c];
-      a3 += (double)part[(int64_t)(b + 3 * PRS_GROUPS) * C + c];
+      a0 += (double)part[(int64_t)b * stride + c];
+      a1 += (double)part[(int64_t)(b + PRS_GROUPS) * stride + c];
+      a2 += (double)part[(int64_t)(b + 2 * PRS_GROUPS) * stride + c];
+      a3 += (double)part[(int64_t)(b + 3 * PRS_GROUPS) * stride + c];
     }
-    for (; b < nb; b += PRS_GROUPS) a0 += (double)part[(int64_t)b * C + c];
+    for (; b < nb; b += PRS_GROUPS) a0 += (double)part[(int64_t)b * stride + c];
     acc = (a0 + a1) + (a2 + a3);
   }
   red[ty][tx] = acc;

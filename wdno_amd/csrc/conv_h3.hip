@@ -201,7 +201,8 @@ extern "C" int wdno_split_f16_colsum(const float* x, const float* amax, void* hi
   if (ws_bytes < wdno_split_colsum_ws_bytes(rows, C8)) return WDNO_EWORKSPACE;
   const int grid = stream_grid(rows * g8, 256);
   split_colsum_kernel<<<grid, 256, 0, as_stream(s)>>>(x, amax, (_Float16*)hi, (_Float16*)lo, scale_out, (double*)ws, rows, C, C8);
-  partial_rows_sum_kernel<double><<<cdiv(C8, 32), PRS_THREADS, 0, as_stream(s)>>>((const double*)ws, colsum_out, grid, C8);
+  if (colsum_out)      // NULL: the caller sums the ws_bytes / (8 C8) rows of partials later (wdno_rows_sum_multi)
+    partial_rows_sum_kernel<double><<<cdiv(C8, 32), PRS_THREADS, 0, as_stream(s)>>>((const double*)ws, colsum_out, grid, C8);
   return wdno_check_launch();
 }
 
@@ -213,7 +214,8 @@ extern "C" int wdno_cast_bf16_colsum(const float* x, void* out, float* colsum_ou
   if (ws_bytes < wdno_split_colsum_ws_bytes(rows, C8)) return WDNO_EWORKSPACE;
   const int grid = stream_grid(rows * g8, 256);
   split_colsum_kernel<<<grid, 256, 0, as_stream(s)>>>(x, nullptr, (_Float16*)out, nullptr, nullptr, (double*)ws, rows, C, C8);
-  partial_rows_sum_kernel<double><<<cdiv(C8, 32), PRS_THREADS, 0, as_stream(s)>>>((const double*)ws, colsum_out, grid, C8);
+  if (colsum_out)
+    partial_rows_sum_kernel<double><<<cdiv(C8, 32), PRS_THREADS, 0, as_stream(s)>>>((const double*)ws, colsum_out, grid, C8);
   return wdno_check_launch();
 }
 

@@ -758,6 +758,15 @@ static inline int gn_planes_grid(int64_t N, int64_t S, int C) {
 extern "C" size_t wdno_groupnorm_bwd_planes_ws_bytes(int64_t N, int64_t S, int C, int G) {
   return wdno_groupnorm_ws_bytes(N, S, C, G) + (size_t)N * gn_chunks(S, N, C) * 2 * sizeof(float) + (size_t)N * 128 * C * sizeof(double) + 64;
 }
+// where the column-sum partials of dx live inside ws (doubles [rows][C]) when the backward is called with dx_colsum == NULL
+extern "C" int wdno_groupnorm_bwd_planes_tail(int64_t N, int64_t S, int C, int G, size_t* csp_offset, int* rows) {
+  int rc = gn_check(N, S, C, G);
+  if (rc) return rc;
+  WDNO_REQUIRE(csp_offset && rows);
+  *csp_offset = (wdno_groupnorm_ws_bytes(N, S, C, G) + 63) & ~(size_t)63;
+  *rows = (int)N * gn_planes_grid(N, S, C);
+  return WDNO_OK;
+}
 extern "C" int wdno_groupnorm_act_bwd_planes_t(const void* x, int x_bf16, const void* dy, int dy_bf16, const float* gamma, const float* beta, const float* ss,
                                              const float* stats, void* dx_hi, void* dx_lo, float* dx_scale, float* dx_colsum,
                                              float* dgb_partial, float* dgb_sum, float* dss, float* bound_rec, int64_t N, int64_t S, int C, int G, int silu,
@@ -789,8 +798,10 @@ extern "C" int wdno_groupnorm_act_bwd_planes_t(const void* x, int x_bf16, const 
   GN_BWD_TYPES(GN_K_BWD_APPLY, x, dy, cb, gb, (_Float16*)dx_hi, (_Float16*)dx_lo, dx_scale, bound_rec, csp, S, C, C / G, G, silu);
   // one launch for both reductions that end the backward: the column sums of dx (partials of the apply pass) and, when dgb_sum is given, the
   // sum over the samples of the per-sample parameter-gradient pieces (was a colsum_rows launch of the caller: same fp64 sum in row order)
-  const int nbx = cdiv(C, 32), nby = dgb_sum ? cdiv(2 * C, 32) : 0;
-  gn_bwd_tail_kernel<<<nbx + nby, PRS_THREADS, 0, st>>>(csp, dx_colsum, (int)N * gx, C, nbx, dgb_partial, dgb_sum, (int)N);
+  // (dx_colsum == NULL: the caller sums the partials later with everything else that ends the backward -- wdno_rows_sum_multi over the
+  // N * gx rows at wdno_groupnorm_bwd_planes_tail's offset of ws, and over the N rows of dgb_partial)
+  const int nbx = dx_colsum ? cdiv(C, 32) : 0, nby = dgb_sum ? cdiv(2 * C, 32) : 0;
+  if (nbx + nby) gn_bwd_tail_kernel<<<nbx + nby, PRS_THREADS, 0, st>>>(csp, dx_colsum, (int)N * gx, C, nbx, dgb_partial, dgb_sum, (int)N);
   return wdno_check_launch();
 }
 

@@ -369,6 +369,36 @@ extern "C" int wdno_colsum(const float* in, float* out, int64_t P, int C, void* 
   return wdno_check_launch();
 }
 
+// Many row sums in one launch (include/wdno_hip.h: wdno_rows_sum_multi): items by value in the kernel arguments, a block = 32 columns of one item
+struct RowsSumArgs { wdno_rows_sum_item it[WDNO_ROWS_SUM_MAX]; int n; };
+__global__ __launch_bounds__(PRS_THREADS) void rows_sum_multi_kernel(RowsSumArgs a) {
+  int b = (int)blockIdx.x, i = 0;
+  for (; i < a.n; ++i) {                       // (uniform: scalar registers)
+    const int nb = (a.it[i].ncols + 31) >> 5;
+    if (b < nb) break;
+    b -= nb;
+  }
+  if (i >= a.n) return;
+  const wdno_rows_sum_item& t = a.it[i];
+  if (t.is_double) partial_rows_sum_body<double>((const double*)t.part + t.col0, t.out, t.rows, t.ncols, b, t.stride);
+  else partial_rows_sum_body<float>((const float*)t.part + t.col0, t.out, t.rows, t.ncols, b, t.stride);
+}
+extern "C" int wdno_rows_sum_multi(const wdno_rows_sum_item* items, int n_items, wdno_stream_t s) {
+  WDNO_REQUIRE(n_items >= 0 && (items || n_items == 0));
+  for (int base = 0; base < n_items; base += WDNO_ROWS_SUM_MAX) {
+    RowsSumArgs a;
+    a.n = n_items - base < WDNO_ROWS_SUM_MAX ? n_items - base : WDNO_ROWS_SUM_MAX;
+    int blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.it[i] = items[base + i];
+      WDNO_REQUIRE(a.it[i].part && a.it[i].out && a.it[i].rows > 0 && a.it[i].ncols > 0 && a.it[i].col0 >= 0 && a.it[i].stride >= a.it[i].col0 + a.it[i].ncols);
+      blocks += cdiv(a.it[i].ncols, 32);
+    }
+    rows_sum_multi_kernel<<<blocks, PRS_THREADS, 0, as_stream(s)>>>(a);
+  }
+  return wdno_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------- trainer step
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ ws) {
   __shared__ double red[4];

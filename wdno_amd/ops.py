@@ -525,32 +525,38 @@ def split_f16(x2d, amax=None, c8=None):
     return hi, lo, scale
 
 
-def split_f16_colsum(x2d, amax=None):
+def split_f16_colsum(x2d, amax=None, bias=None, k=None):
     """split_f16 that also returns the column sums [C] of x2d from the same pass (bias gradient of a convolution whose dy
-    is being split anyway); falls back to split_f16 + colsum for channel counts the fused kernel does not take."""
+    is being split anyway); falls back to split_f16 + colsum for channel counts the fused kernel does not take. bias (the nn.Parameter the
+    first k sums are the gradient of): inside a trainer's backward the final sum over the sweep's partial rows is queued for the launch that
+    ends the backward (rows_sum_for_param) and the returned sums are the parameter's span of the flat gradient buffer, [k]."""
     rows, c = x2d.shape
     c8 = pad8(c)
     g8 = c8 // 8
     if g8 > 256 or (g8 & (g8 - 1)):
         return split_f16(x2d, amax), colsum(x2d)
     lib = _lib_()
-    if _lp():
-        hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
-        cs = torch.empty(c8, device=x2d.device, dtype=torch.float32)
-        nb = lib.wdno_split_colsum_ws_bytes(rows, c8)
-        ws = _ws(nb, x2d.device)
-        _lib.check(lib.wdno_cast_bf16_colsum(_p(x2d), _p(hi), _p(cs), _p(ws), nb, rows, c, c8, _stream()), 'cast_bf16_colsum')
-        return (hi, None, None), cs[:c]
-    if amax is None:
-        amax = tensor_amax(x2d)
-    hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
-    lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
-    scale = amax[1:2]
-    cs = torch.empty(c8, device=x2d.device, dtype=torch.float32)
     nb = lib.wdno_split_colsum_ws_bytes(rows, c8)
     ws = _ws(nb, x2d.device)
-    _lib.check(lib.wdno_split_f16_colsum(_p(x2d), _p(amax), _p(hi), _p(lo), _p(scale), _p(cs), _p(ws), nb, rows, c, c8, _stream()), 'split_f16_colsum')
-    return (hi, lo, scale), cs[:c]
+    flat = None
+    if bias is not None and DEFER_ROW_SUMS and _WGRAD_PENDING is not None:
+        flat = _flat_grad_out(bias, (k,))
+    cs = None if flat is not None else torch.empty(c8, device=x2d.device, dtype=torch.float32)
+    if _lp():
+        hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+        _lib.check(lib.wdno_cast_bf16_colsum(_p(x2d), _p(hi), _p(cs), _p(ws), nb, rows, c, c8, _stream()), 'cast_bf16_colsum')
+        planes = (hi, None, None)
+    else:
+        if amax is None:
+            amax = tensor_amax(x2d)
+        hi = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+        lo = torch.empty((rows, c8), device=x2d.device, dtype=torch.float16)
+        scale = amax[1:2]
+        _lib.check(lib.wdno_split_f16_colsum(_p(x2d), _p(amax), _p(hi), _p(lo), _p(scale), _p(cs), _p(ws), nb, rows, c, c8, _stream()), 'split_f16_colsum')
+        planes = (hi, lo, scale)
+    if flat is not None:
+        return planes, rows_sum_for_param(_RowsJob(ws, ws.data_ptr(), nb // (8 * c8), c8, 0, k, 1), bias, out=flat)
+    return planes, cs[:c]
 
 
 class _WPlan:
@@ -870,6 +876,8 @@ DEFER_WGRAD_REDUCE = True  # ... and their split reductions are collected and ru
 _WGRAD_PENDING = None     # [(item, workspace), ...] while a trainer's backward is running. NOT the destination tensor: autograd's AccumulateGrad
 #                           steals a gradient only when nobody else references it, and CLONES it otherwise -- a clone of a still unwritten tensor
 WGRAD_FLUSH_BYTES = int(os.environ.get('WDNO_WGRAD_FLUSH_MB', '0')) << 20      # 0: one flush when the backward has returned (measured best, see conv_wgrad_h3)
+DEFER_ROW_SUMS = True      # ... and so are the row sums that end a backward pass (bias gradients from column-sum partials, GroupNorm d(gamma) / d(beta)): rows_sum_for_param
+_ROWSUM_PENDING = []      # [(RowsSumItem, keep-alive of the partial matrix), ...] -- filled only while _WGRAD_PENDING is a list
 _DEFERRED_DSTS = set()    # flat-buffer addresses the flushed reductions wrote to (FlatBuffers.gather_grads checks that autograd kept those views)
 
 
@@ -877,14 +885,52 @@ def flush_wgrad_reduces():
     """The ordered split reductions of every weight gradient whose partial sums are waiting (conv_wgrad_h3 inside flat_wgrad_scope), in one launch
     of wdno_wgrad_reduce_multi. Until it has run, those gradient tensors are UNWRITTEN: the scope flushes when the backward returns, and anything that
     reads a gradient earlier (the bucket all-reduces that OverlappedAllReduce starts from gradient hooks) calls this first."""
-    global _WGRAD_PENDING
-    pend = _WGRAD_PENDING
+    global _WGRAD_PENDING, _ROWSUM_PENDING
+    pend, rows = _WGRAD_PENDING, _ROWSUM_PENDING
+    if rows:                  # the row sums collected beside them (rows_sum_for_param): one more launch for all of them
+        _ROWSUM_PENDING = []
+        ritems = (_lib.RowsSumItem * len(rows))(*[it for it, _ in rows])
+        _lib.check(_lib_().wdno_rows_sum_multi(C.cast(ritems, C.c_void_p), len(rows), _stream()), 'rows_sum_multi')
+        _DEFERRED_DSTS.update(int(it.out) for it, _ in rows)
     if not pend:
         return
     _WGRAD_PENDING = [] if _FLAT_ARMED else None
     items = (_lib.WgradReduceItem * len(pend))(*[it for it, _ in pend])
     _lib.check(_lib_().wdno_wgrad_reduce_multi(C.cast(items, C.c_void_p), len(pend), _stream()), 'wgrad_reduce_multi')
     _DEFERRED_DSTS.update(int(it.dw) for it, _ in pend)
+
+
+class _RowsJob:
+    """A sum over the rows of a partial matrix that is still to be run: out[j] = sum_r part[r * stride + col0 + j] (csrc/pointwise.hip:
+    rows_sum_multi_kernel, the fp64 sums of partial_rows_sum in the same order). `keep` holds the matrix alive."""
+    __slots__ = ('keep', 'ptr', 'rows', 'stride', 'col0', 'ncols', 'is_double')
+
+    def __init__(self, keep, ptr, rows, stride, col0, ncols, is_double):
+        self.keep, self.ptr, self.rows, self.stride, self.col0, self.ncols, self.is_double = keep, ptr, rows, stride, col0, ncols, is_double
+
+    def item(self, out, ncols=None):
+        it = _lib.RowsSumItem()
+        it.part, it.out, it.rows, it.stride, it.col0 = self.ptr, out.data_ptr(), self.rows, self.stride, self.col0
+        it.ncols, it.is_double, it.reserved = self.ncols if ncols is None else ncols, self.is_double, 0
+        return it
+
+
+def rows_sum_for_param(job, param, ncols=None, out=None):
+    """The gradient [ncols] of `param` from a _RowsJob. Inside a trainer's backward, when this is the parameter's first gradient since zero_grad()
+    (`out` = its span of the flat gradient buffer, claimed here or by the caller): queued, run with all the others in ONE launch when the backward
+    has returned (flush_wgrad_reduces) -- until then the returned view is unwritten, which is safe for the same reason as for deferred weight
+    gradients (autograd only stores it). Otherwise: one launch now into a fresh tensor."""
+    n = job.ncols if ncols is None else ncols
+    if out is None and DEFER_ROW_SUMS and _WGRAD_PENDING is not None and param is not None:
+        out = _flat_grad_out(param, (n,))
+    if out is not None:
+        _ROWSUM_PENDING.append((job.item(out, n), job.keep))
+        return out
+    dev = job.keep.device
+    out = torch.empty((n,), device=dev, dtype=torch.float32)
+    items = (_lib.RowsSumItem * 1)(job.item(out, n))
+    _lib.check(_lib_().wdno_rows_sum_multi(C.cast(items, C.c_void_p), 1, _stream()), 'rows_sum_multi')
+    return out
 
 
 def take_deferred_dsts():
@@ -1126,6 +1172,7 @@ class _Conv(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual, stride, padding, with_skip=False, grad_planes=False, to_norm=False):
         ctx.with_skip = with_skip
         ctx.to_norm = to_norm and grad_planes          # the caller's statement: y goes to a GroupNorm and nowhere else
+        ctx.bias_ref = bias                            # (the parameter object: its span of a trainer's flat gradient buffer, rows_sum_for_param)
         y = _Conv._forward(ctx, x, weight, bias, residual, stride, padding)
         # grad_planes: the caller states that y goes to a GroupNorm and nowhere else; if this convolution's backward reads dy
         # only through the split kernels, the norm may deliver dy as planes (and leave the fp32 tensor unwritten)
@@ -1248,9 +1295,9 @@ class _Conv(torch.autograd.Function):
             if not (will_split and (not ctx.needs_input_grad[0] or (stride == (1, 1, 1) and _use_h3(n * d * h * w, kp * ks[0] * ks[1] * ks[2])))):
                 raise RuntimeError('wdno_amd: a planes-only gradient reached a convolution whose backward needs fp32 dy')
             if want_gb:
-                gb = gb_given[:k].contiguous()
+                gb = rows_sum_for_param(gb_given, getattr(ctx, 'bias_ref', None), k) if isinstance(gb_given, _RowsJob) else gb_given[:k].contiguous()
         elif want_gb and will_split:               # dy is split for the gradient kernels anyway: column sums from the same pass
-            gyplanes, gbs = split_f16_colsum(gy5.reshape(-1, kp), grec)
+            gyplanes, gbs = split_f16_colsum(gy5.reshape(-1, kp), grec, bias=getattr(ctx, 'bias_ref', None), k=k)
             gb = gbs[:k].contiguous()
         if ctx.needs_input_grad[0]:
             gs5 = None if gskip is None else _chk(gskip, 'skip gradient').reshape(n, d, h, w, cp)      # conv_cl_skip: + gradient over the skip
@@ -1609,6 +1656,27 @@ class _GroupNormAct(torch.autograd.Function):
                 lo = torch.empty((n * s, c), device=x.device, dtype=torch.float16)
                 rec = _amax_slot(x.device)
                 scale = rec[1:2]
+            # Inside a trainer's backward the three sums that end this backward -- the column sums of dx (the bias gradient of the convolution in
+            # front) and the sums over the samples of the d(gamma) / d(beta) pieces -- wait for the launch that ends the pass (rows_sum_for_param):
+            # they feed parameters only. Needs gamma's and beta's spans of the flat gradient buffer; the bias span is claimed by the convolution.
+            og = ob = None
+            if DEFER_ROW_SUMS and _WGRAD_PENDING is not None and n > 1:
+                og = _flat_grad_out(gamma, (c,))
+                ob = _flat_grad_out(beta, (c,)) if og is not None else None
+                if og is not None and ob is None:
+                    gamma._wdno_flat_busy = False            # (give the claim back: the single-launch tail below writes fresh tensors)
+                    og = None
+            if og is not None:
+                off, prow = C.c_size_t(0), C.c_int(0)
+                _lib.check(lib.wdno_groupnorm_bwd_planes_tail(n, s, c, groups, C.byref(off), C.byref(prow)), 'groupnorm_bwd_planes_tail')
+                _lib.check(lib.wdno_groupnorm_act_bwd_planes_t(_p(x), x16, _p(gy), dy16, _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), None,
+                                                               _p(dgb), None, _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
+                           'groupnorm_bwd_planes')
+                dx = _poison(torch.empty_like(x))
+                dx._wdno_planes_only = ((hi, lo, scale), _RowsJob(ws, ws.data_ptr() + off.value, prow.value, c, 0, c, 1), dx._version, CONV_MATH)
+                dgam = rows_sum_for_param(_RowsJob(dgb, dgb.data_ptr(), n, 2 * c, 0, c, 0), gamma, out=og)
+                dbet = rows_sum_for_param(_RowsJob(dgb, dgb.data_ptr(), n, 2 * c, c, c, 0), beta, out=ob)
+                return dx, dgam, dbet, dss, None, None, None, None
             red = torch.empty((2 * c,), device=x.device, dtype=torch.float32) if n > 1 else None      # sum over the samples, from the same launch
             _lib.check(lib.wdno_groupnorm_act_bwd_planes_t(_p(x), x16, _p(gy), dy16, _p(gamma), _p(beta), _p(ss), _p(stats), _p(hi), _p(lo), _p(scale), _p(cs),
                                                            _p(dgb), _p(red), _p(dss), _p(rec), n, s, c, groups, act_silu, _p(ws), nb, _stream()),
