@@ -166,3 +166,34 @@ def test_stem_forward_on_192_pixel_tiles_equals_the_256_pixel_tiles(xs):
     assert torch.equal(res[0], res[72])
     ref = torch.nn.functional.conv3d(x[..., :42].permute(0, 4, 1, 2, 3).double(), w.double(), b.double(), padding=3).permute(0, 2, 3, 4, 1).float()
     assert float((res[0] - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+def test_rows_sum_multi_windows_dtypes_and_more_items_than_one_launch_holds():
+    """wdno_rows_sum_multi: out[j] = sum_r part[r * stride + col0 + j] for a host list of items -- float and double partial matrices, column windows
+    of wider matrices (GroupNorm's [N][2 C] pieces: d(gamma) = columns 0 .. C-1, d(beta) = C .. 2C-1), 1 .. 2048 rows, 150 items = three launches of
+    WDNO_ROWS_SUM_MAX (64); against torch's fp64 sum to fp32 rounding, and bit-identical to the single-tensor launch it replaces (wdno_colsum's finish
+    = partial_rows_sum over the same rows)."""
+    from wdno_amd import ops, _lib
+    lib = ops._lib_()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    items, wants, outs, keep = [], [], [], []
+    for i in range(150):
+        rows = [1, 7, 32, 33, 257, 2048][i % 6]
+        ncols = [5, 32, 64, 100, 256][i % 5]
+        stride = ncols * (2 if i % 2 else 1) + (3 if i % 3 == 0 else 0)
+        col0 = (stride - ncols) if i % 2 else 0
+        dbl = i % 4 < 2
+        part = torch.randn(rows, stride, device=DEV, generator=g, dtype=torch.float64 if dbl else torch.float32)
+        out = torch.full((ncols,), float('nan'), device=DEV)
+        keep.append(part)
+        outs.append(out)
+        wants.append(part[:, col0:col0 + ncols].double().sum(0).float())
+        items.append(_lib.RowsSumItem(part.data_ptr(), out.data_ptr(), rows, stride, col0, ncols, int(dbl), 0))
+    arr = (_lib.RowsSumItem * len(items))(*items)
+    _lib.check(lib.wdno_rows_sum_multi(C.cast(arr, C.c_void_p), len(items), ops._stream()), 'rows_sum_multi')
+    torch.cuda.synchronize()
+    bad = [i for i, (o, w) in enumerate(zip(outs, wants)) if not torch.allclose(o, w, rtol=2e-6, atol=1e-5)]
+    assert not bad, bad
+    # the job form used by the backward passes, run at once (no trainer scope) == the queued form above, bit for bit
+    job = ops._RowsJob(keep[5], keep[5].data_ptr(), 2048, items[5].stride, items[5].col0, items[5].ncols, items[5].is_double)
+    assert torch.equal(ops.rows_sum_for_param(job, None), outs[5])
