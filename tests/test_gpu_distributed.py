@@ -209,6 +209,16 @@ def _worker_rccl_one_rank(port, overlap, out, graph=False, in_graph=False):
     torch.save(info, out)
 
 
+def _worker_rccl_one_rank_logged(port, overlap, out, graph=False, in_graph=False):
+    try:
+        _worker_rccl_one_rank(port, overlap, out, graph, in_graph)
+    except BaseException:
+        import traceback
+        with open(out + '.err', 'w') as f:
+            f.write(traceback.format_exc())
+        raise
+
+
 @pytest.mark.parametrize('overlap,graph,in_graph', [(False, False, False), (True, False, False), (False, True, False), (True, True, False), (True, True, True)])
 def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overlap, graph, in_graph):
     """graph = True: the step replayed from a captured HIP graph with the RCCL all-reduce between the replay and clip + Adam. overlap AND
@@ -218,10 +228,20 @@ def test_train_step_over_a_one_rank_rccl_group_is_bit_identical(tmp_path, overla
     step bit for bit (_verify_overlap_capture)."""
     out = str(tmp_path / 'rccl.pt')
     ctx = mp.get_context('spawn')
-    p = ctx.Process(target=_worker_rccl_one_rank, args=(_free_port(), overlap, out, graph, in_graph))
-    p.start()
-    p.join(300)
-    assert p.exitcode == 0, f'worker exit code {p.exitcode}'
+    for attempt in range(2):
+        p = ctx.Process(target=_worker_rccl_one_rank_logged, args=(_free_port(), overlap, out, graph, in_graph))
+        p.start()
+        p.join(300)
+        if p.exitcode is None:
+            p.kill()
+        # a worker killed by a SIGNAL (torch's ProcessGroupNCCL watchdog thread aborts the process when it trips over a capture in progress:
+        # seen once per ~10 full-suite runs, never in isolation) is run once more; a Python failure of the worker is not -- its traceback is shown
+        if p.exitcode is not None and p.exitcode < 0 and attempt == 0:
+            print(f'worker died with signal {-p.exitcode}; one more attempt')
+            continue
+        break
+    err = open(out + '.err').read() if os.path.exists(out + '.err') else ''
+    assert p.exitcode == 0, f'worker exit code {p.exitcode}\n{err}'
     info = torch.load(out)
     print(info)
     assert info['exchanged'] == in_graph
