@@ -802,7 +802,7 @@ def conv_roofline(ts_step, ops):
     achieved = fl / (ms * 1e-3) / 1e12
     split = 'h3' in dom and ops.CONV_MATH == 'f16x3'
     peak = PEAK_F32_MFMA_TFLOPS if 'h3' not in dom else PEAK_F16_MFMA_TFLOPS
-    traffic = path = None          # HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json)
+    traffic = path = stale = None  # HBM bytes per launch from the committed PMC passes (profiles/*_pmc_traffic.json); stale: the kernel sources changed since
     try:
         fam, dims = dom.split('<')
         dims = dims.rstrip('>').split(',')
@@ -810,14 +810,20 @@ def conv_roofline(ts_step, ops):
         path = next((q for q in (PROFILE_JSON, os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json'), os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'))
                      if os.path.exists(q)), PROFILE_JSON)
         with open(path) as f:
-            recs = json.load(f)['kernels']
+            prof = json.load(f)
+            recs = prof['kernels']
+            import glob, hashlib
+            hh = hashlib.sha256()
+            for q in sorted(glob.glob(os.path.join(ROOT, 'wdno_amd', 'csrc', '*.h*'))):
+                hh.update(open(q, 'rb').read())
+            stale = None if 'csrc_sha16' not in prof else prof['csrc_sha16'] != hh.hexdigest()[:16]
             hit = [r for k, r in recs.items() if sym and sym in k] or [r for k, r in recs.items() if (fam + 'I') in k]
             if hit:                               # entries are ordered by total time: the first match is the main instantiation
                 traffic = round(hit[0]['hbm_bytes_per_launch'])
     except Exception:
         traffic = None
     return {'bound': 'mfma', 'kernel': dom, 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': (os.path.relpath(path, ROOT) + ' (committed rocprofv3 --pmc passes of this kernel; a lookup, not a counter read in this run)') if traffic is not None else None,
+            'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_stale': stale if traffic is not None else None, 'traffic_source': (os.path.relpath(path, ROOT) + ' (committed rocprofv3 --pmc passes of this kernel; a lookup, not a counter read in this run)') if traffic is not None else None,
             'launches_per_step': n,
             'frac_of_fp32_equivalent_ceiling': round(achieved / (peak / 3), 4) if split else None,
             'note': ('fp32-equivalent 3 x fp16-split MFMA: 3 matrix flop per algorithmic flop, so frac <= 0.333; the exact-fp32 MFMA peak is 157.3 TFLOP/s'

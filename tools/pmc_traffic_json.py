@@ -1,6 +1,6 @@
 """profiles/rNN_bench_pmc.md (tools/pmc_summary.py) -> profiles/rNN_pmc_traffic.json: per-kernel fabric / HBM bytes per launch
 and MFMA busy fraction, the numbers bench.py looks up for its roofline object."""
-import json, sys
+import glob, hashlib, json, os, sys
 src, dst = sys.argv[1], sys.argv[2]
 lines = [l for l in open(src) if l.startswith('|')]
 cols = [c.strip() for c in lines[0].strip().strip('|').split('|')]
@@ -27,5 +27,10 @@ for l in lines[2:]:
     out['kernels'][name] = {'fetch_kb': f, 'write_kb': w, 'l2_fabric_bytes_per_launch': b, 'hbm_bytes_per_launch': b,
                             'SQ_LDS_BANK_CONFLICT': num(rec.get('SQ_LDS_BANK_CONFLICT', '-')) or 0.0, 'SQ_INSTS_MFMA': mf,
                             'GRBM_GUI_ACTIVE': ga, 'mfma_busy_frac': round(32 * mf / (ga / 8 * 1024), 4) if ga else None}
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, 'wdno_amd', 'csrc', '*.h*'))):      # *.hip and *.h: what the profiled library was built from
+    h.update(open(f, 'rb').read())
+out['csrc_sha16'] = h.hexdigest()[:16]          # bench.py marks the looked-up traffic stale when the sources have changed since
 json.dump(out, open(dst, 'w'), indent=1)
 print('wrote', dst, len(out['kernels']), 'kernels')
